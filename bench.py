@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the wass_stereo dense-stereo hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--ndirs 5|8] [--config B|A|E]
+
+One "step" = one synthetic rectified stereo pair pushed through the whole GPU
+hot path (inputs already resident in HBM).  With N > 1 (launched by
+torch.distributed.run, one rank per GPU) every rank processes its own frames
+-- stereo frames are independent, there is no data-path collective -- and the
+reported value is the whole-job rate (weak scaling).
+
+Prints ONE JSON line (rank 0) with BASELINE.json's metric plus
+  roofline     -- aggregation kernel family vs the 8 TB/s HBM roofline
+  cpu_baseline -- the CPU oracle timed on this box's host cores (rank 0, N=1)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (w, h, D)   -- BASELINE.json configs[0], [1], [4]
+    "A": (640, 480, 64),
+    "B": (2456, 2058, 256),
+    "E": (3840, 2160, 512),
+}
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def cpu_baseline(w: int, D: int, ndirs: int, budget_rows: int = 192):
+    """Time the CPU oracle (scalar C restatement, 1 thread) on a bounded band of the same workload."""
+    from oracle import oracle as O
+    from wass_amd import synth
+    h = budget_rows
+    right, left = synth.make_pair(w, h, D, frame_idx=1000)
+    p = O.wass_params(D, mode=ndirs)
+    t0 = time.perf_counter()
+    O.dense_disparity16(right, left, p)
+    dt = time.perf_counter() - t0
+    mdisp = w * h * D / 1e6 / dt
+    return {"value": round(mdisp, 2), "unit": "Mdisp/s", "cores": 1, "kind": "port",
+            "sample": f"{w}x{h} band of the workload, D={D}, {ndirs}-path, scalar C oracle, 1 thread, {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--ndirs", type=int, default=8, choices=(5, 8))
+    ap.add_argument("--config", default="B", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import wass_amd
+    from wass_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    w, h, D = CONFIGS[args.config]
+    params = wass_amd.default_sgm_params(D, ndirs=args.ndirs)
+    ctx = wass_amd.Context(local_rank)
+
+    # two different resident frames per rank, alternated, so no step can reuse a previous result
+    frames = []
+    for k in range(2):
+        r, l = synth.make_pair(w, h, D, frame_idx=rank * 16 + k)
+        frames.append((torch.from_numpy(r).to(dev), torch.from_numpy(l).to(dev)))
+    out = torch.empty((h, w), dtype=torch.int16, device=dev)
+
+    def step(i):
+        dr, dl = frames[i % 2]
+        ctx.sgm_disparity_dev(dr, dl, params, out)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    agg_ms, cost_ms, sel_ms = [], [], []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+        # stage timings come from hipEvents recorded on the context's own stream; reading them
+        # waits for this frame, which is the reference's per-frame execution model anyway
+        t = ctx.sgm_timings()
+        agg_ms.append(t.aggregate_ms); cost_ms.append(t.cost_ms); sel_ms.append(t.select_ms)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+    overflow = ctx.sgm_timings().cost_overflow
+
+    if rank == 0:
+        pairs = world * args.steps
+        pairs_s = pairs / elapsed
+        cells = w * h * D
+        alg_bytes = cells * (2 * args.ndirs + 4)             # (2R+4) B per cell
+        t_agg = float(np.mean(agg_ms)) * 1e-3
+        achieved = alg_bytes / t_agg / 1e9
+        line = {
+            "metric": "stereo_pairs_per_sec", "value": round(pairs_s, 4), "unit": "pairs/s",
+            "mdisp_per_sec": round(pairs_s * cells / 1e6, 1),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u16", "data": "synthetic",
+            "config": {"workload": f"config {args.config}: {w}x{h} rectified pair, D={D}, {args.ndirs}-path SGBM "
+                                   f"(cost volume + aggregation + WTA/LR + median), frame-parallel over ranks",
+                       "width": w, "height": h, "num_disp": D, "ndirs": args.ndirs, "pairs_per_rank": args.steps},
+            "roofline": {"bound": "hbm", "kernel": "k_sweep (path aggregation, all launches of one frame)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes": alg_bytes, "ms": round(t_agg * 1e3, 3)},
+            "stage_ms": {"cost_volume": round(float(np.mean(cost_ms)), 3), "aggregate": round(t_agg * 1e3, 3),
+                         "select": round(float(np.mean(sel_ms)), 3)},
+            "cost_overflow": int(overflow),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(w, D, args.ndirs)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

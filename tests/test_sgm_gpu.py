@@ -1,0 +1,127 @@
+"""GPU parity of the SGBM stages against the CPU oracle.
+
+Bit-exact: every stage is integer arithmetic.  All calls go through the C ABI.
+"""
+import numpy as np
+import pytest
+
+from wass_amd import default_sgm_params, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_params(O, p):
+    return O.SgbmParams(p.min_disp, p.num_disp, p.win, p.P1, p.P2, p.uniq_ratio, p.disp12_max_diff,
+                        p.prefilter_cap, p.speckle_win, p.speckle_range, p.ndirs)
+
+
+def _pad(right, left, D, off=0):
+    h, w = right.shape
+    offp, comp = max(off, 0), max(-off, 0)
+    Wp = w + D + offp
+    R = np.zeros((h, Wp), np.uint8); L = np.zeros((h, Wp), np.uint8)
+    R[:, D:D + w] = right
+    L[:, D + offp - comp:D + offp - comp + w] = left
+    return R, L
+
+
+CASES = [
+    # w, h, D, ndirs, win, min_disp, off
+    (64, 48, 16, 5, 13, 1, 0),
+    (64, 48, 16, 8, 13, 1, 0),
+    (160, 120, 32, 5, 13, 1, 0),
+    (160, 120, 32, 8, 13, 1, 0),
+    (200, 90, 64, 5, 13, 1, 0),
+    (200, 90, 64, 8, 9, 1, 0),
+    (150, 70, 128, 8, 13, 1, 0),
+    (150, 70, 128, 5, 5, 0, 0),
+    (131, 77, 48, 8, 13, 2, 0),       # ragged sizes, D not a multiple of 64, minD = 2
+    (131, 77, 80, 5, 7, 1, 3),        # positive DISPARITY_OFFSET
+    (131, 77, 80, 8, 7, 1, -4),       # negative DISPARITY_OFFSET
+    (320, 64, 256, 8, 13, 1, 0),
+    (300, 40, 160, 5, 13, 1, 0),      # NP = 2 with padded slots
+    (340, 32, 272, 8, 13, 1, 0),      # NP = 3
+]
+
+
+@pytest.mark.parametrize("w,h,D,ndirs,win,mind,off", CASES)
+def test_stage_parity(gpu_ctx, oracle, w, h, D, ndirs, win, mind, off):
+    right, left = synth.make_pair(w, h, D, frame_idx=w + h + D)
+    p = default_sgm_params(D, ndirs=ndirs, win=win, min_disp=mind, disp_offset=off)
+    got = gpu_ctx.sgm_disparity(right, left, p)
+    Cg, Sg, rawg = gpu_ctx.sgm_debug_fetch(w, h, p)
+
+    R, L = _pad(right, left, D, off)
+    disp, st, Co, So, rawo = oracle.sgbm_compute(R, L, _oracle_params(oracle, p), dump=True)
+    assert not st.overflow
+    assert Cg.shape == Co.shape
+    np.testing.assert_array_equal(Cg, Co, err_msg="cost volume C")
+    np.testing.assert_array_equal(Sg, So, err_msg="aggregated volume S")
+    np.testing.assert_array_equal(rawg, rawo, err_msg="raw disparity (WTA/uniqueness/subpixel/LR)")
+    np.testing.assert_array_equal(got, disp[:, D:D + w], err_msg="median + crop")
+    # and the wass-level wrapper of the oracle agrees with itself
+    d2, _ = oracle.dense_disparity16(right, left, _oracle_params(oracle, p), off)
+    np.testing.assert_array_equal(got, d2)
+
+
+def test_random_noise_images(gpu_ctx, oracle):
+    """Untextured/random inputs: many ties, rejected pixels and saturated S."""
+    rng = np.random.default_rng(7)
+    w, h, D = 140, 60, 32
+    right = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    left = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    for ndirs in (5, 8):
+        p = default_sgm_params(D, ndirs=ndirs, p2_mult=16)
+        got = gpu_ctx.sgm_disparity(right, left, p, allow_overflow=True)
+        d2, st = oracle.dense_disparity16(right, left, _oracle_params(oracle, p))
+        if not st.overflow:
+            np.testing.assert_array_equal(got, d2)
+
+
+def test_constant_images(gpu_ctx, oracle):
+    """KAT (i) of SURVEY.md 8c: all costs zero -> d = 0 everywhere valid."""
+    c = np.full((40, 100), 77, np.uint8)
+    for ndirs in (5, 8):
+        p = default_sgm_params(16, ndirs=ndirs)
+        got = gpu_ctx.sgm_disparity(c, c, p)
+        d2, _ = oracle.dense_disparity16(c, c, _oracle_params(oracle, p))
+        np.testing.assert_array_equal(got, d2)
+        assert set(np.unique(got)) <= {0, 16}
+
+
+def test_integer_shift(gpu_ctx):
+    """KAT (ii): right(x) = left(x - k) -> raw disparity 16*k in the interior."""
+    rng = np.random.default_rng(1)
+    w, h, D, k = 160, 60, 32, 7
+    left = rng.integers(1, 255, (h, w), dtype=np.uint8)
+    right = np.zeros_like(left); right[:, k:] = left[:, :w - k]
+    for ndirs in (5, 8):
+        got = gpu_ctx.sgm_disparity(right, left, default_sgm_params(D, ndirs=ndirs))
+        assert (got[10:-10, 40:-10] == 16 * k).all()
+
+
+def test_device_pointer_entry(gpu_ctx, oracle):
+    import torch
+    w, h, D = 160, 120, 32
+    right, left = synth.make_pair(w, h, D, frame_idx=3)
+    p = default_sgm_params(D, ndirs=8)
+    dr = torch.from_numpy(right).cuda(); dl = torch.from_numpy(left).cuda()
+    out = gpu_ctx.sgm_disparity_dev(dr, dl, p)
+    gpu_ctx.synchronize()
+    d2, _ = oracle.dense_disparity16(right, left, _oracle_params(oracle, p))
+    np.testing.assert_array_equal(out.cpu().numpy(), d2)
+    t = gpu_ctx.sgm_timings()
+    assert t.total_ms > 0 and t.aggregate_launches >= 1 and t.cost_overflow == 0
+
+
+def test_overflow_is_reported(gpu_ctx):
+    """Costs beyond the int16 precondition (A.7) are flagged, not silently wrong."""
+    import wass_amd
+    rng = np.random.default_rng(3)
+    w, h, D = 120, 50, 16
+    right = (rng.integers(0, 2, (h, w)) * 255).astype(np.uint8)
+    left = (rng.integers(0, 2, (h, w)) * 255).astype(np.uint8)
+    p = default_sgm_params(D, ndirs=5, win=17, p2_mult=100)
+    with pytest.raises(wass_amd.WassError) as e:
+        gpu_ctx.sgm_disparity(right, left, p)
+    assert e.value.code == -5

@@ -1,0 +1,78 @@
+"""ctypes binding of libwassgpu.so (the C ABI declared in include/wass_gpu.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a call
+fails, an exception is raised.  The CPU oracle under oracle/ is never used
+from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libwassgpu.so")
+
+WASS_OK = 0
+WASS_ERR_COST_OVERFLOW = -5
+
+
+class WassError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libwassgpu error {code}: {msg}")
+        self.code = code
+
+
+class SgmParams(C.Structure):
+    """wass_sgm_params -- cv::StereoSGBM set-up of wass_stereo.cpp:742-782."""
+    _fields_ = [(n, C.c_int) for n in (
+        "min_disp", "num_disp", "win", "P1", "P2", "uniq_ratio", "disp12_max_diff", "prefilter_cap",
+        "speckle_win", "speckle_range", "ndirs", "disp_offset")] + [("dense_scale", C.c_double)]
+
+
+class SgmTimings(C.Structure):
+    _fields_ = [("prefilter_ms", C.c_float), ("cost_ms", C.c_float), ("aggregate_ms", C.c_float),
+                ("select_ms", C.c_float), ("median_ms", C.c_float), ("total_ms", C.c_float),
+                ("aggregate_launches", C.c_int), ("cost_overflow", C.c_int)]
+
+
+def default_sgm_params(num_disp: int, ndirs: int = 5, min_disp: int = 1, win: int = 13, p1_mult: int = 2,
+                       p2_mult: int = 64, disp_offset: int = 0) -> SgmParams:
+    """Defaults of SURVEY.md Appendix C (wass_stereo.cpp:742-759)."""
+    return SgmParams(min_disp, num_disp, win, p1_mult * win * win, p2_mult * win * win, 1, -1, 60, -70, 16,
+                     ndirs, disp_offset, 1.0)
+
+
+# every symbol include/wass_gpu.h declares: name -> (restype, argtypes)
+_vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
+SYMBOLS = {
+    "wass_version": (C.c_char_p, []),
+    "wass_ctx_create": (_i, [_i, C.POINTER(_vp)]),
+    "wass_ctx_destroy": (None, [_vp]),
+    "wass_last_error": (C.c_char_p, [_vp]),
+    "wass_ctx_stream": (_vp, [_vp]),
+    "wass_ctx_synchronize": (_i, [_vp]),
+    "wass_sgm_disparity": (_i, [_vp, _vp, _vp, _i, _i, _sz, C.POINTER(SgmParams), _vp]),
+    "wass_sgm_disparity_dev": (_i, [_vp, _vp, _vp, _i, _i, _sz, C.POINTER(SgmParams), _vp]),
+    "wass_sgm_last_timings": (_i, [_vp, C.POINTER(SgmTimings)]),
+    "wass_sgm_debug_fetch": (_i, [_vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libwassgpu.so and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError(
+            f"{SO_PATH} not found: build the HIP extension first (python -m wass_amd.build). "
+            "wass_amd has no CPU fallback.")
+    lib = C.CDLL(SO_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

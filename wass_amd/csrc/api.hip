@@ -1,0 +1,236 @@
+// api.hip -- context management and the C-ABI entry points of libwassgpu.
+#include "common.h"
+
+#include <stdarg.h>
+#include <new>
+
+namespace wass {
+
+int set_err(wass_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+int ensure(wass_ctx* c, Buf& b, size_t bytes)
+{
+    if (bytes <= b.cap) return WASS_OK;
+    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    // round up so that slightly different frame sizes do not thrash the allocator
+    const size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return set_err(c, WASS_ERR_NO_MEMORY, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    b.cap = want;
+    return WASS_OK;
+}
+
+static void release(Buf& b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr; b.cap = 0;
+}
+
+// derived parameters
+static int make_dims(wass_ctx* c, int w, int h, const wass_sgm_params* p, SgmDims& d)
+{
+    if (!p || w <= 0 || h <= 0) return set_err(c, WASS_ERR_INVALID_ARG, "bad image size %dx%d", w, h);
+    if (p->num_disp <= 0 || (p->num_disp % 16) != 0)
+        return set_err(c, WASS_ERR_INVALID_ARG, "MAX_DISPARITY must be a positive multiple of 16 (got %d)", p->num_disp);
+    if (p->num_disp > 1024) return set_err(c, WASS_ERR_UNSUPPORTED, "MAX_DISPARITY %d > 1024", p->num_disp);
+    if (p->min_disp < 0) return set_err(c, WASS_ERR_UNSUPPORTED, "negative MIN_DISPARITY is not supported");
+    if (p->ndirs != 5 && p->ndirs != 8) return set_err(c, WASS_ERR_INVALID_ARG, "ndirs must be 5 or 8");
+    if (p->speckle_win > 0)
+        return set_err(c, WASS_ERR_UNSUPPORTED, "DENSE_SPECKLE_WINDOW_SIZE > 0 (filterSpeckles) is not supported");
+    if (p->dense_scale != 1.0) return set_err(c, WASS_ERR_UNSUPPORTED, "DENSE_SCALE != 1.0 is not supported");
+    const int win = p->win > 0 ? p->win : 5;
+    if (win > 17) return set_err(c, WASS_ERR_UNSUPPORTED, "WINSIZE %d > 17 is not supported", win);
+    d.w = w; d.h = h; d.D = p->num_disp;
+    d.off_pos = p->disp_offset > 0 ? p->disp_offset : 0;
+    d.comp = p->disp_offset > 0 ? 0 : -p->disp_offset;
+    if (d.D + d.off_pos - d.comp < 0)
+        return set_err(c, WASS_ERR_INVALID_ARG, "DISPARITY_OFFSET %d exceeds MAX_DISPARITY", p->disp_offset);
+    d.Wp = w + d.D + d.off_pos;
+    d.NP = (d.D + 127) / 128;
+    d.Dp = 128 * d.NP;
+    d.minD = p->min_disp; d.maxD = d.minD + d.D;
+    d.minX1 = d.maxD;
+    d.width1 = d.Wp - d.maxD;
+    d.SW2 = win / 2;
+    d.P1 = p->P1 > 0 ? p->P1 : 2;
+    d.P2 = p->P2 > 0 ? p->P2 : 5;
+    if (d.P2 < d.P1 + 1) d.P2 = d.P1 + 1;
+    if (d.P2 > 32767) return set_err(c, WASS_ERR_INVALID_ARG, "P2 %d does not fit the int16 cost type", d.P2);
+    d.uniq = p->uniq_ratio >= 0 ? p->uniq_ratio : 10;
+    d.d12 = p->disp12_max_diff > 0 ? p->disp12_max_diff : 1;
+    d.ftzero = (p->prefilter_cap > 15 ? p->prefilter_cap : 15) | 1;
+    if (d.ftzero > 127) return set_err(c, WASS_ERR_UNSUPPORTED, "DENSE_PREFILTER_CAP %d > 126", p->prefilter_cap);
+    d.ndirs = p->ndirs;
+    if (d.width1 <= d.SW2) return set_err(c, WASS_ERR_INVALID_ARG, "image too narrow for the matching window");
+    return WASS_OK;
+}
+
+}  // namespace wass
+
+using namespace wass;
+
+extern "C" {
+
+const char* wass_version(void) { return "wass_amd 0.1 (gfx950)"; }
+
+int wass_ctx_create(int device_id, wass_ctx** out)
+{
+    if (!out) return WASS_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return WASS_ERR_DEVICE;
+    if (hipSetDevice(device_id) != hipSuccess) return WASS_ERR_DEVICE;
+    wass_ctx* c = new (std::nothrow) wass_ctx();
+    if (!c) return WASS_ERR_NO_MEMORY;
+    c->device = device_id;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
+    for (auto& e : c->ev)
+        if (hipEventCreate(&e) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
+    if (ensure(c, c->flags, 64) != WASS_OK) { delete c; return WASS_ERR_NO_MEMORY; }
+    *out = c;
+    return WASS_OK;
+}
+
+void wass_ctx_destroy(wass_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (Buf* b : { &c->img1, &c->img2, &c->bt1, &c->bt2, &c->hsum, &c->C, &c->S, &c->sel_d16, &c->sel_key, &c->raw,
+                    &c->flags, &c->tmp_in0, &c->tmp_in1, &c->tmp_out })
+        release(*b);
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* wass_last_error(const wass_ctx* c) { return c ? c->err.c_str() : "null context"; }
+void* wass_ctx_stream(wass_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int wass_ctx_synchronize(wass_ctx* c)
+{
+    if (!c) return WASS_ERR_INVALID_ARG;
+    WASS_HIP(c, hipStreamSynchronize(c->stream));
+    return WASS_OK;
+}
+
+int wass_sgm_disparity_dev(wass_ctx* c, const uint8_t* d_right, const uint8_t* d_left, int w, int h, size_t pitch,
+                           const wass_sgm_params* p, int16_t* d_out)
+{
+    if (!c || !d_right || !d_left || !d_out) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    if (pitch < (size_t)w) return set_err(c, WASS_ERR_INVALID_ARG, "pitch %zu < width %d", pitch, w);
+    SgmDims d;
+    int rc = make_dims(c, w, h, p, d);
+    if (rc) return rc;
+    WASS_HIP(c, hipSetDevice(c->device));
+
+    const size_t npad = (size_t)d.Wp * d.h;
+    const size_t vol = d.cells() * sizeof(uint16_t);
+    if ((rc = ensure(c, c->img1, npad)) || (rc = ensure(c, c->img2, npad)) ||
+        (rc = ensure(c, c->bt1, npad * 8)) || (rc = ensure(c, c->bt2, npad * 8)) ||
+        (rc = ensure(c, c->hsum, vol)) || (rc = ensure(c, c->C, vol)) || (rc = ensure(c, c->S, vol)) ||
+        (rc = ensure(c, c->sel_d16, (size_t)d.width1 * d.h * 2)) ||
+        (rc = ensure(c, c->sel_key, (size_t)d.width1 * d.h * 4)) || (rc = ensure(c, c->raw, npad * 2)))
+        return rc;
+
+    hipStream_t s = c->stream;
+    c->timings_valid = false;
+    WASS_HIP(c, hipEventRecord(c->ev[0], s));
+    // wass_stereo.cpp:820-831: zero images, left at column D+off-comp, right at column D
+    WASS_HIP(c, hipMemsetAsync(c->img1.p, 0, npad, s));
+    WASS_HIP(c, hipMemsetAsync(c->img2.p, 0, npad, s));
+    WASS_HIP(c, hipMemsetAsync(c->flags.p, 0, 64, s));
+    WASS_HIP(c, hipMemcpy2DAsync((uint8_t*)c->img1.p + d.D, d.Wp, d_right, pitch, w, h, hipMemcpyDeviceToDevice, s));
+    WASS_HIP(c, hipMemcpy2DAsync((uint8_t*)c->img2.p + (d.D + d.off_pos - d.comp), d.Wp, d_left, pitch, w, h,
+                                 hipMemcpyDeviceToDevice, s));
+    if ((rc = launch_prefilter(c, d))) return rc;
+    WASS_HIP(c, hipEventRecord(c->ev[1], s));
+    if ((rc = launch_cost_volume(c, d))) return rc;
+    WASS_HIP(c, hipEventRecord(c->ev[2], s));
+    int nl = 0;
+    if ((rc = launch_aggregate(c, d, &nl))) return rc;
+    WASS_HIP(c, hipEventRecord(c->ev[3], s));
+    if ((rc = launch_select(c, d))) return rc;
+    WASS_HIP(c, hipEventRecord(c->ev[4], s));
+    if ((rc = launch_median_crop(c, d, d_out))) return rc;
+    WASS_HIP(c, hipEventRecord(c->ev[5], s));
+    c->last = d; c->have_last = true;
+    c->timings.aggregate_launches = nl;
+    c->timings_valid = true;
+    return WASS_OK;
+}
+
+int wass_sgm_last_timings(wass_ctx* c, wass_sgm_timings* out)
+{
+    if (!c || !out) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    if (!c->timings_valid) return set_err(c, WASS_ERR_INVALID_ARG, "no completed wass_sgm_disparity call");
+    WASS_HIP(c, hipEventSynchronize(c->ev[5]));
+    wass_sgm_timings& t = c->timings;
+    WASS_HIP(c, hipEventElapsedTime(&t.prefilter_ms, c->ev[0], c->ev[1]));
+    WASS_HIP(c, hipEventElapsedTime(&t.cost_ms, c->ev[1], c->ev[2]));
+    WASS_HIP(c, hipEventElapsedTime(&t.aggregate_ms, c->ev[2], c->ev[3]));
+    WASS_HIP(c, hipEventElapsedTime(&t.select_ms, c->ev[3], c->ev[4]));
+    WASS_HIP(c, hipEventElapsedTime(&t.median_ms, c->ev[4], c->ev[5]));
+    WASS_HIP(c, hipEventElapsedTime(&t.total_ms, c->ev[0], c->ev[5]));
+    uint32_t fl = 0;
+    WASS_HIP(c, hipMemcpy(&fl, c->flags.p, 4, hipMemcpyDeviceToHost));
+    t.cost_overflow = (int)(fl & 1);
+    *out = t;
+    return WASS_OK;
+}
+
+int wass_sgm_disparity(wass_ctx* c, const uint8_t* right, const uint8_t* left, int w, int h, size_t pitch,
+                       const wass_sgm_params* p, int16_t* disp16_out)
+{
+    if (!c || !right || !left || !disp16_out) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    if (w <= 0 || h <= 0 || pitch < (size_t)w) return set_err(c, WASS_ERR_INVALID_ARG, "bad image geometry");
+    WASS_HIP(c, hipSetDevice(c->device));
+    const size_t n = (size_t)w * h;
+    int rc;
+    if ((rc = ensure(c, c->tmp_in0, n)) || (rc = ensure(c, c->tmp_in1, n)) || (rc = ensure(c, c->tmp_out, n * 2)))
+        return rc;
+    WASS_HIP(c, hipMemcpy2DAsync(c->tmp_in0.p, w, right, pitch, w, h, hipMemcpyHostToDevice, c->stream));
+    WASS_HIP(c, hipMemcpy2DAsync(c->tmp_in1.p, w, left, pitch, w, h, hipMemcpyHostToDevice, c->stream));
+    rc = wass_sgm_disparity_dev(c, (const uint8_t*)c->tmp_in0.p, (const uint8_t*)c->tmp_in1.p, w, h, w, p,
+                                (int16_t*)c->tmp_out.p);
+    if (rc) return rc;
+    WASS_HIP(c, hipMemcpyAsync(disp16_out, c->tmp_out.p, n * 2, hipMemcpyDeviceToHost, c->stream));
+    uint32_t fl = 0;
+    WASS_HIP(c, hipMemcpyAsync(&fl, c->flags.p, 4, hipMemcpyDeviceToHost, c->stream));
+    WASS_HIP(c, hipStreamSynchronize(c->stream));
+    if (fl & 1)
+        return set_err(c, WASS_ERR_COST_OVERFLOW,
+                       "block cost + P2 exceeded 32767: outside the range where the reference is well defined");
+    return WASS_OK;
+}
+
+int wass_sgm_debug_fetch(wass_ctx* c, int16_t* C_out, int16_t* S_out, int16_t* raw_out)
+{
+    if (!c) return WASS_ERR_INVALID_ARG;
+    if (!c->have_last) return set_err(c, WASS_ERR_INVALID_ARG, "no completed wass_sgm_disparity call");
+    const SgmDims& d = c->last;
+    WASS_HIP(c, hipStreamSynchronize(c->stream));
+    // volumes are [h][width1][Dp] on the device; the caller gets [h][width1][D]
+    const size_t npx = (size_t)d.h * d.width1;
+    if (C_out)
+        WASS_HIP(c, hipMemcpy2D(C_out, (size_t)d.D * 2, c->C.p, (size_t)d.Dp * 2, (size_t)d.D * 2, npx, hipMemcpyDeviceToHost));
+    if (S_out)
+        WASS_HIP(c, hipMemcpy2D(S_out, (size_t)d.D * 2, c->S.p, (size_t)d.Dp * 2, (size_t)d.D * 2, npx, hipMemcpyDeviceToHost));
+    if (raw_out)
+        WASS_HIP(c, hipMemcpy(raw_out, c->raw.p, (size_t)d.Wp * d.h * 2, hipMemcpyDeviceToHost));
+    return WASS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,122 @@
+// common.h -- shared declarations for libwassgpu (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+
+#include "../../include/wass_gpu.h"
+
+namespace wass {
+
+// ---------------------------------------------------------------- packed u16
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ us2 pk_min(us2 a, us2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ us2 pk_max(us2 a, us2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ us2 pk_adds(us2 a, us2 b) { return __builtin_elementwise_add_sat(a, b); }
+__device__ __forceinline__ us2 pk_subs(us2 a, us2 b) { return __builtin_elementwise_sub_sat(a, b); }
+__device__ __forceinline__ us2 pk_splat(unsigned v) { us2 r; r.x = (unsigned short)v; r.y = (unsigned short)v; return r; }
+__device__ __forceinline__ uint32_t as_u32(us2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ us2 as_us2(uint32_t v) { return __builtin_bit_cast(us2, v); }
+
+// lanes: DPP controls (gfx9 encoding)
+enum : int {
+    DPP_QUAD_XOR1 = 0xB1,       // quad_perm:[1,0,3,2]
+    DPP_QUAD_XOR2 = 0x4E,       // quad_perm:[2,3,0,1]
+    DPP_ROW_HALF_MIRROR = 0x141,
+    DPP_ROW_MIRROR = 0x140,
+    DPP_ROW_BCAST15 = 0x142,
+    DPP_ROW_BCAST31 = 0x143,
+    DPP_WAVE_SHL1 = 0x130,      // lane i <- lane i+1
+    DPP_WAVE_SHR1 = 0x138,      // lane i <- lane i-1
+};
+
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t old, uint32_t src)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, BANK_MASK, false);
+}
+
+// minimum of a u32 over the 64 lanes of the wave, returned uniformly (SGPR).
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+    v = min(v, dpp_mov<DPP_QUAD_XOR1>(v, v));
+    v = min(v, dpp_mov<DPP_QUAD_XOR2>(v, v));
+    v = min(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v, v));
+    v = min(v, dpp_mov<DPP_ROW_MIRROR>(v, v));          // every row of 16 uniform
+    v = min(v, dpp_mov<DPP_ROW_BCAST15, 0xa>(v, v));    // rows 1,3 <- min(row, previous row)
+    v = min(v, dpp_mov<DPP_ROW_BCAST31, 0xc>(v, v));    // rows 2,3 <- min(row, lane 31)
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// ------------------------------------------------------------------ geometry
+// Derived sizes of one padded SGBM problem.
+struct SgmDims {
+    int w, h;            // unpadded crop
+    int Wp;              // padded width  = w + D + max(off,0)
+    int D;               // numDisparities
+    int NP;              // packed u16 pairs per lane: ceil(D / 128)
+    int Dp;              // padded disparity count = 128 * NP
+    int minD, maxD;      // minDisparity, minD + D
+    int minX1;           // = maxD
+    int width1;          // = Wp - maxD
+    int SW2;             // blockSize / 2
+    int P1, P2;
+    int uniq, d12;
+    int ftzero;
+    int ndirs;
+    int off_pos, comp;   // max(off,0), max(-off,0)
+    size_t cells() const { return (size_t)h * width1 * Dp; }
+};
+
+struct Buf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace wass
+
+struct wass_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // scratch HBM (grown on demand, never shrunk)
+    wass::Buf img1, img2;          // padded u8 images (right / left)
+    wass::Buf bt1, bt2;            // 8 B per pixel: {sobel v,lo,hi, raw v,lo,hi, 0,0}
+    wass::Buf hsum, C, S;          // u16 volumes [h][width1][Dp]
+    wass::Buf sel_d16, sel_key;    // per (y,x): raw fixed-point disparity / (minS<<16|d)
+    wass::Buf raw;                 // padded-width raw disparity [h][Wp] int16
+    wass::Buf flags;               // u32[4]: [0] = cost overflow
+    wass::Buf tmp_in0, tmp_in1, tmp_out;   // staging for the host-pointer entry points
+    hipEvent_t ev[8] = {};
+    wass::SgmDims last = {};
+    bool have_last = false;
+    wass_sgm_timings timings = {};
+    bool timings_valid = false;
+};
+
+namespace wass {
+
+int set_err(wass_ctx* c, int code, const char* fmt, ...);
+int ensure(wass_ctx* c, Buf& b, size_t bytes);
+
+#define WASS_HIP(ctx, call)                                                                 \
+    do {                                                                                    \
+        hipError_t e__ = (call);                                                            \
+        if (e__ != hipSuccess)                                                              \
+            return wass::set_err((ctx), WASS_ERR_DEVICE, "%s failed: %s (%s:%d)", #call,    \
+                                 hipGetErrorString(e__), __FILE__, __LINE__);               \
+    } while (0)
+
+// stage launchers (each enqueues on c->stream)
+int launch_prefilter(wass_ctx* c, const SgmDims& d);
+int launch_cost_volume(wass_ctx* c, const SgmDims& d);
+int launch_aggregate(wass_ctx* c, const SgmDims& d, int* n_launches);
+int launch_select(wass_ctx* c, const SgmDims& d);
+int launch_median_crop(wass_ctx* c, const SgmDims& d, int16_t* d_out);
+
+}  // namespace wass
