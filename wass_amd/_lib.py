@@ -69,6 +69,13 @@ def load() -> C.CDLL:
         raise ImportError(
             f"{SO_PATH} not found: build the HIP extension first (python -m wass_amd.build). "
             "wass_amd has no CPU fallback.")
+    # PyTorch bundles its own libamdhip64 (NEEDED as the unversioned "libamdhip64.so", SONAME .so.7).
+    # If /opt/rocm's copy were loaded first, a later `import torch` would pull in a SECOND HIP runtime
+    # and fail with "No HIP GPUs are available"; importing torch first makes both share one runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(SO_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
