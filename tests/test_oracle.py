@@ -1,0 +1,273 @@
+"""CPU tests of the oracle: known-answer tests, format fixtures produced with the
+reference's own reader, and hand-made cases for the reference's quirks.  No GPU."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from wass_amd import synth
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# ---------------------------------------------------------------- SGBM KATs
+def test_kat_constant_images(oracle):
+    c = np.full((40, 100), 77, np.uint8)
+    for mode in (5, 8):
+        d, st = oracle.dense_disparity16(c, c, oracle.wass_params(16, mode))
+        assert set(np.unique(d)) <= {0, 16}          # d=0 -> (0+minD)*16, later dropped by dval<=mindisp
+        assert not st.overflow
+        assert (oracle.clean_and_convert(d, 1, 16) == 0).all()
+
+
+@pytest.mark.parametrize("k", [3, 7, 12])
+def test_kat_integer_shift(oracle, k):
+    rng = np.random.default_rng(1)
+    w, h, D = 160, 60, 32
+    left = rng.integers(1, 255, (h, w), dtype=np.uint8)
+    right = np.zeros_like(left); right[:, k:] = left[:, :w - k]
+    for mode in (5, 8):
+        d, _ = oracle.dense_disparity16(right, left, oracle.wass_params(D, mode))
+        assert (d[10:-10, 40:-10] == 16 * k).all()
+        f = oracle.clean_and_convert(d, 1, D)
+        assert (f[10:-10, 40:-10] == float(k)).all()
+
+
+def test_first_cropped_column_is_invalid(oracle):
+    """Padded column D < minX1 = D + minD: never computed (Appendix A.6)."""
+    r, l = synth.make_pair(96, 64, 32, 5)
+    d, _ = oracle.dense_disparity16(r, l, oracle.wass_params(32, 5))
+    raw = oracle.sgbm_compute(*_pad(r, l, 32), oracle.wass_params(32, 5), dump=True)[4]
+    assert (raw[:, :33] == 0).all()
+
+
+def _pad(right, left, D):
+    h, w = right.shape
+    R = np.zeros((h, w + D), np.uint8); L = np.zeros((h, w + D), np.uint8)
+    R[:, D:] = right; L[:, D:] = left
+    return R, L
+
+
+def test_sgbm_synthetic_accuracy(oracle):
+    w, h, D = 320, 240, 64
+    r, l = synth.make_pair(w, h, D)
+    gt = synth.true_disparity(w, h, D)
+    for mode, tol in ((5, 0.8), (8, 0.3)):
+        d, st = oracle.dense_disparity16(r, l, oracle.wass_params(D, mode))
+        f = oracle.clean_and_convert(d, 1, D)
+        m = f > 0
+        assert m.mean() > 0.85 and not st.overflow
+        assert np.abs(f[m] - gt[m]).mean() < tol
+
+
+def test_sgbm_regression_fixture(oracle):
+    z = np.load(os.path.join(G, "sgbm_regress.npz"))
+    for name in "abc":
+        w, h, D, mode = z[f"{name}_cfg"]
+        d, _ = oracle.dense_disparity16(z[f"{name}_right"], z[f"{name}_left"], oracle.wass_params(int(D), int(mode)))
+        np.testing.assert_array_equal(d, z[f"{name}_disp"])
+
+
+def test_mode8_equals_mode5_plus_three_paths_structure(oracle):
+    """S of MODE_HH >= S of MODE_SGBM cell by cell (three more non-negative path costs, same saturation)."""
+    r, l = synth.make_pair(90, 50, 32, 9)
+    R, L = _pad(r, l, 32)
+    _, _, C5, S5, _ = oracle.sgbm_compute(R, L, oracle.wass_params(32, 5), dump=True)
+    _, _, C8, S8, _ = oracle.sgbm_compute(R, L, oracle.wass_params(32, 8), dump=True)
+    np.testing.assert_array_equal(C5, C8)
+    assert (S8 >= S5).all() and (C5 >= 0).all()
+
+
+def test_median3_matches_numpy(oracle):
+    rng = np.random.default_rng(0)
+    a = rng.integers(-300, 5000, (37, 53)).astype(np.int16)
+    p = np.pad(a, 1, mode="edge")
+    win = np.stack([p[i:i + 37, j:j + 53] for i in range(3) for j in range(3)], 0)
+    np.testing.assert_array_equal(oracle.median3_i16(a), np.median(win, axis=0).astype(np.int16))
+    one = rng.integers(0, 100, (1, 9)).astype(np.int16)       # degenerate height
+    pp = np.pad(one, ((0, 0), (1, 1)), mode="edge")
+    np.testing.assert_array_equal(oracle.median3_i16(one)[0], np.median(np.stack([pp[0, :-2], pp[0, 1:-1], pp[0, 2:]]), 0))
+
+
+# ------------------------------------------------ disparity clean-up (a7-a9)
+def test_clean_and_convert_edges(oracle):
+    d = np.array([[0, 16, 17, 32, 16 * 64, 16 * 64 + 1, -16, 100]], np.int16)
+    out = oracle.clean_and_convert(d, 1, 64, disp_offset=0)
+    np.testing.assert_array_equal(out, np.array([[0, 0, 17 / 16, 2, 64, 0, 0, 6.25]], np.float32))
+    out = oracle.clean_and_convert(d, 1, 64, disp_offset=3)
+    assert out[0, 3] == 5.0 and out[0, 1] == 0
+
+
+def test_dilate_quirk_column_shift(oracle):
+    """wass_stereo.cpp:626-638: pixel (i,k) is filled from the 8-neighbourhood of (i,k+1)."""
+    a = np.zeros((5, 8), np.float32)
+    a[1, 4] = 2.0; a[3, 4] = 4.0          # two positive values around (2,4)
+    out = oracle.dilate_zero(a)
+    # neighbourhood centred on column 4 is evaluated for OUTPUT column 3
+    assert out[2, 3] == 3.0
+    # output columns 2 and 4 see the pair through the stencils centred on columns 3 and 5
+    assert out[2, 2] == 3.0 and out[2, 4] == 3.0
+    assert out[2, 5] == 0.0
+    # the last two columns are never written
+    b = np.zeros((5, 8), np.float32); b[1, 7] = 1; b[3, 7] = 1; b[1, 6] = 1
+    ob = oracle.dilate_zero(b)
+    assert ob[2, 6] == 0 and ob[2, 7] == 0
+    # a single positive neighbour is not enough (avgnum > 1)
+    c = np.zeros((5, 8), np.float32); c[1, 4] = 2.0
+    assert (oracle.dilate_zero(c) == c).all()
+
+
+def test_erode(oracle):
+    a = np.ones((6, 7), np.float32) * 5
+    a[3, 3] = 0
+    out = oracle.erode_zero(a)
+    assert (out[0] == 0).all() and (out[-1] == 0).all() and (out[:, 0] == 0).all() and (out[:, -1] == 0).all()
+    assert (out[2:5, 2:5] == 0).sum() == 8 + 1
+    assert out[1, 1] == 5 and out[1, 5] == 5
+
+
+def test_postprocess_is_three_erosions(oracle):
+    r, l = synth.make_pair(120, 80, 32, 4)
+    d, _ = oracle.dense_disparity16(r, l, oracle.wass_params(32, 5))
+    f = oracle.clean_and_convert(d, 1, 32)
+    x = oracle.dilate_zero(f)
+    for _ in range(3):
+        x = oracle.erode_zero(x)
+    np.testing.assert_array_equal(oracle.disparity_postprocess(d, 1, 32), x)
+
+
+# ------------------------------------------------------------ geometry / mesh
+def test_triangulate_point_ideal_rig(oracle):
+    # R=I, T=(1,0,0): X_right = X_left + T ; point (X,Y,Z) in left frame
+    P = np.array([0.7, -0.4, 25.0])
+    p = P[:2] / P[2]
+    Pr = P + np.array([1.0, 0, 0]); q = Pr[:2] / Pr[2]
+    out = oracle.triangulate_point(p, q, np.eye(3), [1.0, 0, 0])
+    np.testing.assert_allclose(out, P, rtol=1e-9)
+
+
+def _plane_cloud(w=80, h=60, z0=30.0, noise=0.0, seed=0):
+    rng = np.random.default_rng(seed)
+    u, v = np.meshgrid(np.arange(w), np.arange(h))
+    p3d = np.stack([(u - w / 2) * 0.5, (v - h / 2) * 0.5, np.full((h, w), z0) + rng.normal(0, noise, (h, w))], -1)
+    return np.ones((h, w), np.uint8), np.ascontiguousarray(p3d, dtype=np.float64)
+
+
+def test_kat_plane_ransac_and_refine(oracle):
+    valid, p3d = _plane_cloud()
+    uv = oracle.ransac_sample(80, 60, 50, seed=12345)
+    assert uv.shape == (50, 6) and (uv[:, 0::2] < 80).all() and (uv[:, 1::2] < 60).all()
+    ok, plane, best, per = oracle.ransac_plane(valid, p3d, uv, 1.0)
+    assert ok and best == 80 * 60
+    np.testing.assert_allclose(plane, [0, 0, 1, -30.0], atol=1e-12)
+    plane2, n, mom = oracle.refine_plane(valid, p3d)
+    assert n == 80 * 60
+    np.testing.assert_allclose(plane2, [0, 0, 1, -30.0], atol=1e-9)
+
+
+def test_ransac_invalid_sample_consumes_round_and_failure_threshold(oracle):
+    valid, p3d = _plane_cloud()
+    valid[:] = 0; valid[:5, :5] = 1          # almost nothing valid: samples mostly invalid
+    uv = oracle.ransac_sample(80, 60, 40, seed=1)
+    ok, plane, best, per = oracle.ransac_plane(valid, p3d, uv, 1.0)
+    assert not ok and (per == -1).sum() > 30    # best < W*H/10 -> failure (PovMesh.cpp:773)
+
+
+def test_ransac_sampler_min_distance(oracle):
+    uv = oracle.ransac_sample(200, 300, 400, seed=7)
+    p = uv.reshape(-1, 3, 2).astype(float)
+    for a, b in ((0, 1), (1, 2), (0, 2)):
+        assert (np.linalg.norm(p[:, a] - p[:, b], axis=1) >= 3.0).all()
+
+
+def test_crop_plane(oracle):
+    valid, p3d = _plane_cloud(noise=1.0, seed=3)
+    v2, k = oracle.crop_plane(valid, p3d, [0, 0, 1, -30.0], 0.5)
+    expect = np.abs(p3d[..., 2] - 30.0) < 0.5
+    np.testing.assert_array_equal(v2.astype(bool), expect)
+    assert k == expect.sum()
+
+
+def test_zgap_percentile(oracle):
+    valid, p3d = _plane_cloud(noise=0.3, seed=5)
+    valid[10:20, 10:20] = 0
+    val, n = oracle.zgap_percentile(valid, p3d, 99.0)
+    z = p3d[..., 2]; gaps = []
+    h, w = valid.shape
+    for i in range(1, h):
+        for j in range(1, w - 1):
+            if valid[i, j]:
+                for dj in (-1, 0, 1):
+                    if valid[i - 1, j + dj]:
+                        gaps.append(abs(z[i, j] - z[i - 1, j + dj]))
+    gaps = np.sort(np.array(gaps))
+    assert n == len(gaps)
+    assert val == gaps[int(np.floor(0.99 * len(gaps)))]
+
+
+def test_biggest_component(oracle):
+    h, w = 30, 40
+    valid = np.zeros((h, w), np.uint8)
+    p3d = np.zeros((h, w, 3))
+    valid[2:10, 2:10] = 1                    # 64 px
+    valid[15:28, 5:30] = 1                   # 325 px but split by a z step into 13*12 and 13*13
+    p3d[15:28, 5:17, 2] = 10.0
+    p3d[15:28, 17:30, 2] = 20.0
+    v2, size = oracle.keep_biggest_component(valid, p3d, 1.0)
+    assert size == 13 * 13
+    exp = np.zeros_like(valid); exp[15:28, 17:30] = 1
+    np.testing.assert_array_equal(v2, exp)
+    # tie: the component whose column-major first pixel comes first wins
+    valid2 = np.zeros((h, w), np.uint8); valid2[20:25, 3:8] = 1; valid2[2:7, 10:15] = 1
+    v3, size3 = oracle.keep_biggest_component(valid2, np.zeros((h, w, 3)), 1.0)
+    assert size3 == 25 and v3[20:25, 3:8].all() and not v3[2:7, 10:15].any()
+
+
+def test_rt_from_plane_golden(oracle):
+    z = np.load(os.path.join(G, "rt_from_plane.npz"))
+    for pl, Rref, Tref in zip(z["planes"], z["R"], z["T"]):
+        R, T, Ri, Ti = oracle.RT_from_plane(pl)
+        np.testing.assert_array_equal(R, Rref)           # same formula, same op order
+        np.testing.assert_array_equal(T, Tref)
+        np.testing.assert_allclose(R @ Ri, np.eye(3), atol=1e-6)
+        np.testing.assert_allclose(R @ pl[:3], [0, 0, 1], atol=1e-6)
+        np.testing.assert_allclose(Ti, Ri @ (-T))
+
+
+def test_xyzc_golden_against_reference_reader(oracle):
+    """Bytes emitted today == committed bytes; points decoded by the reference's reader are within one
+    quantisation step of the input."""
+    for case in range(2):
+        z = np.load(os.path.join(G, f"xyzc_case{case}.npz"))
+        blob = oracle.encode_xyzc(z["valid"], z["p3d"], z["plane"])
+        assert blob == z["xyzc"].tobytes()
+        n = struct.unpack("<I", blob[:4])[0]
+        assert n == int(z["valid"].sum()) and len(blob) == 148 + 6 * n
+        pts = z["p3d"][z["valid"].astype(bool)]           # raster order
+        dec = z["ref_decoded"].T
+        scale = np.frombuffer(blob[4:28], np.float64)
+        step = np.linalg.norm(1.0 / scale)
+        assert np.abs(dec - pts).max() < step + 1e-3      # + float32 arithmetic of the reader
+
+
+def test_planes_nanmean_fixture():
+    z = np.load(os.path.join(G, "planes_txt.npz"))
+    arr = np.array([[float(x) for x in l.split()] for l in str(z["text"]).strip().split("\n")])
+    np.testing.assert_array_equal(np.nanmean(arr, axis=0), z["nanmean"])
+    assert int(z["n_valid"]) == 2
+
+
+def test_smallest_eigvec(oracle):
+    rng = np.random.default_rng(2)
+    for _ in range(10):
+        M = rng.normal(size=(3, 3)); A = M @ M.T
+        v = oracle.smallest_eigvec3(A)
+        wv, V = np.linalg.eigh(A)
+        assert abs(abs(v @ V[:, 0]) - 1) < 1e-9
+
+
+def test_synth_is_deterministic():
+    a = synth.make_pair(64, 48, 16, 3); b = synth.make_pair(64, 48, 16, 3); c = synth.make_pair(64, 48, 16, 4)
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[0] != c[0]).any()
+    assert a[0].min() >= 1 and a[0].max() <= 254
