@@ -46,6 +46,8 @@ const char* wass_last_error(const wass_ctx* ctx);
 /* raw hipStream_t of the context (for callers that enqueue their own work) */
 void* wass_ctx_stream(wass_ctx* ctx);
 int wass_ctx_synchronize(wass_ctx* ctx);
+/* test mode: keep intermediates (the finished S volume) that production never writes to HBM */
+int wass_ctx_set_debug(wass_ctx* ctx, int on);
 const char* wass_version(void);
 
 /* ------------------------------------------------------------------------
@@ -99,7 +101,8 @@ int wass_sgm_last_timings(wass_ctx* ctx, wass_sgm_timings* out);
 /* Test hooks: copy intermediates of the last wass_sgm_disparity call to host.
  * C/S are [h][width1][num_disp] int16 with width1 = w + max(disp_offset,0) -
  * min_disp (C without the +P2 bias); raw is the padded-width disparity before
- * the 3x3 median ([h][w + num_disp + max(disp_offset,0)]).  Any may be NULL. */
+ * the 3x3 median ([h][w + num_disp + max(disp_offset,0)]).  Any may be NULL.
+ * S_out requires wass_ctx_set_debug(ctx, 1) before the disparity call. */
 int wass_sgm_debug_fetch(wass_ctx* ctx, int16_t* C_out, int16_t* S_out, int16_t* raw_out);
 
 #ifdef __cplusplus

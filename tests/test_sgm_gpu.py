@@ -41,6 +41,11 @@ CASES = [
     (320, 64, 256, 8, 13, 1, 0),
     (300, 40, 160, 5, 13, 1, 0),      # NP = 2 with padded slots
     (340, 32, 272, 8, 13, 1, 0),      # NP = 3
+    (330, 40, 272, 5, 13, 1, 0),
+    (560, 24, 512, 8, 13, 1, 0),      # NP = 4
+    (700, 20, 640, 5, 13, 1, 0),      # NP = 5: the WASS default MAX_DISPARITY
+    (40, 300, 16, 8, 13, 1, 0),       # tall and narrow: long columns, short rows
+    (33, 29, 16, 8, 3, 1, 0),         # tiny
 ]
 
 
@@ -48,8 +53,14 @@ CASES = [
 def test_stage_parity(gpu_ctx, oracle, w, h, D, ndirs, win, mind, off):
     right, left = synth.make_pair(w, h, D, frame_idx=w + h + D)
     p = default_sgm_params(D, ndirs=ndirs, win=win, min_disp=mind, disp_offset=off)
-    got = gpu_ctx.sgm_disparity(right, left, p)
-    Cg, Sg, rawg = gpu_ctx.sgm_debug_fetch(w, h, p)
+    gpu_ctx.set_debug(True)
+    try:
+        got = gpu_ctx.sgm_disparity(right, left, p)
+        Cg, Sg, rawg = gpu_ctx.sgm_debug_fetch(w, h, p)
+    finally:
+        gpu_ctx.set_debug(False)
+    # production mode (S never written) must give the same map
+    np.testing.assert_array_equal(gpu_ctx.sgm_disparity(right, left, p), got)
 
     R, L = _pad(right, left, D, off)
     disp, st, Co, So, rawo = oracle.sgbm_compute(R, L, _oracle_params(oracle, p), dump=True)

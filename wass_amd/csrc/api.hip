@@ -108,7 +108,7 @@ void wass_ctx_destroy(wass_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (Buf* b : { &c->img1, &c->img2, &c->bt1, &c->bt2, &c->hsum, &c->C, &c->S, &c->sel_d16, &c->sel_key, &c->raw,
+    for (Buf* b : { &c->img1, &c->img2, &c->bt1, &c->bt2, &c->hsum, &c->C, &c->S, &c->ckpt, &c->sel_d16, &c->sel_key, &c->raw,
                     &c->flags, &c->tmp_in0, &c->tmp_in1, &c->tmp_out })
         release(*b);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -118,6 +118,13 @@ void wass_ctx_destroy(wass_ctx* c)
 
 const char* wass_last_error(const wass_ctx* c) { return c ? c->err.c_str() : "null context"; }
 void* wass_ctx_stream(wass_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int wass_ctx_set_debug(wass_ctx* c, int on)
+{
+    if (!c) return WASS_ERR_INVALID_ARG;
+    c->debug = on != 0;
+    return WASS_OK;
+}
 
 int wass_ctx_synchronize(wass_ctx* c)
 {
@@ -220,6 +227,8 @@ int wass_sgm_debug_fetch(wass_ctx* c, int16_t* C_out, int16_t* S_out, int16_t* r
 {
     if (!c) return WASS_ERR_INVALID_ARG;
     if (!c->have_last) return set_err(c, WASS_ERR_INVALID_ARG, "no completed wass_sgm_disparity call");
+    if (S_out && !c->debug)
+        return set_err(c, WASS_ERR_INVALID_ARG, "S is only kept when wass_ctx_set_debug(ctx, 1) was set before the call");
     const SgmDims& d = c->last;
     WASS_HIP(c, hipStreamSynchronize(c->stream));
     // volumes are [h][width1][Dp] on the device; the caller gets [h][width1][D]

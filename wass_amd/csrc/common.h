@@ -88,6 +88,7 @@ struct wass_ctx {
     wass::Buf img1, img2;          // padded u8 images (right / left)
     wass::Buf bt1, bt2;            // 8 B per pixel: {sobel v,lo,hi, raw v,lo,hi, 0,0}
     wass::Buf hsum, C, S;          // u16 volumes [h][width1][Dp]
+    wass::Buf ckpt;                // forward-path checkpoints of k_pair (1/K of a volume)
     wass::Buf sel_d16, sel_key;    // per (y,x): raw fixed-point disparity / (minS<<16|d)
     wass::Buf raw;                 // padded-width raw disparity [h][Wp] int16
     wass::Buf flags;               // u32[4]: [0] = cost overflow
@@ -95,6 +96,7 @@ struct wass_ctx {
     hipEvent_t ev[8] = {};
     wass::SgmDims last = {};
     bool have_last = false;
+    bool debug = false;            // keep the finished S volume for wass_sgm_debug_fetch
     wass_sgm_timings timings = {};
     bool timings_valid = false;
 };

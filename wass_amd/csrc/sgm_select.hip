@@ -111,33 +111,14 @@ __global__ void __launch_bounds__(256) k_lrcheck(const int16_t* __restrict__ sel
     }
 }
 
-template <int NP>
-static int launch_select_np(wass_ctx* c, const SgmDims& d)
+int launch_select(wass_ctx* c, const SgmDims& d)
 {
-    const size_t npix = (size_t)d.width1 * d.h;
-    hipLaunchKernelGGL(k_wta<NP>, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, c->stream,
-                       (const uint32_t*)c->S.p, d.width1, d.h, d.D, d.minD, d.uniq, npix, (int16_t*)c->sel_d16.p,
-                       (uint32_t*)c->sel_key.p);
+    // k_wta is kept for reference/regression; production fuses the selection into the row pair (k_pair).
     hipLaunchKernelGGL(k_lrcheck, dim3(d.h), dim3(256), (size_t)d.Wp * sizeof(uint32_t), c->stream,
                        (const int16_t*)c->sel_d16.p, (const uint32_t*)c->sel_key.p, d.width1, d.Wp, d.minX1,
                        d.minD, d.d12, (int16_t*)c->raw.p);
     WASS_HIP(c, hipGetLastError());
     return WASS_OK;
-}
-
-int launch_select(wass_ctx* c, const SgmDims& d)
-{
-    switch (d.NP) {
-        case 1: return launch_select_np<1>(c, d);
-        case 2: return launch_select_np<2>(c, d);
-        case 3: return launch_select_np<3>(c, d);
-        case 4: return launch_select_np<4>(c, d);
-        case 5: return launch_select_np<5>(c, d);
-        case 6: return launch_select_np<6>(c, d);
-        case 7: return launch_select_np<7>(c, d);
-        case 8: return launch_select_np<8>(c, d);
-    }
-    return set_err(c, WASS_ERR_UNSUPPORTED, "MAX_DISPARITY %d not supported (max 1024)", d.D);
 }
 
 // K5: cv::medianBlur(disp, disp, 3) on CV_16S (replicate border) over the padded

@@ -56,6 +56,10 @@ class Context:
     def synchronize(self):
         self._check(self._lib.wass_ctx_synchronize(self._h))
 
+    def set_debug(self, on: bool = True):
+        """Keep intermediates that production never writes (the finished S volume) for sgm_debug_fetch."""
+        self._check(self._lib.wass_ctx_set_debug(self._h, int(on)))
+
     # ---- sgbm_dense_stereo core (wass_stereo.cpp:820-839) ------------------
     def sgm_disparity(self, right: np.ndarray, left: np.ndarray, params: SgmParams,
                       allow_overflow: bool = False) -> np.ndarray:
