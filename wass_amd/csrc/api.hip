@@ -96,8 +96,12 @@ int wass_ctx_create(int device_id, wass_ctx** out)
     if (!c) return WASS_ERR_NO_MEMORY;
     c->device = device_id;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
     for (auto& e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
+    if (hipEventCreateWithFlags(&c->ev_cost, hipEventDisableTiming) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
+    for (auto& e : c->ev_ckpt)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
     if (ensure(c, c->flags, 64) != WASS_OK) { delete c; return WASS_ERR_NO_MEMORY; }
     *out = c;
     return WASS_OK;
@@ -112,6 +116,9 @@ void wass_ctx_destroy(wass_ctx* c)
                     &c->flags, &c->tmp_in0, &c->tmp_in1, &c->tmp_out })
         release(*b);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_ckpt) if (e) (void)hipEventDestroy(e);
+    if (c->ev_cost) (void)hipEventDestroy(c->ev_cost);
+    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -44,13 +44,32 @@ __device__ __forceinline__ uint32_t dpp_mov(uint32_t old, uint32_t src)
 // minimum of a u32 over the 64 lanes of the wave, returned uniformly (SGPR).
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 {
-    v = min(v, dpp_mov<DPP_QUAD_XOR1>(v, v));
-    v = min(v, dpp_mov<DPP_QUAD_XOR2>(v, v));
-    v = min(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v, v));
-    v = min(v, dpp_mov<DPP_ROW_MIRROR>(v, v));          // every row of 16 uniform
-    v = min(v, dpp_mov<DPP_ROW_BCAST15, 0xa>(v, v));    // rows 1,3 <- min(row, previous row)
-    v = min(v, dpp_mov<DPP_ROW_BCAST31, 0xc>(v, v));    // rows 2,3 <- min(row, lane 31)
+    v = min(v, dpp_mov<DPP_QUAD_XOR1>(0xFFFFFFFFu, v));
+    v = min(v, dpp_mov<DPP_QUAD_XOR2>(0xFFFFFFFFu, v));
+    v = min(v, dpp_mov<DPP_ROW_HALF_MIRROR>(0xFFFFFFFFu, v));
+    v = min(v, dpp_mov<DPP_ROW_MIRROR>(0xFFFFFFFFu, v));          // every row of 16 uniform
+    v = min(v, dpp_mov<DPP_ROW_BCAST15, 0xa>(0xFFFFFFFFu, v));    // rows 1,3 <- min(row, previous row)
+    v = min(v, dpp_mov<DPP_ROW_BCAST31, 0xc>(0xFFFFFFFFu, v));    // rows 2,3 <- min(row, lane 31)
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// two independent reductions in lock-step: each fills the other's DPP wait states
+__device__ __forceinline__ void wave_min2_u32(uint32_t& a, uint32_t& b)
+{
+    a = min(a, dpp_mov<DPP_QUAD_XOR1>(0xFFFFFFFFu, a));
+    b = min(b, dpp_mov<DPP_QUAD_XOR1>(0xFFFFFFFFu, b));
+    a = min(a, dpp_mov<DPP_QUAD_XOR2>(0xFFFFFFFFu, a));
+    b = min(b, dpp_mov<DPP_QUAD_XOR2>(0xFFFFFFFFu, b));
+    a = min(a, dpp_mov<DPP_ROW_HALF_MIRROR>(0xFFFFFFFFu, a));
+    b = min(b, dpp_mov<DPP_ROW_HALF_MIRROR>(0xFFFFFFFFu, b));
+    a = min(a, dpp_mov<DPP_ROW_MIRROR>(0xFFFFFFFFu, a));
+    b = min(b, dpp_mov<DPP_ROW_MIRROR>(0xFFFFFFFFu, b));
+    a = min(a, dpp_mov<DPP_ROW_BCAST15, 0xa>(0xFFFFFFFFu, a));
+    b = min(b, dpp_mov<DPP_ROW_BCAST15, 0xa>(0xFFFFFFFFu, b));
+    a = min(a, dpp_mov<DPP_ROW_BCAST31, 0xc>(0xFFFFFFFFu, a));
+    b = min(b, dpp_mov<DPP_ROW_BCAST31, 0xc>(0xFFFFFFFFu, b));
+    a = (uint32_t)__builtin_amdgcn_readlane((int)a, 63);
+    b = (uint32_t)__builtin_amdgcn_readlane((int)b, 63);
 }
 
 // ------------------------------------------------------------------ geometry
@@ -94,6 +113,8 @@ struct wass_ctx {
     wass::Buf flags;               // u32[4]: [0] = cost overflow
     wass::Buf tmp_in0, tmp_in1, tmp_out;   // staging for the host-pointer entry points
     hipEvent_t ev[8] = {};
+    hipStream_t side = nullptr;    // checkpoint sweeps run ahead here
+    hipEvent_t ev_cost = nullptr, ev_ckpt[4] = {};
     wass::SgmDims last = {};
     bool have_last = false;
     bool debug = false;            // keep the finished S volume for wass_sgm_debug_fetch

@@ -22,29 +22,110 @@
 
 namespace wass {
 
+// State carried along one chain: the (un-normalised) path costs of the previous
+// pixel and their minimum over d.  Keeping the minimum as a separate wave-uniform
+// scalar takes its cross-lane reduction off the critical path of the next step:
+//   L'(d) = C(d) + min(L(d), min(L(d-1), L(d+1)) + P1, m + P2) - m,   m' = min_d L'
+// (same value as the normalised form in the header comment; only L - m matters).
 template <int NP>
-__device__ __forceinline__ void sgm_step(us2 (&N)[NP], const us2 (&c)[NP], us2 (&L)[NP], const us2 P1v,
-                                         const us2 P2v)
+struct PathState {
+    us2 L[NP];
+    uint32_t m;
+    // destinations of the two wave-shift DPP moves.  Lane 0 (resp. 63) has no source lane and keeps
+    // its value, so initialising them once with 0xFFFFFFFF provides the d=-1 / d=Dp sentinels
+    // without re-materialising the constant every step.
+    uint32_t shr = 0xFFFFFFFFu, shl = 0xFFFFFFFFu;
+    __device__ __forceinline__ void reset()
+    {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) L[j] = pk_splat(0);
+        m = 0;
+    }
+    // checkpoint form: costs relative to their minimum
+    __device__ __forceinline__ void store_normalised(uint32_t* __restrict__ p) const
+    {
+        const us2 mv = pk_splat(m);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) p[j] = as_u32(L[j] - mv);
+    }
+    __device__ __forceinline__ void load_normalised(const us2 (&v)[NP])
+    {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) L[j] = v[j];
+        m = 0;
+    }
+};
+
+template <int NP>
+__device__ __forceinline__ void sgm_step(PathState<NP>& st, const us2 (&c)[NP], us2 (&Lo)[NP], const us2 P1v,
+                                         const uint32_t P2)
 {
     // pair holding d-1 of this lane's first value / d+1 of its last value (0xFFFF outside [0,Dp))
-    const uint32_t prev_last = dpp_mov<DPP_WAVE_SHR1>(0xFFFFFFFFu, as_u32(N[NP - 1]));
-    const uint32_t next_first = dpp_mov<DPP_WAVE_SHL1>(0xFFFFFFFFu, as_u32(N[0]));
+    st.shr = dpp_mov<DPP_WAVE_SHR1>(st.shr, as_u32(st.L[NP - 1]));
+    st.shl = dpp_mov<DPP_WAVE_SHL1>(st.shl, as_u32(st.L[0]));
+    const uint32_t prev_last = st.shr, next_first = st.shl;
+    const us2 mv = pk_splat(st.m), mp2 = pk_splat(st.m + P2);
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-        const uint32_t lo = j == 0 ? prev_last : as_u32(N[j - 1]);
-        const uint32_t hi = j == NP - 1 ? next_first : as_u32(N[j + 1]);
-        const us2 nl = as_us2(__builtin_amdgcn_alignbit(as_u32(N[j]), lo, 16));   // (d-1, d)
-        const us2 nr = as_us2(__builtin_amdgcn_alignbit(hi, as_u32(N[j]), 16));   // (d+1, d+2)
-        const us2 t = pk_min(pk_min(N[j], pk_adds(pk_min(nl, nr), P1v)), P2v);
-        L[j] = pk_adds(c[j], t);
+        const uint32_t lo = j == 0 ? prev_last : as_u32(st.L[j - 1]);
+        const uint32_t hi = j == NP - 1 ? next_first : as_u32(st.L[j + 1]);
+        const us2 nl = as_us2(__builtin_amdgcn_alignbit(as_u32(st.L[j]), lo, 16));   // (d-1, d)
+        const us2 nr = as_us2(__builtin_amdgcn_alignbit(hi, as_u32(st.L[j]), 16));   // (d+1, d+2)
+        const us2 x = pk_min(st.L[j], pk_adds(pk_min(nl, nr), P1v));
+        Lo[j] = pk_adds(c[j], pk_min(x, mp2) - mv);
     }
-    us2 m = L[0];
+    us2 m = Lo[0];
 #pragma unroll
-    for (int j = 1; j < NP; ++j) m = pk_min(m, L[j]);
-    const uint32_t mn = wave_min_u32(min((uint32_t)m.x, (uint32_t)m.y));
-    const us2 mv = pk_splat(mn);
+    for (int j = 1; j < NP; ++j) m = pk_min(m, Lo[j]);
+    st.m = wave_min_u32(min((uint32_t)m.x, (uint32_t)m.y));
 #pragma unroll
-    for (int j = 0; j < NP; ++j) N[j] = L[j] - mv;
+    for (int j = 0; j < NP; ++j) st.L[j] = Lo[j];
+}
+
+// Two independent chains advanced together, statement by statement, so that each one's dependent
+// packed-math / DPP wait states are filled by the other's instructions.
+template <int NP>
+__device__ __forceinline__ void sgm_step_pair(PathState<NP>& a, const us2 (&ca)[NP], us2 (&La)[NP],
+                                              PathState<NP>& b, const us2 (&cb)[NP], us2 (&Lb)[NP],
+                                              const us2 P1v, const uint32_t P2)
+{
+    a.shr = dpp_mov<DPP_WAVE_SHR1>(a.shr, as_u32(a.L[NP - 1]));
+    b.shr = dpp_mov<DPP_WAVE_SHR1>(b.shr, as_u32(b.L[NP - 1]));
+    a.shl = dpp_mov<DPP_WAVE_SHL1>(a.shl, as_u32(a.L[0]));
+    b.shl = dpp_mov<DPP_WAVE_SHL1>(b.shl, as_u32(b.L[0]));
+    const us2 amv = pk_splat(a.m), amp2 = pk_splat(a.m + P2);
+    const us2 bmv = pk_splat(b.m), bmp2 = pk_splat(b.m + P2);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const uint32_t alo = j == 0 ? a.shr : as_u32(a.L[j - 1]);
+        const uint32_t blo = j == 0 ? b.shr : as_u32(b.L[j - 1]);
+        const uint32_t ahi = j == NP - 1 ? a.shl : as_u32(a.L[j + 1]);
+        const uint32_t bhi = j == NP - 1 ? b.shl : as_u32(b.L[j + 1]);
+        const us2 anl = as_us2(__builtin_amdgcn_alignbit(as_u32(a.L[j]), alo, 16));
+        const us2 bnl = as_us2(__builtin_amdgcn_alignbit(as_u32(b.L[j]), blo, 16));
+        const us2 anr = as_us2(__builtin_amdgcn_alignbit(ahi, as_u32(a.L[j]), 16));
+        const us2 bnr = as_us2(__builtin_amdgcn_alignbit(bhi, as_u32(b.L[j]), 16));
+        us2 ax = pk_min(anl, anr);
+        us2 bx = pk_min(bnl, bnr);
+        ax = pk_adds(ax, P1v);
+        bx = pk_adds(bx, P1v);
+        ax = pk_min(a.L[j], ax);
+        bx = pk_min(b.L[j], bx);
+        ax = pk_min(ax, amp2);
+        bx = pk_min(bx, bmp2);
+        ax = ax - amv;
+        bx = bx - bmv;
+        La[j] = pk_adds(ca[j], ax);
+        Lb[j] = pk_adds(cb[j], bx);
+    }
+    us2 am = La[0], bm = Lb[0];
+#pragma unroll
+    for (int j = 1; j < NP; ++j) { am = pk_min(am, La[j]); bm = pk_min(bm, Lb[j]); }
+    uint32_t ra = min((uint32_t)am.x, (uint32_t)am.y), rb = min((uint32_t)bm.x, (uint32_t)bm.y);
+    wave_min2_u32(ra, rb);
+    a.m = ra; b.m = rb;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) { a.L[j] = La[j]; b.L[j] = Lb[j]; }
 }
 
 // chain c of direction (dx,dy): start cell and length
@@ -61,7 +142,29 @@ __device__ __forceinline__ void chain_geometry(int c, int dx, int dy, int width1
     }
 }
 
+// K consecutive vectors of a chain -> registers; GUARD: only the first len exist
+template <int NP, int K, bool GUARD>
+__device__ __forceinline__ void load_seg(const uint32_t* __restrict__ p, long long step, int len, us2 (&dst)[K][NP])
+{
+#pragma unroll
+    for (int u = 0; u < K; ++u)
+        if (!GUARD || u < len) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) dst[u][j] = as_us2(p[u * step + j]);
+        }
+}
+
+template <int NP, int K>
+__device__ __forceinline__ void copy_seg(us2 (&dst)[K][NP], const us2 (&src)[K][NP])
+{
+#pragma unroll
+    for (int u = 0; u < K; ++u)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) dst[u][j] = src[u][j];
+}
+
 // One path, every chain: S (+)= L_r.  FIRST: S is written, not accumulated.
+// Loads of the next U steps are in flight while the current U steps compute.
 template <int NP, bool FIRST, int U>
 __global__ void __launch_bounds__(256) k_sweep(const uint32_t* __restrict__ C, uint32_t* __restrict__ S,
                                                int width1, int h, int dx, int dy, int P1, int P2, int nchains)
@@ -75,39 +178,52 @@ __global__ void __launch_bounds__(256) k_sweep(const uint32_t* __restrict__ C, u
     const long long step = ((long long)dy * width1 + dx) * vec;
     const uint32_t* cp = C + ((long long)y0 * width1 + x0) * vec + lane * NP;
     uint32_t* sp = S + ((long long)y0 * width1 + x0) * vec + lane * NP;
-    const us2 P1v = pk_splat(P1), P2v = pk_splat(P2), cap = pk_splat(0x7FFF);
+    const us2 P1v = pk_splat(P1), cap = pk_splat(0x7FFF);
 
-    us2 N[NP];
+    PathState<NP> st;
+    st.reset();
+    const int F = n / U, r = n - F * U;
+    us2 cb[U][NP], sb[U][NP], cn[U][NP], sn[U][NP];
+    if (F > 0) {
+        load_seg<NP, U, false>(cp, step, U, cb);
+        if (!FIRST) load_seg<NP, U, false>(sp, step, U, sb);
+    }
+    for (int g = 0; g < F; ++g) {
+        if (g + 1 < F) {
+            load_seg<NP, U, false>(cp + U * step, step, U, cn);
+            if (!FIRST) load_seg<NP, U, false>(sp + U * step, step, U, sn);
+        }
 #pragma unroll
-    for (int j = 0; j < NP; ++j) N[j] = pk_splat(0);
-
-    for (int k0 = 0; k0 < n; k0 += U) {
-        us2 cb[U][NP], sb[U][NP];
+        for (int u = 0; u < U; ++u) {
+            us2 L[NP];
+            sgm_step<NP>(st, cb[u], L, P1v, P2);
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (k0 + u < n) {
-#pragma unroll
-                for (int j = 0; j < NP; ++j) {
-                    cb[u][j] = as_us2(cp[u * step + j]);
-                    if (!FIRST) sb[u][j] = as_us2(sp[u * step + j]);
-                }
+            for (int j = 0; j < NP; ++j) {
+                const us2 sv = FIRST ? pk_min(L[j], cap) : pk_min(pk_adds(sb[u][j], L[j]), cap);
+                sp[u * step + j] = as_u32(sv);
             }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (k0 + u < n) {
-                us2 L[NP];
-                sgm_step<NP>(N, cb[u], L, P1v, P2v);
-#pragma unroll
-                for (int j = 0; j < NP; ++j) {
-                    const us2 s = FIRST ? pk_min(L[j], cap) : pk_min(pk_adds(sb[u][j], L[j]), cap);
-                    sp[u * step + j] = as_u32(s);
-                }
-            }
+        }
+        copy_seg<NP, U>(cb, cn);
+        if (!FIRST) copy_seg<NP, U>(sb, sn);
         cp += U * step;
         sp += U * step;
     }
+    if (r > 0) {
+        load_seg<NP, U, true>(cp, step, r, cb);
+        if (!FIRST) load_seg<NP, U, true>(sp, step, r, sb);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (u < r) {
+                us2 L[NP];
+                sgm_step<NP>(st, cb[u], L, P1v, P2);
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const us2 sv = FIRST ? pk_min(L[j], cap) : pk_min(pk_adds(sb[u][j], L[j]), cap);
+                    sp[u * step + j] = as_u32(sv);
+                }
+            }
+    }
 }
-
 
 // ---------------------------------------------------------------------------
 // Winner-take-all on a finished S vector held in registers (Appendix A.5 steps
@@ -177,6 +293,47 @@ __device__ __forceinline__ void wta_select(const us2 (&Sv)[NP], int lane, int D,
 // read, finished in registers and handed to wta_select; it is stored only if
 // keepS (debug fetch).
 // ---------------------------------------------------------------------------
+// Phase 1 of a chain-family pair: the forward path over every chain, keeping only the (normalised)
+// state at the end of each K-step segment -- 1/K of a volume.  Reads C once, touches nothing else, so
+// the checkpoint sweeps of all families can run concurrently with any other kernel.
+template <int NP, int K>
+__global__ void __launch_bounds__(256) k_ckpt(const uint32_t* __restrict__ C, uint32_t* __restrict__ ckpt,
+                                              int width1, int h, int dx, int dy, int P1, int P2, int nchains,
+                                              int maxseg)
+{
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
+    if (c >= nchains) return;
+    int x0, y0, n;
+    chain_geometry(c, dx, dy, width1, h, x0, y0, n);
+    const long long vec = 64 * NP;
+    const long long step = ((long long)dy * width1 + dx) * vec;
+    const uint32_t* cp0 = C + ((long long)y0 * width1 + x0) * vec + lane * NP;
+    uint32_t* ck = ckpt + ((long long)c * maxseg) * vec + lane * NP;
+    const us2 P1v = pk_splat(P1);
+    const int F = n / K, r = n - F * K;            // F full segments, then a tail of r steps
+    const int ncp = F - (r > 0 ? 0 : 1);           // checkpoints needed: end of segments 0 .. ncp-1
+    {
+        PathState<NP> st;
+        st.reset();
+        us2 cb[K][NP], cn[K][NP];
+        const uint32_t* cp = cp0;
+        if (ncp > 0) load_seg<NP, K, false>(cp, step, K, cb);
+        for (int s = 0; s < ncp; ++s) {
+            if (s + 1 < ncp) load_seg<NP, K, false>(cp + K * step, step, K, cn);
+#pragma unroll
+            for (int u = 0; u < K; ++u) {
+                us2 L[NP];
+                sgm_step<NP>(st, cb[u], L, P1v, P2);
+            }
+            st.store_normalised(ck + (long long)s * vec);
+            copy_seg<NP, K>(cb, cn);
+            cp += K * step;
+        }
+    }
+
+}
+
 template <int NP, int K, int SMODE>
 __global__ void __launch_bounds__(256) k_pair(const uint32_t* __restrict__ C, uint32_t* __restrict__ S,
                                               uint32_t* __restrict__ ckpt, int width1, int h, int dx, int dy,
@@ -197,75 +354,110 @@ __global__ void __launch_bounds__(256) k_pair(const uint32_t* __restrict__ C, ui
     const uint32_t* cp0 = C + base;
     uint32_t* sp0 = S + base;
     uint32_t* ck = ckpt + ((long long)c * maxseg) * vec + lane * NP;
-    const us2 P1v = pk_splat(P1), P2v = pk_splat(P2), cap = pk_splat(0x7FFF);
-    const int nseg = (n + K - 1) / K;
+    const us2 P1v = pk_splat(P1), cap = pk_splat(0x7FFF);
+    const int F = n / K, r = n - F * K;            // F full segments, then a tail of r steps
 
-    // ---- phase 1: checkpoints of the forward path (the last segment is never needed)
-    {
-        us2 N[NP];
+    // one finished backward step: S handling + optional winner-take-all
+    auto finish = [&](const us2 (&lf)[NP], const us2 (&lb)[NP], const us2 (&sin)[NP], uint32_t* sp, long long pix) {
+        us2 sv[NP];
 #pragma unroll
-        for (int j = 0; j < NP; ++j) N[j] = pk_splat(0);
-        const uint32_t* cp = cp0;
-        for (int s = 0; s < nseg - 1; ++s) {
-            us2 cb[K][NP];
-#pragma unroll
-            for (int u = 0; u < K; ++u)
-#pragma unroll
-                for (int j = 0; j < NP; ++j) cb[u][j] = as_us2(cp[u * step + j]);
-#pragma unroll
-            for (int u = 0; u < K; ++u) {
-                us2 L[NP];
-                sgm_step<NP>(N, cb[u], L, P1v, P2v);
-            }
-#pragma unroll
-            for (int j = 0; j < NP; ++j) ck[(long long)s * vec + j] = as_u32(N[j]);
-            cp += K * step;
+        for (int j = 0; j < NP; ++j) {
+            const us2 both = pk_adds(lf[j], lb[j]);
+            sv[j] = SMODE == 0 ? pk_min(both, cap) : pk_min(pk_adds(sin[j], both), cap);
         }
-    }
-    // ---- phase 2: backward over the segments
-    us2 Nb[NP];
+        if (SMODE != 2 || keepS) {
 #pragma unroll
-    for (int j = 0; j < NP; ++j) Nb[j] = pk_splat(0);
-    for (int s = nseg - 1; s >= 0; --s) {
-        const int k0 = s * K;
-        const int len = min(K, n - k0);
-        const uint32_t* cp = cp0 + (long long)k0 * step;
-        uint32_t* sp = sp0 + (long long)k0 * step;
+            for (int j = 0; j < NP; ++j) sp[j] = as_u32(sv[j]);
+        }
+        if (SMODE == 2) wta_select<NP>(sv, lane, D, minD, uniq, sel_d16 + pix, sel_key + pix);
+    };
+
+    // ---- phase 2: the chain in reverse ------------------------------------------------------------
+    PathState<NP> bw;
+    bw.reset();
+    if (r > 0) {                                   // tail segment F (guarded, not pipelined)
+        const uint32_t* cp = cp0 + (long long)F * K * step;
+        uint32_t* sp = sp0 + (long long)F * K * step;
         us2 cb[K][NP], lf[K][NP], sb[K][NP];
+        load_seg<NP, K, true>(cp, step, r, cb);
+        if (SMODE != 0) load_seg<NP, K, true>(sp, step, r, sb);
+        PathState<NP> fw;
+        fw.reset();
+        if (F > 0) {
+            us2 nv[NP];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) nv[j] = as_us2(ck[(long long)(F - 1) * vec + j]);
+            fw.load_normalised(nv);
+        }
 #pragma unroll
         for (int u = 0; u < K; ++u)
-            if (u < len) {
-#pragma unroll
-                for (int j = 0; j < NP; ++j) {
-                    cb[u][j] = as_us2(cp[u * step + j]);
-                    if (SMODE != 0) sb[u][j] = as_us2(sp[u * step + j]);
-                }
-            }
-        us2 Nf[NP];
-#pragma unroll
-        for (int j = 0; j < NP; ++j) Nf[j] = s == 0 ? pk_splat(0) : as_us2(ck[(long long)(s - 1) * vec + j]);
-#pragma unroll
-        for (int u = 0; u < K; ++u)
-            if (u < len) sgm_step<NP>(Nf, cb[u], lf[u], P1v, P2v);
+            if (u < r) sgm_step<NP>(fw, cb[u], lf[u], P1v, P2);
 #pragma unroll
         for (int u = K - 1; u >= 0; --u)
-            if (u < len) {
-                us2 L[NP], sv[NP];
-                sgm_step<NP>(Nb, cb[u], L, P1v, P2v);
-#pragma unroll
-                for (int j = 0; j < NP; ++j) {
-                    const us2 both = pk_adds(lf[u][j], L[j]);
-                    sv[j] = SMODE == 0 ? pk_min(both, cap) : pk_min(pk_adds(sb[u][j], both), cap);
-                }
-                if (SMODE != 2 || keepS) {
-#pragma unroll
-                    for (int j = 0; j < NP; ++j) sp[u * step + j] = as_u32(sv[j]);
-                }
-                if (SMODE == 2) {
-                    const long long pix = pix0 + (long long)(k0 + u) * pixstep;
-                    wta_select<NP>(sv, lane, D, minD, uniq, sel_d16 + pix, sel_key + pix);
-                }
+            if (u < r) {
+                us2 L[NP];
+                sgm_step<NP>(bw, cb[u], L, P1v, P2);
+                finish(lf[u], L, sb[u], sp + u * step, pix0 + (long long)(F * K + u) * pixstep);
             }
+    }
+    if (F == 0) return;
+
+    // software pipeline over the full segments s = F-1 .. 0:
+    //   iteration s:  backward(s)  ||  forward recompute(s-1)  ||  loads of C(s-2), S(s-1), ckpt(s-3) in flight
+    us2 cA[K][NP], cB[K][NP], cC[K][NP];           // cost vectors of segments s, s-1, s-2
+    us2 lA[K][NP], lB[K][NP];                      // forward path costs of segments s, s-1
+    us2 sA[K][NP], sB[K][NP];                      // S of segments s, s-1
+    us2 nvB[NP], nvC[NP];                          // checkpoints entering segments s-1, s-2
+    {
+        const int s = F - 1;
+        load_seg<NP, K, false>(cp0 + (long long)s * K * step, step, K, cA);
+        if (SMODE != 0) load_seg<NP, K, false>(sp0 + (long long)s * K * step, step, K, sA);
+        if (s >= 1) load_seg<NP, K, false>(cp0 + (long long)(s - 1) * K * step, step, K, cB);
+        PathState<NP> fw;
+        fw.reset();
+        if (s >= 1) {
+            us2 nv[NP];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) nv[j] = as_us2(ck[(long long)(s - 1) * vec + j]);
+            fw.load_normalised(nv);
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) nvB[j] = s >= 2 ? as_us2(ck[(long long)(s - 2) * vec + j]) : pk_splat(0);
+#pragma unroll
+        for (int u = 0; u < K; ++u) sgm_step<NP>(fw, cA[u], lA[u], P1v, P2);
+    }
+    for (int s = F - 1; s >= 1; --s) {
+        // prefetch for the next iterations
+        if (s >= 2) load_seg<NP, K, false>(cp0 + (long long)(s - 2) * K * step, step, K, cC);
+        if (SMODE != 0) load_seg<NP, K, false>(sp0 + (long long)(s - 1) * K * step, step, K, sB);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) nvC[j] = s >= 3 ? as_us2(ck[(long long)(s - 3) * vec + j]) : pk_splat(0);
+        PathState<NP> fw;
+        fw.load_normalised(nvB);                   // zeros when s-1 == 0
+        uint32_t* sp = sp0 + (long long)s * K * step;
+        const long long pixs = pix0 + (long long)s * K * pixstep;
+        // two independent dependency chains in one block: the scheduler interleaves them
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            const int v = K - 1 - u;
+            us2 L[NP];
+            sgm_step_pair<NP>(fw, cB[u], lB[u], bw, cA[v], L, P1v, P2);
+            finish(lA[v], L, sA[v], sp + v * step, pixs + v * pixstep);
+        }
+        copy_seg<NP, K>(cA, cB);
+        copy_seg<NP, K>(cB, cC);
+        copy_seg<NP, K>(lA, lB);
+        if (SMODE != 0) copy_seg<NP, K>(sA, sB);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) nvB[j] = nvC[j];
+    }
+    {                                              // epilogue: backward over segment 0
+#pragma unroll
+        for (int v = K - 1; v >= 0; --v) {
+            us2 L[NP];
+            sgm_step<NP>(bw, cA[v], L, P1v, P2);
+            finish(lA[v], L, sA[v], sp0 + v * step, pix0 + v * pixstep);
+        }
     }
 }
 
@@ -276,7 +468,7 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
     // MODE_HH adds 5:(-1,+1) 6:(0,+1) 7:(+1,+1).  (dx,dy) below is the direction of travel = -r.
     // Opposite paths share their chains: rows {0,4}, columns {2,6}, diagonals {1,7}, anti-diagonals {3,5}.
     constexpr int U = NP <= 2 ? 8 : (NP <= 4 ? 4 : 2);
-    constexpr int K = NP <= 2 ? 16 : (NP == 3 ? 10 : (NP == 4 ? 8 : (NP == 5 ? 6 : (NP == 6 ? 5 : 4))));
+    constexpr int K = NP <= 2 ? 8 : (NP <= 4 ? 4 : 2);
     const uint32_t* C = (const uint32_t*)c->C.p;
     uint32_t* S = (uint32_t*)c->S.p;
     int16_t* sd = (int16_t*)c->sel_d16.p;
@@ -285,25 +477,36 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
     auto nchains = [&](int dx, int dy) { return dy == 0 ? d.h : (dx == 0 ? d.width1 : d.width1 + d.h - 1); };
     auto maxlen = [&](int dx, int dy) { return dy == 0 ? d.width1 : (dx == 0 ? d.h : (d.width1 < d.h ? d.width1 : d.h)); };
     auto ckpt_bytes = [&](int dx, int dy) {
-        return (size_t)nchains(dx, dy) * ((maxlen(dx, dy) + K - 1) / K) * (64 * NP) * sizeof(uint32_t);
+        const size_t b = (size_t)nchains(dx, dy) * ((maxlen(dx, dy) + K - 1) / K) * (64 * NP) * sizeof(uint32_t);
+        return (b + 255) & ~(size_t)255;
     };
-    size_t need = ckpt_bytes(1, 0);
+    // families in launch order; every family has its own checkpoint region so that all checkpoint
+    // sweeps (which only read C) can run ahead on the side stream while the main stream accumulates S
+    struct Fam { int dx, dy, smode; };
+    Fam fam[4];
+    int nf = 0;
     if (d.ndirs == 8) {
-        need = need > ckpt_bytes(0, 1) ? need : ckpt_bytes(0, 1);
-        need = need > ckpt_bytes(1, 1) ? need : ckpt_bytes(1, 1);
+        fam[nf++] = { 0, 1, 0 };     // columns:        paths 2 + 6
+        fam[nf++] = { 1, 1, 1 };     // diagonals:      paths 1 + 7
+        fam[nf++] = { -1, 1, 1 };    // anti-diagonals: paths 3 + 5
     }
-    int rc = ensure(c, c->ckpt, need);
+    fam[nf++] = { 1, 0, 2 };         // rows: paths 0 + 4, winner-take-all fused
+    size_t off[5] = { 0 };
+    for (int f = 0; f < nf; ++f) off[f + 1] = off[f] + ckpt_bytes(fam[f].dx, fam[f].dy);
+    int rc = ensure(c, c->ckpt, off[nf]);
     if (rc) return rc;
-    uint32_t* ck = (uint32_t*)c->ckpt.p;
 
-#define WASS_PAIR(SMODE, dx, dy)                                                                             \
-    do {                                                                                                     \
-        const int nch = nchains(dx, dy), mseg = (maxlen(dx, dy) + K - 1) / K;                                \
-        hipLaunchKernelGGL((k_pair<NP, K, SMODE>), dim3((nch + 3) / 4), dim3(256), 0, c->stream, C, S, ck,   \
-                           d.width1, d.h, dx, dy, d.P1, d.P2, nch, mseg, d.D, d.minD, d.uniq,                \
-                           c->debug ? 1 : 0, sd, sk);                                                        \
-        ++nl;                                                                                                \
-    } while (0)
+    WASS_HIP(c, hipEventRecord(c->ev_cost, c->stream));
+    WASS_HIP(c, hipStreamWaitEvent(c->side, c->ev_cost, 0));
+    for (int f = 0; f < nf; ++f) {
+        const int dx = fam[f].dx, dy = fam[f].dy;
+        const int nch = nchains(dx, dy), mseg = (maxlen(dx, dy) + K - 1) / K;
+        hipLaunchKernelGGL((k_ckpt<NP, K>), dim3((nch + 3) / 4), dim3(256), 0, c->side, C,
+                           (uint32_t*)((char*)c->ckpt.p + off[f]), d.width1, d.h, dx, dy, d.P1, d.P2, nch, mseg);
+        WASS_HIP(c, hipEventRecord(c->ev_ckpt[f], c->side));
+        ++nl;
+    }
+
 #define WASS_SWEEP(FIRST, dx, dy)                                                                            \
     do {                                                                                                     \
         const int nch = nchains(dx, dy);                                                                     \
@@ -311,20 +514,28 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
                            d.width1, d.h, dx, dy, d.P1, d.P2, nch);                                          \
         ++nl;                                                                                                \
     } while (0)
-
-    if (d.ndirs == 8) {
-        WASS_PAIR(0, 0, 1);      // columns:        paths 2 + 6
-        WASS_PAIR(1, 1, 1);      // diagonals:      paths 1 + 7
-        WASS_PAIR(1, -1, 1);     // anti-diagonals: paths 3 + 5
-        WASS_PAIR(2, 1, 0);      // rows:           paths 0 + 4, winner-take-all fused
-    } else {
-        WASS_SWEEP(true, 0, 1);  // path 2
-        WASS_SWEEP(false, 1, 1); // path 1
-        WASS_SWEEP(false, -1, 1);// path 3
-        WASS_PAIR(2, 1, 0);      // rows: paths 0 + 4, winner-take-all fused
+    if (d.ndirs == 5) {
+        WASS_SWEEP(true, 0, 1);   // path 2
+        WASS_SWEEP(false, 1, 1);  // path 1
+        WASS_SWEEP(false, -1, 1); // path 3
     }
-#undef WASS_PAIR
 #undef WASS_SWEEP
+
+    for (int f = 0; f < nf; ++f) {
+        const int dx = fam[f].dx, dy = fam[f].dy;
+        const int nch = nchains(dx, dy), mseg = (maxlen(dx, dy) + K - 1) / K;
+        uint32_t* ck = (uint32_t*)((char*)c->ckpt.p + off[f]);
+        WASS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_ckpt[f], 0));
+        const dim3 grid((nch + 3) / 4), block(256);
+#define WASS_PAIR(SMODE)                                                                                     \
+        hipLaunchKernelGGL((k_pair<NP, K, SMODE>), grid, block, 0, c->stream, C, S, ck, d.width1, d.h, dx, dy, \
+                           d.P1, d.P2, nch, mseg, d.D, d.minD, d.uniq, c->debug ? 1 : 0, sd, sk)
+        if (fam[f].smode == 0) WASS_PAIR(0);
+        else if (fam[f].smode == 1) WASS_PAIR(1);
+        else WASS_PAIR(2);
+#undef WASS_PAIR
+        ++nl;
+    }
     if (n_launches) *n_launches = nl;
     WASS_HIP(c, hipGetLastError());
     return WASS_OK;
