@@ -105,6 +105,117 @@ int wass_sgm_last_timings(wass_ctx* ctx, wass_sgm_timings* out);
  * S_out requires wass_ctx_set_debug(ctx, 1) before the disparity call. */
 int wass_sgm_debug_fetch(wass_ctx* ctx, int16_t* C_out, int16_t* S_out, int16_t* raw_out);
 
+
+/* ------------------------------------------------------------------------
+ * Disparity clean-up, rows a7-a9.  Replaces wass_stereo.cpp:853-945 at
+ * DENSE_SCALE == 1: clean_and_convert_disparity (:714-733), DISP_DILATE_STEPS
+ * x matrix_dilate_zero (:617-662, including its column-shift quirk),
+ * DISP_EROSION_STEPS x matrix_erode_zero (:665-711), the same-size
+ * NN/cubic resize + extra erosion mask (:903-928) and the optional
+ * cv::medianBlur (:941-945; MEDIAN_FILTER_WSIZE 0, 3 or 5).
+ * disp16: w x h int16 as produced by wass_sgm_disparity; out: w x h float32.
+ * ------------------------------------------------------------------------ */
+int wass_disparity_postprocess(wass_ctx* ctx, const int16_t* disp16, int w, int h,
+                               const wass_sgm_params* p, int dilate_steps, int erode_steps,
+                               int median_wsize, float* disp_f32_out);
+int wass_disparity_postprocess_dev(wass_ctx* ctx, const int16_t* d_disp16, int w, int h,
+                                   const wass_sgm_params* p, int dilate_steps, int erode_steps,
+                                   int median_wsize, float* d_disp_f32_out);
+
+/* ------------------------------------------------------------------------
+ * Triangulation, rows a10-a13.  Replaces triangulate(StereoMatchEnv&)
+ * (wass_stereo.cpp:1039-1386), StereoMatchEnv::unrectify (:299-324) and
+ * triangulate(p,q,R,T) (wass_lib/triangulate.hpp:26-72).  All matrices are
+ * row-major doubles.
+ * ------------------------------------------------------------------------ */
+typedef struct {
+    double K_left[9], K_right[9];   /* env.intrinsics_left / _right                 */
+    double R[9], T[3];              /* env.R, env.T (|T| = 1, :360-370)             */
+    int    use_custom;              /* USE_CUSTOM_STEREORECTIFY                     */
+    double R1[9], R2[9];            /* env.rec_R1 / rec_R2        (OpenCV path)     */
+    double P1[12], P2[12];          /* env.rec_P1 / rec_P2 (3x4)  (OpenCV path)     */
+    double HLi[9], HRi[9];          /* env.HLi / HRi              (custom path)     */
+    double disparity_compensation;  /* env.disparity_compensation (:804-812)        */
+    double dense_scale;             /* DENSE_SCALE                                  */
+} wass_geom;
+
+typedef struct {
+    double min_angle_deg;           /* TRIANG_MIN_ANGLE                             */
+    double bbox[4];                 /* left, top, right, bottom in the left image;
+                                       defaults (0,0,cols,rows) (:1046-1054)        */
+    double cam_distance;            /* env.cam_distance (= 1)                       */
+} wass_tri_params;
+
+/* organised point cloud on the device: PovMesh (wass_stereo/PovMesh.h:28-88) as
+ * structure-of-arrays (valid u8, x/y/z f64, gray u8), index v*width+u */
+typedef struct wass_mesh wass_mesh;
+
+/* disp_roi: roi_r[2] x roi_r[3] float32, the part of env.disparity inside
+ * roi_comb_right (the reference map is zero elsewhere).  W,H: size of the
+ * rectified frames.  roi_* = {x, y, width, height}.  right_img: the undistorted
+ * RIGHT image (env.right, img_w x img_h) sampled for the point grey value
+ * (:1342).  left_mask/right_mask: 0/1 images of the originals' size or NULL
+ * (= all ones) (:1057-1093).  Host pointers; *_dev takes device pointers. */
+int wass_triangulate(wass_ctx* ctx, const float* disp_roi, int W, int H,
+                     const int roi_l[4], const int roi_r[4], const wass_geom* g,
+                     const uint8_t* right_img, int img_w, int img_h,
+                     const uint8_t* left_mask, const uint8_t* right_mask,
+                     const wass_tri_params* tp, wass_mesh** out, uint64_t* n_pts);
+int wass_triangulate_dev(wass_ctx* ctx, const float* d_disp_roi, int W, int H,
+                         const int roi_l[4], const int roi_r[4], const wass_geom* g,
+                         const uint8_t* d_right_img, int img_w, int img_h,
+                         const uint8_t* d_left_mask, const uint8_t* d_right_mask,
+                         const wass_tri_params* tp, wass_mesh** out, uint64_t* n_pts);
+void wass_mesh_destroy(wass_mesh* m);
+int wass_mesh_size(const wass_mesh* m, int* width, int* height);
+/* copy the cloud to host (test hook, PLY / xyzbin writers): valid[w*h],
+ * p3d[w*h*3] (interleaved xyz), gray[w*h]; any may be NULL */
+int wass_mesh_download(wass_ctx* ctx, const wass_mesh* m, uint8_t* valid, double* p3d, uint8_t* gray);
+/* build a mesh from host arrays (test hook) */
+int wass_mesh_upload(wass_ctx* ctx, int width, int height, const uint8_t* valid, const double* p3d,
+                     const uint8_t* gray, wass_mesh** out);
+
+/* ------------------------------------------------------------------------
+ * PovMesh stages, rows a14-a20 (wass_stereo/PovMesh.cpp).
+ * ------------------------------------------------------------------------ */
+/* compute_zgap_percentile (:888-926); exact order statistic; NaN if no gaps */
+int wass_mesh_zgap_percentile(wass_ctx* ctx, wass_mesh* m, double percentile, double* out, uint64_t* n_gaps);
+/* cluster_biggest_connected_component (:929-987): keep the largest 4-connected
+ * component of valid points whose |dz| < zgap (first in column-major order on ties) */
+int wass_mesh_keep_biggest_component(wass_ctx* ctx, wass_mesh* m, double zgap, uint64_t* size_out);
+/* ransac_find_plane (:665-777).  uv_triplets[rounds][6] = {u1,v1,u2,v2,u3,v3}
+ * drawn by the caller with rand() as in :680-691 (wass_ransac_sample does that).
+ * Returns WASS_OK with *found = 0 when best < width*height/10 (:773). */
+int wass_ransac_sample(int width, int height, int rounds, int32_t* uv_triplets);
+int wass_mesh_ransac_plane(wass_ctx* ctx, wass_mesh* m, const int32_t* uv_triplets, int rounds,
+                           double thr, double plane_out[4], uint64_t* best_inliers, int* found);
+/* crop_plane (:780-815) */
+int wass_mesh_crop_plane(wass_ctx* ctx, wass_mesh* m, const double plane[4], double thr, uint64_t* kept);
+typedef struct {
+    double xmin, xmax, ymin, ymax;  /* PLANE_REFINE_{XMIN,XMAX,YMIN,YMAX}           */
+    double max_distance;            /* PLANE_REFINEMENT_MAX_DISTANCE                */
+    int weight_by_distance;         /* PLANE_WEIGHT_PROPORTIONAL_TO_DISTANCE        */
+    int central_third_only;         /* PLANE_USE_CENTRAL_THIRD_ONLY                 */
+} wass_refine_params;
+/* refine_plane (:581-660): weighted PCA plane through the inliers */
+int wass_mesh_refine_plane(wass_ctx* ctx, wass_mesh* m, const wass_refine_params* rp,
+                           double plane_out[4], uint64_t* n_inliers);
+/* RT_from_plane (:1044-1069); pure host math */
+void wass_RT_from_plane(const double plane[4], double R[9], double T[3], double Rinv[9], double Tinv[3]);
+/* save_as_xyz_compressed (:377-460): returns the exact bytes of mesh_cam.xyzC
+ * in a malloc'ed host buffer (free with wass_free).  plane == NULL (RANSAC
+ * failed): identity R, zero T are used (the reference reads uninitialised
+ * memory there; documented divergence). */
+int wass_mesh_encode_xyzc(wass_ctx* ctx, wass_mesh* m, const double plane[4], void** bytes, size_t* nbytes);
+void wass_free(void* p);
+
+/* Coll-1: NaN-aware mean of per-frame planes (np.nanmean of planes.txt,
+ * gridding/wassgridsurface/wassgridsurface.py:672-678).  Reduces
+ * [sum a, sum b, sum c, sum d, n_valid] into acc5 (caller all-reduces acc5
+ * over ranks with RCCL/torch.distributed, then calls wass_planes_mean_finish). */
+void wass_planes_mean_accumulate(const double* planes, int n, double acc5[5]);
+void wass_planes_mean_finish(const double acc5[5], double mean_out[4], int* n_valid);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     src = open(os.path.join(ROOT, "include", "wass_gpu.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(wass_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(wass_[A-Za-z0-9_]+)\s*\(", src)))
 
 
 @pytest.fixture(scope="module")

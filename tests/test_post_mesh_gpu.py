@@ -1,0 +1,314 @@
+"""GPU parity for SURVEY.md section 8 rows a7-a20 against the CPU oracle, through the C ABI.
+
+Bit-exact where the arithmetic is integer / float32 with a fixed operation order / exact fp64 comparisons
+(filters, validity masks, inlier counts, order statistics, xyzC bytes); fp64 sums whose order differs on the
+GPU (plane refinement) are compared with the tolerance written in the test.
+"""
+import struct
+
+import numpy as np
+import pytest
+
+import wass_amd
+from wass_amd import default_sgm_params, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_params(O, p):
+    return O.SgbmParams(p.min_disp, p.num_disp, p.win, p.P1, p.P2, p.uniq_ratio, p.disp12_max_diff,
+                        p.prefilter_cap, p.speckle_win, p.speckle_range, p.ndirs)
+
+
+# ------------------------------------------------------------------ a7-a9
+@pytest.mark.parametrize("w,h,D,dil,ero,off", [(160, 120, 32, 1, 2, 0), (131, 77, 48, 2, 1, 0), (131, 77, 48, 0, 0, 3),
+                                               (97, 64, 32, 3, 3, -2), (20, 3, 16, 1, 2, 0), (40, 2, 16, 1, 1, 0)])
+def test_postprocess_parity(gpu_ctx, oracle, w, h, D, dil, ero, off):
+    right, left = synth.make_pair(w, h, D, frame_idx=7 * w + h)
+    p = default_sgm_params(D, ndirs=5, disp_offset=off)
+    d16, _ = oracle.dense_disparity16(right, left, _oracle_params(oracle, p), off)
+    # punch holes so that dilate/erode have work to do
+    rng = np.random.default_rng(w)
+    d16 = d16.copy(); d16[rng.random(d16.shape) < 0.05] = 0
+    got = gpu_ctx.disparity_postprocess(d16, p, dil, ero, 0)
+    ref = oracle.disparity_postprocess(d16, p.min_disp, D, max(off, 0), dil, ero)
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_postprocess_stage_by_stage(gpu_ctx, oracle):
+    """dilate only / erode only, against the oracle's single filters (the mask step adds one erosion)."""
+    rng = np.random.default_rng(5)
+    d16 = (rng.integers(20, 400, (60, 90))).astype(np.int16)
+    d16[rng.random(d16.shape) < 0.2] = 0
+    p = default_sgm_params(32)
+    f = oracle.clean_and_convert(d16, 1, 32)
+    got = gpu_ctx.disparity_postprocess(d16, p, 1, 0, 0)
+    np.testing.assert_array_equal(got, oracle.erode_zero(oracle.dilate_zero(f)))
+    got = gpu_ctx.disparity_postprocess(d16, p, 0, 1, 0)
+    np.testing.assert_array_equal(got, oracle.erode_zero(oracle.erode_zero(f)))
+
+
+@pytest.mark.parametrize("ks", [3, 5])
+def test_postprocess_median(gpu_ctx, oracle, ks):
+    rng = np.random.default_rng(9)
+    d16 = (rng.integers(20, 400, (50, 70))).astype(np.int16)
+    p = default_sgm_params(32)
+    base = oracle.disparity_postprocess(d16, 1, 32, 0, 0, 0)
+    got = gpu_ctx.disparity_postprocess(d16, p, 0, 0, ks)
+    r = ks // 2
+    pad = np.pad(base, r, mode="edge")
+    win = np.stack([pad[i:i + 50, j:j + 70] for i in range(ks) for j in range(ks)], 0)
+    np.testing.assert_array_equal(got, np.median(win, axis=0).astype(np.float32))
+
+
+def test_postprocess_device_entry(gpu_ctx, oracle):
+    import torch
+    rng = np.random.default_rng(2)
+    d16 = (rng.integers(0, 600, (64, 80))).astype(np.int16)
+    p = default_sgm_params(32)
+    out = gpu_ctx.disparity_postprocess_dev(torch.from_numpy(d16).cuda(), p)
+    gpu_ctx.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(), oracle.disparity_postprocess(d16, 1, 32))
+
+
+# ------------------------------------------------------------------ a10-a13
+def _scene(w=200, h=150, D=48, frame=11):
+    right, left = synth.make_pair(w, h, D, frame_idx=frame)
+    gt = synth.true_disparity(w, h, D).astype(np.float32)
+    rng = np.random.default_rng(frame)
+    disp = gt.copy()
+    disp[rng.random(disp.shape) < 0.1] = 0          # holes
+    disp[:, :3] = 0.5                               # below min_disp
+    return right, left, disp
+
+
+@pytest.mark.parametrize("use_custom", [False, True])
+def test_triangulate_parity(gpu_ctx, oracle, use_custom):
+    w, h, D = 200, 150, 48
+    right, left, disp = _scene(w, h, D)
+    rig = synth.rig_geometry(w, h)
+    if use_custom:                                   # a non-trivial homography pair
+        Hl = np.array([[1.01, 0.002, -1.5], [-0.001, 0.995, 0.7], [1e-6, -2e-6, 1.0]])
+        Hr = np.array([[0.995, -0.001, 0.8], [0.0015, 1.005, -0.4], [-1e-6, 1e-6, 1.0]])
+        rig["HLi"] = np.linalg.inv(Hl); rig["HRi"] = np.linalg.inv(Hr)
+    else:                                            # a small rectifying rotation
+        a = 0.01
+        Rr = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+        rig["R1"] = Rr; rig["R2"] = Rr.T
+    roi_l, roi_r = (2, 1, w - 4, h - 3), (3, 1, w - 4, h - 3)
+    droi = np.ascontiguousarray(disp[roi_r[1]:roi_r[1] + roi_r[3], roi_r[0]:roi_r[0] + roi_r[2]])
+    full = np.zeros((h, w), np.float32); full[roi_r[1]:roi_r[1] + roi_r[3], roi_r[0]:roi_r[0] + roi_r[2]] = droi
+    lmask = (np.random.default_rng(1).random((h, w)) > 0.05).astype(np.uint8)
+    rmask = (right <= 254).astype(np.uint8)
+    bbox = (5.0, 4.0, w - 6.0, h - 5.0)
+    og = oracle.make_geom(rig, use_custom=use_custom, disparity_compensation=1.0)
+    n_ref, v_ref, p_ref, g_ref = oracle.triangulate(full, roi_l, roi_r, og, right, lmask, rmask, 20.0, bbox, 1.0)
+    gg = wass_amd.make_geom(rig, use_custom=use_custom, disparity_compensation=1.0)
+    mesh, n = gpu_ctx.triangulate(droi, w, h, roi_l, roi_r, gg, right, lmask, rmask, 20.0, bbox, 1.0)
+    valid, p3d, gray = mesh.download()
+    assert n_ref > 1000
+    # acos() differs in the last bits between glibc and the device: allow a handful of threshold flips
+    flips = int((valid != v_ref).sum())
+    assert flips <= 2 and abs(n - n_ref) <= 2
+    both = (valid == 1) & (v_ref == 1)
+    np.testing.assert_allclose(p3d[both], p_ref[both], rtol=1e-12, atol=1e-12)   # fp64, same op order
+    np.testing.assert_array_equal(gray[both], g_ref[both])
+    assert (p3d[valid == 0] == 0).all()
+
+
+def test_triangulate_depth_matches_ground_truth(gpu_ctx):
+    """Z = f*B/d for the ideal rig (B = 1): ties the geometry to the synthetic scene."""
+    w, h, D = 160, 120, 32
+    right, left = synth.make_pair(w, h, D)
+    gt = synth.true_disparity(w, h, D).astype(np.float32)
+    rig = synth.rig_geometry(w, h)
+    mesh, n = gpu_ctx.triangulate(gt, w, h, (0, 0, w, h), (0, 0, w, h), wass_amd.make_geom(rig), right)
+    valid, p3d, _ = mesh.download()
+    m = valid == 1
+    assert m.mean() > 0.5
+    np.testing.assert_allclose(p3d[..., 2][m], (0.9 * w) / gt[m], rtol=1e-5)
+
+
+# ------------------------------------------------------------------ a14-a20
+def _cloud(w=210, h=140, seed=0, holes=0.15, outliers=0.03):
+    rng = np.random.default_rng(seed)
+    n = np.array([0.04, -0.45, 0.89]); n /= np.linalg.norm(n)
+    d = -18.0
+    u, v = np.meshgrid(np.arange(w), np.arange(h))
+    x = (u - w / 2) * 0.12 + rng.normal(0, 0.01, (h, w))
+    y = (v - h / 2) * 0.1 + rng.normal(0, 0.01, (h, w))
+    z = (-d - n[0] * x - n[1] * y) / n[2] + rng.normal(0, 0.15, (h, w))
+    o = rng.random((h, w)) < outliers
+    z[o] += rng.uniform(3, 30, o.sum())
+    valid = (rng.random((h, w)) > holes).astype(np.uint8)
+    valid[60:64, :] = 0; valid[60:64, 100:103] = 1          # a thin bridge between two big parts
+    p3d = np.ascontiguousarray(np.stack([x, y, z], -1))
+    p3d[valid == 0] = 0
+    return valid, p3d, np.array([*n, d])
+
+
+def test_mesh_roundtrip(gpu_ctx):
+    valid, p3d, _ = _cloud()
+    gray = (np.arange(valid.size) % 251).astype(np.uint8).reshape(valid.shape)
+    m = gpu_ctx.mesh_upload(valid, p3d, gray)
+    v2, p2, g2 = m.download()
+    np.testing.assert_array_equal(v2, valid); np.testing.assert_array_equal(p2, p3d); np.testing.assert_array_equal(g2, gray)
+
+
+@pytest.mark.parametrize("pct", [99.0, 50.0, 0.0, 100.0, 98.7])
+def test_zgap_percentile_exact(gpu_ctx, oracle, pct):
+    valid, p3d, _ = _cloud(seed=3)
+    m = gpu_ctx.mesh_upload(valid, p3d)
+    got, n = m.zgap_percentile(pct)
+    ref, n_ref = oracle.zgap_percentile(valid, p3d, pct)
+    assert n == n_ref and got == ref
+
+
+def test_zgap_empty(gpu_ctx):
+    valid = np.zeros((10, 12), np.uint8)
+    m = gpu_ctx.mesh_upload(valid, np.zeros((10, 12, 3)))
+    got, n = m.zgap_percentile(99.0)
+    assert n == 0 and np.isnan(got)
+
+
+@pytest.mark.parametrize("seed,gapscale", [(0, 1.0), (1, 0.5), (2, 0.2), (3, 3.0)])
+def test_biggest_component_exact(gpu_ctx, oracle, seed, gapscale):
+    valid, p3d, _ = _cloud(seed=seed)
+    zgap, _ = oracle.zgap_percentile(valid, p3d, 90.0)
+    zgap *= gapscale
+    m = gpu_ctx.mesh_upload(valid, p3d)
+    size = m.keep_biggest_component(zgap)
+    v_ref, size_ref = oracle.keep_biggest_component(valid, p3d, zgap)
+    v_got, _, _ = m.download()
+    assert size == size_ref
+    np.testing.assert_array_equal(v_got, v_ref)
+
+
+def test_biggest_component_tie_break_and_empty(gpu_ctx, oracle):
+    h, w = 30, 40
+    valid = np.zeros((h, w), np.uint8); valid[20:25, 3:8] = 1; valid[2:7, 10:15] = 1
+    p3d = np.zeros((h, w, 3))
+    m = gpu_ctx.mesh_upload(valid, p3d)
+    assert m.keep_biggest_component(1.0) == 25
+    v_ref, _ = oracle.keep_biggest_component(valid, p3d, 1.0)
+    np.testing.assert_array_equal(m.download()[0], v_ref)
+    e = gpu_ctx.mesh_upload(np.zeros((5, 6), np.uint8), np.zeros((5, 6, 3)))
+    assert e.keep_biggest_component(1.0) == 0 and not e.download()[0].any()
+
+
+def test_ransac_sampler_matches_oracle(oracle):
+    a = wass_amd.ransac_sample(210, 140, 400, 12345)
+    b = oracle.ransac_sample(210, 140, 400, 12345)
+    np.testing.assert_array_equal(a, b)
+
+
+def test_ransac_exact_counts_and_plane(gpu_ctx, oracle):
+    valid, p3d, plane_true = _cloud(seed=4)
+    uv = wass_amd.ransac_sample(valid.shape[1], valid.shape[0], 400, 12345)
+    m = gpu_ctx.mesh_upload(valid, p3d)
+    found, plane, best = m.ransac_plane(uv, 1.0)
+    ok_ref, plane_ref, best_ref, per = oracle.ransac_plane(valid, p3d, uv, 1.0)
+    assert found == ok_ref and best == best_ref          # same fp64 operations -> same inlier count
+    np.testing.assert_array_equal(plane, plane_ref)
+    assert abs(abs(plane[:3] @ plane_true[:3]) - 1) < 1e-2
+    # failure path: best < W*H/10
+    v2 = valid.copy(); v2[:] = 0; v2[:6, :6] = 1
+    found2, _, best2 = gpu_ctx.mesh_upload(v2, p3d).ransac_plane(uv, 1.0)
+    ok2, _, bref2, _ = oracle.ransac_plane(v2, p3d, uv, 1.0)
+    assert found2 == ok2 == False and best2 == bref2   # noqa: E712
+
+
+def test_crop_plane_exact(gpu_ctx, oracle):
+    valid, p3d, plane = _cloud(seed=5)
+    m = gpu_ctx.mesh_upload(valid, p3d)
+    kept = m.crop_plane(plane, 0.2)
+    v_ref, k_ref = oracle.crop_plane(valid, p3d, plane, 0.2)
+    assert kept == k_ref
+    np.testing.assert_array_equal(m.download()[0], v_ref)
+
+
+@pytest.mark.parametrize("weighted,central", [(True, False), (False, False), (True, True)])
+def test_refine_plane(gpu_ctx, oracle, weighted, central):
+    valid, p3d, plane = _cloud(seed=6, outliers=0.0)
+    m = gpu_ctx.mesh_upload(valid, p3d)
+    got, n = m.refine_plane(xmin=-9.0, xmax=9999.0, weight_by_distance=weighted, central_third_only=central)
+    ref, n_ref, _ = oracle.refine_plane(valid, p3d, xmin=-9.0, xmax=9999.0, weight_by_distance=weighted,
+                                        central_third_only=central)
+    assert n == n_ref
+    # tolerance: fp64 sums in a different (tree) order; 1e-9 on a unit normal / d ~ 18
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-9)
+    assert abs(got[:3] @ plane[:3]) > 0.999
+
+
+def test_rt_from_plane_matches_oracle(oracle):
+    pl = np.array([0.0123, -0.4567, 0.8895, -11.2]); pl[:3] /= np.linalg.norm(pl[:3])
+    for a, b in zip(wass_amd.RT_from_plane(pl), oracle.RT_from_plane(pl)):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_xyzc_bytes_exact(gpu_ctx, oracle):
+    valid, p3d, plane = _cloud(seed=7)
+    m = gpu_ctx.mesh_upload(valid, p3d)
+    blob = m.encode_xyzc(plane)
+    ref = oracle.encode_xyzc(valid, p3d, plane)
+    assert len(blob) == len(ref) == 148 + 6 * int(valid.sum())
+    assert blob == ref
+    # format sanity (Appendix B.1) and the no-plane fallback
+    n = struct.unpack("<I", blob[:4])[0]
+    assert n == valid.sum()
+    blob2 = m.encode_xyzc(None)
+    Rinv = np.frombuffer(blob2[52:124], np.float64).reshape(3, 3)
+    np.testing.assert_array_equal(Rinv, np.eye(3))
+
+
+def test_planes_mean(oracle):
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "planes_txt.npz"))
+    acc = wass_amd.planes_mean_accumulate(z["planes"][:2])
+    acc = wass_amd.planes_mean_accumulate(z["planes"][2:], acc)
+    mean, n = wass_amd.planes_mean_finish(acc)
+    assert n == int(z["n_valid"])
+    np.testing.assert_allclose(mean, z["nanmean"], rtol=1e-15)
+
+
+def test_full_chain_small(gpu_ctx, oracle):
+    """The whole path a1-a20 on one small synthetic frame: GPU chain vs oracle chain."""
+    w, h, D = 320, 240, 64
+    right, left = synth.make_pair(w, h, D, frame_idx=21)
+    p = default_sgm_params(D, ndirs=5)
+    rig = synth.rig_geometry(w, h)
+    roi = (0, 0, w, h)
+    # GPU
+    d16 = gpu_ctx.sgm_disparity(right, left, p)
+    f = gpu_ctx.disparity_postprocess(d16, p)
+    mesh, n = gpu_ctx.triangulate(f, w, h, roi, roi, wass_amd.make_geom(rig), right, None, (right <= 254).astype(np.uint8))
+    zg, _ = mesh.zgap_percentile(99.0)
+    mesh.keep_biggest_component(zg)
+    uv = wass_amd.ransac_sample(w, h, 400, 12345)
+    found, pl, best = mesh.ransac_plane(uv, 1.0)
+    assert found
+    mesh.crop_plane(pl, 1.0)
+    pl2, ninl = mesh.refine_plane()
+    mesh.crop_plane(pl2, 1.5)
+    blob = mesh.encode_xyzc(pl2)
+    # oracle
+    od16, _ = oracle.dense_disparity16(right, left, _oracle_params(oracle, p))
+    of = oracle.disparity_postprocess(od16, 1, D)
+    on, ov, op3, og = oracle.triangulate(of, roi, roi, oracle.make_geom(rig), right, None, (right <= 254).astype(np.uint8))
+    ozg, _ = oracle.zgap_percentile(ov, op3, 99.0)
+    ov, _ = oracle.keep_biggest_component(ov, op3, ozg)
+    ok, opl, obest, _ = oracle.ransac_plane(ov, op3, uv, 1.0)
+    ov, _ = oracle.crop_plane(ov, op3, opl, 1.0)
+    opl2, oninl, _ = oracle.refine_plane(ov, op3)
+    ov, _ = oracle.crop_plane(ov, op3, opl2, 1.5)
+    np.testing.assert_array_equal(d16, od16)
+    np.testing.assert_array_equal(f, of)
+    assert n == on and zg == ozg and best == obest and ninl == oninl
+    np.testing.assert_array_equal(pl, opl)
+    # refined plane: 1e-9 absolute (unit normal, |d| ~ 20 baseline units) = far below the xyzC quantisation
+    np.testing.assert_allclose(pl2, opl2, rtol=0, atol=1e-9)
+    v_got = mesh.download()[0]
+    assert (v_got != ov).sum() <= 2                      # a point within 1e-9 of the 1.5 threshold may flip
+    # the plane must be the synthetic sea plane: affine disparity <=> planar surface
+    assert n > 0.7 * w * h and best > 0.8 * n
+    assert len(blob) == 148 + 6 * int(v_got.sum())

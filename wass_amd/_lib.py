@@ -35,6 +35,25 @@ class SgmTimings(C.Structure):
                 ("aggregate_launches", C.c_int), ("cost_overflow", C.c_int)]
 
 
+class Geom(C.Structure):
+    """wass_geom"""
+    _fields_ = [("K_left", C.c_double * 9), ("K_right", C.c_double * 9), ("R", C.c_double * 9), ("T", C.c_double * 3),
+                ("use_custom", C.c_int), ("R1", C.c_double * 9), ("R2", C.c_double * 9), ("P1", C.c_double * 12),
+                ("P2", C.c_double * 12), ("HLi", C.c_double * 9), ("HRi", C.c_double * 9),
+                ("disparity_compensation", C.c_double), ("dense_scale", C.c_double)]
+
+
+class TriParams(C.Structure):
+    """wass_tri_params"""
+    _fields_ = [("min_angle_deg", C.c_double), ("bbox", C.c_double * 4), ("cam_distance", C.c_double)]
+
+
+class RefineParams(C.Structure):
+    """wass_refine_params"""
+    _fields_ = [("xmin", C.c_double), ("xmax", C.c_double), ("ymin", C.c_double), ("ymax", C.c_double),
+                ("max_distance", C.c_double), ("weight_by_distance", C.c_int), ("central_third_only", C.c_int)]
+
+
 def default_sgm_params(num_disp: int, ndirs: int = 5, min_disp: int = 1, win: int = 13, p1_mult: int = 2,
                        p2_mult: int = 64, disp_offset: int = 0) -> SgmParams:
     """Defaults of SURVEY.md Appendix C (wass_stereo.cpp:742-759)."""
@@ -56,6 +75,28 @@ SYMBOLS = {
     "wass_sgm_disparity_dev": (_i, [_vp, _vp, _vp, _i, _i, _sz, C.POINTER(SgmParams), _vp]),
     "wass_sgm_last_timings": (_i, [_vp, C.POINTER(SgmTimings)]),
     "wass_sgm_debug_fetch": (_i, [_vp, _vp, _vp, _vp]),
+    "wass_disparity_postprocess": (_i, [_vp, _vp, _i, _i, C.POINTER(SgmParams), _i, _i, _i, _vp]),
+    "wass_disparity_postprocess_dev": (_i, [_vp, _vp, _i, _i, C.POINTER(SgmParams), _i, _i, _i, _vp]),
+    "wass_triangulate": (_i, [_vp, _vp, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(Geom), _vp, _i, _i, _vp, _vp,
+                              C.POINTER(TriParams), C.POINTER(_vp), C.POINTER(C.c_uint64)]),
+    "wass_triangulate_dev": (_i, [_vp, _vp, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(Geom), _vp, _i, _i, _vp, _vp,
+                                  C.POINTER(TriParams), C.POINTER(_vp), C.POINTER(C.c_uint64)]),
+    "wass_mesh_destroy": (None, [_vp]),
+    "wass_mesh_size": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "wass_mesh_download": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "wass_mesh_upload": (_i, [_vp, _i, _i, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "wass_mesh_zgap_percentile": (_i, [_vp, _vp, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "wass_mesh_keep_biggest_component": (_i, [_vp, _vp, C.c_double, C.POINTER(C.c_uint64)]),
+    "wass_ransac_sample": (_i, [_i, _i, _i, _vp]),
+    "wass_mesh_ransac_plane": (_i, [_vp, _vp, _vp, _i, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
+                                    C.POINTER(_i)]),
+    "wass_mesh_crop_plane": (_i, [_vp, _vp, C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_uint64)]),
+    "wass_mesh_refine_plane": (_i, [_vp, _vp, C.POINTER(RefineParams), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "wass_RT_from_plane": (None, [C.POINTER(C.c_double)] * 5),
+    "wass_mesh_encode_xyzc": (_i, [_vp, _vp, C.POINTER(C.c_double), C.POINTER(_vp), C.POINTER(_sz)]),
+    "wass_free": (None, [_vp]),
+    "wass_planes_mean_accumulate": (None, [C.POINTER(C.c_double), _i, C.POINTER(C.c_double)]),
+    "wass_planes_mean_finish": (None, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
 }
 
 _lib = None

@@ -112,6 +112,9 @@ struct wass_ctx {
     wass::Buf raw;                 // padded-width raw disparity [h][Wp] int16
     wass::Buf flags;               // u32[4]: [0] = cost overflow
     wass::Buf tmp_in0, tmp_in1, tmp_out;   // staging for the host-pointer entry points
+    wass::Buf tmp_mask;
+    wass::Buf fA, fB, fC;          // float32 maps of the disparity clean-up
+    wass::Buf scratch;             // mesh stages: gaps / labels / partial sums / packed output
     hipEvent_t ev[8] = {};
     hipStream_t side = nullptr;    // checkpoint sweeps run ahead here
     hipEvent_t ev_cost = nullptr, ev_ckpt[4] = {};

@@ -1,0 +1,998 @@
+// mesh.hip -- triangulation and the PovMesh stages on the device
+// (SURVEY.md section 8 rows a10-a20).
+//
+// The reference keeps the organised cloud as a 40-byte AoS
+// (wass_stereo/PovMesh.h:33-51); here it is structure-of-arrays in HBM
+// (valid u8, x/y/z f64, gray u8) so that every pass streams only what it
+// needs.  All geometry is fp64 and compiled with -ffp-contract=off: the same
+// operations in the same order as the reference's plain x86-64 build, so the
+// inlier counts of RANSAC / crop_plane are reproduced exactly.
+#include "common.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <new>
+#include <vector>
+
+struct wass_mesh {
+    int w = 0, h = 0;
+    uint8_t* valid = nullptr;
+    double* x = nullptr;
+    double* y = nullptr;
+    double* z = nullptr;
+    uint8_t* gray = nullptr;
+    size_t n() const { return (size_t)w * h; }
+};
+
+namespace wass {
+
+struct GeomDev {
+    double Kl[9], Kr[9], R[9], T[3];
+    int use_custom;
+    double R1[9], R2[9], P1[12], P2[12], HLi[9], HRi[9];
+    double comp_over_scale;
+};
+
+__device__ __forceinline__ void mulv(const double* M, const double* v, double* o)
+{
+    o[0] = M[0] * v[0] + M[1] * v[1] + M[2] * v[2];
+    o[1] = M[3] * v[0] + M[4] * v[1] + M[5] * v[2];
+    o[2] = M[6] * v[0] + M[7] * v[1] + M[8] * v[2];
+}
+__device__ __forceinline__ void tmulv(const double* M, const double* v, double* o)
+{
+    o[0] = M[0] * v[0] + M[3] * v[1] + M[6] * v[2];
+    o[1] = M[1] * v[0] + M[4] * v[1] + M[7] * v[2];
+    o[2] = M[2] * v[0] + M[5] * v[1] + M[8] * v[2];
+}
+
+// StereoMatchEnv::unrectify (wass_stereo.cpp:299-324)
+__device__ __forceinline__ void unrectify(const GeomDev& g, double u, double v, bool left, double* out)
+{
+    if (g.use_custom) {
+        const double in[3] = { u, v, 1.0 };
+        double r[3];
+        mulv(left ? g.HLi : g.HRi, in, r);
+        out[0] = r[0] / r[2]; out[1] = r[1] / r[2];
+    } else {
+        const double* K = left ? g.Kl : g.Kr;
+        const double* P = left ? g.P1 : g.P2;
+        const double xyw[3] = { (u - P[2]) / P[0], (v - P[6]) / P[5], 1.0 };
+        double r[3];
+        tmulv(left ? g.R1 : g.R2, xyw, r);
+        r[0] /= r[2]; r[1] /= r[2];
+        out[0] = r[0] * K[0] + K[2];
+        out[1] = r[1] * K[4] + K[5];
+    }
+}
+
+// triangulate(p,q,R,T) (wass_lib/triangulate.hpp:26-72) with the closed-form 3x3 solve
+__device__ __forceinline__ void triangulate_point(const double* p, const double* q, const double* R, const double* T,
+                                                  double* out)
+{
+    double Af[12], Bf[4], A[9], b[3];
+    Af[0] = -1.0; Af[1] = 0.0; Af[2] = p[0];
+    Af[3] = 0.0; Af[4] = -1.0; Af[5] = p[1];
+    Af[6] = q[0] * R[6] - R[0]; Af[7] = q[0] * R[7] - R[1]; Af[8] = q[0] * R[8] - R[2];
+    Af[9] = q[1] * R[6] - R[3]; Af[10] = q[1] * R[7] - R[4]; Af[11] = q[1] * R[8] - R[5];
+    Bf[0] = 0.0; Bf[1] = 0.0;
+    Bf[2] = T[0] - T[2] * q[0];
+    Bf[3] = T[1] - T[2] * q[1];
+    A[0] = Af[0] * Af[0] + Af[3] * Af[3] + Af[6] * Af[6] + Af[9] * Af[9];
+    A[1] = Af[0] * Af[1] + Af[3] * Af[4] + Af[10] * Af[9] + Af[6] * Af[7];
+    A[2] = Af[0] * Af[2] + Af[3] * Af[5] + Af[11] * Af[9] + Af[6] * Af[8];
+    A[3] = A[1];
+    A[4] = Af[1] * Af[1] + Af[10] * Af[10] + Af[4] * Af[4] + Af[7] * Af[7];
+    A[5] = Af[10] * Af[11] + Af[1] * Af[2] + Af[4] * Af[5] + Af[7] * Af[8];
+    A[6] = A[2];
+    A[7] = A[5];
+    A[8] = Af[11] * Af[11] + Af[2] * Af[2] + Af[5] * Af[5] + Af[8] * Af[8];
+    b[0] = Af[0] * Bf[0] + Af[3] * Bf[1] + Af[6] * Bf[2] + Af[9] * Bf[3];
+    b[1] = Af[1] * Bf[0] + Af[10] * Bf[3] + Af[4] * Bf[1] + Af[7] * Bf[2];
+    b[2] = Af[2] * Bf[0] + Af[11] * Bf[3] + Af[5] * Bf[1] + Af[8] * Bf[2];
+    double det = A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) +
+                 A[2] * (A[3] * A[7] - A[4] * A[6]);
+    if (det != 0) {
+        det = 1. / det;
+        out[0] = det * (b[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (b[1] * A[8] - A[5] * b[2]) +
+                        A[2] * (b[1] * A[7] - A[4] * b[2]));
+        out[1] = det * (A[0] * (b[1] * A[8] - A[5] * b[2]) - b[0] * (A[3] * A[8] - A[5] * A[6]) +
+                        A[2] * (A[3] * b[2] - b[1] * A[6]));
+        out[2] = det * (A[0] * (A[4] * b[2] - b[1] * A[7]) - A[1] * (A[3] * b[2] - b[1] * A[6]) +
+                        b[0] * (A[3] * A[7] - A[4] * A[6]));
+    } else {
+        out[0] = out[1] = out[2] = 0.0;
+    }
+}
+
+// triangulate(StereoMatchEnv&) (wass_stereo.cpp:1173-1365): one thread per ROI pixel
+__global__ void __launch_bounds__(256) k_triangulate(const float* __restrict__ disp, int W, int H, int rlx, int rrx, int rry,
+                                                     int mw, int mh, GeomDev g, const uint8_t* __restrict__ right_img,
+                                                     int img_w, int img_h, const uint8_t* __restrict__ lmask,
+                                                     const uint8_t* __restrict__ rmask, double min_angle, double bx0,
+                                                     double by0, double bx1, double by1, double cam_distance,
+                                                     uint8_t* __restrict__ valid, double* __restrict__ X,
+                                                     double* __restrict__ Y, double* __restrict__ Z,
+                                                     uint8_t* __restrict__ gray, unsigned long long* __restrict__ count)
+{
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    const int v = blockIdx.y;
+    if (u >= mw) return;
+    const size_t idx = (size_t)v * mw + u;
+    bool ok = false;
+    double P[3] = { 0, 0, 0 };
+    uint8_t gv = 0;
+    const float dv = disp[idx];
+    const int xr = rrx + u, yr = rry + v;
+    if (dv > 1.0f) {                                                  // min_disp = 1 (:1100,1177)
+        const float xl = (float)((float)(xr - rrx + rlx) - dv + g.comp_over_scale);   // :1180
+        const float yl = (float)yr;
+        if (!(xl < 0 || xl >= (float)W)) {                            // :1183
+            double pi[2], qi[2];
+            unrectify(g, (double)xl, (double)yl, true, pi);
+            unrectify(g, (double)xr, (double)yr, false, qi);
+            bool skip = false;
+            if (pi[0] < 1 || pi[0] >= img_w - 1 || pi[1] < 1 || pi[1] >= img_h - 1 ||
+                qi[0] < 1 || qi[0] >= img_w - 1 || qi[1] < 1 || qi[1] >= img_h - 1)
+                skip = true;                                          // :1223
+            const double p[2] = { (pi[0] - g.Kl[2]) / g.Kl[0], (pi[1] - g.Kl[5]) / g.Kl[4] };
+            const double q[2] = { (qi[0] - g.Kr[2]) / g.Kr[0], (qi[1] - g.Kr[5]) / g.Kr[4] };
+            if (pi[0] <= bx0 || pi[1] <= by0 || pi[0] >= bx1 || pi[1] >= by1) skip = true;   // :1236
+            if (!skip) {                                              // :1244,1250 (short-circuited: no OOB reads)
+                if (lmask && lmask[(size_t)(int)pi[1] * img_w + (int)pi[0]] == 0) skip = true;
+                if (rmask && rmask[(size_t)(int)qi[1] * img_w + (int)qi[0]] == 0) skip = true;
+            }
+            if (min_angle > 0) {                                      // :1258-1269
+                double d1[3] = { p[0], p[1], 1.0 }, qq[3] = { q[0], q[1], 1.0 }, d2[3];
+                mulv(g.R, qq, d2);
+                d2[0] += g.T[0]; d2[1] += g.T[1]; d2[2] += g.T[2];
+                const double n1 = sqrt(d1[0] * d1[0] + d1[1] * d1[1] + d1[2] * d1[2]);
+                const double n2 = sqrt(d2[0] * d2[0] + d2[1] * d2[1] + d2[2] * d2[2]);
+                d1[0] /= n1; d1[1] /= n1; d1[2] /= n1;
+                d2[0] /= n2; d2[1] /= n2; d2[2] /= n2;
+                const double ang = fabs(acos(d1[0] * d2[0] + d1[1] * d2[1] + d1[2] * d2[2]) * 57.29577951);
+                if (ang < min_angle) skip = true;
+            }
+            if (!skip) {
+                triangulate_point(p, q, g.R, g.T, P);                 // :1286
+                const double dist = sqrt(P[0] * P[0] + P[1] * P[1] + P[2] * P[2]);
+                if (!(dist < cam_distance / 10.0 || P[2] < 1.0) && !(dist > cam_distance * 200.0 || P[2] > 1E30)) {
+                    ok = true;                                        // :1329-1340
+                    gv = right_img[(size_t)(int)qi[1] * img_w + (int)qi[0]];   // :1342
+                }
+            }
+        }
+    }
+    valid[idx] = ok ? 1 : 0;
+    X[idx] = ok ? P[0] : 0.0; Y[idx] = ok ? P[1] : 0.0; Z[idx] = ok ? P[2] : 0.0;
+    gray[idx] = gv;
+    const unsigned long long b = __ballot(ok);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, (unsigned long long)__popcll(b));
+}
+
+// ------------------------------------------------------------------ z-gap percentile (PovMesh.cpp:888-926)
+// gaps[3*idx + k] = |z - z(neighbour k in the row above)| as the fp64 bit pattern, ~0 when absent.
+__global__ void __launch_bounds__(256) k_zgaps(const uint8_t* __restrict__ valid, const double* __restrict__ Z, int w, int h,
+                                               unsigned long long* __restrict__ gaps, unsigned long long* __restrict__ count)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= w) return;
+    const size_t c = (size_t)i * w + j;
+    unsigned long long g[3] = { ~0ull, ~0ull, ~0ull };
+    int n = 0;
+    if (i >= 1 && j >= 1 && j < w - 1 && valid[c]) {
+        const double z = Z[c];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const size_t nb = c - w - 1 + k;
+            if (valid[nb]) { g[k] = (unsigned long long)__double_as_longlong(fabs(z - Z[nb])); ++n; }
+        }
+    }
+    gaps[3 * c] = g[0]; gaps[3 * c + 1] = g[1]; gaps[3 * c + 2] = g[2];
+    // wave-level count
+    int s = n;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(count, (unsigned long long)s);
+}
+
+// one MSD radix-select pass: histogram of an 11-bit digit among keys whose higher bits equal `prefix`
+__global__ void __launch_bounds__(256) k_radix_hist(const unsigned long long* __restrict__ keys, size_t n, int shift,
+                                                    unsigned int mask, int hi_shift, unsigned long long prefix,
+                                                    unsigned int* __restrict__ hist)
+{
+    __shared__ unsigned int lh[2048];
+    for (int i = threadIdx.x; i < 2048; i += 256) lh[i] = 0;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const unsigned long long k = keys[i];
+        if (k == ~0ull) continue;
+        if (hi_shift < 64 && (k >> hi_shift) != prefix) continue;
+        atomicAdd(&lh[(unsigned)(k >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2048; i += 256)
+        if (lh[i]) atomicAdd(&hist[i], lh[i]);
+}
+
+// ------------------------------------------------------------------ connected components (PovMesh.cpp:929-987)
+// Labels live in COLUMN-MAJOR index space (cm = u*h + v): the reference scans seeds column by
+// column, so the smallest cm index of a component is its seed and decides ties.
+__device__ __forceinline__ int uf_find(int* __restrict__ parent, int a)
+{
+    int p = parent[a];
+    while (p != a) { a = p; p = parent[a]; }
+    return a;
+}
+__device__ __forceinline__ void uf_union(int* __restrict__ parent, int a, int b)
+{
+    for (;;) {
+        a = uf_find(parent, a);
+        b = uf_find(parent, b);
+        if (a == b) return;
+        if (a > b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(&parent[b], a);
+        if (old == b) return;
+        b = old;
+    }
+}
+__global__ void __launch_bounds__(256) k_ccl_init(const uint8_t* __restrict__ valid, int w, int h, int* __restrict__ parent,
+                                                  unsigned int* __restrict__ size)
+{
+    const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
+    if (u >= w) return;
+    const int cm = u * h + v;
+    parent[cm] = valid[(size_t)v * w + u] ? cm : -1;
+    size[cm] = 0;
+}
+__global__ void __launch_bounds__(256) k_ccl_merge(const uint8_t* __restrict__ valid, const double* __restrict__ Z, int w, int h,
+                                                   double zgap, int* __restrict__ parent)
+{
+    const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
+    if (u >= w) return;
+    const size_t c = (size_t)v * w + u;
+    if (!valid[c]) return;
+    const double z = Z[c];
+    const int cm = u * h + v;
+    if (u + 1 < w && valid[c + 1] && fabs(z - Z[c + 1]) < zgap) uf_union(parent, cm, cm + h);
+    if (v + 1 < h && valid[c + w] && fabs(z - Z[c + w]) < zgap) uf_union(parent, cm, cm + 1);
+}
+__global__ void __launch_bounds__(256) k_ccl_count(int w, int h, int* __restrict__ parent, unsigned int* __restrict__ size)
+{
+    const int cm = blockIdx.x * 256 + threadIdx.x;
+    if (cm >= w * h || parent[cm] < 0) return;
+    const int r = uf_find(parent, cm);
+    parent[cm] = r;                                  // benign race: every writer stores a valid ancestor
+    atomicAdd(&size[r], 1u);
+}
+// best = max over roots of (size << 32 | ~root): largest size, then smallest column-major seed
+__global__ void __launch_bounds__(256) k_ccl_best(int n, const int* __restrict__ parent, const unsigned int* __restrict__ size,
+                                                  unsigned long long* __restrict__ best)
+{
+    const int cm = blockIdx.x * 256 + threadIdx.x;
+    unsigned long long key = 0;
+    if (cm < n && parent[cm] == cm) key = ((unsigned long long)size[cm] << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)cm);
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_down(key, o);
+        key = other > key ? other : key;
+    }
+    if ((threadIdx.x & 63) == 0 && key) atomicMax(best, key);
+}
+__global__ void __launch_bounds__(256) k_ccl_keep(uint8_t* __restrict__ valid, int w, int h, const int* __restrict__ parent,
+                                                  int root)
+{
+    const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
+    if (u >= w) return;
+    const int cm = u * h + v;
+    int r = parent[cm];
+    if (r >= 0) r = uf_find((int*)parent, cm);
+    valid[(size_t)v * w + u] = (r == root) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ RANSAC (PovMesh.cpp:665-777)
+struct PlaneCand { double n[3]; double d; int ok; int pad; };
+
+__global__ void k_ransac_planes(const uint8_t* __restrict__ valid, const double* __restrict__ X, const double* __restrict__ Y,
+                                const double* __restrict__ Z, int w, const int32_t* __restrict__ uv, int rounds,
+                                PlaneCand* __restrict__ cand)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rounds) return;
+    const int32_t* c = uv + (size_t)r * 6;
+    const size_t i1 = (size_t)c[1] * w + c[0], i2 = (size_t)c[3] * w + c[2], i3 = (size_t)c[5] * w + c[4];
+    PlaneCand pc;
+    pc.ok = valid[i1] && valid[i2] && valid[i3];
+    pc.pad = 0;
+    pc.n[0] = pc.n[1] = pc.n[2] = pc.d = 0.0;
+    if (pc.ok) {
+        const double a[3] = { X[i2] - X[i1], Y[i2] - Y[i1], Z[i2] - Z[i1] };
+        const double b[3] = { X[i3] - X[i1], Y[i3] - Y[i1], Z[i3] - Z[i1] };
+        double n[3] = { a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0] };
+        const double nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        n[0] = n[0] / nn; n[1] = n[1] / nn; n[2] = n[2] / nn;
+        if (n[2] < 0) { n[0] = n[0] * -1.0; n[1] = n[1] * -1.0; n[2] = n[2] * -1.0; }
+        pc.n[0] = n[0]; pc.n[1] = n[1]; pc.n[2] = n[2];
+        pc.d = -(n[0] * X[i1] + n[1] * Y[i1] + n[2] * Z[i1]);
+    }
+    cand[r] = pc;
+}
+
+// every candidate plane scored in ONE pass over the points: each thread keeps PTS points in registers
+// and walks the plane list held in LDS; a ballot turns 64 comparisons into one counter update.
+template <int PTS>
+__global__ void __launch_bounds__(256) k_ransac_score(const uint8_t* __restrict__ valid, const double* __restrict__ X,
+                                                      const double* __restrict__ Y, const double* __restrict__ Z, size_t n,
+                                                      const PlaneCand* __restrict__ cand, int rounds, double thr,
+                                                      unsigned long long* __restrict__ counts)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* pl = (double*)smem;                                   // [rounds][4]
+    unsigned int* lc = (unsigned int*)(pl + (size_t)rounds * 4);  // [rounds]
+    for (int r = threadIdx.x; r < rounds; r += 256) {
+        pl[r * 4] = cand[r].n[0]; pl[r * 4 + 1] = cand[r].n[1]; pl[r * 4 + 2] = cand[r].n[2]; pl[r * 4 + 3] = cand[r].d;
+        lc[r] = 0;
+    }
+    __syncthreads();
+    double px[PTS], py[PTS], pz[PTS];
+    bool pv[PTS];
+    const size_t base = (size_t)blockIdx.x * 256 * PTS + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < PTS; ++k) {
+        const size_t i = base + (size_t)k * 256;
+        pv[k] = i < n && valid[i];
+        px[k] = pv[k] ? X[i] : 0.0; py[k] = pv[k] ? Y[i] : 0.0; pz[k] = pv[k] ? Z[i] : 0.0;
+    }
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < PTS; ++k) any |= pv[k];
+    if (__syncthreads_or(any)) {
+        for (int r = 0; r < rounds; ++r) {
+            const double a = pl[r * 4], b = pl[r * 4 + 1], c = pl[r * 4 + 2], d = pl[r * 4 + 3];
+            unsigned int cnt = 0;
+#pragma unroll
+            for (int k = 0; k < PTS; ++k) {
+                const bool in = pv[k] && fabs((a * px[k] + b * py[k] + c * pz[k]) + d) < thr;
+                cnt += (unsigned)__popcll(__ballot(in));
+            }
+            if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&lc[r], cnt);
+        }
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < rounds; r += 256)
+        if (lc[r]) atomicAdd(&counts[r], (unsigned long long)lc[r]);
+}
+
+// ------------------------------------------------------------------ crop_plane (PovMesh.cpp:780-815)
+__global__ void __launch_bounds__(256) k_crop_plane(uint8_t* __restrict__ valid, const double* __restrict__ X,
+                                                    const double* __restrict__ Y, const double* __restrict__ Z, size_t n,
+                                                    double a, double b, double c, double d, double thr,
+                                                    unsigned long long* __restrict__ kept)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    bool keep = false;
+    if (i < n && valid[i]) {
+        keep = fabs((a * X[i] + b * Y[i] + c * Z[i]) + d) < thr;
+        if (!keep) valid[i] = 0;
+    }
+    const unsigned long long bal = __ballot(keep);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(kept, (unsigned long long)__popcll(bal));
+}
+
+// ------------------------------------------------------------------ refine_plane (PovMesh.cpp:581-660)
+struct RefineDev { double xmin, xmax, ymin, ymax, maxd; int weighted, umin, umax, vmin, vmax; };
+
+// block-level sum of NV doubles; partial sums go to out[block][NV] and are added on the host in block
+// order, so the result does not depend on scheduling
+template <int NV>
+__device__ __forceinline__ void block_sum_store(double (&v)[NV], double* __restrict__ out)
+{
+    __shared__ double sh[4][NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_down(v[k], o);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) sh[wv][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) out[(size_t)blockIdx.x * NV + k] = ((sh[0][k] + sh[1][k]) + sh[2][k]) + sh[3][k];
+}
+
+__device__ __forceinline__ bool refine_inlier(const RefineDev& rp, const uint8_t* valid, const double* X, const double* Y,
+                                              const double* Z, int w, size_t i, double& px, double& py, double& pz, double& wt)
+{
+    const int u = (int)(i % w), v = (int)(i / w);
+    if (u < rp.umin || u > rp.umax || v < rp.vmin || v > rp.vmax || !valid[i]) return false;
+    px = X[i]; py = Y[i]; pz = Z[i];
+    const double dist = sqrt(px * px + py * py + pz * pz);
+    if (!(px > rp.xmin && px < rp.xmax && py > rp.ymin && py < rp.ymax && dist < rp.maxd)) return false;
+    wt = rp.weighted ? dist : 1.0;
+    return true;
+}
+
+// pass 0: {count, wsum, sum w*x, sum w*y, sum w*z}
+__global__ void __launch_bounds__(256) k_refine_moments(const uint8_t* __restrict__ valid, const double* __restrict__ X,
+                                                        const double* __restrict__ Y, const double* __restrict__ Z, int w,
+                                                        size_t n, RefineDev rp, double* __restrict__ partial)
+{
+    double acc[5] = { 0, 0, 0, 0, 0 };
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        double px, py, pz, wt;
+        if (refine_inlier(rp, valid, X, Y, Z, w, i, px, py, pz, wt)) {
+            acc[0] += 1.0; acc[1] += wt; acc[2] += px * wt; acc[3] += py * wt; acc[4] += pz * wt;
+        }
+    }
+    block_sum_store<5>(acc, partial);
+}
+// pass 1: weighted scatter matrix around the centroid (6 unique entries)
+__global__ void __launch_bounds__(256) k_refine_cov(const uint8_t* __restrict__ valid, const double* __restrict__ X,
+                                                    const double* __restrict__ Y, const double* __restrict__ Z, int w, size_t n,
+                                                    RefineDev rp, double cx, double cy, double cz,
+                                                    double* __restrict__ partial)
+{
+    double acc[6] = { 0, 0, 0, 0, 0, 0 };
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        double px, py, pz, wt;
+        if (refine_inlier(rp, valid, X, Y, Z, w, i, px, py, pz, wt)) {
+            const double qx = px - cx, qy = py - cy, qz = pz - cz;
+            acc[0] += wt * qx * qx; acc[1] += wt * qx * qy; acc[2] += wt * qx * qz;
+            acc[3] += wt * qy * qy; acc[4] += wt * qy * qz; acc[5] += wt * qz * qz;
+        }
+    }
+    block_sum_store<6>(acc, partial);
+}
+
+// ------------------------------------------------------------------ xyzC (PovMesh.cpp:377-460)
+struct RTDev { double R[9], T[3]; };
+
+__device__ __forceinline__ unsigned long long dkey(double v)     // order-preserving map double -> u64
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+__host__ __device__ __forceinline__ double dunkey(unsigned long long k)
+{
+    const unsigned long long b = (k & 0x8000000000000000ull) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    double d;
+    memcpy(&d, &b, 8);
+    return d;
+}
+// min/max of R*p+T per axis (exact, order independent) + number of valid points per block
+__global__ void __launch_bounds__(256) k_xyzc_limits(const uint8_t* __restrict__ valid, const double* __restrict__ X,
+                                                     const double* __restrict__ Y, const double* __restrict__ Z, size_t n,
+                                                     RTDev rt, unsigned long long* __restrict__ lim /* min[3], max[3] as keys */,
+                                                     unsigned int* __restrict__ blockcnt)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool v = i < n && valid[i];
+    unsigned long long mn[3] = { ~0ull, ~0ull, ~0ull }, mx[3] = { 0, 0, 0 };
+    if (v) {
+        const double p[3] = { X[i], Y[i], Z[i] };
+        double t[3];
+        mulv(rt.R, p, t);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { mn[k] = mx[k] = dkey(t[k] + rt.T[k]); }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long a = __shfl_down(mn[k], o), b = __shfl_down(mx[k], o);
+            mn[k] = a < mn[k] ? a : mn[k];
+            mx[k] = b > mx[k] ? b : mx[k];
+        }
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (mn[k] != ~0ull) atomicMin(&lim[k], mn[k]);
+            if (mx[k] != 0) atomicMax(&lim[3 + k], mx[k]);
+        }
+    const int c = __syncthreads_count(v);
+    if (threadIdx.x == 0) blockcnt[blockIdx.x] = (unsigned)c;
+}
+// exclusive scan of the per-block counts (single block; nblocks <= ~25k at full size)
+__global__ void __launch_bounds__(1024) k_scan_blocks(unsigned int* __restrict__ cnt, int nb, unsigned int* __restrict__ total)
+{
+    __shared__ unsigned int sh[1024];
+    unsigned int carry = 0;
+    for (int base = 0; base < nb; base += 1024) {
+        const int i = base + threadIdx.x;
+        const unsigned int v = i < nb ? cnt[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const unsigned int t = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nb) cnt[i] = carry + sh[threadIdx.x] - v;
+        const unsigned int tot = sh[1023];
+        __syncthreads();
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+__global__ void __launch_bounds__(256) k_xyzc_pack(const uint8_t* __restrict__ valid, const double* __restrict__ X,
+                                                   const double* __restrict__ Y, const double* __restrict__ Z, size_t n,
+                                                   RTDev rt, double mnx, double mny, double mnz, double sx, double sy,
+                                                   double sz, const unsigned int* __restrict__ blockoff,
+                                                   uint16_t* __restrict__ out)
+{
+    __shared__ unsigned int wsum[4];
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool v = i < n && valid[i];
+    const unsigned long long bal = __ballot(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) wsum[wv] = (unsigned)__popcll(bal);
+    __syncthreads();
+    unsigned int off = blockoff[blockIdx.x];
+    for (int k = 0; k < wv; ++k) off += wsum[k];
+    off += (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+    if (v) {
+        const double p[3] = { X[i], Y[i], Z[i] };
+        double t[3];
+        mulv(rt.R, p, t);
+        t[0] += rt.T[0]; t[1] += rt.T[1]; t[2] += rt.T[2];
+        out[(size_t)off * 3 + 0] = (uint16_t)((t[0] - mnx) * sx);
+        out[(size_t)off * 3 + 1] = (uint16_t)((t[1] - mny) * sy);
+        out[(size_t)off * 3 + 2] = (uint16_t)((t[2] - mnz) * sz);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_interleave(const double* __restrict__ X, const double* __restrict__ Y,
+                                                    const double* __restrict__ Z, size_t n, double* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { out[3 * i] = X[i]; out[3 * i + 1] = Y[i]; out[3 * i + 2] = Z[i]; }
+}
+__global__ void __launch_bounds__(256) k_deinterleave(const double* __restrict__ in, size_t n, double* __restrict__ X,
+                                                      double* __restrict__ Y, double* __restrict__ Z)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { X[i] = in[3 * i]; Y[i] = in[3 * i + 1]; Z[i] = in[3 * i + 2]; }
+}
+
+static int mesh_alloc(wass_ctx* c, int w, int h, wass_mesh** out)
+{
+    wass_mesh* m = new (std::nothrow) wass_mesh();
+    if (!m) return set_err(c, WASS_ERR_NO_MEMORY, "out of host memory");
+    m->w = w; m->h = h;
+    const size_t n = m->n();
+    // one allocation: x | y | z | valid | gray
+    void* base = nullptr;
+    const size_t bytes = n * 8 * 3 + ((n + 255) & ~(size_t)255) * 2;
+    if (hipMalloc(&base, bytes) != hipSuccess) { delete m; return set_err(c, WASS_ERR_NO_MEMORY, "hipMalloc(%zu) failed", bytes); }
+    m->x = (double*)base; m->y = m->x + n; m->z = m->y + n;
+    m->valid = (uint8_t*)(m->z + n);
+    m->gray = m->valid + ((n + 255) & ~(size_t)255);
+    *out = m;
+    return WASS_OK;
+}
+
+static inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
+
+// smallest-eigenvalue eigenvector of a symmetric 3x3 (cyclic Jacobi); stands in for row 2 of cv::SVD's vt
+static void smallest_eigvec3(const double Ain[9], double vout[3])
+{
+    double A[3][3], V[3][3] = { { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } };
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) A[i][j] = Ain[i * 3 + j];
+    for (int it = 0; it < 64; it++) {
+        const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        const double diag = fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]);
+        if (off <= 1e-300 || off <= 1e-22 * diag) break;
+        for (int i = 0; i < 2; i++)
+            for (int j = i + 1; j < 3; j++) {
+                if (A[i][j] == 0.0) continue;
+                const double theta = (A[j][j] - A[i][i]) / (2.0 * A[i][j]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < 3; k++) { const double a = A[i][k], b = A[j][k]; A[i][k] = cs * a - sn * b; A[j][k] = sn * a + cs * b; }
+                for (int k = 0; k < 3; k++) { const double a = A[k][i], b = A[k][j]; A[k][i] = cs * a - sn * b; A[k][j] = sn * a + cs * b; }
+                for (int k = 0; k < 3; k++) { const double a = V[k][i], b = V[k][j]; V[k][i] = cs * a - sn * b; V[k][j] = sn * a + cs * b; }
+            }
+    }
+    int m = 0;
+    for (int i = 1; i < 3; i++) if (A[i][i] < A[m][m]) m = i;
+    const double nn = sqrt(V[0][m] * V[0][m] + V[1][m] * V[1][m] + V[2][m] * V[2][m]);
+    vout[0] = V[0][m] / nn; vout[1] = V[1][m] / nn; vout[2] = V[2][m] / nn;
+}
+
+}  // namespace wass
+
+using namespace wass;
+
+extern "C" {
+
+void wass_mesh_destroy(wass_mesh* m)
+{
+    if (!m) return;
+    if (m->x) (void)hipFree(m->x);
+    delete m;
+}
+
+int wass_mesh_size(const wass_mesh* m, int* width, int* height)
+{
+    if (!m) return WASS_ERR_INVALID_ARG;
+    if (width) *width = m->w;
+    if (height) *height = m->h;
+    return WASS_OK;
+}
+
+void wass_free(void* p) { free(p); }
+
+int wass_triangulate_dev(wass_ctx* c, const float* d_disp, int W, int H, const int roi_l[4], const int roi_r[4],
+                         const wass_geom* g, const uint8_t* d_right_img, int img_w, int img_h, const uint8_t* d_lmask,
+                         const uint8_t* d_rmask, const wass_tri_params* tp, wass_mesh** out, uint64_t* n_pts)
+{
+    if (!c || !d_disp || !roi_l || !roi_r || !g || !d_right_img || !tp || !out)
+        return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    if (roi_r[2] <= 0 || roi_r[3] <= 0 || W <= 0 || H <= 0 || img_w <= 0 || img_h <= 0)
+        return set_err(c, WASS_ERR_INVALID_ARG, "bad geometry");
+    if (g->dense_scale == 0.0) return set_err(c, WASS_ERR_INVALID_ARG, "dense_scale must be non-zero");
+    WASS_HIP(c, hipSetDevice(c->device));
+    wass_mesh* m = nullptr;
+    int rc = mesh_alloc(c, roi_r[2], roi_r[3], &m);
+    if (rc) return rc;
+    GeomDev gd;
+    memcpy(gd.Kl, g->K_left, sizeof gd.Kl); memcpy(gd.Kr, g->K_right, sizeof gd.Kr);
+    memcpy(gd.R, g->R, sizeof gd.R); memcpy(gd.T, g->T, sizeof gd.T);
+    gd.use_custom = g->use_custom;
+    memcpy(gd.R1, g->R1, sizeof gd.R1); memcpy(gd.R2, g->R2, sizeof gd.R2);
+    memcpy(gd.P1, g->P1, sizeof gd.P1); memcpy(gd.P2, g->P2, sizeof gd.P2);
+    memcpy(gd.HLi, g->HLi, sizeof gd.HLi); memcpy(gd.HRi, g->HRi, sizeof gd.HRi);
+    gd.comp_over_scale = g->disparity_compensation / g->dense_scale;
+    unsigned long long* cnt = (unsigned long long*)c->flags.p + 1;      // flags[8..15]
+    WASS_HIP(c, hipMemsetAsync(cnt, 0, 8, c->stream));
+    dim3 grid((m->w + 255) / 256, m->h);
+    hipLaunchKernelGGL(k_triangulate, grid, dim3(256), 0, c->stream, d_disp, W, H, roi_l[0], roi_r[0], roi_r[1], m->w, m->h,
+                       gd, d_right_img, img_w, img_h, d_lmask, d_rmask, tp->min_angle_deg, tp->bbox[0], tp->bbox[1],
+                       tp->bbox[2], tp->bbox[3], tp->cam_distance, m->valid, m->x, m->y, m->z, m->gray, cnt);
+    unsigned long long hc = 0;
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&hc, cnt, 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { wass_mesh_destroy(m); return set_err(c, WASS_ERR_DEVICE, "triangulate: %s", hipGetErrorString(e)); }
+    if (n_pts) *n_pts = hc;
+    *out = m;
+    return WASS_OK;
+}
+
+int wass_triangulate(wass_ctx* c, const float* disp, int W, int H, const int roi_l[4], const int roi_r[4], const wass_geom* g,
+                     const uint8_t* right_img, int img_w, int img_h, const uint8_t* lmask, const uint8_t* rmask,
+                     const wass_tri_params* tp, wass_mesh** out, uint64_t* n_pts)
+{
+    if (!c || !disp || !roi_r || !right_img) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    WASS_HIP(c, hipSetDevice(c->device));
+    const size_t nd = (size_t)roi_r[2] * roi_r[3], ni = (size_t)img_w * img_h;
+    int rc;
+    if ((rc = ensure(c, c->fC, nd * 4)) || (rc = ensure(c, c->tmp_in0, ni)) ||
+        (lmask && (rc = ensure(c, c->tmp_in1, ni))) || (rmask && (rc = ensure(c, c->tmp_mask, ni))))
+        return rc;
+    WASS_HIP(c, hipMemcpyAsync(c->fC.p, disp, nd * 4, hipMemcpyHostToDevice, c->stream));
+    WASS_HIP(c, hipMemcpyAsync(c->tmp_in0.p, right_img, ni, hipMemcpyHostToDevice, c->stream));
+    if (lmask) WASS_HIP(c, hipMemcpyAsync(c->tmp_in1.p, lmask, ni, hipMemcpyHostToDevice, c->stream));
+    if (rmask) WASS_HIP(c, hipMemcpyAsync(c->tmp_mask.p, rmask, ni, hipMemcpyHostToDevice, c->stream));
+    return wass_triangulate_dev(c, (const float*)c->fC.p, W, H, roi_l, roi_r, g, (const uint8_t*)c->tmp_in0.p, img_w, img_h,
+                                lmask ? (const uint8_t*)c->tmp_in1.p : nullptr, rmask ? (const uint8_t*)c->tmp_mask.p : nullptr,
+                                tp, out, n_pts);
+}
+
+int wass_mesh_download(wass_ctx* c, const wass_mesh* m, uint8_t* valid, double* p3d, uint8_t* gray)
+{
+    if (!c || !m) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    WASS_HIP(c, hipSetDevice(c->device));
+    const size_t n = m->n();
+    if (valid) WASS_HIP(c, hipMemcpyAsync(valid, m->valid, n, hipMemcpyDeviceToHost, c->stream));
+    if (gray) WASS_HIP(c, hipMemcpyAsync(gray, m->gray, n, hipMemcpyDeviceToHost, c->stream));
+    if (p3d) {
+        int rc = ensure(c, c->scratch, n * 24);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_interleave, dim3(nblk(n)), dim3(256), 0, c->stream, m->x, m->y, m->z, n, (double*)c->scratch.p);
+        WASS_HIP(c, hipMemcpyAsync(p3d, c->scratch.p, n * 24, hipMemcpyDeviceToHost, c->stream));
+    }
+    WASS_HIP(c, hipStreamSynchronize(c->stream));
+    return WASS_OK;
+}
+
+int wass_mesh_upload(wass_ctx* c, int width, int height, const uint8_t* valid, const double* p3d, const uint8_t* gray,
+                     wass_mesh** out)
+{
+    if (!c || !valid || !p3d || !out || width <= 0 || height <= 0) return set_err(c, WASS_ERR_INVALID_ARG, "bad argument");
+    WASS_HIP(c, hipSetDevice(c->device));
+    wass_mesh* m = nullptr;
+    int rc = mesh_alloc(c, width, height, &m);
+    if (rc) return rc;
+    const size_t n = m->n();
+    if ((rc = ensure(c, c->scratch, n * 24))) { wass_mesh_destroy(m); return rc; }
+    hipError_t e = hipMemcpyAsync(m->valid, valid, n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = gray ? hipMemcpyAsync(m->gray, gray, n, hipMemcpyHostToDevice, c->stream)
+                                  : hipMemsetAsync(m->gray, 0, n, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->scratch.p, p3d, n * 24, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_deinterleave, dim3(nblk(n)), dim3(256), 0, c->stream, (const double*)c->scratch.p, n, m->x, m->y, m->z);
+        e = hipStreamSynchronize(c->stream);
+    }
+    if (e != hipSuccess) { wass_mesh_destroy(m); return set_err(c, WASS_ERR_DEVICE, "mesh upload: %s", hipGetErrorString(e)); }
+    *out = m;
+    return WASS_OK;
+}
+
+int wass_mesh_zgap_percentile(wass_ctx* c, wass_mesh* m, double percentile, double* out, uint64_t* n_gaps)
+{
+    if (!c || !m || !out) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    WASS_HIP(c, hipSetDevice(c->device));
+    const size_t n = m->n(), ng = n * 3;
+    int rc = ensure(c, c->scratch, ng * 8 + 2048 * 4 + 64);
+    if (rc) return rc;
+    unsigned long long* gaps = (unsigned long long*)c->scratch.p;
+    unsigned int* hist = (unsigned int*)(gaps + ng);
+    unsigned long long* cnt = (unsigned long long*)c->flags.p + 1;
+    WASS_HIP(c, hipMemsetAsync(cnt, 0, 8, c->stream));
+    hipLaunchKernelGGL(k_zgaps, dim3((m->w + 255) / 256, m->h), dim3(256), 0, c->stream, m->valid, m->z, m->w, m->h, gaps, cnt);
+    unsigned long long total = 0;
+    WASS_HIP(c, hipMemcpyAsync(&total, cnt, 8, hipMemcpyDeviceToHost, c->stream));
+    WASS_HIP(c, hipStreamSynchronize(c->stream));
+    if (n_gaps) *n_gaps = total;
+    if (total == 0) { *out = NAN; return WASS_OK; }
+    // zgaps[floor(p/100 * n)] of the sorted list (:924), index clamped to n-1
+    unsigned long long k = (unsigned long long)floor(percentile / 100.0 * (double)total);
+    if (k >= total) k = total - 1;
+    unsigned long long prefix = 0;
+    std::vector<unsigned int> hh(2048);
+    int hi_shift = 64;
+    for (int pass = 0; pass < 6; ++pass) {
+        const int shift = pass < 5 ? 64 - 11 * (pass + 1) : 0;      // 53,42,31,20,9,0 (last digit: 9 bits)
+        WASS_HIP(c, hipMemsetAsync(hist, 0, 2048 * 4, c->stream));
+        hipLaunchKernelGGL(k_radix_hist, dim3(1024), dim3(256), 0, c->stream, (const unsigned long long*)gaps, ng, shift,
+                           pass < 5 ? 2047u : 511u, hi_shift, prefix, hist);
+        WASS_HIP(c, hipMemcpyAsync(hh.data(), hist, 2048 * 4, hipMemcpyDeviceToHost, c->stream));
+        WASS_HIP(c, hipStreamSynchronize(c->stream));
+        const int nb = pass < 5 ? 2048 : 512;
+        int b = 0;
+        for (; b < nb; ++b) { if (k < hh[b]) break; k -= hh[b]; }
+        if (b >= nb) return set_err(c, WASS_ERR_DEVICE, "radix select lost its rank (internal error)");
+        prefix = (pass < 5 ? (prefix << 11) : (prefix << 9)) | (unsigned long long)b;
+        hi_shift = shift;
+    }
+    double r;
+    memcpy(&r, &prefix, 8);
+    *out = r;
+    return WASS_OK;
+}
+
+int wass_mesh_keep_biggest_component(wass_ctx* c, wass_mesh* m, double zgap, uint64_t* size_out)
+{
+    if (!c || !m) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    WASS_HIP(c, hipSetDevice(c->device));
+    const size_t n = m->n();
+    if (n > 0x7FFFFFFFull) return set_err(c, WASS_ERR_UNSUPPORTED, "mesh too large");
+    int rc = ensure(c, c->scratch, n * 8);
+    if (rc) return rc;
+    int* parent = (int*)c->scratch.p;
+    unsigned int* size = (unsigned int*)(parent + n);
+    unsigned long long* best = (unsigned long long*)c->flags.p + 1;
+    const dim3 g2((m->w + 255) / 256, m->h), blk(256);
+    WASS_HIP(c, hipMemsetAsync(best, 0, 8, c->stream));
+    hipLaunchKernelGGL(k_ccl_init, g2, blk, 0, c->stream, m->valid, m->w, m->h, parent, size);
+    hipLaunchKernelGGL(k_ccl_merge, g2, blk, 0, c->stream, m->valid, m->z, m->w, m->h, zgap, parent);
+    hipLaunchKernelGGL(k_ccl_count, dim3(nblk(n)), blk, 0, c->stream, m->w, m->h, parent, size);
+    hipLaunchKernelGGL(k_ccl_best, dim3(nblk(n)), blk, 0, c->stream, (int)n, (const int*)parent, (const unsigned int*)size, best);
+    unsigned long long hb = 0;
+    WASS_HIP(c, hipMemcpyAsync(&hb, best, 8, hipMemcpyDeviceToHost, c->stream));
+    WASS_HIP(c, hipStreamSynchronize(c->stream));
+    // no valid point at all: the reference keeps component id 0, i.e. nothing
+    const int root = hb ? (int)(0xFFFFFFFFu - (unsigned)(hb & 0xFFFFFFFFull)) : -2;
+    hipLaunchKernelGGL(k_ccl_keep, g2, blk, 0, c->stream, m->valid, m->w, m->h, (const int*)parent, root);
+    WASS_HIP(c, hipGetLastError());
+    if (size_out) *size_out = hb >> 32;
+    return WASS_OK;
+}
+
+// PovMesh.cpp:680-691 with libc rand(); the caller has srand()'ed (wass_stereo.cpp:1864-1872).
+// GCC evaluates the arguments of cv::Vec2i(rand()%iW, rand()%iH) right to left: v is drawn first.
+int wass_ransac_sample(int width, int height, int rounds, int32_t* uv)
+{
+    if (width <= 0 || height <= 0 || rounds < 0 || !uv) return WASS_ERR_INVALID_ARG;
+    const double mindist = height * 0.01;
+    int r = 0;
+    long guard = 0;
+    while (r < rounds) {
+        int p[6];
+        for (int k = 0; k < 3; k++) { const int v = rand() % height; const int u = rand() % width; p[2 * k] = u; p[2 * k + 1] = v; }
+        const double d12 = sqrt((double)(p[0] - p[2]) * (p[0] - p[2]) + (double)(p[1] - p[3]) * (p[1] - p[3]));
+        const double d23 = sqrt((double)(p[2] - p[4]) * (p[2] - p[4]) + (double)(p[3] - p[5]) * (p[3] - p[5]));
+        const double d13 = sqrt((double)(p[0] - p[4]) * (p[0] - p[4]) + (double)(p[1] - p[5]) * (p[1] - p[5]));
+        if (d12 < mindist || d23 < mindist || d13 < mindist) {
+            if (++guard > 100000000L) return WASS_ERR_INVALID_ARG;   // degenerate grid (the reference would spin forever)
+            continue;
+        }
+        for (int k = 0; k < 6; k++) uv[(size_t)r * 6 + k] = p[k];
+        r++;
+    }
+    return WASS_OK;
+}
+
+int wass_mesh_ransac_plane(wass_ctx* c, wass_mesh* m, const int32_t* uv, int rounds, double thr, double plane_out[4],
+                           uint64_t* best_inliers, int* found)
+{
+    if (!c || !m || !uv || !plane_out || rounds <= 0) return set_err(c, WASS_ERR_INVALID_ARG, "bad argument");
+    for (int r = 0; r < rounds * 3; ++r)
+        if (uv[2 * r] < 0 || uv[2 * r] >= m->w || uv[2 * r + 1] < 0 || uv[2 * r + 1] >= m->h)
+            return set_err(c, WASS_ERR_INVALID_ARG, "sample %d outside the mesh grid", r / 3);
+    WASS_HIP(c, hipSetDevice(c->device));
+    const size_t n = m->n();
+    const size_t bytes = (size_t)rounds * (24 + sizeof(PlaneCand) + 8) + 256;
+    int rc = ensure(c, c->scratch, bytes);
+    if (rc) return rc;
+    PlaneCand* cand = (PlaneCand*)c->scratch.p;
+    unsigned long long* counts = (unsigned long long*)(cand + rounds);
+    int32_t* duv = (int32_t*)(counts + rounds);
+    WASS_HIP(c, hipMemcpyAsync(duv, uv, (size_t)rounds * 24, hipMemcpyHostToDevice, c->stream));
+    WASS_HIP(c, hipMemsetAsync(counts, 0, (size_t)rounds * 8, c->stream));
+    hipLaunchKernelGGL(k_ransac_planes, dim3((rounds + 63) / 64), dim3(64), 0, c->stream, m->valid, m->x, m->y, m->z, m->w,
+                       (const int32_t*)duv, rounds, cand);
+    constexpr int PTS = 4;
+    const size_t lds = (size_t)rounds * (32 + 4);
+    if (lds > 64 * 1024) return set_err(c, WASS_ERR_UNSUPPORTED, "PLANE_RANSAC_ROUNDS %d too large (max 1800)", rounds);
+    hipLaunchKernelGGL(k_ransac_score<PTS>, dim3((unsigned)((n + 256 * PTS - 1) / (256 * PTS))), dim3(256), lds, c->stream,
+                       m->valid, m->x, m->y, m->z, n, (const PlaneCand*)cand, rounds, thr, counts);
+    std::vector<PlaneCand> hc(rounds);
+    std::vector<unsigned long long> hn(rounds);
+    WASS_HIP(c, hipMemcpyAsync(hc.data(), cand, (size_t)rounds * sizeof(PlaneCand), hipMemcpyDeviceToHost, c->stream));
+    WASS_HIP(c, hipMemcpyAsync(hn.data(), counts, (size_t)rounds * 8, hipMemcpyDeviceToHost, c->stream));
+    WASS_HIP(c, hipStreamSynchronize(c->stream));
+    unsigned long long best = 0;
+    double bn[3] = { 0, 0, 0 }, bd = 0;
+    for (int r = 0; r < rounds; ++r)          // first strictly better candidate wins (:750-755)
+        if (hc[r].ok && hn[r] > best) { best = hn[r]; bn[0] = hc[r].n[0]; bn[1] = hc[r].n[1]; bn[2] = hc[r].n[2]; bd = hc[r].d; }
+    plane_out[0] = bn[0]; plane_out[1] = bn[1]; plane_out[2] = bn[2]; plane_out[3] = bd;
+    if (best_inliers) *best_inliers = best;
+    if (found) *found = best < n / 10 ? 0 : 1;  // :773
+    return WASS_OK;
+}
+
+int wass_mesh_crop_plane(wass_ctx* c, wass_mesh* m, const double plane[4], double thr, uint64_t* kept)
+{
+    if (!c || !m || !plane) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    WASS_HIP(c, hipSetDevice(c->device));
+    unsigned long long* cnt = (unsigned long long*)c->flags.p + 1;
+    WASS_HIP(c, hipMemsetAsync(cnt, 0, 8, c->stream));
+    hipLaunchKernelGGL(k_crop_plane, dim3(nblk(m->n())), dim3(256), 0, c->stream, m->valid, m->x, m->y, m->z, m->n(), plane[0],
+                       plane[1], plane[2], plane[3], thr, cnt);
+    unsigned long long hk = 0;
+    WASS_HIP(c, hipMemcpyAsync(&hk, cnt, 8, hipMemcpyDeviceToHost, c->stream));
+    WASS_HIP(c, hipStreamSynchronize(c->stream));
+    if (kept) *kept = hk;
+    return WASS_OK;
+}
+
+int wass_mesh_refine_plane(wass_ctx* c, wass_mesh* m, const wass_refine_params* rp, double plane_out[4], uint64_t* n_inliers)
+{
+    if (!c || !m || !rp || !plane_out) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    WASS_HIP(c, hipSetDevice(c->device));
+    RefineDev rd;
+    rd.xmin = rp->xmin; rd.xmax = rp->xmax; rd.ymin = rp->ymin; rd.ymax = rp->ymax; rd.maxd = rp->max_distance;
+    rd.weighted = rp->weight_by_distance;
+    rd.umin = rp->central_third_only ? m->w / 4 : 0;            // :585-588
+    rd.umax = rp->central_third_only ? m->w * 3 / 4 : m->w - 1;
+    rd.vmin = rp->central_third_only ? m->h / 4 : 0;
+    rd.vmax = rp->central_third_only ? m->h * 2 / 3 : m->h - 1;
+    const int NB = 1024;
+    int rc = ensure(c, c->scratch, (size_t)NB * 6 * 8);
+    if (rc) return rc;
+    double* part = (double*)c->scratch.p;
+    std::vector<double> hp((size_t)NB * 6);
+    hipLaunchKernelGGL(k_refine_moments, dim3(NB), dim3(256), 0, c->stream, m->valid, m->x, m->y, m->z, m->w, m->n(), rd, part);
+    WASS_HIP(c, hipMemcpyAsync(hp.data(), part, (size_t)NB * 5 * 8, hipMemcpyDeviceToHost, c->stream));
+    WASS_HIP(c, hipStreamSynchronize(c->stream));
+    double mom[5] = { 0, 0, 0, 0, 0 };
+    for (int b = 0; b < NB; ++b) for (int k = 0; k < 5; ++k) mom[k] += hp[(size_t)b * 5 + k];
+    if (n_inliers) *n_inliers = (uint64_t)(mom[0] + 0.5);
+    if (mom[0] < 3 || !(mom[1] > 0)) return set_err(c, WASS_ERR_TOO_FEW_POINTS, "plane refinement has %g inliers", mom[0]);
+    const double cx = mom[2] / mom[1], cy = mom[3] / mom[1], cz = mom[4] / mom[1];
+    hipLaunchKernelGGL(k_refine_cov, dim3(NB), dim3(256), 0, c->stream, m->valid, m->x, m->y, m->z, m->w, m->n(), rd, cx, cy, cz,
+                       part);
+    WASS_HIP(c, hipMemcpyAsync(hp.data(), part, (size_t)NB * 6 * 8, hipMemcpyDeviceToHost, c->stream));
+    WASS_HIP(c, hipStreamSynchronize(c->stream));
+    double s[6] = { 0, 0, 0, 0, 0, 0 };
+    for (int b = 0; b < NB; ++b) for (int k = 0; k < 6; ++k) s[k] += hp[(size_t)b * 6 + k];
+    const double A[9] = { s[0], s[1], s[2], s[1], s[3], s[4], s[2], s[4], s[5] };
+    double nrm[3];
+    smallest_eigvec3(A, nrm);
+    const double nn = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+    nrm[0] /= nn; nrm[1] /= nn; nrm[2] /= nn;
+    if (nrm[2] < 0) { nrm[0] *= -1.0; nrm[1] *= -1.0; nrm[2] *= -1.0; }   // :646-649
+    plane_out[0] = nrm[0]; plane_out[1] = nrm[1]; plane_out[2] = nrm[2];
+    plane_out[3] = -(nrm[0] * cx + nrm[1] * cy + nrm[2] * cz);
+    return WASS_OK;
+}
+
+void wass_RT_from_plane(const double plane[4], double R[9], double T[3], double Rinv[9], double Tinv[3])
+{
+    const double a = plane[0], b = plane[1], cc = plane[2], d = plane[3];
+    const double q = (1 - cc) / (a * a + b * b);
+    R[0] = 1 - a * a * q; R[1] = -a * b * q; R[2] = -a;
+    R[3] = -a * b * q; R[4] = 1 - b * b * q; R[5] = -b;
+    R[6] = a; R[7] = b; R[8] = cc;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rinv[i * 3 + j] = R[j * 3 + i];
+    T[0] = 0; T[1] = 0; T[2] = d;
+    const double mT[3] = { -T[0], -T[1], -T[2] };
+    for (int i = 0; i < 3; i++) Tinv[i] = Rinv[i * 3] * mT[0] + Rinv[i * 3 + 1] * mT[1] + Rinv[i * 3 + 2] * mT[2];
+}
+
+int wass_mesh_encode_xyzc(wass_ctx* c, wass_mesh* m, const double plane[4], void** bytes, size_t* nbytes)
+{
+    if (!c || !m || !bytes || !nbytes) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    WASS_HIP(c, hipSetDevice(c->device));
+    double R[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }, T[3] = { 0, 0, 0 }, Rinv[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }, Tinv[3] = { 0, 0, 0 };
+    if (plane) wass_RT_from_plane(plane, R, T, Rinv, Tinv);
+    RTDev rt;
+    memcpy(rt.R, R, sizeof R); memcpy(rt.T, T, sizeof T);
+    const size_t n = m->n();
+    const unsigned nb = nblk(n);
+    int rc = ensure(c, c->scratch, 64 + (size_t)nb * 4 + 16 + n * 6);
+    if (rc) return rc;
+    unsigned long long* lim = (unsigned long long*)c->scratch.p;           // 6 keys
+    unsigned int* total = (unsigned int*)(lim + 6);
+    unsigned int* bcnt = (unsigned int*)((char*)c->scratch.p + 64);
+    uint16_t* dq = (uint16_t*)((char*)c->scratch.p + ((64 + (size_t)nb * 4 + 15) & ~(size_t)15));
+    const unsigned long long init[6] = { ~0ull, ~0ull, ~0ull, 0, 0, 0 };
+    WASS_HIP(c, hipMemcpyAsync(lim, init, sizeof init, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_xyzc_limits, dim3(nb), dim3(256), 0, c->stream, m->valid, m->x, m->y, m->z, n, rt, lim, bcnt);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, c->stream, bcnt, (int)nb, total);
+    unsigned long long hl[6];
+    unsigned int npts = 0;
+    WASS_HIP(c, hipMemcpyAsync(hl, lim, sizeof hl, hipMemcpyDeviceToHost, c->stream));
+    WASS_HIP(c, hipMemcpyAsync(&npts, total, 4, hipMemcpyDeviceToHost, c->stream));
+    WASS_HIP(c, hipStreamSynchronize(c->stream));
+    double mn[3], mx[3], sc[3];
+    for (int k = 0; k < 3; ++k) {
+        // no valid point: the reference writes +-DBL_MAX limits; keep that
+        mn[k] = npts ? dunkey(hl[k]) : 1.7976931348623157e308;
+        mx[k] = npts ? dunkey(hl[3 + k]) : -1.7976931348623157e308;
+        sc[k] = 65535.0 / (mx[k] - mn[k]);
+    }
+    if (npts)
+        hipLaunchKernelGGL(k_xyzc_pack, dim3(nb), dim3(256), 0, c->stream, m->valid, m->x, m->y, m->z, n, rt, mn[0], mn[1], mn[2],
+                           sc[0], sc[1], sc[2], (const unsigned int*)bcnt, dq);
+    const size_t total_bytes = 148 + (size_t)npts * 6;
+    unsigned char* buf = (unsigned char*)malloc(total_bytes);
+    if (!buf) return set_err(c, WASS_ERR_NO_MEMORY, "out of host memory");
+    size_t o = 0;
+    const uint32_t n32 = npts;
+    memcpy(buf + o, &n32, 4); o += 4;
+    memcpy(buf + o, sc, 24); o += 24;
+    memcpy(buf + o, mn, 24); o += 24;
+    memcpy(buf + o, Rinv, 72); o += 72;
+    memcpy(buf + o, Tinv, 24); o += 24;
+    if (npts) {
+        hipError_t e = hipMemcpyAsync(buf + o, dq, (size_t)npts * 6, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { free(buf); return set_err(c, WASS_ERR_DEVICE, "xyzC download: %s", hipGetErrorString(e)); }
+    }
+    *bytes = buf;
+    *nbytes = total_bytes;
+    return WASS_OK;
+}
+
+// np.nanmean over planes.txt rows (wassgridsurface.py:672-678): a row counts if none of its entries is NaN
+// ("nan nan nan nan" is the only way wass_stereo writes NaN, wass_stereo.cpp:2104-2106)
+void wass_planes_mean_accumulate(const double* planes, int n, double acc5[5])
+{
+    for (int i = 0; i < n; ++i) {
+        const double* p = planes + (size_t)i * 4;
+        if (p[0] != p[0] || p[1] != p[1] || p[2] != p[2] || p[3] != p[3]) continue;
+        acc5[0] += p[0]; acc5[1] += p[1]; acc5[2] += p[2]; acc5[3] += p[3]; acc5[4] += 1.0;
+    }
+}
+
+void wass_planes_mean_finish(const double acc5[5], double mean_out[4], int* n_valid)
+{
+    const double n = acc5[4];
+    for (int k = 0; k < 4; ++k) mean_out[k] = n > 0 ? acc5[k] / n : NAN;
+    if (n_valid) *n_valid = (int)(n + 0.5);
+}
+
+}  // extern "C"

@@ -1,0 +1,159 @@
+// post.hip -- disparity clean-up after SGBM.
+//
+// float32 throughout, one thread per pixel, same operation order as the
+// reference so that results are bit-identical:
+//   clean_and_convert_disparity  wass_stereo/wass_stereo.cpp:714-733
+//   matrix_dilate_zero<float>    :617-662  (output column k is filled from the
+//                                 8-neighbourhood of column k+1 -- the quirk)
+//   matrix_erode_zero<float>     :665-711
+//   resize/mask step             :903-928  (same-size copies at DENSE_SCALE 1)
+//   cv::medianBlur (3 or 5)      :941-945
+#include "common.h"
+
+namespace wass {
+
+__global__ void __launch_bounds__(256) k_convert(const int16_t* __restrict__ d16, size_t n, int mindisp, int numdisp,
+                                                 int disp_offset, double scale, float* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float dval = ((float)d16[i]) / 16.0f;
+    float r = 0.0f;
+    if (!(dval <= (float)mindisp || dval > (float)numdisp)) {
+        dval += (float)disp_offset;
+        r = (float)((double)dval * scale);
+    }
+    out[i] = r;
+}
+
+__global__ void __launch_bounds__(256) k_dilate_zero(const float* __restrict__ src, float* __restrict__ out, int w, int h)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (k >= w) return;
+    const size_t idx = (size_t)i * w + k;
+    float v = src[idx];
+    // rows 1..h-2, output columns 0..w-3, stencil centred on column k+1
+    if (i >= 1 && i < h - 1 && k <= w - 3 && v == 0.0f) {
+        const float* t = src + (size_t)(i - 1) * w + (k + 1);
+        const float* b = src + (size_t)(i + 1) * w + (k + 1);
+        const float* c = src + (size_t)i * w + (k + 1);
+        float avg = 0.0f; int n = 0;
+        if (t[-1] > 0) { avg += t[-1]; ++n; }
+        if (t[1] > 0) { avg += t[1]; ++n; }
+        if (t[0] > 0) { avg += t[0]; ++n; }
+        if (b[-1] > 0) { avg += b[-1]; ++n; }
+        if (b[1] > 0) { avg += b[1]; ++n; }
+        if (b[0] > 0) { avg += b[0]; ++n; }
+        if (c[-1] > 0) { avg += c[-1]; ++n; }
+        if (c[1] > 0) { avg += c[1]; ++n; }
+        if (n > 1) v = avg / (float)n;
+    }
+    out[idx] = v;
+}
+
+// MASK: out = (eroded value == 0) ? 0 : keep[idx]   (the NN/cubic step, :908-928)
+template <bool MASK>
+__global__ void __launch_bounds__(256) k_erode_zero(const float* __restrict__ src, const float* __restrict__ keep,
+                                                    float* __restrict__ out, int w, int h)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= w) return;
+    const size_t idx = (size_t)i * w + j;
+    float v = src[idx];
+    if (i == 0 || i == h - 1) v = 0.0f;                         // first and last row
+    else if (j == 0 || (j == w - 1 && w >= 2)) v = 0.0f;        // first and last column
+    else if (j < w - 1) {
+        const float* t = src + idx - w;
+        const float* b = src + idx + w;
+        const float* c = src + idx;
+        if (t[0] == 0 || t[-1] == 0 || t[1] == 0 || b[0] == 0 || b[-1] == 0 || b[1] == 0 || c[-1] == 0 || c[1] == 0)
+            v = 0.0f;
+    }
+    out[idx] = MASK ? (v == 0.0f ? 0.0f : keep[idx]) : v;
+}
+
+// cv::medianBlur on CV_32F, ksize 3 or 5, replicate border.
+template <int KS>
+__global__ void __launch_bounds__(256) k_median_f32(const float* __restrict__ src, float* __restrict__ out, int w, int h)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= w) return;
+    constexpr int R = KS / 2, N = KS * KS;
+    float v[N];
+#pragma unroll
+    for (int a = -R; a <= R; ++a)
+#pragma unroll
+        for (int b = -R; b <= R; ++b) {
+            const int yy = min(max(y + a, 0), h - 1), xx = min(max(x + b, 0), w - 1);
+            v[(a + R) * KS + (b + R)] = src[(size_t)yy * w + xx];
+        }
+    // partial selection: after N/2+1 passes v[N/2] is the median
+#pragma unroll
+    for (int i = 0; i <= N / 2; ++i)
+#pragma unroll
+        for (int j = i + 1; j < N; ++j) {
+            const float lo = fminf(v[i], v[j]), hi = fmaxf(v[i], v[j]);
+            v[i] = lo; v[j] = hi;
+        }
+    out[(size_t)y * w + x] = v[N / 2];
+}
+
+}  // namespace wass
+
+using namespace wass;
+
+extern "C" int wass_disparity_postprocess_dev(wass_ctx* c, const int16_t* d_disp16, int w, int h,
+                                              const wass_sgm_params* p, int dilate_steps, int erode_steps,
+                                              int median_wsize, float* d_out)
+{
+    if (!c || !d_disp16 || !p || !d_out || w <= 0 || h <= 0) return set_err(c, WASS_ERR_INVALID_ARG, "bad argument");
+    if (p->dense_scale != 1.0) return set_err(c, WASS_ERR_UNSUPPORTED, "DENSE_SCALE != 1.0 is not supported");
+    if (median_wsize >= 3 && median_wsize != 3 && median_wsize != 5)
+        return set_err(c, WASS_ERR_UNSUPPORTED, "MEDIAN_FILTER_WSIZE must be 0, 3 or 5 for float maps (cv::medianBlur)");
+    WASS_HIP(c, hipSetDevice(c->device));
+    const size_t n = (size_t)w * h;
+    int rc;
+    if ((rc = ensure(c, c->fA, n * 4)) || (rc = ensure(c, c->fB, n * 4))) return rc;
+    float* a = (float*)c->fA.p;
+    float* b = (float*)c->fB.p;
+    hipStream_t s = c->stream;
+    const dim3 grid2((w + 255) / 256, h), blk(256);
+    const int off = p->disp_offset > 0 ? p->disp_offset : 0;    // :803-808
+    hipLaunchKernelGGL(k_convert, dim3((unsigned)((n + 255) / 256)), blk, 0, s, d_disp16, n, p->min_disp, p->num_disp,
+                       off, 1.0 / p->dense_scale, a);
+    for (int k = 1; k <= dilate_steps; ++k) {
+        hipLaunchKernelGGL(k_dilate_zero, grid2, blk, 0, s, (const float*)a, b, w, h);
+        float* t = a; a = b; b = t;
+    }
+    for (int k = 1; k <= erode_steps; ++k) {
+        hipLaunchKernelGGL(k_erode_zero<false>, grid2, blk, 0, s, (const float*)a, (const float*)nullptr, b, w, h);
+        float* t = a; a = b; b = t;
+    }
+    // :903-928  out = cubic copy (== a) where erode(NN copy == a) != 0
+    float* masked = median_wsize >= 3 ? b : d_out;
+    hipLaunchKernelGGL(k_erode_zero<true>, grid2, blk, 0, s, (const float*)a, (const float*)a, masked, w, h);
+    if (median_wsize == 3) hipLaunchKernelGGL(k_median_f32<3>, grid2, blk, 0, s, (const float*)masked, d_out, w, h);
+    else if (median_wsize == 5) hipLaunchKernelGGL(k_median_f32<5>, grid2, blk, 0, s, (const float*)masked, d_out, w, h);
+    WASS_HIP(c, hipGetLastError());
+    return WASS_OK;
+}
+
+extern "C" int wass_disparity_postprocess(wass_ctx* c, const int16_t* disp16, int w, int h, const wass_sgm_params* p,
+                                          int dilate_steps, int erode_steps, int median_wsize, float* out)
+{
+    if (!c || !disp16 || !out || w <= 0 || h <= 0) return set_err(c, WASS_ERR_INVALID_ARG, "bad argument");
+    WASS_HIP(c, hipSetDevice(c->device));
+    const size_t n = (size_t)w * h;
+    int rc;
+    if ((rc = ensure(c, c->tmp_out, n * 2)) || (rc = ensure(c, c->fC, n * 4))) return rc;
+    WASS_HIP(c, hipMemcpyAsync(c->tmp_out.p, disp16, n * 2, hipMemcpyHostToDevice, c->stream));
+    rc = wass_disparity_postprocess_dev(c, (const int16_t*)c->tmp_out.p, w, h, p, dilate_steps, erode_steps, median_wsize,
+                                        (float*)c->fC.p);
+    if (rc) return rc;
+    WASS_HIP(c, hipMemcpyAsync(out, c->fC.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    WASS_HIP(c, hipStreamSynchronize(c->stream));
+    return WASS_OK;
+}

@@ -12,7 +12,8 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import SgmParams, SgmTimings, WassError, default_sgm_params  # noqa: F401
+from ._lib import (Geom, RefineParams, SgmParams, SgmTimings, TriParams, WassError,  # noqa: F401
+                   default_sgm_params)
 
 
 class Context:
@@ -103,3 +104,174 @@ class Context:
             self._h, Cv.ctypes.data if Cv is not None else None, Sv.ctypes.data if Sv is not None else None,
             raw.ctypes.data if raw is not None else None))
         return Cv, Sv, raw
+
+    # ---- disparity clean-up (wass_stereo.cpp:853-945) -----------------------
+    def disparity_postprocess(self, disp16: np.ndarray, params: SgmParams, dilate_steps: int = 1,
+                              erode_steps: int = 2, median_wsize: int = 0) -> np.ndarray:
+        disp16 = np.ascontiguousarray(disp16, np.int16)
+        h, w = disp16.shape
+        out = np.empty((h, w), np.float32)
+        self._check(self._lib.wass_disparity_postprocess(self._h, disp16.ctypes.data, w, h, C.byref(params),
+                                                         dilate_steps, erode_steps, median_wsize, out.ctypes.data))
+        return out
+
+    def disparity_postprocess_dev(self, d_disp16, params: SgmParams, dilate_steps: int = 1, erode_steps: int = 2,
+                                  median_wsize: int = 0, d_out=None):
+        import torch
+        h, w = d_disp16.shape
+        if d_out is None:
+            d_out = torch.empty((h, w), dtype=torch.float32, device=d_disp16.device)
+        self._check(self._lib.wass_disparity_postprocess_dev(self._h, d_disp16.data_ptr(), w, h, C.byref(params),
+                                                             dilate_steps, erode_steps, median_wsize, d_out.data_ptr()))
+        return d_out
+
+    # ---- triangulate(StereoMatchEnv&) (wass_stereo.cpp:1039-1386) ------------
+    def triangulate(self, disp_roi, W, H, roi_l, roi_r, geom: Geom, right_img, left_mask=None, right_mask=None,
+                    min_angle_deg=20.0, bbox=None, cam_distance=1.0):
+        """Host arrays in -> (Mesh, n_points)."""
+        disp_roi = np.ascontiguousarray(disp_roi, np.float32)
+        right_img = np.ascontiguousarray(right_img, np.uint8)
+        ih, iw = right_img.shape
+        assert disp_roi.shape == (roi_r[3], roi_r[2])
+        lm = np.ascontiguousarray(left_mask, np.uint8) if left_mask is not None else None
+        rm = np.ascontiguousarray(right_mask, np.uint8) if right_mask is not None else None
+        tp = TriParams(min_angle_deg, (C.c_double * 4)(*(bbox or (0, 0, iw, ih))), cam_distance)
+        h = C.c_void_p(); n = C.c_uint64()
+        self._check(self._lib.wass_triangulate(
+            self._h, disp_roi.ctypes.data, W, H, (C.c_int * 4)(*roi_l), (C.c_int * 4)(*roi_r), C.byref(geom),
+            right_img.ctypes.data, iw, ih, lm.ctypes.data if lm is not None else None,
+            rm.ctypes.data if rm is not None else None, C.byref(tp), C.byref(h), C.byref(n)))
+        return Mesh(self, h), int(n.value)
+
+    def triangulate_dev(self, d_disp_roi, W, H, roi_l, roi_r, geom: Geom, d_right_img, d_left_mask=None,
+                        d_right_mask=None, min_angle_deg=20.0, bbox=None, cam_distance=1.0):
+        ih, iw = d_right_img.shape
+        tp = TriParams(min_angle_deg, (C.c_double * 4)(*(bbox or (0, 0, iw, ih))), cam_distance)
+        h = C.c_void_p(); n = C.c_uint64()
+        self._check(self._lib.wass_triangulate_dev(
+            self._h, d_disp_roi.data_ptr(), W, H, (C.c_int * 4)(*roi_l), (C.c_int * 4)(*roi_r), C.byref(geom),
+            d_right_img.data_ptr(), iw, ih, d_left_mask.data_ptr() if d_left_mask is not None else None,
+            d_right_mask.data_ptr() if d_right_mask is not None else None, C.byref(tp), C.byref(h), C.byref(n)))
+        return Mesh(self, h), int(n.value)
+
+    def mesh_upload(self, valid, p3d, gray=None):
+        valid = np.ascontiguousarray(valid, np.uint8)
+        p3d = np.ascontiguousarray(p3d, np.float64)
+        hh, ww = valid.shape
+        g = np.ascontiguousarray(gray, np.uint8) if gray is not None else None
+        h = C.c_void_p()
+        self._check(self._lib.wass_mesh_upload(self._h, ww, hh, valid.ctypes.data, p3d.ctypes.data,
+                                               g.ctypes.data if g is not None else None, C.byref(h)))
+        return Mesh(self, h)
+
+
+def make_geom(g: dict, use_custom=False, disparity_compensation=0.0, dense_scale=1.0) -> Geom:
+    """Fill a wass_geom from a dict of numpy matrices (keys as in synth.rig_geometry)."""
+    G = Geom()
+    for k in ("K_left", "K_right", "R", "T", "R1", "R2", "P1", "P2", "HLi", "HRi"):
+        getattr(G, k)[:] = np.asarray(g[k], np.float64).ravel().tolist()
+    G.use_custom = int(use_custom)
+    G.disparity_compensation = disparity_compensation
+    G.dense_scale = dense_scale
+    return G
+
+
+def ransac_sample(width: int, height: int, rounds: int, seed: int) -> np.ndarray:
+    """srand(seed) + the reference's sampling loop (PovMesh.cpp:680-691)."""
+    lib = _lib.load()
+    C.CDLL(None).srand(C.c_uint(seed))
+    uv = np.empty((rounds, 6), np.int32)
+    rc = lib.wass_ransac_sample(width, height, rounds, uv.ctypes.data)
+    if rc != 0:
+        raise WassError(rc, "wass_ransac_sample failed")
+    return uv
+
+
+def RT_from_plane(plane):
+    lib = _lib.load()
+    R = (C.c_double * 9)(); T = (C.c_double * 3)(); Ri = (C.c_double * 9)(); Ti = (C.c_double * 3)()
+    lib.wass_RT_from_plane((C.c_double * 4)(*plane), R, T, Ri, Ti)
+    return np.array(R[:]).reshape(3, 3), np.array(T[:]), np.array(Ri[:]).reshape(3, 3), np.array(Ti[:])
+
+
+def planes_mean_accumulate(planes, acc=None) -> np.ndarray:
+    lib = _lib.load()
+    planes = np.ascontiguousarray(planes, np.float64).reshape(-1, 4)
+    a = (C.c_double * 5)(*(acc if acc is not None else [0.0] * 5))
+    lib.wass_planes_mean_accumulate(planes.ctypes.data_as(C.POINTER(C.c_double)), len(planes), a)
+    return np.array(a[:])
+
+
+def planes_mean_finish(acc5):
+    lib = _lib.load()
+    out = (C.c_double * 4)(); n = C.c_int()
+    lib.wass_planes_mean_finish((C.c_double * 5)(*acc5), out, C.byref(n))
+    return np.array(out[:]), int(n.value)
+
+
+class Mesh:
+    """Device-resident organised point cloud (wass_mesh) -- the PovMesh of the reference."""
+
+    def __init__(self, ctx: Context, handle):
+        self.ctx, self._h = ctx, handle
+        w = C.c_int(); h = C.c_int()
+        ctx._lib.wass_mesh_size(handle, C.byref(w), C.byref(h))
+        self.width, self.height = w.value, h.value
+
+    def close(self):
+        if self._h:
+            self.ctx._lib.wass_mesh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def download(self):
+        n = self.width * self.height
+        valid = np.empty((self.height, self.width), np.uint8)
+        p3d = np.empty((self.height, self.width, 3), np.float64)
+        gray = np.empty((self.height, self.width), np.uint8)
+        self.ctx._check(self.ctx._lib.wass_mesh_download(self.ctx._h, self._h, valid.ctypes.data, p3d.ctypes.data,
+                                                         gray.ctypes.data))
+        return valid, p3d, gray
+
+    def zgap_percentile(self, pct: float):
+        out = C.c_double(); n = C.c_uint64()
+        self.ctx._check(self.ctx._lib.wass_mesh_zgap_percentile(self.ctx._h, self._h, pct, C.byref(out), C.byref(n)))
+        return out.value, int(n.value)
+
+    def keep_biggest_component(self, zgap: float) -> int:
+        n = C.c_uint64()
+        self.ctx._check(self.ctx._lib.wass_mesh_keep_biggest_component(self.ctx._h, self._h, zgap, C.byref(n)))
+        return int(n.value)
+
+    def ransac_plane(self, uv, thr: float):
+        uv = np.ascontiguousarray(uv, np.int32)
+        plane = (C.c_double * 4)(); best = C.c_uint64(); found = C.c_int()
+        self.ctx._check(self.ctx._lib.wass_mesh_ransac_plane(self.ctx._h, self._h, uv.ctypes.data, len(uv), thr, plane,
+                                                             C.byref(best), C.byref(found)))
+        return bool(found.value), np.array(plane[:]), int(best.value)
+
+    def crop_plane(self, plane, thr: float) -> int:
+        k = C.c_uint64()
+        self.ctx._check(self.ctx._lib.wass_mesh_crop_plane(self.ctx._h, self._h, (C.c_double * 4)(*plane), thr, C.byref(k)))
+        return int(k.value)
+
+    def refine_plane(self, xmin=-9999., xmax=9999., ymin=-9999., ymax=9999., max_distance=70.0,
+                     weight_by_distance=True, central_third_only=False):
+        rp = RefineParams(xmin, xmax, ymin, ymax, max_distance, int(weight_by_distance), int(central_third_only))
+        plane = (C.c_double * 4)(); n = C.c_uint64()
+        self.ctx._check(self.ctx._lib.wass_mesh_refine_plane(self.ctx._h, self._h, C.byref(rp), plane, C.byref(n)))
+        return np.array(plane[:]), int(n.value)
+
+    def encode_xyzc(self, plane=None) -> bytes:
+        buf = C.c_void_p(); nb = C.c_size_t()
+        pl = (C.c_double * 4)(*plane) if plane is not None else None
+        self.ctx._check(self.ctx._lib.wass_mesh_encode_xyzc(self.ctx._h, self._h, pl, C.byref(buf), C.byref(nb)))
+        try:
+            return C.string_at(buf, nb.value)
+        finally:
+            self.ctx._lib.wass_free(buf)
