@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--ndirs", type=int, default=8, choices=(5, 8))
     ap.add_argument("--config", default="B", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stage", default="full", choices=("full", "sgm"),
+                    help="full = a1-a20 (SGBM, clean-up, triangulation, plane fit, xyzC); sgm = a1-a6 only")
     args = ap.parse_args()
 
     import torch
@@ -86,10 +88,34 @@ def main():
         r, l = synth.make_pair(w, h, D, frame_idx=rank * 16 + k)
         frames.append((torch.from_numpy(r).to(dev), torch.from_numpy(l).to(dev)))
     out = torch.empty((h, w), dtype=torch.int16, device=dev)
+    dispf = torch.empty((h, w), dtype=torch.float32, device=dev)
+    geom = wass_amd.make_geom(synth.rig_geometry(w, h))
+    roi = (0, 0, w, h)
+    burned = [(fr[0] <= 254).to(torch.uint8) for fr in frames]      # DISCARD_BURNED_AREAS masks (right image)
+    planes, npts_hist, nbytes_hist = [], [], []
+    xyzc_host = torch.empty(148 + 6 * w * h, dtype=torch.uint8, pin_memory=True)    # mesh_cam.xyzC lands here
 
     def step(i):
         dr, dl = frames[i % 2]
         ctx.sgm_disparity_dev(dr, dl, params, out)
+        if args.stage == "sgm":
+            return
+        # wass_stereo.cpp main(): clean-up -> triangulate -> z-gap / biggest component -> RANSAC -> crop ->
+        # refine -> crop -> mesh_cam.xyzC (defaults of SURVEY.md Appendix C, RANDOM_SEED=12345)
+        ctx.disparity_postprocess_dev(out, params, 1, 2, 0, dispf)
+        mesh, n = ctx.triangulate_dev(dispf, w, h, roi, roi, geom, dr, None, burned[i % 2], 20.0, None, 1.0)
+        zg, _ = mesh.zgap_percentile(99.0)
+        mesh.keep_biggest_component(zg)
+        uv = wass_amd.ransac_sample(w, h, 400, 12345)
+        found, pl, _ = mesh.ransac_plane(uv, 1.0)
+        if found:
+            mesh.crop_plane(pl, 1.0)
+            pl, _ = mesh.refine_plane()
+            mesh.crop_plane(pl, 1.5)
+        nbytes = mesh.encode_xyzc_to(pl if found else None, xyzc_host.data_ptr(), xyzc_host.numel())
+        planes.append(pl if found else np.full(4, np.nan))
+        npts_hist.append(n); nbytes_hist.append(nbytes)
+        mesh.close()
 
     def barrier():
         torch.cuda.synchronize()
@@ -100,16 +126,24 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
-    agg_ms, cost_ms, sel_ms = [], [], []
+    planes.clear(); npts_hist.clear(); nbytes_hist.clear()
+    agg_ms, cost_ms, sel_ms, sgm_ms = [], [], [], []
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
         # stage timings come from hipEvents recorded on the context's own stream; reading them
         # waits for this frame, which is the reference's per-frame execution model anyway
         t = ctx.sgm_timings()
-        agg_ms.append(t.aggregate_ms); cost_ms.append(t.cost_ms); sel_ms.append(t.select_ms)
+        agg_ms.append(t.aggregate_ms); cost_ms.append(t.cost_ms); sel_ms.append(t.select_ms); sgm_ms.append(t.total_ms)
     barrier()
     elapsed = time.perf_counter() - t0
+    # Coll-1: sequence mean plane = NaN-aware mean over every rank's frames (5 doubles all-reduced over RCCL)
+    acc = wass_amd.planes_mean_accumulate(np.array(planes).reshape(-1, 4)) if planes else np.zeros(5)
+    if dist is not None:
+        acc_t = torch.tensor(acc, dtype=torch.float64, device=dev)
+        dist.all_reduce(acc_t, op=dist.ReduceOp.SUM)
+        acc = acc_t.cpu().numpy()
+    mean_plane, n_planes = wass_amd.planes_mean_finish(acc)
     if dist is not None:
         el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -131,14 +165,19 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16", "data": "synthetic",
             "config": {"workload": f"config {args.config}: {w}x{h} rectified pair, D={D}, {args.ndirs}-path SGBM "
-                                   f"(cost volume + aggregation + WTA/LR + median), frame-parallel over ranks",
-                       "width": w, "height": h, "num_disp": D, "ndirs": args.ndirs, "pairs_per_rank": args.steps},
+                                   + ("+ disparity clean-up + triangulation + z-gap/CC + RANSAC plane + refine + xyzC encode"
+                                      if args.stage == "full" else "(a1-a6 only)") + ", frame-parallel over ranks",
+                       "width": w, "height": h, "num_disp": D, "ndirs": args.ndirs, "pairs_per_rank": args.steps,
+                       "stage": args.stage},
             "roofline": {"bound": "hbm", "kernel": "k_sweep (path aggregation, all launches of one frame)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "algorithmic_bytes": alg_bytes, "ms": round(t_agg * 1e3, 3)},
             "stage_ms": {"cost_volume": round(float(np.mean(cost_ms)), 3), "aggregate": round(t_agg * 1e3, 3),
-                         "select": round(float(np.mean(sel_ms)), 3)},
+                         "select": round(float(np.mean(sel_ms)), 3), "sgm_total": round(float(np.mean(sgm_ms)), 3)},
+            "mean_plane": [None if x != x else round(float(x), 9) for x in mean_plane], "planes_averaged": n_planes,
+            "points_per_frame": int(np.mean(npts_hist)) if npts_hist else None,
+            "xyzc_bytes_per_frame": int(np.mean(nbytes_hist)) if nbytes_hist else None,
             "cost_overflow": int(overflow),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -207,6 +207,10 @@ void wass_RT_from_plane(const double plane[4], double R[9], double T[3], double 
  * failed): identity R, zero T are used (the reference reads uninitialised
  * memory there; documented divergence). */
 int wass_mesh_encode_xyzc(wass_ctx* ctx, wass_mesh* m, const double plane[4], void** bytes, size_t* nbytes);
+/* same, into a caller-owned buffer (>= 148 + 6*width*height bytes is always enough; pinned memory avoids a
+ * staging copy) */
+int wass_mesh_encode_xyzc_to(wass_ctx* ctx, wass_mesh* m, const double plane[4], void* dst, size_t capacity,
+                             size_t* nbytes);
 void wass_free(void* p);
 
 /* Coll-1: NaN-aware mean of per-frame planes (np.nanmean of planes.txt,

@@ -256,6 +256,11 @@ def test_xyzc_bytes_exact(gpu_ctx, oracle):
     # format sanity (Appendix B.1) and the no-plane fallback
     n = struct.unpack("<I", blob[:4])[0]
     assert n == valid.sum()
+    buf = np.empty(148 + 6 * valid.size, np.uint8)
+    nb = m.encode_xyzc_to(plane, buf.ctypes.data, buf.size)
+    assert buf[:nb].tobytes() == ref
+    with pytest.raises(wass_amd.WassError):
+        m.encode_xyzc_to(plane, buf.ctypes.data, 200)
     blob2 = m.encode_xyzc(None)
     Rinv = np.frombuffer(blob2[52:124], np.float64).reshape(3, 3)
     np.testing.assert_array_equal(Rinv, np.eye(3))

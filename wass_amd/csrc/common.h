@@ -114,6 +114,7 @@ struct wass_ctx {
     wass::Buf tmp_in0, tmp_in1, tmp_out;   // staging for the host-pointer entry points
     wass::Buf tmp_mask;
     wass::Buf fA, fB, fC;          // float32 maps of the disparity clean-up
+    wass::Buf counters;            // striped atomics of the mesh stages
     wass::Buf scratch;             // mesh stages: gaps / labels / partial sums / packed output
     hipEvent_t ev[8] = {};
     hipStream_t side = nullptr;    // checkpoint sweeps run ahead here

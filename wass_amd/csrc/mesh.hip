@@ -11,6 +11,7 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -21,6 +22,8 @@ struct wass_mesh {
     double* y = nullptr;
     double* z = nullptr;
     uint8_t* gray = nullptr;
+    size_t bytes = 0;
+    int device = 0;
     size_t n() const { return (size_t)w * h; }
 };
 
@@ -45,6 +48,11 @@ __device__ __forceinline__ void tmulv(const double* M, const double* v, double* 
     o[1] = M[1] * v[0] + M[4] * v[1] + M[7] * v[2];
     o[2] = M[2] * v[0] + M[5] * v[1] + M[8] * v[2];
 }
+
+// Counters are striped over NSLOT addresses (summed on the host): tens of thousands of waves hitting one
+// address serialise at ~12 ns per atomic, which would dominate these otherwise trivial kernels.
+constexpr int NSLOT = 64;
+__device__ __forceinline__ int slot_of_block() { return (int)((blockIdx.x * 7u + blockIdx.y * 13u + (threadIdx.x >> 6)) & (NSLOT - 1)); }
 
 // StereoMatchEnv::unrectify (wass_stereo.cpp:299-324)
 __device__ __forceinline__ void unrectify(const GeomDev& g, double u, double v, bool left, double* out)
@@ -167,7 +175,7 @@ __global__ void __launch_bounds__(256) k_triangulate(const float* __restrict__ d
     X[idx] = ok ? P[0] : 0.0; Y[idx] = ok ? P[1] : 0.0; Z[idx] = ok ? P[2] : 0.0;
     gray[idx] = gv;
     const unsigned long long b = __ballot(ok);
-    if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, (unsigned long long)__popcll(b));
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(count + slot_of_block(), (unsigned long long)__popcll(b));
 }
 
 // ------------------------------------------------------------------ z-gap percentile (PovMesh.cpp:888-926)
@@ -193,7 +201,7 @@ __global__ void __launch_bounds__(256) k_zgaps(const uint8_t* __restrict__ valid
     // wave-level count
     int s = n;
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd(count, (unsigned long long)s);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(count + slot_of_block(), (unsigned long long)s);
 }
 
 // one MSD radix-select pass: histogram of an 11-bit digit among keys whose higher bits equal `prefix`
@@ -216,15 +224,21 @@ __global__ void __launch_bounds__(256) k_radix_hist(const unsigned long long* __
 }
 
 // ------------------------------------------------------------------ connected components (PovMesh.cpp:929-987)
-// Labels live in COLUMN-MAJOR index space (cm = u*h + v): the reference scans seeds column by
-// column, so the smallest cm index of a component is its seed and decides ties.
-__device__ __forceinline__ int uf_find(int* __restrict__ parent, int a)
+// Union-find over RASTER indices (coalesced, neighbours are near in memory).  Horizontal runs are
+// labelled up front by a segmented scan, so the merge pass only stitches runs that touch vertically.
+// The reference finds seeds in COLUMN-MAJOR order and keeps the first strictly largest component, so
+// ties are decided by the smallest column-major index (u*h + v) of a component -- tracked per root.
+__device__ __forceinline__ int uf_find(int* parent, int a)
 {
+    // path halving: every visited node is re-pointed at its grandparent.  Labels only ever move towards
+    // smaller ancestors, so the unsynchronised writes always store a valid ancestor.
     int p = parent[a];
-    while (p != a) { a = p; p = parent[a]; }
-    return a;
+    if (p == a) return a;
+    int g;
+    while ((g = parent[p]) != p) { parent[a] = g; a = p; p = g; }
+    return p;
 }
-__device__ __forceinline__ void uf_union(int* __restrict__ parent, int a, int b)
+__device__ __forceinline__ void uf_union(int* parent, int a, int b)
 {
     for (;;) {
         a = uf_find(parent, a);
@@ -236,57 +250,111 @@ __device__ __forceinline__ void uf_union(int* __restrict__ parent, int a, int b)
         b = old;
     }
 }
-__global__ void __launch_bounds__(256) k_ccl_init(const uint8_t* __restrict__ valid, int w, int h, int* __restrict__ parent,
-                                                  unsigned int* __restrict__ size)
+// link between raster pixel i and its left neighbour (same row)
+__device__ __forceinline__ bool hlink(const uint8_t* valid, const double* Z, int w, int i, double zgap)
 {
-    const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
-    if (u >= w) return;
-    const int cm = u * h + v;
-    parent[cm] = valid[(size_t)v * w + u] ? cm : -1;
-    size[cm] = 0;
+    return (i % w) != 0 && valid[i] && valid[i - 1] && fabs(Z[i] - Z[i - 1]) < zgap;
 }
-__global__ void __launch_bounds__(256) k_ccl_merge(const uint8_t* __restrict__ valid, const double* __restrict__ Z, int w, int h,
-                                                   double zgap, int* __restrict__ parent)
+// link between raster pixel i and the pixel below it
+__device__ __forceinline__ bool vlink(const uint8_t* valid, const double* Z, int w, int n, int i, double zgap)
 {
-    const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
-    if (u >= w) return;
-    const size_t c = (size_t)v * w + u;
-    if (!valid[c]) return;
-    const double z = Z[c];
-    const int cm = u * h + v;
-    if (u + 1 < w && valid[c + 1] && fabs(z - Z[c + 1]) < zgap) uf_union(parent, cm, cm + h);
-    if (v + 1 < h && valid[c + w] && fabs(z - Z[c + w]) < zgap) uf_union(parent, cm, cm + 1);
+    return i + w < n && valid[i] && valid[i + w] && fabs(Z[i] - Z[i + w]) < zgap;
 }
-__global__ void __launch_bounds__(256) k_ccl_count(int w, int h, int* __restrict__ parent, unsigned int* __restrict__ size)
+__global__ void __launch_bounds__(256) k_ccl_init(const uint8_t* __restrict__ valid, const double* __restrict__ Z, int w, int n,
+                                                  double zgap, int* __restrict__ parent, unsigned int* __restrict__ size,
+                                                  unsigned int* __restrict__ mincm)
 {
-    const int cm = blockIdx.x * 256 + threadIdx.x;
-    if (cm >= w * h || parent[cm] < 0) return;
-    const int r = uf_find(parent, cm);
-    parent[cm] = r;                                  // benign race: every writer stores a valid ancestor
-    atomicAdd(&size[r], 1u);
+    __shared__ int wmax[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool v = i < n && valid[i];
+    // start of my horizontal run inside this block = last "break" at or before me
+    int s = (threadIdx.x == 0 || !v || !hlink(valid, Z, w, i, zgap)) ? i : -1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(s, o); if (lane >= o) s = max(s, t); }
+    if (lane == 63) wmax[wv] = s;
+    __syncthreads();
+    for (int k = 0; k < wv; ++k) s = max(s, wmax[k]);
+    if (i < n) { parent[i] = v ? s : -1; size[i] = 0; mincm[i] = 0xFFFFFFFFu; }
 }
-// best = max over roots of (size << 32 | ~root): largest size, then smallest column-major seed
+__global__ void __launch_bounds__(256) k_ccl_merge(const uint8_t* __restrict__ valid, const double* __restrict__ Z, int w, int n,
+                                                   double zgap, int* parent)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !valid[i]) return;
+    // runs were cut at block boundaries: stitch them
+    if (threadIdx.x == 0 && hlink(valid, Z, w, i, zgap)) uf_union(parent, i, i - 1);
+    if (vlink(valid, Z, w, n, i, zgap)) {
+        // the pixel to the left already made this union if both rows continue their runs and it links down too
+        const bool dup = hlink(valid, Z, w, i, zgap) && hlink(valid, Z, w, i + w, zgap) && vlink(valid, Z, w, n, i - 1, zgap);
+        if (!dup) uf_union(parent, i, i + w);
+    }
+}
+// every node points straight at its root.  Roots are fixed once merging is done; each thread writes only its
+// own entry (a read-only walk), so no concurrent path-halving write can leave a node short of its root.
+__global__ void __launch_bounds__(256) k_ccl_flatten(int n, int* parent)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int p = parent[i];
+    if (p < 0) return;
+    int a = i;
+    while (p != a) { a = p; p = parent[a]; }
+    parent[i] = a;
+}
+// component sizes and smallest column-major index: one update per run of equal roots inside a wave, and the
+// dominant root of a block is pre-aggregated in LDS
+__global__ void __launch_bounds__(1024) k_ccl_count(int n, int w, int h, const int* __restrict__ parent,
+                                                    unsigned int* __restrict__ size, unsigned int* __restrict__ mincm)
+{
+    __shared__ int r0s;
+    __shared__ unsigned int agg, aggmin;
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const int r = i < n ? parent[i] : -1;
+    if (threadIdx.x == 0) { r0s = r; agg = 0; aggmin = 0xFFFFFFFFu; }
+    __syncthreads();
+    const int r0 = r0s;
+    const int lane = threadIdx.x & 63;
+    const int prev = __shfl_up(r, 1);
+    // a run also ends at a row boundary so that its head has the smallest column index of the run
+    const bool head = r >= 0 && (lane == 0 || prev != r || (i % w) == 0);
+    const unsigned long long heads = __ballot(head || r < 0);
+    if (head) {
+        const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+        const int len = above ? (__ffsll((long long)above)) : (64 - lane);
+        const unsigned int cm = (unsigned)((i % w) * h + (i / w));
+        if (r == r0) { atomicAdd(&agg, (unsigned)len); atomicMin(&aggmin, cm); }      // LDS
+        else { atomicAdd(&size[r], (unsigned)len); atomicMin(&mincm[r], cm); }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && agg) { atomicAdd(&size[r0], agg); atomicMin(&mincm[r0], aggmin); }
+}
+// best = max over roots of (size << 32 | ~mincm): largest size, then earliest column-major seed
 __global__ void __launch_bounds__(256) k_ccl_best(int n, const int* __restrict__ parent, const unsigned int* __restrict__ size,
-                                                  unsigned long long* __restrict__ best)
+                                                  const unsigned int* __restrict__ mincm, unsigned long long* __restrict__ best)
 {
-    const int cm = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 256 + threadIdx.x;
     unsigned long long key = 0;
-    if (cm < n && parent[cm] == cm) key = ((unsigned long long)size[cm] << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)cm);
+    if (i < n && parent[i] == i) key = ((unsigned long long)size[i] << 32) | (unsigned long long)(0xFFFFFFFFu - mincm[i]);
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned long long other = __shfl_down(key, o);
         key = other > key ? other : key;
     }
     if ((threadIdx.x & 63) == 0 && key) atomicMax(best, key);
 }
-__global__ void __launch_bounds__(256) k_ccl_keep(uint8_t* __restrict__ valid, int w, int h, const int* __restrict__ parent,
-                                                  int root)
+// keep the component whose (size, mincm) equals the winner
+__global__ void __launch_bounds__(256) k_ccl_keep(uint8_t* __restrict__ valid, int n, const int* __restrict__ parent,
+                                                  const unsigned int* __restrict__ size, const unsigned int* __restrict__ mincm,
+                                                  const unsigned long long* __restrict__ best)
 {
-    const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
-    if (u >= w) return;
-    const int cm = u * h + v;
-    int r = parent[cm];
-    if (r >= 0) r = uf_find((int*)parent, cm);
-    valid[(size_t)v * w + u] = (r == root) ? 1 : 0;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int r = parent[i];
+    bool keep = false;
+    if (r >= 0) {
+        const unsigned long long key = ((unsigned long long)size[r] << 32) | (unsigned long long)(0xFFFFFFFFu - mincm[r]);
+        keep = key == *best;
+    }
+    valid[i] = keep ? 1 : 0;
 }
 
 // ------------------------------------------------------------------ RANSAC (PovMesh.cpp:665-777)
@@ -375,7 +443,7 @@ __global__ void __launch_bounds__(256) k_crop_plane(uint8_t* __restrict__ valid,
         if (!keep) valid[i] = 0;
     }
     const unsigned long long bal = __ballot(keep);
-    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(kept, (unsigned long long)__popcll(bal));
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(kept + slot_of_block(), (unsigned long long)__popcll(bal));
 }
 
 // ------------------------------------------------------------------ refine_plane (PovMesh.cpp:581-660)
@@ -460,20 +528,29 @@ __host__ __device__ __forceinline__ double dunkey(unsigned long long k)
     return d;
 }
 // min/max of R*p+T per axis (exact, order independent) + number of valid points per block
-__global__ void __launch_bounds__(256) k_xyzc_limits(const uint8_t* __restrict__ valid, const double* __restrict__ X,
-                                                     const double* __restrict__ Y, const double* __restrict__ Z, size_t n,
-                                                     RTDev rt, unsigned long long* __restrict__ lim /* min[3], max[3] as keys */,
-                                                     unsigned int* __restrict__ blockcnt)
+__global__ void __launch_bounds__(256) k_block_counts(const uint8_t* __restrict__ valid, size_t n,
+                                                      unsigned int* __restrict__ blockcnt)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const bool v = i < n && valid[i];
+    const int c = __syncthreads_count(i < n && valid[i]);
+    if (threadIdx.x == 0) blockcnt[blockIdx.x] = (unsigned)c;
+}
+__global__ void __launch_bounds__(256) k_xyzc_limits(const uint8_t* __restrict__ valid, const double* __restrict__ X,
+                                                     const double* __restrict__ Y, const double* __restrict__ Z, size_t n,
+                                                     RTDev rt, unsigned long long* __restrict__ lim /* [NSLOT][6] keys */)
+{
     unsigned long long mn[3] = { ~0ull, ~0ull, ~0ull }, mx[3] = { 0, 0, 0 };
-    if (v) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        if (!valid[i]) continue;
         const double p[3] = { X[i], Y[i], Z[i] };
         double t[3];
         mulv(rt.R, p, t);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { mn[k] = mx[k] = dkey(t[k] + rt.T[k]); }
+        for (int k = 0; k < 3; ++k) {
+            const unsigned long long key = dkey(t[k] + rt.T[k]);
+            mn[k] = key < mn[k] ? key : mn[k];
+            mx[k] = key > mx[k] ? key : mx[k];
+        }
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k)
@@ -482,14 +559,14 @@ __global__ void __launch_bounds__(256) k_xyzc_limits(const uint8_t* __restrict__
             mn[k] = a < mn[k] ? a : mn[k];
             mx[k] = b > mx[k] ? b : mx[k];
         }
-    if ((threadIdx.x & 63) == 0)
+    if ((threadIdx.x & 63) == 0) {
+        unsigned long long* l = lim + (size_t)slot_of_block() * 6;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            if (mn[k] != ~0ull) atomicMin(&lim[k], mn[k]);
-            if (mx[k] != 0) atomicMax(&lim[3 + k], mx[k]);
+            if (mn[k] != ~0ull) atomicMin(&l[k], mn[k]);
+            if (mx[k] != 0) atomicMax(&l[3 + k], mx[k]);
         }
-    const int c = __syncthreads_count(v);
-    if (threadIdx.x == 0) blockcnt[blockIdx.x] = (unsigned)c;
+    }
 }
 // exclusive scan of the per-block counts (single block; nblocks <= ~25k at full size)
 __global__ void __launch_bounds__(1024) k_scan_blocks(unsigned int* __restrict__ cnt, int nb, unsigned int* __restrict__ total)
@@ -554,6 +631,26 @@ __global__ void __launch_bounds__(256) k_deinterleave(const double* __restrict__
     if (i < n) { X[i] = in[3 * i]; Y[i] = in[3 * i + 1]; Z[i] = in[3 * i + 2]; }
 }
 
+// hipMalloc / hipFree cost milliseconds and synchronise the device, so destroyed meshes park their allocation in a
+// small process-wide pool and the next frame of the same size takes it back.
+struct PoolEntry { void* p; size_t bytes; int device; };
+static PoolEntry g_pool[4];
+static std::mutex g_pool_mu;
+static void* pool_take(size_t bytes, int device)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (auto& e : g_pool)
+        if (e.p && e.bytes == bytes && e.device == device) { void* p = e.p; e.p = nullptr; return p; }
+    return nullptr;
+}
+static bool pool_give(void* p, size_t bytes, int device)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (auto& e : g_pool)
+        if (!e.p) { e.p = p; e.bytes = bytes; e.device = device; return true; }
+    return false;
+}
+
 static int mesh_alloc(wass_ctx* c, int w, int h, wass_mesh** out)
 {
     wass_mesh* m = new (std::nothrow) wass_mesh();
@@ -561,9 +658,10 @@ static int mesh_alloc(wass_ctx* c, int w, int h, wass_mesh** out)
     m->w = w; m->h = h;
     const size_t n = m->n();
     // one allocation: x | y | z | valid | gray
-    void* base = nullptr;
     const size_t bytes = n * 8 * 3 + ((n + 255) & ~(size_t)255) * 2;
-    if (hipMalloc(&base, bytes) != hipSuccess) { delete m; return set_err(c, WASS_ERR_NO_MEMORY, "hipMalloc(%zu) failed", bytes); }
+    m->bytes = bytes; m->device = c->device;
+    void* base = pool_take(bytes, c->device);
+    if (!base && hipMalloc(&base, bytes) != hipSuccess) { delete m; return set_err(c, WASS_ERR_NO_MEMORY, "hipMalloc(%zu) failed", bytes); }
     m->x = (double*)base; m->y = m->x + n; m->z = m->y + n;
     m->valid = (uint8_t*)(m->z + n);
     m->gray = m->valid + ((n + 255) & ~(size_t)255);
@@ -572,6 +670,26 @@ static int mesh_alloc(wass_ctx* c, int w, int h, wass_mesh** out)
 }
 
 static inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
+
+// striped device counters (NSLOT u64) -> host sum
+static int counters_reset(wass_ctx* c, unsigned long long** cnt)
+{
+    int rc = ensure(c, c->counters, (size_t)NSLOT * 6 * 8);
+    if (rc) return rc;
+    *cnt = (unsigned long long*)c->counters.p;
+    WASS_HIP(c, hipMemsetAsync(*cnt, 0, (size_t)NSLOT * 8, c->stream));
+    return WASS_OK;
+}
+static int counters_sum(wass_ctx* c, const unsigned long long* cnt, unsigned long long* out)
+{
+    unsigned long long h[NSLOT];
+    WASS_HIP(c, hipMemcpyAsync(h, cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    WASS_HIP(c, hipStreamSynchronize(c->stream));
+    unsigned long long s = 0;
+    for (int i = 0; i < NSLOT; ++i) s += h[i];
+    *out = s;
+    return WASS_OK;
+}
 
 // smallest-eigenvalue eigenvector of a symmetric 3x3 (cyclic Jacobi); stands in for row 2 of cv::SVD's vt
 static void smallest_eigvec3(const double Ain[9], double vout[3])
@@ -608,7 +726,7 @@ extern "C" {
 void wass_mesh_destroy(wass_mesh* m)
 {
     if (!m) return;
-    if (m->x) (void)hipFree(m->x);
+    if (m->x && !pool_give(m->x, m->bytes, m->device)) { (void)hipSetDevice(m->device); (void)hipFree(m->x); }
     delete m;
 }
 
@@ -643,17 +761,16 @@ int wass_triangulate_dev(wass_ctx* c, const float* d_disp, int W, int H, const i
     memcpy(gd.P1, g->P1, sizeof gd.P1); memcpy(gd.P2, g->P2, sizeof gd.P2);
     memcpy(gd.HLi, g->HLi, sizeof gd.HLi); memcpy(gd.HRi, g->HRi, sizeof gd.HRi);
     gd.comp_over_scale = g->disparity_compensation / g->dense_scale;
-    unsigned long long* cnt = (unsigned long long*)c->flags.p + 1;      // flags[8..15]
-    WASS_HIP(c, hipMemsetAsync(cnt, 0, 8, c->stream));
+    unsigned long long* cnt = nullptr;
+    if ((rc = counters_reset(c, &cnt))) { wass_mesh_destroy(m); return rc; }
     dim3 grid((m->w + 255) / 256, m->h);
     hipLaunchKernelGGL(k_triangulate, grid, dim3(256), 0, c->stream, d_disp, W, H, roi_l[0], roi_r[0], roi_r[1], m->w, m->h,
                        gd, d_right_img, img_w, img_h, d_lmask, d_rmask, tp->min_angle_deg, tp->bbox[0], tp->bbox[1],
                        tp->bbox[2], tp->bbox[3], tp->cam_distance, m->valid, m->x, m->y, m->z, m->gray, cnt);
     unsigned long long hc = 0;
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(&hc, cnt, 8, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { wass_mesh_destroy(m); return set_err(c, WASS_ERR_DEVICE, "triangulate: %s", hipGetErrorString(e)); }
+    if ((rc = counters_sum(c, cnt, &hc))) { wass_mesh_destroy(m); return rc; }
     if (n_pts) *n_pts = hc;
     *out = m;
     return WASS_OK;
@@ -728,12 +845,11 @@ int wass_mesh_zgap_percentile(wass_ctx* c, wass_mesh* m, double percentile, doub
     if (rc) return rc;
     unsigned long long* gaps = (unsigned long long*)c->scratch.p;
     unsigned int* hist = (unsigned int*)(gaps + ng);
-    unsigned long long* cnt = (unsigned long long*)c->flags.p + 1;
-    WASS_HIP(c, hipMemsetAsync(cnt, 0, 8, c->stream));
+    unsigned long long* cnt = nullptr;
+    if ((rc = counters_reset(c, &cnt))) return rc;
     hipLaunchKernelGGL(k_zgaps, dim3((m->w + 255) / 256, m->h), dim3(256), 0, c->stream, m->valid, m->z, m->w, m->h, gaps, cnt);
     unsigned long long total = 0;
-    WASS_HIP(c, hipMemcpyAsync(&total, cnt, 8, hipMemcpyDeviceToHost, c->stream));
-    WASS_HIP(c, hipStreamSynchronize(c->stream));
+    if ((rc = counters_sum(c, cnt, &total))) return rc;
     if (n_gaps) *n_gaps = total;
     if (total == 0) { *out = NAN; return WASS_OK; }
     // zgaps[floor(p/100 * n)] of the sorted list (:924), index clamped to n-1
@@ -768,25 +884,32 @@ int wass_mesh_keep_biggest_component(wass_ctx* c, wass_mesh* m, double zgap, uin
     WASS_HIP(c, hipSetDevice(c->device));
     const size_t n = m->n();
     if (n > 0x7FFFFFFFull) return set_err(c, WASS_ERR_UNSUPPORTED, "mesh too large");
-    int rc = ensure(c, c->scratch, n * 8);
+    int rc = ensure(c, c->scratch, n * 12);
     if (rc) return rc;
     int* parent = (int*)c->scratch.p;
     unsigned int* size = (unsigned int*)(parent + n);
+    unsigned int* mincm = size + n;
     unsigned long long* best = (unsigned long long*)c->flags.p + 1;
-    const dim3 g2((m->w + 255) / 256, m->h), blk(256);
+    const dim3 blk(256), g1(nblk(n));
     WASS_HIP(c, hipMemsetAsync(best, 0, 8, c->stream));
-    hipLaunchKernelGGL(k_ccl_init, g2, blk, 0, c->stream, m->valid, m->w, m->h, parent, size);
-    hipLaunchKernelGGL(k_ccl_merge, g2, blk, 0, c->stream, m->valid, m->z, m->w, m->h, zgap, parent);
-    hipLaunchKernelGGL(k_ccl_count, dim3(nblk(n)), blk, 0, c->stream, m->w, m->h, parent, size);
-    hipLaunchKernelGGL(k_ccl_best, dim3(nblk(n)), blk, 0, c->stream, (int)n, (const int*)parent, (const unsigned int*)size, best);
-    unsigned long long hb = 0;
-    WASS_HIP(c, hipMemcpyAsync(&hb, best, 8, hipMemcpyDeviceToHost, c->stream));
-    WASS_HIP(c, hipStreamSynchronize(c->stream));
-    // no valid point at all: the reference keeps component id 0, i.e. nothing
-    const int root = hb ? (int)(0xFFFFFFFFu - (unsigned)(hb & 0xFFFFFFFFull)) : -2;
-    hipLaunchKernelGGL(k_ccl_keep, g2, blk, 0, c->stream, m->valid, m->w, m->h, (const int*)parent, root);
+    hipLaunchKernelGGL(k_ccl_init, g1, blk, 0, c->stream, m->valid, m->z, m->w, (int)n, zgap, parent, size, mincm);
+    hipLaunchKernelGGL(k_ccl_merge, g1, blk, 0, c->stream, m->valid, m->z, m->w, (int)n, zgap, parent);
+    hipLaunchKernelGGL(k_ccl_flatten, g1, blk, 0, c->stream, (int)n, parent);
+    hipLaunchKernelGGL(k_ccl_count, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, c->stream, (int)n, m->w, m->h,
+                       (const int*)parent, size, mincm);
+    hipLaunchKernelGGL(k_ccl_best, g1, blk, 0, c->stream, (int)n, (const int*)parent, (const unsigned int*)size,
+                       (const unsigned int*)mincm, best);
+    // no valid point at all: best stays 0 and no root key can equal it (sizes are >= 1) -> nothing kept, as in the
+    // reference where extract_component(0) then matches no point
+    hipLaunchKernelGGL(k_ccl_keep, g1, blk, 0, c->stream, m->valid, (int)n, (const int*)parent, (const unsigned int*)size,
+                       (const unsigned int*)mincm, (const unsigned long long*)best);
     WASS_HIP(c, hipGetLastError());
-    if (size_out) *size_out = hb >> 32;
+    if (size_out) {
+        unsigned long long hb = 0;
+        WASS_HIP(c, hipMemcpyAsync(&hb, best, 8, hipMemcpyDeviceToHost, c->stream));
+        WASS_HIP(c, hipStreamSynchronize(c->stream));
+        *size_out = hb >> 32;
+    }
     return WASS_OK;
 }
 
@@ -857,13 +980,13 @@ int wass_mesh_crop_plane(wass_ctx* c, wass_mesh* m, const double plane[4], doubl
 {
     if (!c || !m || !plane) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
     WASS_HIP(c, hipSetDevice(c->device));
-    unsigned long long* cnt = (unsigned long long*)c->flags.p + 1;
-    WASS_HIP(c, hipMemsetAsync(cnt, 0, 8, c->stream));
+    unsigned long long* cnt = nullptr;
+    int rc = counters_reset(c, &cnt);
+    if (rc) return rc;
     hipLaunchKernelGGL(k_crop_plane, dim3(nblk(m->n())), dim3(256), 0, c->stream, m->valid, m->x, m->y, m->z, m->n(), plane[0],
                        plane[1], plane[2], plane[3], thr, cnt);
     unsigned long long hk = 0;
-    WASS_HIP(c, hipMemcpyAsync(&hk, cnt, 8, hipMemcpyDeviceToHost, c->stream));
-    WASS_HIP(c, hipStreamSynchronize(c->stream));
+    if ((rc = counters_sum(c, cnt, &hk))) return rc;
     if (kept) *kept = hk;
     return WASS_OK;
 }
@@ -925,6 +1048,18 @@ void wass_RT_from_plane(const double plane[4], double R[9], double T[3], double 
 int wass_mesh_encode_xyzc(wass_ctx* c, wass_mesh* m, const double plane[4], void** bytes, size_t* nbytes)
 {
     if (!c || !m || !bytes || !nbytes) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    const size_t cap = 148 + m->n() * 6;
+    void* buf = malloc(cap);
+    if (!buf) return set_err(c, WASS_ERR_NO_MEMORY, "out of host memory");
+    int rc = wass_mesh_encode_xyzc_to(c, m, plane, buf, cap, nbytes);
+    if (rc) { free(buf); return rc; }
+    *bytes = buf;
+    return WASS_OK;
+}
+
+int wass_mesh_encode_xyzc_to(wass_ctx* c, wass_mesh* m, const double plane[4], void* dst, size_t capacity, size_t* nbytes)
+{
+    if (!c || !m || !dst || !nbytes) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
     WASS_HIP(c, hipSetDevice(c->device));
     double R[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }, T[3] = { 0, 0, 0 }, Rinv[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }, Tinv[3] = { 0, 0, 0 };
     if (plane) wass_RT_from_plane(plane, R, T, Rinv, Tinv);
@@ -934,19 +1069,27 @@ int wass_mesh_encode_xyzc(wass_ctx* c, wass_mesh* m, const double plane[4], void
     const unsigned nb = nblk(n);
     int rc = ensure(c, c->scratch, 64 + (size_t)nb * 4 + 16 + n * 6);
     if (rc) return rc;
-    unsigned long long* lim = (unsigned long long*)c->scratch.p;           // 6 keys
-    unsigned int* total = (unsigned int*)(lim + 6);
+    if ((rc = ensure(c, c->counters, (size_t)NSLOT * 6 * 8))) return rc;
+    unsigned long long* lim = (unsigned long long*)c->counters.p;          // [NSLOT][6] keys
+    unsigned int* total = (unsigned int*)c->scratch.p;
     unsigned int* bcnt = (unsigned int*)((char*)c->scratch.p + 64);
     uint16_t* dq = (uint16_t*)((char*)c->scratch.p + ((64 + (size_t)nb * 4 + 15) & ~(size_t)15));
-    const unsigned long long init[6] = { ~0ull, ~0ull, ~0ull, 0, 0, 0 };
+    unsigned long long init[NSLOT * 6];
+    for (int i = 0; i < NSLOT; ++i) for (int k = 0; k < 6; ++k) init[i * 6 + k] = k < 3 ? ~0ull : 0ull;
     WASS_HIP(c, hipMemcpyAsync(lim, init, sizeof init, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_xyzc_limits, dim3(nb), dim3(256), 0, c->stream, m->valid, m->x, m->y, m->z, n, rt, lim, bcnt);
+    hipLaunchKernelGGL(k_xyzc_limits, dim3(1024), dim3(256), 0, c->stream, m->valid, m->x, m->y, m->z, n, rt, lim);
+    hipLaunchKernelGGL(k_block_counts, dim3(nb), dim3(256), 0, c->stream, m->valid, n, bcnt);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, c->stream, bcnt, (int)nb, total);
-    unsigned long long hl[6];
+    unsigned long long hs[NSLOT * 6], hl[6] = { ~0ull, ~0ull, ~0ull, 0, 0, 0 };
     unsigned int npts = 0;
-    WASS_HIP(c, hipMemcpyAsync(hl, lim, sizeof hl, hipMemcpyDeviceToHost, c->stream));
+    WASS_HIP(c, hipMemcpyAsync(hs, lim, sizeof hs, hipMemcpyDeviceToHost, c->stream));
     WASS_HIP(c, hipMemcpyAsync(&npts, total, 4, hipMemcpyDeviceToHost, c->stream));
     WASS_HIP(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < NSLOT; ++i)
+        for (int k = 0; k < 3; ++k) {
+            if (hs[i * 6 + k] < hl[k]) hl[k] = hs[i * 6 + k];
+            if (hs[i * 6 + 3 + k] > hl[3 + k]) hl[3 + k] = hs[i * 6 + 3 + k];
+        }
     double mn[3], mx[3], sc[3];
     for (int k = 0; k < 3; ++k) {
         // no valid point: the reference writes +-DBL_MAX limits; keep that
@@ -958,8 +1101,9 @@ int wass_mesh_encode_xyzc(wass_ctx* c, wass_mesh* m, const double plane[4], void
         hipLaunchKernelGGL(k_xyzc_pack, dim3(nb), dim3(256), 0, c->stream, m->valid, m->x, m->y, m->z, n, rt, mn[0], mn[1], mn[2],
                            sc[0], sc[1], sc[2], (const unsigned int*)bcnt, dq);
     const size_t total_bytes = 148 + (size_t)npts * 6;
-    unsigned char* buf = (unsigned char*)malloc(total_bytes);
-    if (!buf) return set_err(c, WASS_ERR_NO_MEMORY, "out of host memory");
+    if (total_bytes > capacity)
+        return set_err(c, WASS_ERR_INVALID_ARG, "xyzC needs %zu bytes, buffer has %zu", total_bytes, capacity);
+    unsigned char* buf = (unsigned char*)dst;
     size_t o = 0;
     const uint32_t n32 = npts;
     memcpy(buf + o, &n32, 4); o += 4;
@@ -970,9 +1114,8 @@ int wass_mesh_encode_xyzc(wass_ctx* c, wass_mesh* m, const double plane[4], void
     if (npts) {
         hipError_t e = hipMemcpyAsync(buf + o, dq, (size_t)npts * 6, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) { free(buf); return set_err(c, WASS_ERR_DEVICE, "xyzC download: %s", hipGetErrorString(e)); }
+        if (e != hipSuccess) return set_err(c, WASS_ERR_DEVICE, "xyzC download: %s", hipGetErrorString(e));
     }
-    *bytes = buf;
     *nbytes = total_bytes;
     return WASS_OK;
 }

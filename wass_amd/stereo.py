@@ -267,6 +267,13 @@ class Mesh:
         self.ctx._check(self.ctx._lib.wass_mesh_refine_plane(self.ctx._h, self._h, C.byref(rp), plane, C.byref(n)))
         return np.array(plane[:]), int(n.value)
 
+    def encode_xyzc_to(self, plane, dst_ptr: int, capacity: int) -> int:
+        """mesh_cam.xyzC bytes into a caller-owned host buffer (e.g. a pinned torch tensor); returns the size."""
+        nb = C.c_size_t()
+        pl = (C.c_double * 4)(*plane) if plane is not None else None
+        self.ctx._check(self.ctx._lib.wass_mesh_encode_xyzc_to(self.ctx._h, self._h, pl, dst_ptr, capacity, C.byref(nb)))
+        return int(nb.value)
+
     def encode_xyzc(self, plane=None) -> bytes:
         buf = C.c_void_p(); nb = C.c_size_t()
         pl = (C.c_double * 4)(*plane) if plane is not None else None
