@@ -1,0 +1,211 @@
+"""The drop-in wass_stereo executable: argv / exit codes / config format / file outputs.
+
+CPU tests cover everything up to and including --rectify-only (pure host code); the GPU test runs BASELINE
+config A (640x480, D=64) end to end through the CLI and checks its outputs against the oracle chain.
+"""
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from wass_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def cli():
+    from wass_amd import build
+    return build.build_host()
+
+
+def _write_png(path, img):
+    h, w = img.shape
+    raw = b"".join(b"\x00" + img[y].tobytes() for y in range(h))
+
+    def chunk(t, d):
+        c = struct.pack(">I", len(d)) + t + d
+        return c + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+def _write_xml(path, node, m):
+    m = np.atleast_2d(np.asarray(m, float))
+    data = " ".join(repr(float(v)) for v in m.ravel())
+    with open(path, "w") as f:
+        f.write(f'<?xml version="1.0"?>\n<opencv_storage>\n<{node} type_id="opencv-matrix">\n  <rows>{m.shape[0]}</rows>\n'
+                f'  <cols>{m.shape[1]}</cols>\n  <dt>d</dt>\n  <data>\n    {data}</data></{node}>\n</opencv_storage>\n')
+
+
+def make_workdir(tmp, w, h, D, frame=0, extra_cfg=""):
+    """A wass_prepare/wass_match/wass_autocalibrate-style workdir for the ideal rig of SURVEY.md 8(d)."""
+    wd = os.path.join(tmp, "000000_wd")
+    os.makedirs(os.path.join(wd, "undistorted"))
+    right, left = synth.make_pair(w, h, D, frame_idx=frame)
+    rig = synth.rig_geometry(w, h)
+    _write_png(os.path.join(wd, "undistorted", "00000000.png"), left)     # cam0 = left (T.x > 0: no swap)
+    _write_png(os.path.join(wd, "undistorted", "00000001.png"), right)
+    _write_xml(os.path.join(wd, "intrinsics_00000000.xml"), "intr", rig["K_left"])
+    _write_xml(os.path.join(wd, "intrinsics_00000001.xml"), "intr", rig["K_right"])
+    _write_xml(os.path.join(wd, "ext_R.xml"), "R", rig["R"])
+    _write_xml(os.path.join(wd, "ext_T.xml"), "T", np.array(rig["T"]).reshape(3, 1) * 2.5)   # 2.5 m baseline -> normalised
+    cfg = os.path.join(tmp, "stereo_config.txt")
+    with open(cfg, "w") as f:
+        f.write(f"# synthetic rig\nMAX_DISPARITY={D}\nRANDOM_SEED=12345\nUSE_CUSTOM_STEREORECTIFY=true\n"
+                f"RECTIFY_ANGLE=1e-6\nDISABLE_RECTIFY_ROI=true\n" + extra_cfg)
+    return wd, cfg, right, left, rig
+
+
+def run(cli, *args, cwd=None):
+    return subprocess.run([cli, *args], capture_output=True, text=True, cwd=cwd)
+
+
+# ------------------------------------------------------------------ CPU: boundary behaviour
+def test_no_arguments_prints_usage_and_exits_zero(cli):
+    r = run(cli)
+    assert r.returncode == 0 and "Usage:" in r.stdout and "wass_stereo [--genconfig] <config_file> <workdir>" in r.stdout
+
+
+def test_invalid_argument_count(cli):
+    r = run(cli, "a")
+    assert r.returncode == 255 and "Invalid arguments" in r.stderr
+    r = run(cli, "a", "b", "c", "d")
+    assert r.returncode == 255
+
+
+def test_missing_workdir(cli, tmp_path):
+    r = run(cli, "cfg.txt", str(tmp_path / "nope"))
+    assert r.returncode == 255 and "does not exists" in r.stderr
+
+
+def test_genconfig_format(cli, tmp_path):
+    r = run(cli, "--genconfig", cwd=str(tmp_path))
+    assert r.returncode == 0
+    txt = open(tmp_path / "stereo_config.txt").read()
+    blocks = [b for b in txt.split("\n\n") if b.strip()]
+    keys = []
+    for b in blocks:
+        lines = b.split("\n")
+        assert len(lines) == 3 and lines[0].startswith("# ") and lines[1] == "# " and lines[2].startswith("#")
+        keys.append(lines[2][1:].split("=")[0])
+    assert keys == sorted(keys)                                   # alphabetical
+    d = dict(b.split("\n")[2][1:].split("=", 1) for b in blocks)
+    assert d["MAX_DISPARITY"] == "640" and d["WINSIZE"] == "13" and d["DENSE_SPECKLE_WINDOW_SIZE"] == "-70"
+    assert d["LEFT_MASK_IMAGE"] == "none" and d["SAVE_COMPRESSED"] == "true" and d["PLANE_RANSAC_ROUNDS"] == "400"
+    assert len(keys) >= 46
+
+
+def test_bad_config_is_an_error(cli, tmp_path):
+    wd, cfg, *_ = make_workdir(str(tmp_path), 64, 48, 16)
+    open(cfg, "a").write("NO_SUCH_KEY=1\n")
+    r = run(cli, cfg, wd)
+    assert r.returncode == 255 and "unknown option NO_SUCH_KEY" in r.stdout
+    open(cfg, "w").write("MAX_DISPARITY=abc\n")
+    r = run(cli, cfg, wd)
+    assert r.returncode == 255 and "invalid value" in r.stdout
+
+
+def test_rectify_only_is_identity_for_the_ideal_rig(cli, tmp_path):
+    w, h, D = 160, 120, 32
+    wd, cfg, right, left, rig = make_workdir(str(tmp_path), w, h, D)
+    r = run(cli, cfg, wd, "--rectify-only")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "[P|10|100]" in r.stdout and "[P|20|100]" in r.stdout and "All done." in r.stdout
+    for f in ("P0cam.txt", "P1cam.txt", "Cam0_poseR.txt", "Cam0_poseT.txt", "Cam1_poseR.txt", "Cam1_poseT.txt", "H0_rect.txt",
+              "H1_rect.txt", "stereo_config.txt", "wass_stereo_log.txt", "K0_small.txt", "scale.txt"):
+        assert os.path.exists(os.path.join(wd, f)), f
+    H0 = np.loadtxt(os.path.join(wd, "H0_rect.txt")); H1 = np.loadtxt(os.path.join(wd, "H1_rect.txt"))
+    np.testing.assert_allclose(H0 / H0[2, 2], np.eye(3), atol=1e-6)
+    np.testing.assert_allclose(H1 / H1[2, 2], np.eye(3), atol=1e-6)
+    T1 = np.loadtxt(os.path.join(wd, "Cam1_poseT.txt"))
+    np.testing.assert_allclose(T1, [1, 0, 0], atol=1e-15)         # |T| normalised to 1 (wass_stereo.cpp:360-370)
+    P1 = np.loadtxt(os.path.join(wd, "P1cam.txt"))
+    np.testing.assert_allclose(P1, rig["K_right"] @ np.hstack([np.eye(3), [[1], [0], [0]]]), rtol=1e-15)
+    txt = open(os.path.join(wd, "P0cam.txt")).read()
+    assert not txt.endswith("\n") and "e+0" in txt                # scientific, 16 digits, no trailing newline
+    assert "load_data [info ] image 0 loaded, Size: 160x120" in open(os.path.join(wd, "wass_stereo_log.txt")).read()
+
+
+def test_opencv_rectification_is_rejected_clearly(cli, tmp_path):
+    wd, cfg, *_ = make_workdir(str(tmp_path), 64, 48, 16)
+    open(cfg, "a").write("USE_CUSTOM_STEREORECTIFY=false\n")
+    r = run(cli, cfg, wd, "--rectify-only")
+    assert r.returncode == 255 and "not implemented" in r.stdout
+
+
+def test_no_gpu_is_a_loud_failure(cli, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    wd, cfg, *_ = make_workdir(str(tmp_path), 64, 48, 16)
+    r = run(cli, cfg, wd)
+    assert r.returncode == 255 and "no usable MI355X GPU" in r.stdout
+    assert not os.path.exists(os.path.join(wd, "mesh_cam.xyzC"))
+
+
+# ------------------------------------------------------------------ GPU: BASELINE config A through the CLI
+@pytest.mark.gpu
+def test_config_a_end_to_end_matches_oracle_chain(cli, tmp_path, oracle):
+    w, h, D = 640, 480, 64
+    wd, cfg, right, left, rig = make_workdir(str(tmp_path), w, h, D, extra_cfg="SAVE_AS_PLY=true\n")
+    r = run(cli, cfg, wd)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr
+    for marker in ("[P|10|100]", "[P|20|100]", "[P|40|100]", "[P|60|100]", "[P|80|100]", "[P|90|100]", "[P|100|100]", "All done."):
+        assert marker in r.stdout
+    for stage in ("Data load", "Rectification", "Dense Stereo", "Triangulation", "Z-gap stats", "Outlier removal", "Plane fitting",
+                  "Plane refinement", "TOTAL"):
+        assert stage in r.stdout
+    # oracle chain on the same inputs, using the homographies the CLI wrote
+    H0 = np.loadtxt(os.path.join(wd, "H0_rect.txt")); H1 = np.loadtxt(os.path.join(wd, "H1_rect.txt"))
+    g = dict(rig); g["HLi"] = np.linalg.inv(H0); g["HRi"] = np.linalg.inv(H1)
+    p = oracle.wass_params(D, 5)
+    d16, _ = oracle.dense_disparity16(right, left, p)
+    f = oracle.disparity_postprocess(d16, 1, D)
+    roi = (0, 0, w, h)
+    n, v, p3, gr = oracle.triangulate(f, roi, roi, oracle.make_geom(g, use_custom=True), right,
+                                      (left <= 254).astype(np.uint8), (right <= 254).astype(np.uint8))
+    zg, _ = oracle.zgap_percentile(v, p3, 99.0)
+    v, _ = oracle.keep_biggest_component(v, p3, zg)
+    uv = oracle.ransac_sample(w, h, 400, 12345)
+    ok, pl, best, _ = oracle.ransac_plane(v, p3, uv, 1.0)
+    assert ok
+    v, _ = oracle.crop_plane(v, p3, pl, 1.0)
+    pl2, ninl, _ = oracle.refine_plane(v, p3)
+    v, _ = oracle.crop_plane(v, p3, pl2, 1.5)
+
+    assert f"{n} valid points found" in r.stdout
+    assert f"400 ransac rounds, {best} best inliers" in r.stdout
+    plane = np.loadtxt(os.path.join(wd, "plane.txt"))
+    assert plane.shape == (4,)
+    # tolerance: 1e-8 absolute on a unit normal / d in baseline units.  With the paper's 2.5 m baseline that is
+    # 2.5e-5 mm -- three orders of magnitude below the xyzC quantisation step.
+    np.testing.assert_allclose(plane, pl2, rtol=0, atol=1e-8)
+    blob = open(os.path.join(wd, "mesh_cam.xyzC"), "rb").read()
+    npts = struct.unpack("<I", blob[:4])[0]
+    assert abs(npts - int(v.sum())) <= 2 and len(blob) == 148 + 6 * npts
+    if npts == int(v.sum()):
+        ref = oracle.encode_xyzc(v, p3, plane)                    # same plane -> same bytes
+        q = np.frombuffer(blob[148:], np.uint16); qr = np.frombuffer(ref[148:], np.uint16)
+        assert (q != qr).mean() < 1e-4                            # a last-bit difference in HLi may move a few quanta
+    # the recovered surface is the synthetic sea plane: > 70 % of the pixels end up in the cloud
+    assert npts > 0.7 * w * h
+    # mesh.ply header (PovMesh.cpp:473-483)
+    head = open(os.path.join(wd, "mesh.ply"), "rb").read(200).decode("latin1")
+    assert head.startswith(f"ply\nformat binary_little_endian 1.0\nelement vertex {npts}\nproperty float x\n")
+    assert os.path.exists(os.path.join(wd, "plane_refinement_inliers.xyz"))
+
+
+@pytest.mark.gpu
+def test_ransac_failure_writes_nan_plane_and_continues(cli, tmp_path):
+    """Untextured input -> (almost) nothing triangulated -> too few points -> exit -1, like the reference (:1993)."""
+    wd, cfg, *_ = make_workdir(str(tmp_path), 160, 120, 32)
+    flat = np.full((120, 160), 90, np.uint8)
+    _write_png(os.path.join(wd, "undistorted", "00000000.png"), flat)
+    _write_png(os.path.join(wd, "undistorted", "00000001.png"), flat)
+    r = run(cli, cfg, wd)
+    assert r.returncode == 255 and "Too few points triangulated" in r.stdout

@@ -54,5 +54,26 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return SO
 
 
+HOST_DIR = os.path.join(_HERE, "host")
+BIN_DIR = os.path.join(_HERE, "bin")
+CLI = os.path.join(BIN_DIR, "wass_stereo")
+
+
+def build_host(force: bool = False, verbose: bool = False) -> str:
+    """The drop-in wass_stereo executable: plain C++17 (g++) above the C ABI, linked against libwassgpu.so."""
+    build(force=False)
+    os.makedirs(BIN_DIR, exist_ok=True)
+    src = os.path.join(HOST_DIR, "wass_stereo.cpp")
+    deps = sorted(glob.glob(os.path.join(HOST_DIR, "*.hpp"))) + [os.path.join(_HERE, "..", "include", "wass_gpu.h"), SO]
+    if force or _newer(src, CLI, deps):
+        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", "-Wno-unused-function", src, "-o", CLI,
+               "-L" + _HERE, "-lwassgpu", "-lz", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath-link," + "/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return CLI
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,262 @@
+// hostio.hpp -- the small amount of file I/O the wass_stereo boundary needs, without OpenCV / Boost:
+//   logger            src/include/log.hpp:105-168        "<scope> [info ] message" to stdout and <wd>/wass_stereo_log.txt
+//   OpenCV XML matrix src/include/utils.hpp:32-66        first top-level node of a FileStorage XML
+//   matrix .txt       src/include/utils.hpp:69-92        precision(16), scientific, no trailing newline (App. B.4)
+//   PNG gray8         cv::imread(IMREAD_GRAYSCALE)       wass_stereo.cpp:393,396  (zlib inflate + PNG unfilter)
+//   PLY / xyzbin      src/wass_stereo/PovMesh.cpp:346-375,463-517 (App. B.2, B.6)
+#pragma once
+
+#include <zlib.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace wasshost {
+
+// ------------------------------------------------------------------ logger
+struct LogState {
+    std::string scope;
+    std::unique_ptr<std::ofstream> file;
+    static LogState& get() { static LogState s; return s; }
+};
+inline void setup_logger(const std::string& filename = std::string())
+{
+    if (!filename.empty()) LogState::get().file.reset(new std::ofstream(filename.c_str()));
+}
+class LogLine {
+public:
+    explicit LogLine(const char* sev) { emit(LogState::get().scope + " [" + sev + "] "); }
+    ~LogLine() { std::cout << std::endl; auto& f = LogState::get().file; if (f) (*f) << std::endl; }
+    template <typename T> LogLine& operator<<(const T& v) { std::ostringstream os; os << v; emit(os.str()); return *this; }
+private:
+    static void emit(const std::string& s) { std::cout << s; auto& f = LogState::get().file; if (f) (*f) << s; }
+};
+#define WLOG_SCOPE(name) (wasshost::LogState::get().scope = std::string(name))
+#define WLOGI wasshost::LogLine("info ")
+#define WLOGE wasshost::LogLine("error")
+
+// ------------------------------------------------------------------ matrices
+struct Mat {
+    int rows = 0, cols = 0;
+    std::vector<double> d;
+    Mat() {}
+    Mat(int r, int c) : rows(r), cols(c), d((size_t)r * c, 0.0) {}
+    double& operator()(int i, int j) { return d[(size_t)i * cols + j]; }
+    double operator()(int i, int j) const { return d[(size_t)i * cols + j]; }
+    bool empty() const { return d.empty(); }
+    static Mat eye(int n) { Mat m(n, n); for (int i = 0; i < n; ++i) m(i, i) = 1; return m; }
+};
+inline Mat matmul(const Mat& a, const Mat& b)
+{
+    Mat r(a.rows, b.cols);
+    for (int i = 0; i < a.rows; ++i)
+        for (int j = 0; j < b.cols; ++j) { double s = 0; for (int k = 0; k < a.cols; ++k) s += a(i, k) * b(k, j); r(i, j) = s; }
+    return r;
+}
+inline Mat transpose(const Mat& a) { Mat r(a.cols, a.rows); for (int i = 0; i < a.rows; ++i) for (int j = 0; j < a.cols; ++j) r(j, i) = a(i, j); return r; }
+inline Mat scaled(const Mat& a, double s) { Mat r = a; for (auto& v : r.d) v *= s; return r; }
+inline double det3(const Mat& m)
+{
+    return m(0, 0) * (m(1, 1) * m(2, 2) - m(1, 2) * m(2, 1)) - m(0, 1) * (m(1, 0) * m(2, 2) - m(1, 2) * m(2, 0)) +
+           m(0, 2) * (m(1, 0) * m(2, 1) - m(1, 1) * m(2, 0));
+}
+inline Mat inv3(const Mat& m)
+{
+    const double d = 1.0 / det3(m);
+    Mat r(3, 3);
+    r(0, 0) = (m(1, 1) * m(2, 2) - m(1, 2) * m(2, 1)) * d; r(0, 1) = (m(0, 2) * m(2, 1) - m(0, 1) * m(2, 2)) * d; r(0, 2) = (m(0, 1) * m(1, 2) - m(0, 2) * m(1, 1)) * d;
+    r(1, 0) = (m(1, 2) * m(2, 0) - m(1, 0) * m(2, 2)) * d; r(1, 1) = (m(0, 0) * m(2, 2) - m(0, 2) * m(2, 0)) * d; r(1, 2) = (m(0, 2) * m(1, 0) - m(0, 0) * m(1, 2)) * d;
+    r(2, 0) = (m(1, 0) * m(2, 1) - m(1, 1) * m(2, 0)) * d; r(2, 1) = (m(0, 1) * m(2, 0) - m(0, 0) * m(2, 1)) * d; r(2, 2) = (m(0, 0) * m(1, 1) - m(0, 1) * m(1, 0)) * d;
+    return r;
+}
+
+// OpenCV FileStorage XML: <opencv_storage><NAME type_id="opencv-matrix"><rows>..<cols>..<dt>d</dt><data>..</data></NAME>
+inline Mat load_matrix_xml(const std::string& filename)
+{
+    std::ifstream ifs(filename.c_str());
+    if (!ifs.is_open()) { WLOGE << "Unable to load " << filename; return Mat(); }
+    std::stringstream ss; ss << ifs.rdbuf();
+    const std::string s = ss.str();
+    auto tag = [&](const std::string& name, size_t from, std::string& out) -> size_t {
+        const size_t a = s.find("<" + name + ">", from);
+        if (a == std::string::npos) return std::string::npos;
+        const size_t b = s.find("</" + name + ">", a);
+        if (b == std::string::npos) return std::string::npos;
+        out = s.substr(a + name.size() + 2, b - a - name.size() - 2);
+        return b;
+    };
+    const size_t root = s.find("<opencv_storage>");
+    if (root == std::string::npos) { WLOGE << filename << " is not an OpenCV storage file"; return Mat(); }
+    std::string rows, cols, dt, data;
+    size_t p = tag("rows", root, rows);                       // first top-level node = first <rows> after the root
+    if (p == std::string::npos || tag("cols", root, cols) == std::string::npos || tag("dt", root, dt) == std::string::npos ||
+        tag("data", root, data) == std::string::npos) { WLOGE << filename << ": no opencv-matrix node"; return Mat(); }
+    Mat m(std::stoi(rows), std::stoi(cols));
+    std::istringstream ds(data);
+    for (auto& v : m.d) if (!(ds >> v)) { WLOGE << filename << ": matrix data truncated"; return Mat(); }
+    return m;
+}
+inline bool save_matrix_xml(const std::string& filename, const std::string& node, const Mat& m)   // test fixtures
+{
+    std::ofstream ofs(filename.c_str());
+    if (ofs.fail()) return false;
+    ofs << "<?xml version=\"1.0\"?>\n<opencv_storage>\n<" << node << " type_id=\"opencv-matrix\">\n  <rows>" << m.rows << "</rows>\n  <cols>"
+        << m.cols << "</cols>\n  <dt>d</dt>\n  <data>\n   ";
+    ofs << std::setprecision(17);
+    for (double v : m.d) ofs << " " << v;
+    ofs << "</data></" << node << ">\n</opencv_storage>\n";
+    return true;
+}
+inline bool save_matrix_txt(const std::string& filename, const Mat& m)
+{
+    std::ofstream ofs(filename.c_str());
+    if (ofs.fail()) return false;
+    ofs.precision(16);
+    ofs << std::scientific;
+    for (int i = 0; i < m.rows; ++i) {
+        for (int j = 0; j < m.cols; ++j) { ofs << m(i, j); if (j != m.cols - 1) ofs << " "; }
+        if (i != m.rows - 1) ofs << std::endl;
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------ images
+struct Image {
+    int w = 0, h = 0;
+    std::vector<uint8_t> px;
+    Image() {}
+    Image(int w_, int h_, uint8_t v = 0) : w(w_), h(h_), px((size_t)w_ * h_, v) {}
+    bool empty() const { return px.empty(); }
+    uint8_t& at(int y, int x) { return px[(size_t)y * w + x]; }
+    uint8_t at(int y, int x) const { return px[(size_t)y * w + x]; }
+};
+
+inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+// 8-bit grey PNG (what wass_prepare writes, wass_prepare.cpp:92,275); 8-bit grey+alpha / RGB / RGBA are converted
+// like cv::imread(IMREAD_GRAYSCALE) (BT.601 fixed point); anything else is rejected with a clear message.
+inline Image read_png_gray(const std::string& filename)
+{
+    std::ifstream ifs(filename.c_str(), std::ios::binary);
+    if (!ifs.is_open()) throw std::runtime_error("unable to open " + filename);
+    std::vector<uint8_t> f((std::istreambuf_iterator<char>(ifs)), std::istreambuf_iterator<char>());
+    static const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a };
+    if (f.size() < 33 || memcmp(f.data(), sig, 8) != 0) throw std::runtime_error(filename + " is not a PNG file");
+    int w = 0, h = 0, depth = 0, ctype = 0, interlace = 0;
+    std::vector<uint8_t> idat;
+    for (size_t p = 8; p + 12 <= f.size();) {
+        const uint32_t len = be32(&f[p]);
+        const char* type = (const char*)&f[p + 4];
+        if (p + 12 + len > f.size()) throw std::runtime_error(filename + ": truncated PNG chunk");
+        if (!memcmp(type, "IHDR", 4)) { w = (int)be32(&f[p + 8]); h = (int)be32(&f[p + 12]); depth = f[p + 16]; ctype = f[p + 17]; interlace = f[p + 20]; }
+        else if (!memcmp(type, "IDAT", 4)) idat.insert(idat.end(), f.begin() + p + 8, f.begin() + p + 8 + len);
+        else if (!memcmp(type, "IEND", 4)) break;
+        p += 12 + len;
+    }
+    if (w <= 0 || h <= 0) throw std::runtime_error(filename + ": missing IHDR");
+    if (depth != 8 || interlace != 0 || (ctype != 0 && ctype != 2 && ctype != 4 && ctype != 6))
+        throw std::runtime_error(filename + ": only non-interlaced 8-bit grey/RGB(A) PNG files are supported");
+    const int ch = ctype == 0 ? 1 : (ctype == 4 ? 2 : (ctype == 2 ? 3 : 4));
+    const size_t stride = (size_t)w * ch;
+    std::vector<uint8_t> raw((stride + 1) * h);
+    uLongf rawlen = (uLongf)raw.size();
+    if (uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size())
+        throw std::runtime_error(filename + ": zlib inflate failed");
+    std::vector<uint8_t> cur(stride), prev(stride, 0);
+    Image img(w, h);
+    for (int y = 0; y < h; ++y) {
+        const uint8_t ft = raw[(stride + 1) * y];
+        const uint8_t* in = &raw[(stride + 1) * y + 1];
+        for (size_t i = 0; i < stride; ++i) {
+            const int a = i >= (size_t)ch ? cur[i - ch] : 0, b = prev[i], c = i >= (size_t)ch ? prev[i - ch] : 0;
+            int v = in[i];
+            switch (ft) {
+                case 0: break;
+                case 1: v += a; break;
+                case 2: v += b; break;
+                case 3: v += (a + b) / 2; break;
+                case 4: { const int pp = a + b - c, pa = std::abs(pp - a), pb = std::abs(pp - b), pc = std::abs(pp - c);
+                          v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
+                default: throw std::runtime_error(filename + ": bad PNG filter");
+            }
+            cur[i] = (uint8_t)v;
+        }
+        for (int x = 0; x < w; ++x) {
+            const uint8_t* p = &cur[(size_t)x * ch];
+            img.at(y, x) = ch <= 2 ? p[0] : (uint8_t)((p[0] * 4899 + p[1] * 9617 + p[2] * 1868 + 8192) >> 14);
+        }
+        prev.swap(cur);
+    }
+    return img;
+}
+
+inline bool write_png_gray(const std::string& filename, const Image& img)
+{
+    std::vector<uint8_t> raw((size_t)(img.w + 1) * img.h);
+    for (int y = 0; y < img.h; ++y) { raw[(size_t)(img.w + 1) * y] = 0; memcpy(&raw[(size_t)(img.w + 1) * y + 1], &img.px[(size_t)y * img.w], img.w); }
+    uLongf clen = compressBound((uLong)raw.size());
+    std::vector<uint8_t> comp(clen);
+    if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 3) != Z_OK) return false;
+    std::ofstream ofs(filename.c_str(), std::ios::binary);
+    if (ofs.fail()) return false;
+    auto chunk = [&](const char* type, const uint8_t* data, uint32_t len) {
+        uint8_t hdr[8] = { (uint8_t)(len >> 24), (uint8_t)(len >> 16), (uint8_t)(len >> 8), (uint8_t)len, (uint8_t)type[0], (uint8_t)type[1], (uint8_t)type[2], (uint8_t)type[3] };
+        ofs.write((const char*)hdr, 8);
+        if (len) ofs.write((const char*)data, len);
+        uLong crc = crc32(0L, (const Bytef*)type, 4);
+        if (len) crc = crc32(crc, data, len);
+        const uint8_t c[4] = { (uint8_t)(crc >> 24), (uint8_t)(crc >> 16), (uint8_t)(crc >> 8), (uint8_t)crc };
+        ofs.write((const char*)c, 4);
+    };
+    static const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a };
+    ofs.write((const char*)sig, 8);
+    uint8_t ihdr[13] = { (uint8_t)(img.w >> 24), (uint8_t)(img.w >> 16), (uint8_t)(img.w >> 8), (uint8_t)img.w,
+                         (uint8_t)(img.h >> 24), (uint8_t)(img.h >> 16), (uint8_t)(img.h >> 8), (uint8_t)img.h, 8, 0, 0, 0, 0 };
+    chunk("IHDR", ihdr, 13);
+    chunk("IDAT", comp.data(), (uint32_t)clen);
+    chunk("IEND", nullptr, 0);
+    return !ofs.fail();
+}
+
+// ------------------------------------------------------------------ point-cloud writers (host copies of the mesh)
+inline bool save_xyz_binary(const std::string& filename, const std::vector<uint8_t>& valid, const std::vector<double>& p3d)
+{
+    std::ofstream ofs(filename.c_str(), std::ios::binary);
+    if (ofs.fail()) return false;
+    std::vector<float> pts;
+    for (size_t i = 0; i < valid.size(); ++i)
+        if (valid[i]) { pts.push_back((float)p3d[3 * i]); pts.push_back((float)p3d[3 * i + 1]); pts.push_back((float)p3d[3 * i + 2]); }
+    const uint32_t n = (uint32_t)(pts.size() / 3);
+    ofs.write((const char*)&n, 4);
+    ofs.write((const char*)pts.data(), (std::streamsize)(pts.size() * 4));
+    return !ofs.fail();
+}
+inline bool save_ply_points(const std::string& filename, const std::vector<uint8_t>& valid, const std::vector<double>& p3d,
+                            const std::vector<uint8_t>& gray)
+{
+    std::ofstream ofs(filename.c_str(), std::ios::binary);
+    if (ofs.fail()) return false;
+    size_t n = 0;
+    for (uint8_t v : valid) n += v ? 1 : 0;
+    ofs << "ply\nformat binary_little_endian 1.0\nelement vertex " << n
+        << "\nproperty float x\nproperty float y\nproperty float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n";
+    for (size_t i = 0; i < valid.size(); ++i)
+        if (valid[i]) {
+            const float p[3] = { (float)p3d[3 * i], (float)p3d[3 * i + 1], (float)p3d[3 * i + 2] };
+            const uint8_t c[3] = { gray[i], gray[i], gray[i] };
+            ofs.write((const char*)p, 12);
+            ofs.write((const char*)c, 3);
+        }
+    return !ofs.fail();
+}
+
+}  // namespace wasshost
