@@ -117,7 +117,7 @@ struct wass_ctx {
     wass::Buf counters;            // striped atomics of the mesh stages
     wass::Buf scratch;             // mesh stages: gaps / labels / partial sums / packed output
     hipEvent_t ev[8] = {};
-    hipStream_t side = nullptr;    // checkpoint sweeps run ahead here
+    hipStream_t side = nullptr, side2 = nullptr;   // checkpoint sweeps run ahead here
     hipEvent_t ev_cost = nullptr, ev_ckpt[4] = {};
     wass::SgmDims last = {};
     bool have_last = false;

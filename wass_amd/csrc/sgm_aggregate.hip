@@ -20,6 +20,8 @@
 // Each step touches one contiguous 256*NP-byte vector of C and of S.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace wass {
 
 // State carried along one chain: the (un-normalised) path costs of the previous
@@ -485,12 +487,16 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
     struct Fam { int dx, dy, smode; };
     Fam fam[4];
     int nf = 0;
+    // Order: the family whose backward sweep carries the winner-take-all goes last and should have the most
+    // chains (the WTA adds ~50 instructions per pixel): the anti-diagonals (width1 + h - 1 chains).
     if (d.ndirs == 8) {
-        fam[nf++] = { 0, 1, 0 };     // columns:        paths 2 + 6
+        fam[nf++] = { 1, 0, 0 };     // rows:           paths 0 + 4   (S written)
+        fam[nf++] = { 0, 1, 1 };     // columns:        paths 2 + 6
         fam[nf++] = { 1, 1, 1 };     // diagonals:      paths 1 + 7
-        fam[nf++] = { -1, 1, 1 };    // anti-diagonals: paths 3 + 5
+        fam[nf++] = { -1, 1, 2 };    // anti-diagonals: paths 3 + 5, winner-take-all fused
+    } else {
+        fam[nf++] = { 1, 0, 2 };     // rows: paths 0 + 4 after the three single sweeps, winner-take-all fused
     }
-    fam[nf++] = { 1, 0, 2 };         // rows: paths 0 + 4, winner-take-all fused
     size_t off[5] = { 0 };
     for (int f = 0; f < nf; ++f) off[f + 1] = off[f] + ckpt_bytes(fam[f].dx, fam[f].dy);
     int rc = ensure(c, c->ckpt, off[nf]);
@@ -498,12 +504,15 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
 
     WASS_HIP(c, hipEventRecord(c->ev_cost, c->stream));
     WASS_HIP(c, hipStreamWaitEvent(c->side, c->ev_cost, 0));
+    WASS_HIP(c, hipStreamWaitEvent(c->side2, c->ev_cost, 0));
     for (int f = 0; f < nf; ++f) {
         const int dx = fam[f].dx, dy = fam[f].dy;
         const int nch = nchains(dx, dy), mseg = (maxlen(dx, dy) + K - 1) / K;
-        hipLaunchKernelGGL((k_ckpt<NP, K>), dim3((nch + 3) / 4), dim3(256), 0, c->side, C,
+        static const bool two = getenv("WASS_SIDE_STREAMS") && atoi(getenv("WASS_SIDE_STREAMS")) == 2;
+        hipStream_t ss = (two && (f & 1)) ? c->side2 : c->side;
+        hipLaunchKernelGGL((k_ckpt<NP, K>), dim3((nch + 3) / 4), dim3(256), 0, ss, C,
                            (uint32_t*)((char*)c->ckpt.p + off[f]), d.width1, d.h, dx, dy, d.P1, d.P2, nch, mseg);
-        WASS_HIP(c, hipEventRecord(c->ev_ckpt[f], c->side));
+        WASS_HIP(c, hipEventRecord(c->ev_ckpt[f], ss));
         ++nl;
     }
 
