@@ -92,6 +92,10 @@ struct SgmDims {
     size_t cells() const { return (size_t)h * width1 * Dp; }
 };
 
+// pitch (in u16) of one mirrored image-2 plane; the slack absorbs reads of padded disparity slots past the row
+constexpr int BT2_COPIES = 2;     // shifted copies of every image-2 plane (dword-aligned runs for any start index; 4 copies measured slower)
+static inline int bt2_pitch(int Wp) { return (Wp + 1024 + 63) & ~63; }
+
 struct Buf {
     void* p = nullptr;
     size_t cap = 0;
@@ -105,7 +109,7 @@ struct wass_ctx {
     std::string err;
     // scratch HBM (grown on demand, never shrunk)
     wass::Buf img1, img2;          // padded u8 images (right / left)
-    wass::Buf bt1, bt2;            // 8 B per pixel: {sobel v,lo,hi, raw v,lo,hi, 0,0}
+    wass::Buf bt1, bt2;            // BT interval records: bt1 8 B/pixel; bt2 six mirrored u16 planes per row
     wass::Buf hsum, C, S;          // u16 volumes [h][width1][Dp]
     wass::Buf ckpt;                // forward-path checkpoints of k_pair (1/K of a volume)
     wass::Buf sel_d16, sel_key;    // per (y,x): raw fixed-point disparity / (minS<<16|d)

@@ -165,68 +165,6 @@ __device__ __forceinline__ void copy_seg(us2 (&dst)[K][NP], const us2 (&src)[K][
         for (int j = 0; j < NP; ++j) dst[u][j] = src[u][j];
 }
 
-// One path, every chain: S (+)= L_r.  FIRST: S is written, not accumulated.
-// Loads of the next U steps are in flight while the current U steps compute.
-template <int NP, bool FIRST, int U>
-__global__ void __launch_bounds__(256) k_sweep(const uint32_t* __restrict__ C, uint32_t* __restrict__ S,
-                                               int width1, int h, int dx, int dy, int P1, int P2, int nchains)
-{
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
-    if (c >= nchains) return;
-    int x0, y0, n;
-    chain_geometry(c, dx, dy, width1, h, x0, y0, n);
-    const long long vec = 64 * NP;                               // dwords per pixel vector
-    const long long step = ((long long)dy * width1 + dx) * vec;
-    const uint32_t* cp = C + ((long long)y0 * width1 + x0) * vec + lane * NP;
-    uint32_t* sp = S + ((long long)y0 * width1 + x0) * vec + lane * NP;
-    const us2 P1v = pk_splat(P1), cap = pk_splat(0x7FFF);
-
-    PathState<NP> st;
-    st.reset();
-    const int F = n / U, r = n - F * U;
-    us2 cb[U][NP], sb[U][NP], cn[U][NP], sn[U][NP];
-    if (F > 0) {
-        load_seg<NP, U, false>(cp, step, U, cb);
-        if (!FIRST) load_seg<NP, U, false>(sp, step, U, sb);
-    }
-    for (int g = 0; g < F; ++g) {
-        if (g + 1 < F) {
-            load_seg<NP, U, false>(cp + U * step, step, U, cn);
-            if (!FIRST) load_seg<NP, U, false>(sp + U * step, step, U, sn);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            us2 L[NP];
-            sgm_step<NP>(st, cb[u], L, P1v, P2);
-#pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                const us2 sv = FIRST ? pk_min(L[j], cap) : pk_min(pk_adds(sb[u][j], L[j]), cap);
-                sp[u * step + j] = as_u32(sv);
-            }
-        }
-        copy_seg<NP, U>(cb, cn);
-        if (!FIRST) copy_seg<NP, U>(sb, sn);
-        cp += U * step;
-        sp += U * step;
-    }
-    if (r > 0) {
-        load_seg<NP, U, true>(cp, step, r, cb);
-        if (!FIRST) load_seg<NP, U, true>(sp, step, r, sb);
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (u < r) {
-                us2 L[NP];
-                sgm_step<NP>(st, cb[u], L, P1v, P2);
-#pragma unroll
-                for (int j = 0; j < NP; ++j) {
-                    const us2 sv = FIRST ? pk_min(L[j], cap) : pk_min(pk_adds(sb[u][j], L[j]), cap);
-                    sp[u * step + j] = as_u32(sv);
-                }
-            }
-    }
-}
-
 // ---------------------------------------------------------------------------
 // Winner-take-all on a finished S vector held in registers (Appendix A.5 steps
 // 2, 3 and 5; the right-view scatter and the L-R check need the whole row and
@@ -281,6 +219,77 @@ __device__ __forceinline__ void wta_select(const us2 (&Sv)[NP], int lane, int D,
         out = d + minD * 16;
     }
     if (lane == 0) { *out_d16 = (int16_t)out; *out_key = k; }
+}
+
+// One path, every chain.  SMODE 0: S = L_r (first path)   1: S += L_r   2: last path -- S is read, finished in
+// registers and handed to wta_select (stored only if keepS).  Loads of the next U steps are in flight while the
+// current U steps compute.
+template <int NP, int SMODE, int U>
+__global__ void __launch_bounds__(256) k_sweep(const uint32_t* __restrict__ C, uint32_t* __restrict__ S,
+                                               int width1, int h, int dx, int dy, int P1, int P2, int nchains, int D,
+                                               int minD, int uniq, int keepS, int16_t* __restrict__ sel_d16,
+                                               uint32_t* __restrict__ sel_key)
+{
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
+    if (c >= nchains) return;
+    int x0, y0, n;
+    chain_geometry(c, dx, dy, width1, h, x0, y0, n);
+    const long long vec = 64 * NP;                               // dwords per pixel vector
+    const long long step = ((long long)dy * width1 + dx) * vec;
+    const long long pixstep = (long long)dy * width1 + dx;
+    long long pix = (long long)y0 * width1 + x0;
+    const uint32_t* cp = C + pix * vec + lane * NP;
+    uint32_t* sp = S + pix * vec + lane * NP;
+    const us2 P1v = pk_splat(P1), cap = pk_splat(0x7FFF);
+
+    auto finish = [&](const us2 (&L)[NP], const us2 (&sin)[NP], uint32_t* so, long long px) {
+        us2 sv[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) sv[j] = SMODE == 0 ? pk_min(L[j], cap) : pk_min(pk_adds(sin[j], L[j]), cap);
+        if (SMODE != 2 || keepS) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) so[j] = as_u32(sv[j]);
+        }
+        if (SMODE == 2) wta_select<NP>(sv, lane, D, minD, uniq, sel_d16 + px, sel_key + px);
+    };
+
+    PathState<NP> st;
+    st.reset();
+    const int F = n / U, r = n - F * U;
+    us2 cb[U][NP], sb[U][NP], cn[U][NP], sn[U][NP];
+    if (F > 0) {
+        load_seg<NP, U, false>(cp, step, U, cb);
+        if (SMODE != 0) load_seg<NP, U, false>(sp, step, U, sb);
+    }
+    for (int g = 0; g < F; ++g) {
+        if (g + 1 < F) {
+            load_seg<NP, U, false>(cp + U * step, step, U, cn);
+            if (SMODE != 0) load_seg<NP, U, false>(sp + U * step, step, U, sn);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            us2 L[NP];
+            sgm_step<NP>(st, cb[u], L, P1v, P2);
+            finish(L, sb[u], sp + u * step, pix + u * pixstep);
+        }
+        copy_seg<NP, U>(cb, cn);
+        if (SMODE != 0) copy_seg<NP, U>(sb, sn);
+        cp += U * step;
+        sp += U * step;
+        pix += U * pixstep;
+    }
+    if (r > 0) {
+        load_seg<NP, U, true>(cp, step, r, cb);
+        if (SMODE != 0) load_seg<NP, U, true>(sp, step, r, sb);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (u < r) {
+                us2 L[NP];
+                sgm_step<NP>(st, cb[u], L, P1v, P2);
+                finish(L, sb[u], sp + u * step, pix + u * pixstep);
+            }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -487,15 +496,13 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
     struct Fam { int dx, dy, smode; };
     Fam fam[4];
     int nf = 0;
-    // Order: the family whose backward sweep carries the winner-take-all goes last and should have the most
-    // chains (the WTA adds ~50 instructions per pixel): the anti-diagonals (width1 + h - 1 chains).
+    // Order: the kernel that carries the winner-take-all goes last and should have the most chains (the WTA adds
+    // ~50 instructions per pixel): the anti-diagonals (width1 + h - 1 chains).
+    fam[nf++] = { 1, 0, 0 };         // rows:           paths 0 + 4   (S written)
     if (d.ndirs == 8) {
-        fam[nf++] = { 1, 0, 0 };     // rows:           paths 0 + 4   (S written)
         fam[nf++] = { 0, 1, 1 };     // columns:        paths 2 + 6
         fam[nf++] = { 1, 1, 1 };     // diagonals:      paths 1 + 7
         fam[nf++] = { -1, 1, 2 };    // anti-diagonals: paths 3 + 5, winner-take-all fused
-    } else {
-        fam[nf++] = { 1, 0, 2 };     // rows: paths 0 + 4 after the three single sweeps, winner-take-all fused
     }
     size_t off[5] = { 0 };
     for (int f = 0; f < nf; ++f) off[f + 1] = off[f] + ckpt_bytes(fam[f].dx, fam[f].dy);
@@ -516,20 +523,6 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
         ++nl;
     }
 
-#define WASS_SWEEP(FIRST, dx, dy)                                                                            \
-    do {                                                                                                     \
-        const int nch = nchains(dx, dy);                                                                     \
-        hipLaunchKernelGGL((k_sweep<NP, FIRST, U>), dim3((nch + 3) / 4), dim3(256), 0, c->stream, C, S,      \
-                           d.width1, d.h, dx, dy, d.P1, d.P2, nch);                                          \
-        ++nl;                                                                                                \
-    } while (0)
-    if (d.ndirs == 5) {
-        WASS_SWEEP(true, 0, 1);   // path 2
-        WASS_SWEEP(false, 1, 1);  // path 1
-        WASS_SWEEP(false, -1, 1); // path 3
-    }
-#undef WASS_SWEEP
-
     for (int f = 0; f < nf; ++f) {
         const int dx = fam[f].dx, dy = fam[f].dy;
         const int nch = nchains(dx, dy), mseg = (maxlen(dx, dy) + K - 1) / K;
@@ -545,6 +538,19 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
 #undef WASS_PAIR
         ++nl;
     }
+#define WASS_SWEEP(SMODE, dx, dy)                                                                            \
+    do {                                                                                                     \
+        const int nch = nchains(dx, dy);                                                                     \
+        hipLaunchKernelGGL((k_sweep<NP, SMODE, U>), dim3((nch + 3) / 4), dim3(256), 0, c->stream, C, S,      \
+                           d.width1, d.h, dx, dy, d.P1, d.P2, nch, d.D, d.minD, d.uniq, c->debug ? 1 : 0, sd, sk); \
+        ++nl;                                                                                                \
+    } while (0)
+    if (d.ndirs == 5) {              // MODE_SGBM: the three down-going paths have no partner
+        WASS_SWEEP(1, 0, 1);         // path 2
+        WASS_SWEEP(1, 1, 1);         // path 1
+        WASS_SWEEP(2, -1, 1);        // path 3, winner-take-all fused
+    }
+#undef WASS_SWEEP
     if (n_launches) *n_launches = nl;
     WASS_HIP(c, hipGetLastError());
     return WASS_OK;

@@ -35,8 +35,15 @@ __device__ __forceinline__ int raw_at(const uint8_t* img, int Wp, int X, int y, 
     return img[(size_t)y * Wp + X];
 }
 
-__global__ void __launch_bounds__(256) k_prefilter(const uint8_t* __restrict__ img, int Wp, int h,
-                                                   int ftzero, uint2* __restrict__ out)
+// MIRROR = false: image 1 (the reference image of the match): one 8-byte record per pixel
+//   {sobel v, lo, hi, raw v, lo, hi} -- read wave-uniformly by k_hsum.
+// MIRROR = true: image 2: six u16 planes per row, [y][plane][Wp + pad], stored MIRRORED in x
+//   (index Wp-1-X), so that the values a lane needs for consecutive disparities d, d+1, ... at
+//   column X (image-2 columns X-d, X-d-1, ...) are consecutive, ascending u16 in memory and arrive
+//   as ready-made packed pairs (the same trick OpenCV's calcPixelCostBT uses for its SIMD loop).
+template <bool MIRROR>
+__global__ void __launch_bounds__(256) k_prefilter(const uint8_t* __restrict__ img, int Wp, int h, int ftzero,
+                                                   uint2* __restrict__ out1, unsigned short* __restrict__ out2, int pitch2)
 {
     const int X = blockIdx.x * 256 + threadIdx.x;
     const int y = blockIdx.y;
@@ -49,19 +56,38 @@ __global__ void __launch_bounds__(256) k_prefilter(const uint8_t* __restrict__ i
     int rr = X < Wp - 1 ? (r0 + raw_at(img, Wp, X + 1, y, ftzero)) / 2 : r0;
     int slo = min(min(sl, sr), s0), shi = max(max(sl, sr), s0);
     int rlo = min(min(rl, rr), r0), rhi = max(max(rl, rr), r0);
-    uint2 o;
-    o.x = (uint32_t)s0 | ((uint32_t)slo << 8) | ((uint32_t)shi << 16) | ((uint32_t)r0 << 24);
-    o.y = (uint32_t)rlo | ((uint32_t)rhi << 8);
-    out[(size_t)y * Wp + X] = o;
+    if (!MIRROR) {
+        uint2 o;
+        o.x = (uint32_t)s0 | ((uint32_t)slo << 8) | ((uint32_t)shi << 16) | ((uint32_t)r0 << 24);
+        o.y = (uint32_t)rlo | ((uint32_t)rhi << 8);
+        out1[(size_t)y * Wp + X] = o;
+    } else {
+        // every plane is stored BT2_COPIES times, copy k shifted by k elements, so that a lane's run of values can
+        // always be fetched with naturally aligned vector loads (copy = start index mod BT2_COPIES; misaligned
+        // vector loads are legal on gfx950 but slow)
+        const int xm = Wp - 1 - X;
+        const unsigned short vals[6] = { (unsigned short)s0, (unsigned short)slo, (unsigned short)shi,
+                                         (unsigned short)r0, (unsigned short)rlo, (unsigned short)rhi };
+        unsigned short* row = out2 + (size_t)y * (6 * BT2_COPIES) * pitch2;
+#pragma unroll
+        for (int pl = 0; pl < 6; ++pl)
+#pragma unroll
+            for (int cpy = 0; cpy < BT2_COPIES; ++cpy)
+                if (xm >= cpy) row[(size_t)(BT2_COPIES * pl + cpy) * pitch2 + xm - cpy] = vals[pl];
+    }
 }
+
 
 int launch_prefilter(wass_ctx* c, const SgmDims& d)
 {
     dim3 grid((d.Wp + 255) / 256, d.h);
-    hipLaunchKernelGGL(k_prefilter, grid, dim3(256), 0, c->stream, (const uint8_t*)c->img1.p, d.Wp, d.h,
-                       d.ftzero, (uint2*)c->bt1.p);
-    hipLaunchKernelGGL(k_prefilter, grid, dim3(256), 0, c->stream, (const uint8_t*)c->img2.p, d.Wp, d.h,
-                       d.ftzero, (uint2*)c->bt2.p);
+    const int pitch2 = bt2_pitch(d.Wp);
+    // the slack columns are never written; clear them once per (re)allocation is not enough because sizes change,
+    // but their content only ever feeds padded disparity slots, which k_vsum overwrites with 0xFFFF.
+    hipLaunchKernelGGL(k_prefilter<false>, grid, dim3(256), 0, c->stream, (const uint8_t*)c->img1.p, d.Wp, d.h,
+                       d.ftzero, (uint2*)c->bt1.p, (unsigned short*)nullptr, 0);
+    hipLaunchKernelGGL(k_prefilter<true>, grid, dim3(256), 0, c->stream, (const uint8_t*)c->img2.p, d.Wp, d.h,
+                       d.ftzero, (uint2*)nullptr, (unsigned short*)c->bt2.p, pitch2);
     WASS_HIP(c, hipGetLastError());
     return WASS_OK;
 }
@@ -72,73 +98,110 @@ int launch_prefilter(wass_ctx* c, const SgmDims& d)
 // every column of the chunk plus halo into a wave-private LDS strip, phase 2
 // slides the window over that strip.  No cross-lane traffic at all.
 // ---------------------------------------------------------------------------
+template <int N> struct __attribute__((aligned(4))) UVec { uint32_t v[N]; };   // N dwords, at least dword aligned
+
 template <int NP>
-__device__ __forceinline__ void bt_cost(const uint2 a1, const uint2* __restrict__ row2, int X, int dbase,
-                                        int Wp, us2 (&out)[NP])
+__device__ __forceinline__ void bt_cost(const uint2 a1, const unsigned short* __restrict__ m2, int pitch2, int idx,
+                                        us2 (&out)[NP])
 {
     // image-1 values are uniform over the wave
     const us2 us = pk_splat(a1.x & 0xff), us0 = pk_splat((a1.x >> 8) & 0xff), us1 = pk_splat((a1.x >> 16) & 0xff);
     const us2 ur = pk_splat(a1.x >> 24), ur0 = pk_splat(a1.y & 0xff), ur1 = pk_splat((a1.y >> 8) & 0xff);
+    // odd start index -> the copy shifted by one element, at idx-1: the address is always dword aligned
+    const unsigned short* p = m2 + (idx & (BT2_COPIES - 1)) * pitch2 + (idx & ~(BT2_COPIES - 1));
+    const int pp = BT2_COPIES * pitch2;
+    // one NP-dword load per plane (global_load_dwordx2/x3/x4 for NP = 2/3/4)
+    const UVec<NP> a0 = *(const UVec<NP>*)(p), a1v = *(const UVec<NP>*)(p + pp), a2 = *(const UVec<NP>*)(p + 2 * pp);
+    const UVec<NP> a3 = *(const UVec<NP>*)(p + 3 * pp), a4 = *(const UVec<NP>*)(p + 4 * pp), a5 = *(const UVec<NP>*)(p + 5 * pp);
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-        // disparities dbase+2j and dbase+2j+1 -> image-2 columns X-d (descending)
-        int xa = X - (dbase + 2 * j), xb = xa - 1;
-        xa = xa < 0 ? 0 : xa;             // only padded slots (d >= D) can fall off the row
-        xb = xb < 0 ? 0 : xb;
-        const uint2 va = row2[xa], vb = row2[xb];
-        us2 vs, vs0, vs1, vr, vr0, vr1;
-        vs.x = va.x & 0xff; vs.y = vb.x & 0xff;
-        vs0.x = (va.x >> 8) & 0xff; vs0.y = (vb.x >> 8) & 0xff;
-        vs1.x = (va.x >> 16) & 0xff; vs1.y = (vb.x >> 16) & 0xff;
-        vr.x = va.x >> 24; vr.y = vb.x >> 24;
-        vr0.x = va.y & 0xff; vr0.y = vb.y & 0xff;
-        vr1.x = (va.y >> 8) & 0xff; vr1.y = (vb.y >> 8) & 0xff;
+        const us2 vs = as_us2(a0.v[j]), vs0 = as_us2(a1v.v[j]), vs1 = as_us2(a2.v[j]);
+        const us2 vr = as_us2(a3.v[j]), vr0 = as_us2(a4.v[j]), vr1 = as_us2(a5.v[j]);
         // c0 = max(0, u - v1, v0 - u), c1 = max(0, v - u1, u0 - v), cost = min(c0, c1)
-        us2 cs = pk_min(pk_max(pk_subs(us, vs1), pk_subs(vs0, us)), pk_max(pk_subs(vs, us1), pk_subs(us0, vs)));
-        us2 cr = pk_min(pk_max(pk_subs(ur, vr1), pk_subs(vr0, ur)), pk_max(pk_subs(vr, ur1), pk_subs(ur0, vr)));
+        const us2 cs = pk_min(pk_max(pk_subs(us, vs1), pk_subs(vs0, us)), pk_max(pk_subs(vs, us1), pk_subs(us0, vs)));
+        const us2 cr = pk_min(pk_max(pk_subs(ur, vr1), pk_subs(vr0, ur)), pk_max(pk_subs(vr, ur1), pk_subs(ur0, vr)));
         out[j] = cs + (cr >> 2);
     }
 }
 
+// LDS strip element: pixel costs are <= 122 + 63 = 185, so an even number of packed pairs is stored as bytes
+// (two pairs per dword) -- half the LDS, twice the resident waves.
+template <int NP> struct StripFmt { static constexpr bool BYTES = (NP % 2) == 0; static constexpr int DW = BYTES ? NP / 2 : NP; };
+
 template <int NP>
-__global__ void __launch_bounds__(64) k_hsum(const uint2* __restrict__ bt1, const uint2* __restrict__ bt2,
-                                             int Wp, int width1, int minX1, int minD, int SW2, int XC,
+__device__ __forceinline__ void strip_store(uint32_t* __restrict__ strip, int col, int lane, const us2 (&pix)[NP])
+{
+    if constexpr (StripFmt<NP>::BYTES) {
+#pragma unroll
+        for (int j = 0; j < NP / 2; ++j)
+            strip[(col * (NP / 2) + j) * 64 + lane] = __builtin_amdgcn_perm(as_u32(pix[2 * j + 1]), as_u32(pix[2 * j]), 0x06040200u);
+    } else {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) strip[(col * NP + j) * 64 + lane] = as_u32(pix[j]);
+    }
+}
+template <int NP>
+__device__ __forceinline__ void strip_load(const uint32_t* __restrict__ strip, int col, int lane, us2 (&pix)[NP])
+{
+    if constexpr (StripFmt<NP>::BYTES) {
+#pragma unroll
+        for (int j = 0; j < NP / 2; ++j) {
+            const uint32_t w = strip[(col * (NP / 2) + j) * 64 + lane];
+            pix[2 * j] = as_us2(__builtin_amdgcn_perm(0u, w, 0x0c010c00u));
+            pix[2 * j + 1] = as_us2(__builtin_amdgcn_perm(0u, w, 0x0c030c02u));
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) pix[j] = as_us2(strip[(col * NP + j) * 64 + lane]);
+    }
+}
+
+template <int NP>
+__global__ void __launch_bounds__(64) k_hsum(const uint2* __restrict__ bt1, const unsigned short* __restrict__ bt2,
+                                             int pitch2, int Wp, int width1, int minX1, int minD, int SW2, int XC,
                                              uint32_t* __restrict__ hsum)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t strip[];   // [(XC + 2*SW2)][NP][64]
+    extern __shared__ __attribute__((aligned(16))) uint32_t strip[];   // [(XC + 2*SW2)][StripFmt::DW][64]
     const int lane = threadIdx.x;
     const int y = blockIdx.y;
     const int xs = blockIdx.x * XC;
     const int xe = min(xs + XC, width1);
     const int n = xe - xs;
     const uint2* row1 = bt1 + (size_t)y * Wp;
-    const uint2* row2 = bt2 + (size_t)y * Wp;
+    const unsigned short* row2 = bt2 + (size_t)y * (6 * BT2_COPIES) * pitch2;
     const int dbase = minD + lane * 2 * NP;
 
-    // phase 1
-    for (int i = 0; i < n + 2 * SW2; ++i) {
-        int x = xs - SW2 + i;
-        x = x < 0 ? 0 : (x > width1 - 1 ? width1 - 1 : x);
-        const int X = x + minX1;
-        us2 pix[NP];
-        bt_cost<NP>(row1[X], row2, X, dbase, Wp, pix);
+    // phase 1: four columns per trip so that their (independent) loads are in flight together
+    const int cols = n + 2 * SW2;
+    for (int i0 = 0; i0 < cols; i0 += 4) {
+        us2 pix[4][NP];
 #pragma unroll
-        for (int j = 0; j < NP; ++j) strip[(i * NP + j) * 64 + lane] = as_u32(pix[j]);
+        for (int q = 0; q < 4; ++q) {
+            int x = xs - SW2 + min(i0 + q, cols - 1);
+            x = x < 0 ? 0 : (x > width1 - 1 ? width1 - 1 : x);
+            const int X = x + minX1;
+            bt_cost<NP>(row1[X], row2, pitch2, (Wp - 1 - X) + dbase, pix[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (i0 + q < cols) strip_store<NP>(strip, i0 + q, lane, pix[q]);
     }
     // phase 2
-    us2 acc[NP];
+    us2 acc[NP], t[NP], u[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) acc[j] = pk_splat(0);
-    for (int i = 0; i < 2 * SW2 + 1; ++i)
+    for (int i = 0; i < 2 * SW2 + 1; ++i) {
+        strip_load<NP>(strip, i, lane, t);
 #pragma unroll
-        for (int j = 0; j < NP; ++j) acc[j] += as_us2(strip[(i * NP + j) * 64 + lane]);
+        for (int j = 0; j < NP; ++j) acc[j] += t[j];
+    }
     uint32_t* o = hsum + ((size_t)y * width1 + xs) * (64 * NP) + lane * NP;
     for (int i = 0; i < n; ++i) {
         if (i > 0) {
+            strip_load<NP>(strip, i + 2 * SW2, lane, t);
+            strip_load<NP>(strip, i - 1, lane, u);
 #pragma unroll
-            for (int j = 0; j < NP; ++j)
-                acc[j] = acc[j] + as_us2(strip[((i + 2 * SW2) * NP + j) * 64 + lane]) -
-                         as_us2(strip[((i - 1) * NP + j) * 64 + lane]);
+            for (int j = 0; j < NP; ++j) acc[j] = acc[j] + t[j] - u[j];
         }
 #pragma unroll
         for (int j = 0; j < NP; ++j) o[(size_t)i * (64 * NP) + j] = as_u32(acc[j]);
@@ -148,16 +211,22 @@ __global__ void __launch_bounds__(64) k_hsum(const uint2* __restrict__ bt1, cons
 // ---------------------------------------------------------------------------
 // K2b: C[y][x][d] = sum_{j=-SH2..SH2} hsum[clamp(y+j, 0, h-1)][x][d]   (no +P2
 // bias is stored; it cancels in the path recurrence and only matters for the
-// int16 range check, which is done here).  One wave per (x, segment of rows).
+// int16 range check, which is done here).  One wave per (x, segment of rows);
+// the 2*SH2+1 rows of the window live in a wave-private LDS ring so that every
+// hsum row is fetched once.
 // ---------------------------------------------------------------------------
 template <int NP>
 __global__ void __launch_bounds__(256) k_vsum(const uint32_t* __restrict__ hsum, int width1, int h, int D,
                                               int SH2, int P2, int YSEG, uint32_t* __restrict__ C,
                                               uint32_t* __restrict__ flags)
 {
+    extern __shared__ __attribute__((aligned(16))) uint32_t ringbuf[];   // [4 waves][WIN][NP][64]
     const int lane = threadIdx.x & 63;
-    const int x = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x = blockIdx.x * 4 + wv;
     if (x >= width1) return;
+    const int WIN = 2 * SH2 + 1;
+    uint32_t* ring = ringbuf + (size_t)wv * WIN * NP * 64 + lane;
     const int y0 = blockIdx.y * YSEG, y1 = min(y0 + YSEG, h);
     const size_t rowstride = (size_t)width1 * (64 * NP);
     const uint32_t* hp = hsum + (size_t)x * (64 * NP) + lane * NP;
@@ -168,20 +237,25 @@ __global__ void __launch_bounds__(256) k_vsum(const uint32_t* __restrict__ hsum,
     us2 acc[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) acc[j] = pk_splat(0);
-    for (int k = -SH2; k <= SH2; ++k) {
-        int yy = y0 + k;
+    for (int k = 0; k < WIN; ++k) {                                   // ring slot k holds row clamp(y0 - SH2 + k)
+        int yy = y0 - SH2 + k;
         yy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
 #pragma unroll
-        for (int j = 0; j < NP; ++j) acc[j] += as_us2(hp[(size_t)yy * rowstride + j]);
+        for (int j = 0; j < NP; ++j) {
+            const uint32_t v = hp[(size_t)yy * rowstride + j];
+            ring[(k * NP + j) * 64] = v;
+            acc[j] += as_us2(v);
+        }
     }
     bool over = false;
-    for (int y = y0; y < y1; ++y) {
-        if (y > y0) {
-            const int ya = min(y + SH2, h - 1), ys = max(y - SH2 - 1, 0);
+    int slot = 0;                                                     // slot of row clamp(y - SH2): the one leaving next
+    us2 nxt[NP];
+    {
+        const int ya = min(y0 + SH2 + 1, h - 1);
 #pragma unroll
-            for (int j = 0; j < NP; ++j)
-                acc[j] = acc[j] + as_us2(hp[(size_t)ya * rowstride + j]) - as_us2(hp[(size_t)ys * rowstride + j]);
-        }
+        for (int j = 0; j < NP; ++j) nxt[j] = as_us2(hp[(size_t)ya * rowstride + j]);
+    }
+    for (int y = y0; y < y1; ++y) {
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             us2 v = acc[j];
@@ -190,6 +264,21 @@ __global__ void __launch_bounds__(256) k_vsum(const uint32_t* __restrict__ hsum,
             if (d + 1 < D) over |= (v.y > lim.y); else v.y = 0xFFFF;
             cp[(size_t)y * rowstride + j] = as_u32(v);
         }
+        // slide: row min(y+SH2+1, h-1) enters (already in flight), row clamp(y-SH2) leaves
+        us2 cur[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) cur[j] = nxt[j];
+        if (y + 1 < y1) {
+            const int ya = min(y + SH2 + 2, h - 1);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) nxt[j] = as_us2(hp[(size_t)ya * rowstride + j]);
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            acc[j] = acc[j] + cur[j] - as_us2(ring[(slot * NP + j) * 64]);
+            ring[(slot * NP + j) * 64] = as_u32(cur[j]);
+        }
+        slot = slot + 1 == WIN ? 0 : slot + 1;
     }
     if (__any(over) && lane == 0) atomicOr(flags, 1u);
 }
@@ -198,15 +287,18 @@ template <int NP>
 static int launch_cost_np(wass_ctx* c, const SgmDims& d)
 {
     const int XC = 48;
-    const size_t lds = (size_t)(XC + 2 * d.SW2) * NP * 64 * sizeof(uint32_t);
+    const size_t lds = (size_t)(XC + 2 * d.SW2) * StripFmt<NP>::DW * 64 * sizeof(uint32_t);
     if (lds > 160 * 1024) return set_err(c, WASS_ERR_UNSUPPORTED, "WINSIZE %d too large for the LDS strip", 2 * d.SW2 + 1);
     WASS_HIP(c, hipFuncSetAttribute((const void*)k_hsum<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 g1((d.width1 + XC - 1) / XC, d.h);
-    hipLaunchKernelGGL(k_hsum<NP>, g1, dim3(64), lds, c->stream, (const uint2*)c->bt1.p, (const uint2*)c->bt2.p,
-                       d.Wp, d.width1, d.minX1, d.minD, d.SW2, XC, (uint32_t*)c->hsum.p);
-    const int YSEG = 64;
+    hipLaunchKernelGGL(k_hsum<NP>, g1, dim3(64), lds, c->stream, (const uint2*)c->bt1.p, (const unsigned short*)c->bt2.p,
+                       bt2_pitch(d.Wp), d.Wp, d.width1, d.minX1, d.minD, d.SW2, XC, (uint32_t*)c->hsum.p);
+    const int YSEG = 128;
+    const size_t lds2 = (size_t)4 * (2 * d.SW2 + 1) * NP * 64 * sizeof(uint32_t);
+    if (lds2 > 160 * 1024) return set_err(c, WASS_ERR_UNSUPPORTED, "WINSIZE %d too large for the LDS ring", 2 * d.SW2 + 1);
+    WASS_HIP(c, hipFuncSetAttribute((const void*)k_vsum<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     dim3 g2((d.width1 + 3) / 4, (d.h + YSEG - 1) / YSEG);
-    hipLaunchKernelGGL(k_vsum<NP>, g2, dim3(256), 0, c->stream, (const uint32_t*)c->hsum.p, d.width1, d.h, d.D,
+    hipLaunchKernelGGL(k_vsum<NP>, g2, dim3(256), lds2, c->stream, (const uint32_t*)c->hsum.p, d.width1, d.h, d.D,
                        d.SW2, d.P2, YSEG, (uint32_t*)c->C.p, (uint32_t*)c->flags.p);
     WASS_HIP(c, hipGetLastError());
     return WASS_OK;
