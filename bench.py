@@ -50,6 +50,21 @@ def cpu_baseline(w: int, D: int, ndirs: int, budget_rows: int = 192):
             "sample": f"{w}x{h} band of the workload, D={D}, {ndirs}-path, scalar C oracle, 1 thread, {dt:.1f}s"}
 
 
+def measured_traffic(config: str, ndirs: int):
+    """Per-frame HBM bytes of the aggregation kernels from the committed rocprofv3 PMC summary of this command
+    (profiles/*traffic_<config>_<ndirs>path.json, produced by scripts/profile.sh + scripts/traffic_json.py)."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*traffic_{config}_{ndirs}path.json"))):
+        try:
+            j = json.load(open(f))
+            if j.get("config") == config and j.get("ndirs") == ndirs:
+                best = (j["aggregation_hbm_bytes_per_frame"], os.path.relpath(f, ROOT))
+        except Exception:
+            pass
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,6 +172,7 @@ def main():
         alg_bytes = cells * (2 * args.ndirs + 4)             # (2R+4) B per cell
         t_agg = float(np.mean(agg_ms)) * 1e-3
         achieved = alg_bytes / t_agg / 1e9
+        traffic = measured_traffic(args.config, args.ndirs)
         line = {
             "metric": "stereo_pairs_per_sec", "value": round(pairs_s, 4), "unit": "pairs/s",
             "mdisp_per_sec": round(pairs_s * cells / 1e6, 1),
@@ -169,9 +185,11 @@ def main():
                                       if args.stage == "full" else "(a1-a6 only)") + ", frame-parallel over ranks",
                        "width": w, "height": h, "num_disp": D, "ndirs": args.ndirs, "pairs_per_rank": args.steps,
                        "stage": args.stage},
-            "roofline": {"bound": "hbm", "kernel": "k_sweep (path aggregation, all launches of one frame)",
+            "roofline": {"bound": "hbm", "kernel": "path aggregation family (k_ckpt + k_pair [+ k_sweep]), all launches of one frame",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": int(traffic[0]) if traffic else None,
+                         "traffic_source": traffic[1] if traffic else None,
                          "algorithmic_bytes": alg_bytes, "ms": round(t_agg * 1e3, 3)},
             "stage_ms": {"cost_volume": round(float(np.mean(cost_ms)), 3), "aggregate": round(t_agg * 1e3, 3),
                          "select": round(float(np.mean(sel_ms)), 3), "sgm_total": round(float(np.mean(sgm_ms)), 3)},
