@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--ndirs", type=int, default=8, choices=(5, 8))
     ap.add_argument("--config", default="B", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="frames in flight per GPU (each on its own context/stream/scratch, one host thread each)")
     ap.add_argument("--stage", default="full", choices=("full", "sgm"),
                     help="full = a1-a20 (SGBM, clean-up, triangulation, plane fit, xyzC); sgm = a1-a6 only")
     args = ap.parse_args()
@@ -95,22 +97,25 @@ def main():
 
     w, h, D = CONFIGS[args.config]
     params = wass_amd.default_sgm_params(D, ndirs=args.ndirs)
-    ctx = wass_amd.Context(local_rank)
+    nslot = max(1, args.inflight)
+    ctxs = [wass_amd.Context(local_rank) for _ in range(nslot)]
+    ctx = ctxs[0]
 
     # two different resident frames per rank, alternated, so no step can reuse a previous result
     frames = []
     for k in range(2):
         r, l = synth.make_pair(w, h, D, frame_idx=rank * 16 + k)
         frames.append((torch.from_numpy(r).to(dev), torch.from_numpy(l).to(dev)))
-    out = torch.empty((h, w), dtype=torch.int16, device=dev)
-    dispf = torch.empty((h, w), dtype=torch.float32, device=dev)
+    outs = [torch.empty((h, w), dtype=torch.int16, device=dev) for _ in range(nslot)]
+    dispfs = [torch.empty((h, w), dtype=torch.float32, device=dev) for _ in range(nslot)]
     geom = wass_amd.make_geom(synth.rig_geometry(w, h))
     roi = (0, 0, w, h)
     burned = [(fr[0] <= 254).to(torch.uint8) for fr in frames]      # DISCARD_BURNED_AREAS masks (right image)
     planes, npts_hist, nbytes_hist = [], [], []
-    xyzc_host = torch.empty(148 + 6 * w * h, dtype=torch.uint8, pin_memory=True)    # mesh_cam.xyzC lands here
+    xyzc_hosts = [torch.empty(148 + 6 * w * h, dtype=torch.uint8, pin_memory=True) for _ in range(nslot)]   # mesh_cam.xyzC
 
-    def step(i):
+    def step(i, slot=0):
+        ctx, out, dispf, xyzc_host = ctxs[slot], outs[slot], dispfs[slot], xyzc_hosts[slot]
         dr, dl = frames[i % 2]
         ctx.sgm_disparity_dev(dr, dl, params, out)
         if args.stage == "sgm":
@@ -138,18 +143,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    for i in range(max(args.warmup, nslot)):
+        step(i, i % nslot)
     barrier()
     planes.clear(); npts_hist.clear(); nbytes_hist.clear()
     agg_ms, cost_ms, sel_ms, sgm_ms = [], [], [], []
+
+    def run_slot(slot):
+        # frames slot, slot+nslot, ... : each slot is an independent context (stream + scratch HBM)
+        for i in range(slot, args.steps, nslot):
+            step(i, slot)
+            # stage timings come from hipEvents recorded on the context's own stream; reading them
+            # waits for this frame, which is the reference's per-frame execution model anyway
+            t = ctxs[slot].sgm_timings()
+            agg_ms.append(t.aggregate_ms); cost_ms.append(t.cost_ms); sel_ms.append(t.select_ms); sgm_ms.append(t.total_ms)
+
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-        # stage timings come from hipEvents recorded on the context's own stream; reading them
-        # waits for this frame, which is the reference's per-frame execution model anyway
-        t = ctx.sgm_timings()
-        agg_ms.append(t.aggregate_ms); cost_ms.append(t.cost_ms); sel_ms.append(t.select_ms); sgm_ms.append(t.total_ms)
+    if nslot == 1:
+        run_slot(0)
+    else:
+        import threading
+        th = [threading.Thread(target=run_slot, args=(s_,)) for s_ in range(nslot)]
+        for t_ in th: t_.start()
+        for t_ in th: t_.join()
     barrier()
     elapsed = time.perf_counter() - t0
     # Coll-1: sequence mean plane = NaN-aware mean over every rank's frames (5 doubles all-reduced over RCCL)
@@ -184,7 +200,7 @@ def main():
                                    + ("+ disparity clean-up + triangulation + z-gap/CC + RANSAC plane + refine + xyzC encode"
                                       if args.stage == "full" else "(a1-a6 only)") + ", frame-parallel over ranks",
                        "width": w, "height": h, "num_disp": D, "ndirs": args.ndirs, "pairs_per_rank": args.steps,
-                       "stage": args.stage},
+                       "stage": args.stage, "frames_in_flight": nslot},
             "roofline": {"bound": "hbm", "kernel": "path aggregation family (k_ckpt + k_pair [+ k_sweep]), all launches of one frame",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -204,7 +220,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    for c_ in ctxs:
+        c_.close()
 
 
 if __name__ == "__main__":

@@ -136,3 +136,22 @@ def test_overflow_is_reported(gpu_ctx):
     with pytest.raises(wass_amd.WassError) as e:
         gpu_ctx.sgm_disparity(right, left, p)
     assert e.value.code == -5
+
+
+@pytest.mark.parametrize("ndirs", [5, 8])
+def test_pipelined_strip_schedule_is_bit_exact(gpu_ctx, oracle, ndirs, monkeypatch):
+    """WASS_AGG=trio: the alternative aggregation schedule (neighbour hand-off through HBM) gives the same bits."""
+    monkeypatch.setenv("WASS_AGG", "trio")
+    for (w, h, D) in ((160, 120, 32), (300, 40, 160), (340, 32, 272)):
+        right, left = synth.make_pair(w, h, D, frame_idx=77)
+        p = default_sgm_params(D, ndirs=ndirs)
+        gpu_ctx.set_debug(True)
+        try:
+            got = gpu_ctx.sgm_disparity(right, left, p)
+            _, Sg, _ = gpu_ctx.sgm_debug_fetch(w, h, p, want=("S",))
+        finally:
+            gpu_ctx.set_debug(False)
+        R, L = _pad(right, left, D)
+        disp, st, Co, So, rawo = oracle.sgbm_compute(R, L, _oracle_params(oracle, p), dump=True)
+        np.testing.assert_array_equal(Sg, So)
+        np.testing.assert_array_equal(got, disp[:, D:D + w])

@@ -113,7 +113,7 @@ void wass_ctx_destroy(wass_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (Buf* b : { &c->img1, &c->img2, &c->bt1, &c->bt2, &c->hsum, &c->C, &c->S, &c->ckpt, &c->sel_d16, &c->sel_key, &c->raw,
+    for (Buf* b : { &c->img1, &c->img2, &c->bt1, &c->bt2, &c->hsum, &c->C, &c->S, &c->S2, &c->halo, &c->ckpt, &c->sel_d16, &c->sel_key, &c->raw,
                     &c->flags, &c->tmp_in0, &c->tmp_in1, &c->tmp_out, &c->tmp_mask, &c->fA, &c->fB, &c->fC, &c->scratch, &c->counters })
         release(*b);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -204,6 +204,10 @@ int wass_sgm_last_timings(wass_ctx* c, wass_sgm_timings* out)
     WASS_HIP(c, hipMemcpy(&fl, c->flags.p, 4, hipMemcpyDeviceToHost));
     t.cost_overflow = (int)(fl & 1);
     *out = t;
+    if (fl & 2) {
+        c->halo_dirty = true;
+        return set_err(c, WASS_ERR_DEVICE, "aggregation pipeline timed out waiting for a neighbouring strip");
+    }
     return WASS_OK;
 }
 
@@ -226,6 +230,10 @@ int wass_sgm_disparity(wass_ctx* c, const uint8_t* right, const uint8_t* left, i
     uint32_t fl = 0;
     WASS_HIP(c, hipMemcpyAsync(&fl, c->flags.p, 4, hipMemcpyDeviceToHost, c->stream));
     WASS_HIP(c, hipStreamSynchronize(c->stream));
+    if (fl & 2) {
+        c->halo_dirty = true;
+        return set_err(c, WASS_ERR_DEVICE, "aggregation pipeline timed out waiting for a neighbouring strip");
+    }
     if (fl & 1)
         return set_err(c, WASS_ERR_COST_OVERFLOW,
                        "block cost + P2 exceeded 32767: outside the range where the reference is well defined");

@@ -112,6 +112,9 @@ struct wass_ctx {
     wass::Buf bt1, bt2;            // BT interval records: bt1 8 B/pixel; bt2 six mirrored u16 planes per row
     wass::Buf hsum, C, S;          // u16 volumes [h][width1][Dp]
     wass::Buf ckpt;                // forward-path checkpoints of k_pair (1/K of a volume)
+    wass::Buf S2;                  // second partial-sum volume (pipelined-strip schedule)
+    wass::Buf halo;                // boundary vectors handed between neighbouring strips (two sweeps)
+    bool halo_dirty = false;       // a time-out left the halo buffer in an unknown state
     wass::Buf sel_d16, sel_key;    // per (y,x): raw fixed-point disparity / (minS<<16|d)
     wass::Buf raw;                 // padded-width raw disparity [h][Wp] int16
     wass::Buf flags;               // u32[4]: [0] = cost overflow
@@ -149,5 +152,10 @@ int launch_cost_volume(wass_ctx* c, const SgmDims& d);
 int launch_aggregate(wass_ctx* c, const SgmDims& d, int* n_launches);
 int launch_select(wass_ctx* c, const SgmDims& d);
 int launch_median_crop(wass_ctx* c, const SgmDims& d, int16_t* d_out);
+// pipelined column-strip sweeps (sgm_trio.hip)
+size_t trio_halo_bytes(const SgmDims& d);
+int launch_trio(wass_ctx* c, const SgmDims& d, uint32_t* Sout, unsigned long long* halo, int xdir, int ydir, bool has_v,
+                hipStream_t stream);
+int launch_wta_sum(wass_ctx* c, const SgmDims& d, const uint32_t* S, const uint32_t* S2, hipStream_t stream);
 
 }  // namespace wass

@@ -1,0 +1,207 @@
+// sgm_step.h -- the path-cost recurrence and its helpers, shared by every aggregation kernel
+// (sgm_aggregate.hip: chain sweeps / pairs; sgm_trio.hip: pipelined column strips).
+#pragma once
+
+#include "common.h"
+
+namespace wass {
+
+// State carried along one chain: the (un-normalised) path costs of the previous
+// pixel and their minimum over d.  Keeping the minimum as a separate wave-uniform
+// scalar takes its cross-lane reduction off the critical path of the next step:
+//   L'(d) = C(d) + min(L(d), min(L(d-1), L(d+1)) + P1, m + P2) - m,   m' = min_d L'
+// (same value as the normalised form in the header comment; only L - m matters).
+template <int NP>
+struct PathState {
+    us2 L[NP];
+    uint32_t m;
+    // destinations of the two wave-shift DPP moves.  Lane 0 (resp. 63) has no source lane and keeps
+    // its value, so initialising them once with 0xFFFFFFFF provides the d=-1 / d=Dp sentinels
+    // without re-materialising the constant every step.
+    uint32_t shr = 0xFFFFFFFFu, shl = 0xFFFFFFFFu;
+    __device__ __forceinline__ void reset()
+    {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) L[j] = pk_splat(0);
+        m = 0;
+    }
+    // checkpoint form: costs relative to their minimum
+    __device__ __forceinline__ void store_normalised(uint32_t* __restrict__ p) const
+    {
+        const us2 mv = pk_splat(m);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) p[j] = as_u32(L[j] - mv);
+    }
+    __device__ __forceinline__ void load_normalised(const us2 (&v)[NP])
+    {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) L[j] = v[j];
+        m = 0;
+    }
+};
+
+template <int NP>
+__device__ __forceinline__ void sgm_step(PathState<NP>& st, const us2 (&c)[NP], us2 (&Lo)[NP], const us2 P1v,
+                                         const uint32_t P2)
+{
+    // pair holding d-1 of this lane's first value / d+1 of its last value (0xFFFF outside [0,Dp))
+    st.shr = dpp_mov<DPP_WAVE_SHR1>(st.shr, as_u32(st.L[NP - 1]));
+    st.shl = dpp_mov<DPP_WAVE_SHL1>(st.shl, as_u32(st.L[0]));
+    const uint32_t prev_last = st.shr, next_first = st.shl;
+    const us2 mv = pk_splat(st.m), mp2 = pk_splat(st.m + P2);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const uint32_t lo = j == 0 ? prev_last : as_u32(st.L[j - 1]);
+        const uint32_t hi = j == NP - 1 ? next_first : as_u32(st.L[j + 1]);
+        const us2 nl = as_us2(__builtin_amdgcn_alignbit(as_u32(st.L[j]), lo, 16));   // (d-1, d)
+        const us2 nr = as_us2(__builtin_amdgcn_alignbit(hi, as_u32(st.L[j]), 16));   // (d+1, d+2)
+        const us2 x = pk_min(st.L[j], pk_adds(pk_min(nl, nr), P1v));
+        Lo[j] = pk_adds(c[j], pk_min(x, mp2) - mv);
+    }
+    us2 m = Lo[0];
+#pragma unroll
+    for (int j = 1; j < NP; ++j) m = pk_min(m, Lo[j]);
+    st.m = wave_min_u32(min((uint32_t)m.x, (uint32_t)m.y));
+#pragma unroll
+    for (int j = 0; j < NP; ++j) st.L[j] = Lo[j];
+}
+
+// Two independent chains advanced together, statement by statement, so that each one's dependent
+// packed-math / DPP wait states are filled by the other's instructions.
+template <int NP>
+__device__ __forceinline__ void sgm_step_pair(PathState<NP>& a, const us2 (&ca)[NP], us2 (&La)[NP],
+                                              PathState<NP>& b, const us2 (&cb)[NP], us2 (&Lb)[NP],
+                                              const us2 P1v, const uint32_t P2)
+{
+    a.shr = dpp_mov<DPP_WAVE_SHR1>(a.shr, as_u32(a.L[NP - 1]));
+    b.shr = dpp_mov<DPP_WAVE_SHR1>(b.shr, as_u32(b.L[NP - 1]));
+    a.shl = dpp_mov<DPP_WAVE_SHL1>(a.shl, as_u32(a.L[0]));
+    b.shl = dpp_mov<DPP_WAVE_SHL1>(b.shl, as_u32(b.L[0]));
+    const us2 amv = pk_splat(a.m), amp2 = pk_splat(a.m + P2);
+    const us2 bmv = pk_splat(b.m), bmp2 = pk_splat(b.m + P2);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const uint32_t alo = j == 0 ? a.shr : as_u32(a.L[j - 1]);
+        const uint32_t blo = j == 0 ? b.shr : as_u32(b.L[j - 1]);
+        const uint32_t ahi = j == NP - 1 ? a.shl : as_u32(a.L[j + 1]);
+        const uint32_t bhi = j == NP - 1 ? b.shl : as_u32(b.L[j + 1]);
+        const us2 anl = as_us2(__builtin_amdgcn_alignbit(as_u32(a.L[j]), alo, 16));
+        const us2 bnl = as_us2(__builtin_amdgcn_alignbit(as_u32(b.L[j]), blo, 16));
+        const us2 anr = as_us2(__builtin_amdgcn_alignbit(ahi, as_u32(a.L[j]), 16));
+        const us2 bnr = as_us2(__builtin_amdgcn_alignbit(bhi, as_u32(b.L[j]), 16));
+        us2 ax = pk_min(anl, anr);
+        us2 bx = pk_min(bnl, bnr);
+        ax = pk_adds(ax, P1v);
+        bx = pk_adds(bx, P1v);
+        ax = pk_min(a.L[j], ax);
+        bx = pk_min(b.L[j], bx);
+        ax = pk_min(ax, amp2);
+        bx = pk_min(bx, bmp2);
+        ax = ax - amv;
+        bx = bx - bmv;
+        La[j] = pk_adds(ca[j], ax);
+        Lb[j] = pk_adds(cb[j], bx);
+    }
+    us2 am = La[0], bm = Lb[0];
+#pragma unroll
+    for (int j = 1; j < NP; ++j) { am = pk_min(am, La[j]); bm = pk_min(bm, Lb[j]); }
+    uint32_t ra = min((uint32_t)am.x, (uint32_t)am.y), rb = min((uint32_t)bm.x, (uint32_t)bm.y);
+    wave_min2_u32(ra, rb);
+    a.m = ra; b.m = rb;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) { a.L[j] = La[j]; b.L[j] = Lb[j]; }
+}
+
+// chain c of direction (dx,dy): start cell and length
+__device__ __forceinline__ void chain_geometry(int c, int dx, int dy, int width1, int h, int& x0, int& y0, int& n)
+{
+    if (dy == 0) { y0 = c; x0 = dx > 0 ? 0 : width1 - 1; n = width1; }
+    else if (dx == 0) { x0 = c; y0 = dy > 0 ? 0 : h - 1; n = h; }
+    else {
+        if (c < width1) { x0 = c; y0 = dy > 0 ? 0 : h - 1; }
+        else { const int k = c - width1 + 1; x0 = dx > 0 ? 0 : width1 - 1; y0 = dy > 0 ? k : h - 1 - k; }
+        const int nx = dx > 0 ? width1 - x0 : x0 + 1;
+        const int ny = dy > 0 ? h - y0 : y0 + 1;
+        n = min(nx, ny);
+    }
+}
+
+// K consecutive vectors of a chain -> registers; GUARD: only the first len exist
+template <int NP, int K, bool GUARD>
+__device__ __forceinline__ void load_seg(const uint32_t* __restrict__ p, long long step, int len, us2 (&dst)[K][NP])
+{
+#pragma unroll
+    for (int u = 0; u < K; ++u)
+        if (!GUARD || u < len) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) dst[u][j] = as_us2(p[u * step + j]);
+        }
+}
+
+template <int NP, int K>
+__device__ __forceinline__ void copy_seg(us2 (&dst)[K][NP], const us2 (&src)[K][NP])
+{
+#pragma unroll
+    for (int u = 0; u < K; ++u)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) dst[u][j] = src[u][j];
+}
+
+// ---------------------------------------------------------------------------
+// Winner-take-all on a finished S vector held in registers (Appendix A.5 steps
+// 2, 3 and 5; the right-view scatter and the L-R check need the whole row and
+// stay in k_lrcheck).  key = (S << 16) | d reduced with a wave minimum gives the
+// smallest S and, among equals, the smallest d ("first minimum").
+// ---------------------------------------------------------------------------
+template <int NP>
+__device__ __forceinline__ int s_at(const us2 (&Sv)[NP], int d)
+{
+    const int ln = d / (2 * NP), slot = d % (2 * NP);       // wave-uniform
+    uint32_t pv = 0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j)
+        if ((slot >> 1) == j) pv = (uint32_t)__builtin_amdgcn_readlane((int)as_u32(Sv[j]), ln);
+    return (int)((slot & 1) ? (pv >> 16) : (pv & 0xFFFF));
+}
+
+template <int NP>
+__device__ __forceinline__ void wta_select(const us2 (&Sv)[NP], int lane, int D, int minD, int uniq,
+                                           int16_t* __restrict__ out_d16, uint32_t* __restrict__ out_key)
+{
+    const int dlane = lane * 2 * NP;
+    uint32_t sv[2 * NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) { sv[2 * j] = Sv[j].x; sv[2 * j + 1] = Sv[j].y; }
+    uint32_t key = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < 2 * NP; ++j)
+        if (dlane + j < D) key = min(key, (sv[j] << 16) | (uint32_t)(dlane + j));
+    key = wave_min_u32(key);
+    const int minS = (int)(key >> 16);
+    // "if (Sval < minS)" with minS initialised to MAX_COST never fires when every S is MAX_COST
+    const int best = minS >= 32767 ? -1 : (int)(key & 0xFFFF);
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 2 * NP; ++j) {
+        const int d = dlane + j;
+        if (d < D && (int)sv[j] * (100 - uniq) < minS * 100 && abs(best - d) > 1) bad = true;
+    }
+    const bool reject = __any(bad);
+    int out = (minD - 1) * 16;
+    uint32_t k = 0xFFFFFFFFu;
+    if (!reject) {                                             // wave-uniform
+        int d = best;
+        k = ((uint32_t)minS << 16) | (uint32_t)(best & 0xFFFF);
+        if (0 < d && d < D - 1) {
+            const int a = s_at<NP>(Sv, d - 1), cc = s_at<NP>(Sv, d + 1), b = minS;
+            const int denom2 = max(a + cc - 2 * b, 1);
+            d = d * 16 + ((a - cc) * 16 + denom2) / (denom2 * 2);
+        } else
+            d *= 16;
+        out = d + minD * 16;
+    }
+    if (lane == 0) { *out_d16 = (int16_t)out; *out_key = k; }
+}
+
+
+}  // namespace wass
