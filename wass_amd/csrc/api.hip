@@ -101,6 +101,7 @@ int wass_ctx_create(int device_id, wass_ctx** out)
     for (auto& e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
     if (hipEventCreateWithFlags(&c->ev_cost, hipEventDisableTiming) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
+    if (hipEventCreateWithFlags(&c->ev_cols, hipEventDisableTiming) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
     for (auto& e : c->ev_ckpt)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
     if (ensure(c, c->flags, 64) != WASS_OK) { delete c; return WASS_ERR_NO_MEMORY; }
@@ -119,6 +120,7 @@ void wass_ctx_destroy(wass_ctx* c)
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_ckpt) if (e) (void)hipEventDestroy(e);
     if (c->ev_cost) (void)hipEventDestroy(c->ev_cost);
+    if (c->ev_cols) (void)hipEventDestroy(c->ev_cols);
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     if (c->side2) { (void)hipStreamSynchronize(c->side2); (void)hipStreamDestroy(c->side2); }
     if (c->stream) (void)hipStreamDestroy(c->stream);

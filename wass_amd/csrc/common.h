@@ -125,7 +125,7 @@ struct wass_ctx {
     wass::Buf scratch;             // mesh stages: gaps / labels / partial sums / packed output
     hipEvent_t ev[8] = {};
     hipStream_t side = nullptr, side2 = nullptr;   // checkpoint sweeps run ahead here
-    hipEvent_t ev_cost = nullptr, ev_ckpt[4] = {};
+    hipEvent_t ev_cost = nullptr, ev_ckpt[4] = {}, ev_cols = nullptr;
     wass::SgmDims last = {};
     bool have_last = false;
     bool debug = false;            // keep the finished S volume for wass_sgm_debug_fetch

@@ -149,6 +149,7 @@ __global__ void __launch_bounds__(256) k_ckpt(const uint32_t* __restrict__ C, ui
 }
 
 // SMODE 3: like 2, but the partial sums of the earlier sweeps arrive in two volumes (S + S2).
+// SMODE 4: like 1 with two inputs: S = S + S2 + Lf + Lb.
 template <int NP, int K, int SMODE>
 __global__ void __launch_bounds__(256) k_pair(const uint32_t* __restrict__ C, uint32_t* __restrict__ S,
                                               const uint32_t* __restrict__ S2,
@@ -173,7 +174,7 @@ __global__ void __launch_bounds__(256) k_pair(const uint32_t* __restrict__ C, ui
     uint32_t* ck = ckpt + ((long long)c * maxseg) * vec + lane * NP;
     const us2 P1v = pk_splat(P1), cap = pk_splat(0x7FFF);
     const int F = n / K, r = n - F * K;            // F full segments, then a tail of r steps
-    constexpr bool LAST = SMODE >= 2, TWO = SMODE == 3;
+    constexpr bool LAST = SMODE == 2 || SMODE == 3, TWO = SMODE == 3 || SMODE == 4;
 
     // one finished backward step: S handling + optional winner-take-all
     auto finish = [&](const us2 (&lf)[NP], const us2 (&lb)[NP], const us2 (&sin)[NP], const us2 (&sin2)[NP], uint32_t* sp,
@@ -403,18 +404,36 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
         ++nl;
     }
 
+    // WASS_AGG=concurrent (experiment): the row and the column family, which have the fewest chains, run
+    // concurrently, each writing its own volume (S, S2), and the first diagonal family folds the two together.
+    // Same bytes as the serial order and, measured, the same time (8.3 vs 8.2 ms): the family is bandwidth-bound.
+    const bool conc = d.ndirs == 8 && getenv("WASS_AGG") && !strcmp(getenv("WASS_AGG"), "concurrent");
+    if (conc) {
+        int rc2 = ensure(c, c->S2, d.cells() * sizeof(uint16_t));
+        if (rc2) return rc2;
+    }
+    const uint32_t* S2 = conc ? (const uint32_t*)c->S2.p : (const uint32_t*)S;
     for (int f = 0; f < nf; ++f) {
         const int dx = fam[f].dx, dy = fam[f].dy;
         const int nch = nchains(dx, dy), mseg = (maxlen(dx, dy) + K - 1) / K;
         uint32_t* ck = (uint32_t*)((char*)c->ckpt.p + off[f]);
-        WASS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_ckpt[f], 0));
         const dim3 grid((nch + 3) / 4), block(256);
-#define WASS_PAIR(SMODE)                                                                                     \
-        hipLaunchKernelGGL((k_pair<NP, K, SMODE>), grid, block, 0, c->stream, C, S, (const uint32_t*)S, ck, d.width1, d.h, dx, dy, \
+#define WASS_PAIR(SMODE, STREAM, SOUT)                                                                       \
+        hipLaunchKernelGGL((k_pair<NP, K, SMODE>), grid, block, 0, STREAM, C, SOUT, S2, ck, d.width1, d.h, dx, dy, \
                            d.P1, d.P2, nch, mseg, d.D, d.minD, d.uniq, c->debug ? 1 : 0, sd, sk)
-        if (fam[f].smode == 0) WASS_PAIR(0);
-        else if (fam[f].smode == 1) WASS_PAIR(1);
-        else WASS_PAIR(2);
+        if (conc && f == 1) {                       // columns -> S2 on the second side stream, concurrent with the rows
+            WASS_HIP(c, hipStreamWaitEvent(c->side2, c->ev_ckpt[f], 0));
+            WASS_PAIR(0, c->side2, (uint32_t*)c->S2.p);
+            WASS_HIP(c, hipEventRecord(c->ev_cols, c->side2));
+        } else {
+            WASS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_ckpt[f], 0));
+            if (conc && f == 2) {                   // diagonals: S = S + S2 + pair
+                WASS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_cols, 0));
+                WASS_PAIR(4, c->stream, S);
+            } else if (fam[f].smode == 0) WASS_PAIR(0, c->stream, S);
+            else if (fam[f].smode == 1) WASS_PAIR(1, c->stream, S);
+            else WASS_PAIR(2, c->stream, S);
+        }
 #undef WASS_PAIR
         ++nl;
     }
