@@ -124,14 +124,10 @@ def main():
         # refine -> crop -> mesh_cam.xyzC (defaults of SURVEY.md Appendix C, RANDOM_SEED=12345)
         ctx.disparity_postprocess_dev(out, params, 1, 2, 0, dispf)
         mesh, n = ctx.triangulate_dev(dispf, w, h, roi, roi, geom, dr, None, burned[i % 2], 20.0, None, 1.0)
-        zg, _ = mesh.zgap_percentile(99.0)
-        mesh.keep_biggest_component(zg)
+        mesh.remove_outliers(99.0)
         uv = wass_amd.ransac_sample(w, h, 400, 12345)
-        found, pl, _ = mesh.ransac_plane(uv, 1.0)
-        if found:
-            mesh.crop_plane(pl, 1.0)
-            pl, _ = mesh.refine_plane()
-            mesh.crop_plane(pl, 1.5)
+        res = mesh.fit_plane(uv, 1.0, 1.5)
+        found, pl = bool(res.found), np.array(res.plane[:])
         nbytes = mesh.encode_xyzc_to(pl if found else None, xyzc_host.data_ptr(), xyzc_host.numel())
         planes.append(pl if found else np.full(4, np.nan))
         npts_hist.append(n); nbytes_hist.append(nbytes)

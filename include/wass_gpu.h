@@ -200,6 +200,24 @@ typedef struct {
 /* refine_plane (:581-660): weighted PCA plane through the inliers */
 int wass_mesh_refine_plane(wass_ctx* ctx, wass_mesh* m, const wass_refine_params* rp,
                            double plane_out[4], uint64_t* n_inliers);
+/* Fused forms of the calls above for throughput: same results, but every intermediate decision (radix-select
+ * digits, winning component, best RANSAC candidate, centroid, 3x3 eigenvector) is taken on the device and the
+ * host reads back once.
+ *   wass_mesh_remove_outliers = zgap_percentile + keep_biggest_component   (wass_stereo.cpp:2046-2050)
+ *   wass_mesh_fit_plane       = ransac_plane -> crop_plane(ransac_thr) -> refine_plane -> crop_plane(max_distance)
+ *                               (wass_stereo.cpp:2062-2107); found == 0: nothing cropped, plane = NaN */
+int wass_mesh_remove_outliers(wass_ctx* ctx, wass_mesh* m, double percentile, double* zgap_out, uint64_t* n_gaps,
+                              uint64_t* size_out);
+typedef struct {
+    int      found;                 /* RANSAC succeeded (best >= width*height/10)   */
+    double   ransac_plane[4];
+    uint64_t ransac_inliers;
+    double   plane[4];              /* refined plane                                 */
+    uint64_t refine_inliers;
+    uint64_t kept_after_ransac_crop, kept_final;
+} wass_plane_result;
+int wass_mesh_fit_plane(wass_ctx* ctx, wass_mesh* m, const int32_t* uv_triplets, int rounds, double ransac_thr,
+                        const wass_refine_params* rp, double max_distance, wass_plane_result* out);
 /* RT_from_plane (:1044-1069); pure host math */
 void wass_RT_from_plane(const double plane[4], double R[9], double T[3], double Rinv[9], double Tinv[3]);
 /* save_as_xyz_compressed (:377-460): returns the exact bytes of mesh_cam.xyzC

@@ -266,6 +266,43 @@ def test_xyzc_bytes_exact(gpu_ctx, oracle):
     np.testing.assert_array_equal(Rinv, np.eye(3))
 
 
+@pytest.mark.parametrize("seed", [0, 3])
+def test_fused_calls_equal_step_by_step(gpu_ctx, oracle, seed):
+    """wass_mesh_remove_outliers / wass_mesh_fit_plane take their decisions on the device; same results as the
+    one-call-per-PovMesh-method sequence and as the oracle."""
+    valid, p3d, _ = _cloud(seed=seed)
+    uv = wass_amd.ransac_sample(valid.shape[1], valid.shape[0], 400, 12345)
+    a = gpu_ctx.mesh_upload(valid, p3d)
+    zg, ng = a.zgap_percentile(99.0)
+    sz = a.keep_biggest_component(zg)
+    found, pl, best = a.ransac_plane(uv, 1.0)
+    k1 = a.crop_plane(pl, 1.0)
+    pl2, ninl = a.refine_plane()
+    k2 = a.crop_plane(pl2, 1.5)
+    b = gpu_ctx.mesh_upload(valid, p3d)
+    zg_b, ng_b, sz_b = b.remove_outliers(99.0)
+    assert (zg_b, ng_b, sz_b) == (zg, ng, sz)
+    res = b.fit_plane(uv, 1.0, 1.5)
+    assert bool(res.found) == found and res.ransac_inliers == best
+    np.testing.assert_array_equal(np.array(res.ransac_plane[:]), pl)
+    assert res.kept_after_ransac_crop == k1 and res.refine_inliers == ninl and res.kept_final == k2
+    np.testing.assert_array_equal(np.array(res.plane[:]), pl2)          # same arithmetic on host and device
+    np.testing.assert_array_equal(a.download()[0], b.download()[0])
+    # oracle
+    ozg, _ = oracle.zgap_percentile(valid, p3d, 99.0)
+    assert zg_b == ozg
+    # RANSAC failure path: nothing cropped, plane NaN
+    v2 = valid.copy(); v2[:] = 0; v2[:6, :6] = 1
+    m2 = gpu_ctx.mesh_upload(v2, p3d)
+    r2 = m2.fit_plane(uv, 1.0, 1.5)
+    assert not r2.found and np.isnan(np.array(r2.plane[:])).all()
+    np.testing.assert_array_equal(m2.download()[0], v2)
+    # empty mesh
+    e = gpu_ctx.mesh_upload(np.zeros((9, 11), np.uint8), np.zeros((9, 11, 3)))
+    ze, ne, se = e.remove_outliers(99.0)
+    assert np.isnan(ze) and ne == 0 and se == 0
+
+
 def test_planes_mean(oracle):
     import os
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "planes_txt.npz"))

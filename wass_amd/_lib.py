@@ -54,6 +54,13 @@ class RefineParams(C.Structure):
                 ("max_distance", C.c_double), ("weight_by_distance", C.c_int), ("central_third_only", C.c_int)]
 
 
+class PlaneResult(C.Structure):
+    """wass_plane_result"""
+    _fields_ = [("found", C.c_int), ("ransac_plane", C.c_double * 4), ("ransac_inliers", C.c_uint64),
+                ("plane", C.c_double * 4), ("refine_inliers", C.c_uint64), ("kept_after_ransac_crop", C.c_uint64),
+                ("kept_final", C.c_uint64)]
+
+
 def default_sgm_params(num_disp: int, ndirs: int = 5, min_disp: int = 1, win: int = 13, p1_mult: int = 2,
                        p2_mult: int = 64, disp_offset: int = 0) -> SgmParams:
     """Defaults of SURVEY.md Appendix C (wass_stereo.cpp:742-759)."""
@@ -92,6 +99,10 @@ SYMBOLS = {
                                     C.POINTER(_i)]),
     "wass_mesh_crop_plane": (_i, [_vp, _vp, C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_uint64)]),
     "wass_mesh_refine_plane": (_i, [_vp, _vp, C.POINTER(RefineParams), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "wass_mesh_remove_outliers": (_i, [_vp, _vp, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
+                                       C.POINTER(C.c_uint64)]),
+    "wass_mesh_fit_plane": (_i, [_vp, _vp, _vp, _i, C.c_double, C.POINTER(RefineParams), C.c_double,
+                                 C.POINTER(PlaneResult)]),
     "wass_RT_from_plane": (None, [C.POINTER(C.c_double)] * 5),
     "wass_mesh_encode_xyzc": (_i, [_vp, _vp, C.POINTER(C.c_double), C.POINTER(_vp), C.POINTER(_sz)]),
     "wass_mesh_encode_xyzc_to": (_i, [_vp, _vp, C.POINTER(C.c_double), _vp, _sz, C.POINTER(_sz)]),

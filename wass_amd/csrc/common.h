@@ -122,6 +122,7 @@ struct wass_ctx {
     wass::Buf tmp_mask;
     wass::Buf fA, fB, fC;          // float32 maps of the disparity clean-up
     wass::Buf counters;            // striped atomics of the mesh stages
+    wass::Buf dstate;              // device-resident scalar record + radix histogram (mesh.hip DevState)
     wass::Buf scratch;             // mesh stages: gaps / labels / partial sums / packed output
     hipEvent_t ev[8] = {};
     hipStream_t side = nullptr, side2 = nullptr;   // checkpoint sweeps run ahead here

@@ -123,10 +123,10 @@ __global__ void __launch_bounds__(256) k_triangulate(const float* __restrict__ d
                                                      double* __restrict__ Y, double* __restrict__ Z,
                                                      uint8_t* __restrict__ gray, unsigned long long* __restrict__ count)
 {
-    const int u = blockIdx.x * 256 + threadIdx.x;
-    const int v = blockIdx.y;
-    if (u >= mw) return;
-    const size_t idx = (size_t)v * mw + u;
+    unsigned int found = 0;
+    const size_t npx = (size_t)mw * mh;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < npx; idx += (size_t)gridDim.x * 256) {
+    const int u = (int)(idx % mw), v = (int)(idx / mw);
     bool ok = false;
     double P[3] = { 0, 0, 0 };
     uint8_t gv = 0;
@@ -174,8 +174,10 @@ __global__ void __launch_bounds__(256) k_triangulate(const float* __restrict__ d
     valid[idx] = ok ? 1 : 0;
     X[idx] = ok ? P[0] : 0.0; Y[idx] = ok ? P[1] : 0.0; Z[idx] = ok ? P[2] : 0.0;
     gray[idx] = gv;
-    const unsigned long long b = __ballot(ok);
-    if ((threadIdx.x & 63) == 0 && b) atomicAdd(count + slot_of_block(), (unsigned long long)__popcll(b));
+    found += ok ? 1u : 0u;
+    }
+    for (int o = 32; o > 0; o >>= 1) found += __shfl_down(found, o);
+    if ((threadIdx.x & 63) == 0 && found) atomicAdd(count + slot_of_block(), (unsigned long long)found);
 }
 
 // ------------------------------------------------------------------ z-gap percentile (PovMesh.cpp:888-926)
@@ -261,9 +263,10 @@ __device__ __forceinline__ bool vlink(const uint8_t* valid, const double* Z, int
     return i + w < n && valid[i] && valid[i + w] && fabs(Z[i] - Z[i + w]) < zgap;
 }
 __global__ void __launch_bounds__(256) k_ccl_init(const uint8_t* __restrict__ valid, const double* __restrict__ Z, int w, int n,
-                                                  double zgap, int* __restrict__ parent, unsigned int* __restrict__ size,
-                                                  unsigned int* __restrict__ mincm)
+                                                  const double* __restrict__ zgap_p, int* __restrict__ parent,
+                                                  unsigned int* __restrict__ size, unsigned int* __restrict__ mincm)
 {
+    const double zgap = *zgap_p;
     __shared__ int wmax[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const bool v = i < n && valid[i];
@@ -277,8 +280,9 @@ __global__ void __launch_bounds__(256) k_ccl_init(const uint8_t* __restrict__ va
     if (i < n) { parent[i] = v ? s : -1; size[i] = 0; mincm[i] = 0xFFFFFFFFu; }
 }
 __global__ void __launch_bounds__(256) k_ccl_merge(const uint8_t* __restrict__ valid, const double* __restrict__ Z, int w, int n,
-                                                   double zgap, int* parent)
+                                                   const double* __restrict__ zgap_p, int* parent)
 {
+    const double zgap = *zgap_p;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n || !valid[i]) return;
     // runs were cut at block boundaries: stitch them
@@ -355,6 +359,93 @@ __global__ void __launch_bounds__(256) k_ccl_keep(uint8_t* __restrict__ valid, i
         keep = key == *best;
     }
     valid[i] = keep ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ device-resident scalars
+// Decisions that only need a few numbers (the digit of a radix-select pass, the best RANSAC candidate, a 3x3
+// eigenvector) are taken by single-workgroup kernels writing into this record, so that a whole stage chain runs
+// without host round trips; the host reads the record once at the end.
+struct DevState {
+    unsigned long long sel_k, sel_prefix, sel_total;      // radix select: remaining rank, key prefix, number of keys
+    int sel_hi_shift, sel_fail;
+    double zgap;
+    unsigned long long ccl_best;                          // (size << 32) | ~mincm of the winning component
+    int ransac_found, pad0;
+    unsigned long long ransac_best;
+    double ransac_plane[4];
+    double wsum, centroid[3], ninl;
+    double plane[4];                                      // refined plane
+    int refine_ok, pad1;
+};
+
+// z gaps computed on the fly (no gap array): histogram of one 11-bit digit of the fp64 bit patterns that match the
+// prefix found so far
+__global__ void __launch_bounds__(256) k_gap_hist(const uint8_t* __restrict__ valid, const double* __restrict__ Z, int w, int h,
+                                                  int shift, unsigned int mask, const DevState* __restrict__ ds,
+                                                  unsigned int* __restrict__ hist)
+{
+    __shared__ unsigned int lh[2048];
+    for (int i = threadIdx.x; i < 2048; i += 256) lh[i] = 0;
+    __syncthreads();
+    const int hi_shift = ds->sel_hi_shift;
+    const unsigned long long prefix = ds->sel_prefix;
+    const size_t n = (size_t)w * h;
+    for (size_t c = (size_t)blockIdx.x * 256 + threadIdx.x; c < n; c += (size_t)gridDim.x * 256) {
+        const int i = (int)(c / w), j = (int)(c % w);
+        if (i < 1 || j < 1 || j >= w - 1 || !valid[c]) continue;
+        const double z = Z[c];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const size_t nb = c - w - 1 + k;
+            if (!valid[nb]) continue;
+            const unsigned long long key = (unsigned long long)__double_as_longlong(fabs(z - Z[nb]));
+            if (hi_shift < 64 && (key >> hi_shift) != prefix) continue;
+            atomicAdd(&lh[(unsigned)(key >> shift) & mask], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2048; i += 256)
+        if (lh[i]) atomicAdd(&hist[i], lh[i]);
+}
+// one workgroup: pick the bin that holds rank k, extend the prefix; pass 0 also derives k from the percentile
+__global__ void __launch_bounds__(256) k_radix_pick(unsigned int* __restrict__ hist, int pass, int shift, int nbits,
+                                                    double percentile, DevState* __restrict__ ds)
+{
+    __shared__ unsigned long long tot[256];
+    const int nb = 1 << nbits, per = (nb + 255) / 256;
+    unsigned long long s = 0;
+    for (int b = threadIdx.x * per; b < min(nb, (threadIdx.x + 1) * per); ++b) s += hist[b];
+    tot[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long k = ds->sel_k;
+        if (pass == 0) {
+            unsigned long long total = 0;
+            for (int t = 0; t < 256; ++t) total += tot[t];
+            ds->sel_total = total;
+            k = (unsigned long long)floor(percentile / 100.0 * (double)total);      // PovMesh.cpp:924
+            if (total && k >= total) k = total - 1;
+            ds->sel_prefix = 0;
+            ds->sel_fail = total == 0;
+        }
+        if (!ds->sel_fail) {
+            int t = 0;
+            for (; t < 256; ++t) { if (k < tot[t]) break; k -= tot[t]; }
+            int b = t * per;
+            const int be = min(nb, (t + 1) * per);
+            for (; b < be; ++b) { if (k < hist[b]) break; k -= hist[b]; }
+            if (t >= 256 || b >= be) ds->sel_fail = 2;
+            else {
+                ds->sel_k = k;
+                ds->sel_prefix = (ds->sel_prefix << nbits) | (unsigned long long)b;
+                ds->sel_hi_shift = shift;
+                if (shift == 0) ds->zgap = __longlong_as_double((long long)ds->sel_prefix);
+            }
+        }
+        if (ds->sel_fail == 1) ds->zgap = __longlong_as_double(0x7FF8000000000000ll);     // no gaps: NaN
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2048; i += 256) hist[i] = 0;                           // ready for the next pass
 }
 
 // ------------------------------------------------------------------ RANSAC (PovMesh.cpp:665-777)
@@ -436,14 +527,59 @@ __global__ void __launch_bounds__(256) k_crop_plane(uint8_t* __restrict__ valid,
                                                     double a, double b, double c, double d, double thr,
                                                     unsigned long long* __restrict__ kept)
 {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    bool keep = false;
-    if (i < n && valid[i]) {
-        keep = fabs((a * X[i] + b * Y[i] + c * Z[i]) + d) < thr;
-        if (!keep) valid[i] = 0;
+    unsigned int cnt = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        if (valid[i]) {
+            if (fabs((a * X[i] + b * Y[i] + c * Z[i]) + d) < thr) ++cnt; else valid[i] = 0;
+        }
     }
-    const unsigned long long bal = __ballot(keep);
-    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(kept + slot_of_block(), (unsigned long long)__popcll(bal));
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(kept + slot_of_block(), (unsigned long long)cnt);
+}
+
+// first strictly better candidate wins (PovMesh.cpp:750-755); failure if best < W*H/10 (:773)
+__global__ void __launch_bounds__(64) k_ransac_pick(const PlaneCand* __restrict__ cand, const unsigned long long* __restrict__ counts,
+                                                    int rounds, size_t n, DevState* __restrict__ ds)
+{
+    // key = (count << 32) | ~round : the largest count wins, the earliest round among equals (strict '>' in :750)
+    unsigned long long key = 0;
+    for (int r = threadIdx.x; r < rounds; r += 64)
+        if (cand[r].ok && counts[r] > 0) {
+            const unsigned long long k = (counts[r] << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)r);
+            key = k > key ? k : key;
+        }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_down(key, o);
+        key = other > key ? other : key;
+    }
+    if (threadIdx.x == 0) {
+        const unsigned long long best = key >> 32;
+        double pl[4] = { 0, 0, 0, 0 };
+        if (best) {
+            const int r = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+            pl[0] = cand[r].n[0]; pl[1] = cand[r].n[1]; pl[2] = cand[r].n[2]; pl[3] = cand[r].d;
+        }
+        for (int k = 0; k < 4; ++k) ds->ransac_plane[k] = pl[k];
+        ds->ransac_best = best;
+        ds->ransac_found = best < n / 10 ? 0 : 1;
+    }
+}
+// crop_plane with the plane (and the "RANSAC succeeded" switch) read from device memory
+__global__ void __launch_bounds__(256) k_crop_plane_dev(uint8_t* __restrict__ valid, const double* __restrict__ X,
+                                                        const double* __restrict__ Y, const double* __restrict__ Z, size_t n,
+                                                        const double* __restrict__ plane, const int* __restrict__ enable,
+                                                        double thr, unsigned long long* __restrict__ kept)
+{
+    if (!*enable) return;
+    const double a = plane[0], b = plane[1], c = plane[2], d = plane[3];
+    unsigned int cnt = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        if (valid[i]) {
+            if (fabs((a * X[i] + b * Y[i] + c * Z[i]) + d) < thr) ++cnt; else valid[i] = 0;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(kept + slot_of_block(), (unsigned long long)cnt);
 }
 
 // ------------------------------------------------------------------ refine_plane (PovMesh.cpp:581-660)
@@ -510,6 +646,108 @@ __global__ void __launch_bounds__(256) k_refine_cov(const uint8_t* __restrict__ 
         }
     }
     block_sum_store<6>(acc, partial);
+}
+
+// smallest-eigenvalue eigenvector of a symmetric 3x3 (cyclic Jacobi); stands in for row 2 of cv::SVD's vt
+__host__ __device__ static void smallest_eigvec3(const double Ain[9], double vout[3])
+{
+    double A[3][3], V[3][3] = { { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } };
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) A[i][j] = Ain[i * 3 + j];
+    for (int it = 0; it < 64; it++) {
+        const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        const double diag = fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]);
+        if (off <= 1e-300 || off <= 1e-22 * diag) break;
+        for (int i = 0; i < 2; i++)
+            for (int j = i + 1; j < 3; j++) {
+                if (A[i][j] == 0.0) continue;
+                const double theta = (A[j][j] - A[i][i]) / (2.0 * A[i][j]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < 3; k++) { const double a = A[i][k], b = A[j][k]; A[i][k] = cs * a - sn * b; A[j][k] = sn * a + cs * b; }
+                for (int k = 0; k < 3; k++) { const double a = A[k][i], b = A[k][j]; A[k][i] = cs * a - sn * b; A[k][j] = sn * a + cs * b; }
+                for (int k = 0; k < 3; k++) { const double a = V[k][i], b = V[k][j]; V[k][i] = cs * a - sn * b; V[k][j] = sn * a + cs * b; }
+            }
+    }
+    int m = 0;
+    for (int i = 1; i < 3; i++) if (A[i][i] < A[m][m]) m = i;
+    const double nn = sqrt(V[0][m] * V[0][m] + V[1][m] * V[1][m] + V[2][m] * V[2][m]);
+    vout[0] = V[0][m] / nn; vout[1] = V[1][m] / nn; vout[2] = V[2][m] / nn;
+}
+
+
+// Sum of per-block partials in a fixed two-level order (64 strided sub-sums, then those in index order): the same
+// function runs on the host (step-by-step API) and on the device (fused API), so both give identical bits.
+template <int NV>
+__host__ __device__ static void sum_partials_lane(const double* partial, int nb, int lane, double (&out)[NV])
+{
+    for (int k = 0; k < NV; ++k) out[k] = 0;
+    for (int b = lane; b < nb; b += 64)
+        for (int k = 0; k < NV; ++k) out[k] += partial[(size_t)b * NV + k];
+}
+template <int NV>
+__device__ static void sum_partials_wave(const double* __restrict__ partial, int nb, double (&out)[NV])
+{
+    double mine[NV];
+    sum_partials_lane<NV>(partial, nb, threadIdx.x & 63, mine);
+    for (int k = 0; k < NV; ++k) {
+        double tot = 0;
+        for (int l = 0; l < 64; ++l) tot += __shfl(mine[k], l);          // lane order, every lane computes the same total
+        out[k] = tot;
+    }
+}
+template <int NV>
+static void sum_partials_host(const double* partial, int nb, double (&out)[NV])
+{
+    double lanes[64][NV];
+    for (int l = 0; l < 64; ++l) sum_partials_lane<NV>(partial, nb, l, lanes[l]);
+    for (int k = 0; k < NV; ++k) { double tot = 0; for (int l = 0; l < 64; ++l) tot += lanes[l][k]; out[k] = tot; }
+}
+
+// partial sums of k_refine_moments -> centroid
+__global__ void k_refine_centroid(const double* __restrict__ partial, int nb, const int* __restrict__ enable, DevState* __restrict__ ds)
+{
+    if (blockIdx.x) return;
+    if (!*enable) { if (threadIdx.x == 0) ds->refine_ok = 0; return; }
+    double mom[5];
+    sum_partials_wave<5>(partial, nb, mom);
+    if (threadIdx.x) return;
+    ds->ninl = mom[0]; ds->wsum = mom[1];
+    ds->refine_ok = (mom[0] >= 3 && mom[1] > 0) ? 1 : 0;
+    ds->centroid[0] = mom[2] / mom[1]; ds->centroid[1] = mom[3] / mom[1]; ds->centroid[2] = mom[4] / mom[1];
+}
+__global__ void __launch_bounds__(256) k_refine_cov_dev(const uint8_t* __restrict__ valid, const double* __restrict__ X,
+                                                        const double* __restrict__ Y, const double* __restrict__ Z, int w, size_t n,
+                                                        RefineDev rp, const DevState* __restrict__ ds, double* __restrict__ partial)
+{
+    const double cx = ds->centroid[0], cy = ds->centroid[1], cz = ds->centroid[2];
+    const bool on = ds->refine_ok != 0;
+    double acc[6] = { 0, 0, 0, 0, 0, 0 };
+    if (on)
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+            double px, py, pz, wt;
+            if (refine_inlier(rp, valid, X, Y, Z, w, i, px, py, pz, wt)) {
+                const double qx = px - cx, qy = py - cy, qz = pz - cz;
+                acc[0] += wt * qx * qx; acc[1] += wt * qx * qy; acc[2] += wt * qx * qz;
+                acc[3] += wt * qy * qy; acc[4] += wt * qy * qz; acc[5] += wt * qz * qz;
+            }
+        }
+    block_sum_store<6>(acc, partial);
+}
+// scatter matrix -> plane (PovMesh.cpp:641-656)
+__global__ void k_refine_finish(const double* __restrict__ partial, int nb, DevState* __restrict__ ds)
+{
+    if (blockIdx.x || !ds->refine_ok) return;
+    double s[6];
+    sum_partials_wave<6>(partial, nb, s);
+    if (threadIdx.x) return;
+    const double A[9] = { s[0], s[1], s[2], s[1], s[3], s[4], s[2], s[4], s[5] };
+    double nrm[3];
+    smallest_eigvec3(A, nrm);
+    const double nn = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+    nrm[0] /= nn; nrm[1] /= nn; nrm[2] /= nn;
+    if (nrm[2] < 0) { nrm[0] *= -1.0; nrm[1] *= -1.0; nrm[2] *= -1.0; }
+    ds->plane[0] = nrm[0]; ds->plane[1] = nrm[1]; ds->plane[2] = nrm[2];
+    ds->plane[3] = -(nrm[0] * ds->centroid[0] + nrm[1] * ds->centroid[1] + nrm[2] * ds->centroid[2]);
 }
 
 // ------------------------------------------------------------------ xyzC (PovMesh.cpp:377-460)
@@ -691,32 +929,6 @@ static int counters_sum(wass_ctx* c, const unsigned long long* cnt, unsigned lon
     return WASS_OK;
 }
 
-// smallest-eigenvalue eigenvector of a symmetric 3x3 (cyclic Jacobi); stands in for row 2 of cv::SVD's vt
-static void smallest_eigvec3(const double Ain[9], double vout[3])
-{
-    double A[3][3], V[3][3] = { { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } };
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) A[i][j] = Ain[i * 3 + j];
-    for (int it = 0; it < 64; it++) {
-        const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
-        const double diag = fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]);
-        if (off <= 1e-300 || off <= 1e-22 * diag) break;
-        for (int i = 0; i < 2; i++)
-            for (int j = i + 1; j < 3; j++) {
-                if (A[i][j] == 0.0) continue;
-                const double theta = (A[j][j] - A[i][i]) / (2.0 * A[i][j]);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
-                for (int k = 0; k < 3; k++) { const double a = A[i][k], b = A[j][k]; A[i][k] = cs * a - sn * b; A[j][k] = sn * a + cs * b; }
-                for (int k = 0; k < 3; k++) { const double a = A[k][i], b = A[k][j]; A[k][i] = cs * a - sn * b; A[k][j] = sn * a + cs * b; }
-                for (int k = 0; k < 3; k++) { const double a = V[k][i], b = V[k][j]; V[k][i] = cs * a - sn * b; V[k][j] = sn * a + cs * b; }
-            }
-    }
-    int m = 0;
-    for (int i = 1; i < 3; i++) if (A[i][i] < A[m][m]) m = i;
-    const double nn = sqrt(V[0][m] * V[0][m] + V[1][m] * V[1][m] + V[2][m] * V[2][m]);
-    vout[0] = V[0][m] / nn; vout[1] = V[1][m] / nn; vout[2] = V[2][m] / nn;
-}
-
 }  // namespace wass
 
 using namespace wass;
@@ -763,7 +975,7 @@ int wass_triangulate_dev(wass_ctx* c, const float* d_disp, int W, int H, const i
     gd.comp_over_scale = g->disparity_compensation / g->dense_scale;
     unsigned long long* cnt = nullptr;
     if ((rc = counters_reset(c, &cnt))) { wass_mesh_destroy(m); return rc; }
-    dim3 grid((m->w + 255) / 256, m->h);
+    dim3 grid(4096);
     hipLaunchKernelGGL(k_triangulate, grid, dim3(256), 0, c->stream, d_disp, W, H, roi_l[0], roi_r[0], roi_r[1], m->w, m->h,
                        gd, d_right_img, img_w, img_h, d_lmask, d_rmask, tp->min_angle_deg, tp->bbox[0], tp->bbox[1],
                        tp->bbox[2], tp->bbox[3], tp->cam_distance, m->valid, m->x, m->y, m->z, m->gray, cnt);
@@ -878,10 +1090,18 @@ int wass_mesh_zgap_percentile(wass_ctx* c, wass_mesh* m, double percentile, doub
     return WASS_OK;
 }
 
-int wass_mesh_keep_biggest_component(wass_ctx* c, wass_mesh* m, double zgap, uint64_t* size_out)
+// the device-resident scalar record of this context
+static int dstate(wass_ctx* c, DevState** ds)
 {
-    if (!c || !m) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
-    WASS_HIP(c, hipSetDevice(c->device));
+    int rc = ensure(c, c->dstate, sizeof(DevState) + 2048 * 4);
+    if (rc) return rc;
+    *ds = (DevState*)c->dstate.p;
+    return WASS_OK;
+}
+
+// connected components with the z gap taken from device memory; leaves (size << 32 | ~mincm) in ds->ccl_best
+static int enqueue_ccl(wass_ctx* c, wass_mesh* m, DevState* ds)
+{
     const size_t n = m->n();
     if (n > 0x7FFFFFFFull) return set_err(c, WASS_ERR_UNSUPPORTED, "mesh too large");
     int rc = ensure(c, c->scratch, n * 12);
@@ -889,11 +1109,11 @@ int wass_mesh_keep_biggest_component(wass_ctx* c, wass_mesh* m, double zgap, uin
     int* parent = (int*)c->scratch.p;
     unsigned int* size = (unsigned int*)(parent + n);
     unsigned int* mincm = size + n;
-    unsigned long long* best = (unsigned long long*)c->flags.p + 1;
+    unsigned long long* best = &ds->ccl_best;
     const dim3 blk(256), g1(nblk(n));
     WASS_HIP(c, hipMemsetAsync(best, 0, 8, c->stream));
-    hipLaunchKernelGGL(k_ccl_init, g1, blk, 0, c->stream, m->valid, m->z, m->w, (int)n, zgap, parent, size, mincm);
-    hipLaunchKernelGGL(k_ccl_merge, g1, blk, 0, c->stream, m->valid, m->z, m->w, (int)n, zgap, parent);
+    hipLaunchKernelGGL(k_ccl_init, g1, blk, 0, c->stream, m->valid, m->z, m->w, (int)n, (const double*)&ds->zgap, parent, size, mincm);
+    hipLaunchKernelGGL(k_ccl_merge, g1, blk, 0, c->stream, m->valid, m->z, m->w, (int)n, (const double*)&ds->zgap, parent);
     hipLaunchKernelGGL(k_ccl_flatten, g1, blk, 0, c->stream, (int)n, parent);
     hipLaunchKernelGGL(k_ccl_count, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, c->stream, (int)n, m->w, m->h,
                        (const int*)parent, size, mincm);
@@ -904,12 +1124,57 @@ int wass_mesh_keep_biggest_component(wass_ctx* c, wass_mesh* m, double zgap, uin
     hipLaunchKernelGGL(k_ccl_keep, g1, blk, 0, c->stream, m->valid, (int)n, (const int*)parent, (const unsigned int*)size,
                        (const unsigned int*)mincm, (const unsigned long long*)best);
     WASS_HIP(c, hipGetLastError());
+    return WASS_OK;
+}
+
+int wass_mesh_keep_biggest_component(wass_ctx* c, wass_mesh* m, double zgap, uint64_t* size_out)
+{
+    if (!c || !m) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    WASS_HIP(c, hipSetDevice(c->device));
+    DevState* ds = nullptr;
+    int rc = dstate(c, &ds);
+    if (rc) return rc;
+    WASS_HIP(c, hipMemcpyAsync(&ds->zgap, &zgap, 8, hipMemcpyHostToDevice, c->stream));
+    WASS_HIP(c, hipStreamSynchronize(c->stream));       // zgap lives on the caller's stack
+    if ((rc = enqueue_ccl(c, m, ds))) return rc;
     if (size_out) {
         unsigned long long hb = 0;
-        WASS_HIP(c, hipMemcpyAsync(&hb, best, 8, hipMemcpyDeviceToHost, c->stream));
+        WASS_HIP(c, hipMemcpyAsync(&hb, &ds->ccl_best, 8, hipMemcpyDeviceToHost, c->stream));
         WASS_HIP(c, hipStreamSynchronize(c->stream));
         *size_out = hb >> 32;
     }
+    return WASS_OK;
+}
+
+// wass_stereo.cpp:2046-2050 as one call: compute_zgap_percentile + cluster_biggest_connected_component with every
+// intermediate decision taken on the device (6 radix-select passes, component choice) and one read-back at the end.
+int wass_mesh_remove_outliers(wass_ctx* c, wass_mesh* m, double percentile, double* zgap_out, uint64_t* n_gaps, uint64_t* size_out)
+{
+    if (!c || !m) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    WASS_HIP(c, hipSetDevice(c->device));
+    DevState* ds = nullptr;
+    int rc = dstate(c, &ds);
+    if (rc) return rc;
+    unsigned int* hist = (unsigned int*)(ds + 1);
+    DevState init;
+    memset(&init, 0, sizeof init);
+    init.sel_hi_shift = 64;
+    WASS_HIP(c, hipMemcpyAsync(ds, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
+    WASS_HIP(c, hipMemsetAsync(hist, 0, 2048 * 4, c->stream));
+    for (int pass = 0; pass < 6; ++pass) {
+        const int shift = pass < 5 ? 64 - 11 * (pass + 1) : 0, nbits = pass < 5 ? 11 : 9;
+        hipLaunchKernelGGL(k_gap_hist, dim3(2048), dim3(256), 0, c->stream, m->valid, m->z, m->w, m->h, shift, (1u << nbits) - 1u,
+                           (const DevState*)ds, hist);
+        hipLaunchKernelGGL(k_radix_pick, dim3(1), dim3(256), 0, c->stream, hist, pass, shift, nbits, percentile, ds);
+    }
+    if ((rc = enqueue_ccl(c, m, ds))) return rc;
+    DevState h;
+    WASS_HIP(c, hipMemcpyAsync(&h, ds, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    WASS_HIP(c, hipStreamSynchronize(c->stream));
+    if (h.sel_fail == 2) return set_err(c, WASS_ERR_DEVICE, "radix select lost its rank (internal error)");
+    if (zgap_out) *zgap_out = h.zgap;
+    if (n_gaps) *n_gaps = h.sel_total;
+    if (size_out) *size_out = h.ccl_best >> 32;
     return WASS_OK;
 }
 
@@ -983,7 +1248,7 @@ int wass_mesh_crop_plane(wass_ctx* c, wass_mesh* m, const double plane[4], doubl
     unsigned long long* cnt = nullptr;
     int rc = counters_reset(c, &cnt);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_crop_plane, dim3(nblk(m->n())), dim3(256), 0, c->stream, m->valid, m->x, m->y, m->z, m->n(), plane[0],
+    hipLaunchKernelGGL(k_crop_plane, dim3(2048), dim3(256), 0, c->stream, m->valid, m->x, m->y, m->z, m->n(), plane[0],
                        plane[1], plane[2], plane[3], thr, cnt);
     unsigned long long hk = 0;
     if ((rc = counters_sum(c, cnt, &hk))) return rc;
@@ -1010,8 +1275,8 @@ int wass_mesh_refine_plane(wass_ctx* c, wass_mesh* m, const wass_refine_params* 
     hipLaunchKernelGGL(k_refine_moments, dim3(NB), dim3(256), 0, c->stream, m->valid, m->x, m->y, m->z, m->w, m->n(), rd, part);
     WASS_HIP(c, hipMemcpyAsync(hp.data(), part, (size_t)NB * 5 * 8, hipMemcpyDeviceToHost, c->stream));
     WASS_HIP(c, hipStreamSynchronize(c->stream));
-    double mom[5] = { 0, 0, 0, 0, 0 };
-    for (int b = 0; b < NB; ++b) for (int k = 0; k < 5; ++k) mom[k] += hp[(size_t)b * 5 + k];
+    double mom[5];
+    sum_partials_host<5>(hp.data(), NB, mom);
     if (n_inliers) *n_inliers = (uint64_t)(mom[0] + 0.5);
     if (mom[0] < 3 || !(mom[1] > 0)) return set_err(c, WASS_ERR_TOO_FEW_POINTS, "plane refinement has %g inliers", mom[0]);
     const double cx = mom[2] / mom[1], cy = mom[3] / mom[1], cz = mom[4] / mom[1];
@@ -1019,8 +1284,8 @@ int wass_mesh_refine_plane(wass_ctx* c, wass_mesh* m, const wass_refine_params* 
                        part);
     WASS_HIP(c, hipMemcpyAsync(hp.data(), part, (size_t)NB * 6 * 8, hipMemcpyDeviceToHost, c->stream));
     WASS_HIP(c, hipStreamSynchronize(c->stream));
-    double s[6] = { 0, 0, 0, 0, 0, 0 };
-    for (int b = 0; b < NB; ++b) for (int k = 0; k < 6; ++k) s[k] += hp[(size_t)b * 6 + k];
+    double s[6];
+    sum_partials_host<6>(hp.data(), NB, s);
     const double A[9] = { s[0], s[1], s[2], s[1], s[3], s[4], s[2], s[4], s[5] };
     double nrm[3];
     smallest_eigvec3(A, nrm);
@@ -1029,6 +1294,75 @@ int wass_mesh_refine_plane(wass_ctx* c, wass_mesh* m, const wass_refine_params* 
     if (nrm[2] < 0) { nrm[0] *= -1.0; nrm[1] *= -1.0; nrm[2] *= -1.0; }   // :646-649
     plane_out[0] = nrm[0]; plane_out[1] = nrm[1]; plane_out[2] = nrm[2];
     plane_out[3] = -(nrm[0] * cx + nrm[1] * cy + nrm[2] * cz);
+    return WASS_OK;
+}
+
+// wass_stereo.cpp:2062-2107 as one call: ransac_find_plane -> crop_plane(ransac_thr) -> refine_plane ->
+// crop_plane(max_distance); candidate choice, centroid and the 3x3 eigen-solve run on the device, one read-back.
+int wass_mesh_fit_plane(wass_ctx* c, wass_mesh* m, const int32_t* uv, int rounds, double ransac_thr, const wass_refine_params* rp,
+                        double max_distance, wass_plane_result* out)
+{
+    if (!c || !m || !uv || !rp || !out || rounds <= 0) return set_err(c, WASS_ERR_INVALID_ARG, "bad argument");
+    for (int r = 0; r < rounds * 3; ++r)
+        if (uv[2 * r] < 0 || uv[2 * r] >= m->w || uv[2 * r + 1] < 0 || uv[2 * r + 1] >= m->h)
+            return set_err(c, WASS_ERR_INVALID_ARG, "sample %d outside the mesh grid", r / 3);
+    WASS_HIP(c, hipSetDevice(c->device));
+    const size_t n = m->n();
+    DevState* ds = nullptr;
+    int rc = dstate(c, &ds);
+    if (rc) return rc;
+    const int NB = 1024;
+    const size_t cand_bytes = (((size_t)rounds * (24 + sizeof(PlaneCand) + 8) + 256) + 255) & ~(size_t)255;
+    if ((rc = ensure(c, c->scratch, cand_bytes + (size_t)NB * 6 * 8))) return rc;
+    if ((rc = ensure(c, c->counters, (size_t)NSLOT * 6 * 8))) return rc;
+    PlaneCand* cand = (PlaneCand*)c->scratch.p;
+    unsigned long long* counts = (unsigned long long*)(cand + rounds);
+    int32_t* duv = (int32_t*)(counts + rounds);
+    double* part = (double*)((char*)c->scratch.p + cand_bytes);
+    unsigned long long* kept1 = (unsigned long long*)c->counters.p;            // [NSLOT]
+    unsigned long long* kept2 = kept1 + NSLOT;
+    constexpr int PTS = 4;
+    const size_t lds = (size_t)rounds * (32 + 4);
+    if (lds > 64 * 1024) return set_err(c, WASS_ERR_UNSUPPORTED, "PLANE_RANSAC_ROUNDS %d too large (max 1800)", rounds);
+    hipStream_t s = c->stream;
+    WASS_HIP(c, hipMemcpyAsync(duv, uv, (size_t)rounds * 24, hipMemcpyHostToDevice, s));
+    WASS_HIP(c, hipMemsetAsync(counts, 0, (size_t)rounds * 8, s));
+    WASS_HIP(c, hipMemsetAsync(kept1, 0, (size_t)2 * NSLOT * 8, s));
+    hipLaunchKernelGGL(k_ransac_planes, dim3((rounds + 63) / 64), dim3(64), 0, s, m->valid, m->x, m->y, m->z, m->w, (const int32_t*)duv,
+                       rounds, cand);
+    hipLaunchKernelGGL(k_ransac_score<PTS>, dim3((unsigned)((n + 256 * PTS - 1) / (256 * PTS))), dim3(256), lds, s, m->valid, m->x,
+                       m->y, m->z, n, (const PlaneCand*)cand, rounds, ransac_thr, counts);
+    hipLaunchKernelGGL(k_ransac_pick, dim3(1), dim3(64), 0, s, (const PlaneCand*)cand, (const unsigned long long*)counts, rounds, n, ds);
+    hipLaunchKernelGGL(k_crop_plane_dev, dim3(2048), dim3(256), 0, s, m->valid, m->x, m->y, m->z, n, (const double*)ds->ransac_plane,
+                       (const int*)&ds->ransac_found, ransac_thr, kept1);
+    RefineDev rd;
+    rd.xmin = rp->xmin; rd.xmax = rp->xmax; rd.ymin = rp->ymin; rd.ymax = rp->ymax; rd.maxd = rp->max_distance;
+    rd.weighted = rp->weight_by_distance;
+    rd.umin = rp->central_third_only ? m->w / 4 : 0;
+    rd.umax = rp->central_third_only ? m->w * 3 / 4 : m->w - 1;
+    rd.vmin = rp->central_third_only ? m->h / 4 : 0;
+    rd.vmax = rp->central_third_only ? m->h * 2 / 3 : m->h - 1;
+    hipLaunchKernelGGL(k_refine_moments, dim3(NB), dim3(256), 0, s, m->valid, m->x, m->y, m->z, m->w, n, rd, part);
+    hipLaunchKernelGGL(k_refine_centroid, dim3(1), dim3(64), 0, s, (const double*)part, NB, (const int*)&ds->ransac_found, ds);
+    hipLaunchKernelGGL(k_refine_cov_dev, dim3(NB), dim3(256), 0, s, m->valid, m->x, m->y, m->z, m->w, n, rd, (const DevState*)ds, part);
+    hipLaunchKernelGGL(k_refine_finish, dim3(1), dim3(64), 0, s, (const double*)part, NB, ds);
+    hipLaunchKernelGGL(k_crop_plane_dev, dim3(2048), dim3(256), 0, s, m->valid, m->x, m->y, m->z, n, (const double*)ds->plane,
+                       (const int*)&ds->refine_ok, max_distance, kept2);
+    DevState h;
+    unsigned long long hk[2 * NSLOT];
+    WASS_HIP(c, hipGetLastError());
+    WASS_HIP(c, hipMemcpyAsync(&h, ds, sizeof h, hipMemcpyDeviceToHost, s));
+    WASS_HIP(c, hipMemcpyAsync(hk, kept1, sizeof hk, hipMemcpyDeviceToHost, s));
+    WASS_HIP(c, hipStreamSynchronize(s));
+    memset(out, 0, sizeof *out);
+    out->found = h.ransac_found;
+    out->ransac_inliers = h.ransac_best;
+    for (int k = 0; k < 4; ++k) { out->ransac_plane[k] = h.ransac_plane[k]; out->plane[k] = h.ransac_found && h.refine_ok ? h.plane[k] : NAN; }
+    if (h.ransac_found) {
+        for (int i = 0; i < NSLOT; ++i) { out->kept_after_ransac_crop += hk[i]; out->kept_final += hk[NSLOT + i]; }
+        out->refine_inliers = (uint64_t)(h.ninl + 0.5);
+        if (!h.refine_ok) return set_err(c, WASS_ERR_TOO_FEW_POINTS, "plane refinement has %g inliers", h.ninl);
+    }
     return WASS_OK;
 }
 

@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (Geom, RefineParams, SgmParams, SgmTimings, TriParams, WassError,  # noqa: F401
+from ._lib import (Geom, PlaneResult, RefineParams, SgmParams, SgmTimings, TriParams, WassError,  # noqa: F401
                    default_sgm_params)
 
 
@@ -247,6 +247,22 @@ class Mesh:
         n = C.c_uint64()
         self.ctx._check(self.ctx._lib.wass_mesh_keep_biggest_component(self.ctx._h, self._h, zgap, C.byref(n)))
         return int(n.value)
+
+    def remove_outliers(self, pct: float):
+        """zgap_percentile + keep_biggest_component in one call (device-side decisions) -> (zgap, n_gaps, size)."""
+        z = C.c_double(); n = C.c_uint64(); sz = C.c_uint64()
+        self.ctx._check(self.ctx._lib.wass_mesh_remove_outliers(self.ctx._h, self._h, pct, C.byref(z), C.byref(n), C.byref(sz)))
+        return z.value, int(n.value), int(sz.value)
+
+    def fit_plane(self, uv, ransac_thr=1.0, max_distance=1.5, xmin=-9999., xmax=9999., ymin=-9999., ymax=9999.,
+                  refine_max_distance=70.0, weight_by_distance=True, central_third_only=False) -> PlaneResult:
+        """ransac_plane -> crop_plane -> refine_plane -> crop_plane in one call (wass_stereo.cpp:2062-2107)."""
+        uv = np.ascontiguousarray(uv, np.int32)
+        rp = RefineParams(xmin, xmax, ymin, ymax, refine_max_distance, int(weight_by_distance), int(central_third_only))
+        res = PlaneResult()
+        self.ctx._check(self.ctx._lib.wass_mesh_fit_plane(self.ctx._h, self._h, uv.ctypes.data, len(uv), ransac_thr,
+                                                          C.byref(rp), max_distance, C.byref(res)))
+        return res
 
     def ransac_plane(self, uv, thr: float):
         uv = np.ascontiguousarray(uv, np.int32)
