@@ -12,6 +12,8 @@
 // on v_pk_*_u16.  Slots d >= D hold 0xFFFF in C and never win a minimum.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace wass {
 
 // ---------------------------------------------------------------------------
@@ -208,6 +210,56 @@ __global__ void __launch_bounds__(64) k_hsum(const uint2* __restrict__ bt1, cons
     }
 }
 
+// Register-ring variant for a compile-time window: the last WIN pixel-cost vectors live in registers (the loop
+// is unrolled by WIN so the ring index is static), the running sum is updated as each column is produced, and
+// no LDS is touched at all.  Used for the window sizes instantiated below; other sizes take k_hsum.
+template <int NP, int WIN>
+__global__ void __launch_bounds__(256) k_hsum_ring(const uint2* __restrict__ bt1, const unsigned short* __restrict__ bt2,
+                                                   int pitch2, int Wp, int width1, int minX1, int minD, int XC, int nchunks,
+                                                   uint32_t* __restrict__ hsum)
+{
+    constexpr int SW2 = WIN / 2;
+    const int lane = threadIdx.x & 63;
+    const int chunk = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (chunk >= nchunks) return;
+    const int y = blockIdx.y;
+    const int xs = chunk * XC;
+    const int n = min(XC, width1 - xs);
+    const uint2* row1 = bt1 + (size_t)y * Wp;
+    const unsigned short* row2 = bt2 + (size_t)y * (6 * BT2_COPIES) * pitch2;
+    const int dbase = minD + lane * 2 * NP;
+    uint32_t* o = hsum + ((size_t)y * width1 + xs) * (64 * NP) + lane * NP;
+
+    us2 ring[WIN][NP], acc[NP];
+#pragma unroll
+    for (int r = 0; r < WIN; ++r)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) ring[r][j] = pk_splat(0);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) acc[j] = pk_splat(0);
+    const int cols = n + 2 * SW2;
+    for (int base = 0; base < cols; base += WIN) {
+#pragma unroll
+        for (int r = 0; r < WIN; ++r) {
+            const int i = base + r;
+            if (i < cols) {                                                  // wave-uniform
+                int x = xs - SW2 + i;
+                x = x < 0 ? 0 : (x > width1 - 1 ? width1 - 1 : x);
+                const int X = x + minX1;
+                us2 pix[NP];
+                bt_cost<NP>(row1[X], row2, pitch2, (Wp - 1 - X) + dbase, pix);
+#pragma unroll
+                for (int j = 0; j < NP; ++j) { acc[j] = acc[j] + pix[j] - ring[r][j]; ring[r][j] = pix[j]; }
+                if (i >= 2 * SW2) {
+                    uint32_t* oo = o + (size_t)(i - 2 * SW2) * (64 * NP);
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) oo[j] = as_u32(acc[j]);
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // K2b: C[y][x][d] = sum_{j=-SH2..SH2} hsum[clamp(y+j, 0, h-1)][x][d]   (no +P2
 // bias is stored; it cancels in the path recurrence and only matters for the
@@ -290,9 +342,16 @@ static int launch_cost_np(wass_ctx* c, const SgmDims& d)
     const size_t lds = (size_t)(XC + 2 * d.SW2) * StripFmt<NP>::DW * 64 * sizeof(uint32_t);
     if (lds > 160 * 1024) return set_err(c, WASS_ERR_UNSUPPORTED, "WINSIZE %d too large for the LDS strip", 2 * d.SW2 + 1);
     WASS_HIP(c, hipFuncSetAttribute((const void*)k_hsum<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (2 * d.SW2 + 1 == 13 && !getenv("WASS_HSUM_LDS")) {
+        const int XCR = 13 * 8 - 12, nch = (d.width1 + XCR - 1) / XCR;      // 92 columns + 12 halo = 8 trips of 13
+        hipLaunchKernelGGL((k_hsum_ring<NP, 13>), dim3((nch + 3) / 4, d.h), dim3(256), 0, c->stream, (const uint2*)c->bt1.p,
+                           (const unsigned short*)c->bt2.p, bt2_pitch(d.Wp), d.Wp, d.width1, d.minX1, d.minD, XCR, nch,
+                           (uint32_t*)c->hsum.p);
+    } else {
     dim3 g1((d.width1 + XC - 1) / XC, d.h);
     hipLaunchKernelGGL(k_hsum<NP>, g1, dim3(64), lds, c->stream, (const uint2*)c->bt1.p, (const unsigned short*)c->bt2.p,
                        bt2_pitch(d.Wp), d.Wp, d.width1, d.minX1, d.minD, d.SW2, XC, (uint32_t*)c->hsum.p);
+    }
     const int YSEG = 128;
     const size_t lds2 = (size_t)4 * (2 * d.SW2 + 1) * NP * 64 * sizeof(uint32_t);
     if (lds2 > 160 * 1024) return set_err(c, WASS_ERR_UNSUPPORTED, "WINSIZE %d too large for the LDS ring", 2 * d.SW2 + 1);

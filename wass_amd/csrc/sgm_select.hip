@@ -1,5 +1,5 @@
-// sgm_select.hip -- K4 (winner-take-all, uniqueness, sub-pixel, right-view
-// disparity + left-right check) and K5 (3x3 median of the int16 map + crop).
+// sgm_select.hip -- K4b (right-view disparity + left-right check; the per-pixel winner-take-all is fused into
+// the last aggregation kernel, sgm_step.h: wta_select) and K5 (3x3 median of the int16 map + crop).
 //
 // Replaces the per-row tail of OpenCV's computeDisparitySGBM and the
 // medianBlur in StereoSGBMImpl::compute, reached
@@ -7,59 +7,6 @@
 #include "common.h"
 
 namespace wass {
-
-// K4a: one wave per pixel.  key = (S << 16) | d reduced with a wave minimum
-// gives the smallest S and, among equals, the smallest d ("first minimum").
-template <int NP>
-__global__ void __launch_bounds__(256) k_wta(const uint32_t* __restrict__ S, int width1, int h, int D,
-                                             int minD, int uniq, size_t npix,
-                                             int16_t* __restrict__ sel_d16, uint32_t* __restrict__ sel_key)
-{
-    const int lane = threadIdx.x & 63;
-    const size_t pix = (size_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (pix >= npix) return;
-    const uint32_t* sp = S + pix * (64 * NP) + lane * NP;
-    const unsigned short* s16 = (const unsigned short*)(S + pix * (64 * NP));
-    const int dlane = lane * 2 * NP;
-    uint32_t sv[2 * NP];
-    uint32_t key = 0xFFFFFFFFu;
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        const uint32_t v = sp[j];
-        sv[2 * j] = v & 0xFFFF; sv[2 * j + 1] = v >> 16;
-    }
-#pragma unroll
-    for (int j = 0; j < 2 * NP; ++j)
-        if (dlane + j < D) key = min(key, (sv[j] << 16) | (uint32_t)(dlane + j));
-    key = wave_min_u32(key);
-    const int minS = (int)(key >> 16);
-    // "if (Sval < minS)" with minS initialised to MAX_COST never fires when every S is MAX_COST
-    const int best = minS >= 32767 ? -1 : (int)(key & 0xFFFF);
-    bool bad = false;
-#pragma unroll
-    for (int j = 0; j < 2 * NP; ++j) {
-        const int d = dlane + j;
-        if (d < D && (int)sv[j] * (100 - uniq) < minS * 100 && abs(best - d) > 1) bad = true;
-    }
-    const bool reject = __any(bad);
-    if (lane == 0) {
-        int16_t out = (int16_t)((minD - 1) * 16);
-        uint32_t k = 0xFFFFFFFFu;
-        if (!reject) {
-            int d = best;
-            k = ((uint32_t)minS << 16) | (uint32_t)(best & 0xFFFF);
-            if (0 < d && d < D - 1) {
-                const int a = s16[d - 1], b = s16[d], cc = s16[d + 1];
-                const int denom2 = max(a + cc - 2 * b, 1);
-                d = d * 16 + ((a - cc) * 16 + denom2) / (denom2 * 2);
-            } else
-                d *= 16;
-            out = (int16_t)(d + minD * 16);
-        }
-        sel_d16[pix] = out;
-        sel_key[pix] = k;
-    }
-}
 
 // K4b: one workgroup per image row: right-view disparity by an LDS atomic
 // minimum (equal costs: the larger x wins, as in the descending-x loop of the
@@ -113,7 +60,6 @@ __global__ void __launch_bounds__(256) k_lrcheck(const int16_t* __restrict__ sel
 
 int launch_select(wass_ctx* c, const SgmDims& d)
 {
-    // k_wta is kept for reference/regression; production fuses the selection into the row pair (k_pair).
     hipLaunchKernelGGL(k_lrcheck, dim3(d.h), dim3(256), (size_t)d.Wp * sizeof(uint32_t), c->stream,
                        (const int16_t*)c->sel_d16.p, (const uint32_t*)c->sel_key.p, d.width1, d.Wp, d.minX1,
                        d.minD, d.d12, (int16_t*)c->raw.p);
