@@ -238,6 +238,38 @@ void wass_free(void* p);
 void wass_planes_mean_accumulate(const double* planes, int n, double acc5[5]);
 void wass_planes_mean_finish(const double acc5[5], double mean_out[4], int* n_valid);
 
+/* ---- rectification: rectify() of wass_stereo.cpp:447-613 ------------------------
+ * Rig-constant host math (no GPU work, usable without a context): */
+
+/* cv::stereoRectify(K_left, 0, K_right, 0, size, R, T, R1, R2, P1, P2, Q, flags=0, alpha, size, &roi1, &roi2)
+ * as called at wass_stereo.cpp:541 (Bouguet's algorithm, zero distortion).  3x3 / 3x4 row-major doubles,
+ * roi = {x, y, width, height}.  Returns WASS_ERR_INVALID_ARG for a zero baseline. */
+int wass_stereo_rectify(const double K_left[9], const double K_right[9], int width, int height, const double R[9],
+                        const double T[3], double alpha, double R1[9], double R2[9], double P1[12], double P2[12],
+                        int roi1[4], int roi2[4]);
+/* cv::initUndistortRectifyMap(K, 0, R, P, size, CV_32FC1, map1, map2) (wass_stereo.cpp:600-601); maps are
+ * [height][width] float32 source coordinates. */
+int wass_init_rectify_map(const double K[9], const double R[9], const double P[12], int width, int height,
+                          float* map_x, float* map_y);
+
+/* Per-frame resampling on the GPU.  roi == NULL writes the full dw x dh image; otherwise only the
+ * roi = {x, y, width, height} window of it is produced (the .clone() crops of wass_stereo.cpp:526-528,606-607
+ * fused into the resampler) and dst is roi.width x roi.height, tightly packed. */
+
+/* cv::remap(src, dst, map1, map2, cv::INTER_CUBIC) for CV_8UC1 / CV_32FC1 maps, BORDER_CONSTANT 0
+ * (wass_stereo.cpp:603-604): 1/32-pixel coordinate quantisation, 15-bit fixed-point 4x4 weights. */
+int wass_remap_cubic(wass_ctx* ctx, const uint8_t* src, int sw, int sh, size_t src_stride, const float* map_x,
+                     const float* map_y, int dw, int dh, const int roi[4], uint8_t* dst);
+int wass_remap_cubic_dev(wass_ctx* ctx, const uint8_t* d_src, int sw, int sh, size_t src_stride,
+                         const float* d_map_x, const float* d_map_y, int dw, int dh, const int roi[4],
+                         uint8_t* d_dst);
+/* cv::warpPerspective(src, dst, H, Size(dw,dh)) with the default INTER_LINEAR / BORDER_CONSTANT 0
+ * (wass_stereo.cpp:515-516); H maps source to destination pixels (it is inverted internally). */
+int wass_warp_perspective(wass_ctx* ctx, const uint8_t* src, int sw, int sh, size_t src_stride, const double H[9],
+                          int dw, int dh, const int roi[4], uint8_t* dst);
+int wass_warp_perspective_dev(wass_ctx* ctx, const uint8_t* d_src, int sw, int sh, size_t src_stride,
+                              const double H[9], int dw, int dh, const int roi[4], uint8_t* d_dst);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,7 +16,7 @@ _SO = os.path.join(_HERE, "libwass_oracle.so")
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("sgbm_oracle.c", "wass_oracle.c", "wass_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("sgbm_oracle.c", "wass_oracle.c", "rectify_oracle.c", "wass_oracle.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libwass_oracle.so"], stdout=subprocess.DEVNULL)
     return _SO
@@ -249,3 +249,50 @@ def encode_xyzc(valid, p3d, plane) -> bytes:
     buf = np.empty(148 + 6 * int(valid.sum()), np.uint8)
     n = lib().orc_encode_xyzc(_p(valid, C.c_uint8), _p(p3d, C.c_double), w, h, (C.c_double * 4)(*plane), _p(buf, C.c_uint8))
     return buf[:n].tobytes()
+
+
+# ---- rectification, row f1 (rectify_oracle.c) ----
+def inter_tab(ksize: int) -> np.ndarray:
+    out = np.zeros((1024, ksize, ksize), np.int16)
+    lib().orc_inter_tab(ksize, _p(out, C.c_int16))
+    return out
+
+
+def _d(a):
+    return (C.c_double * len(np.ravel(a)))(*np.asarray(a, float).ravel())
+
+
+def warp_perspective(src, H, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orc_warp_perspective(_p(src, C.c_uint8), src.shape[1], src.shape[0], C.c_size_t(src.shape[1]), _d(H), dw, dh,
+                               _p(dst, C.c_uint8))
+    return dst
+
+
+def remap_cubic(src, map_x, map_y):
+    src = np.ascontiguousarray(src, np.uint8)
+    map_x = np.ascontiguousarray(map_x, np.float32); map_y = np.ascontiguousarray(map_y, np.float32)
+    dh, dw = map_x.shape
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orc_remap_cubic(_p(src, C.c_uint8), src.shape[1], src.shape[0], C.c_size_t(src.shape[1]), _p(map_x, C.c_float),
+                          _p(map_y, C.c_float), dw, dh, _p(dst, C.c_uint8))
+    return dst
+
+
+def init_rectify_map(K, R, P, w, h):
+    mx = np.zeros((h, w), np.float32); my = np.zeros((h, w), np.float32)
+    rc = lib().orc_init_rectify_map(_d(K), _d(R), _d(P), w, h, _p(mx, C.c_float), _p(my, C.c_float))
+    if rc:
+        raise ValueError("singular P*R")
+    return mx, my
+
+
+def stereo_rectify(K1, K2, w, h, R, T, alpha=1.0):
+    R1 = (C.c_double * 9)(); R2 = (C.c_double * 9)(); P1 = (C.c_double * 12)(); P2 = (C.c_double * 12)()
+    r1 = (C.c_int * 4)(); r2 = (C.c_int * 4)()
+    rc = lib().orc_stereo_rectify(_d(K1), _d(K2), w, h, _d(R), _d(T), C.c_double(alpha), R1, R2, P1, P2, r1, r2)
+    if rc:
+        raise ValueError("zero baseline")
+    return dict(R1=np.array(R1[:]).reshape(3, 3), R2=np.array(R2[:]).reshape(3, 3), P1=np.array(P1[:]).reshape(3, 4),
+                P2=np.array(P2[:]).reshape(3, 4), roi1=tuple(r1[:]), roi2=tuple(r2[:]))

@@ -151,6 +151,23 @@ void orc_RT_from_plane(const double plane[4], double R[9], double T[3],
 size_t orc_encode_xyzc(const uint8_t* valid, const double* p3d, int w, int h,
                        const double plane[4], uint8_t* buf);
 
+/* ---- rectification, row f1 (rectify_oracle.c; PARITY UNPINNED, OpenCV restated from knowledge) ---- */
+/* initInterTab2D fixed-point weights: ksize 2 (bilinear) or 4 (bicubic); out = 1024*ksize*ksize int16 */
+void orc_inter_tab(int ksize, int16_t* out);
+/* cv::warpPerspective INTER_LINEAR / BORDER_CONSTANT 0 (wass_stereo.cpp:515-516) */
+void orc_warp_perspective(const uint8_t* src, int sw, int sh, size_t src_stride, const double H[9], int dw, int dh,
+                          uint8_t* dst);
+/* cv::remap INTER_CUBIC, CV_32FC1 maps, BORDER_CONSTANT 0 (wass_stereo.cpp:603-604) */
+void orc_remap_cubic(const uint8_t* src, int sw, int sh, size_t src_stride, const float* map_x, const float* map_y,
+                     int dw, int dh, uint8_t* dst);
+/* cv::initUndistortRectifyMap, zero distortion, CV_32FC1 (wass_stereo.cpp:600-601) */
+int orc_init_rectify_map(const double K[9], const double R[9], const double P[12], int w, int h, float* map_x,
+                         float* map_y);
+/* cv::stereoRectify flags=0 (wass_stereo.cpp:541) */
+int orc_stereo_rectify(const double K1[9], const double K2[9], int W, int H, const double R[9], const double T[3],
+                       double alpha, double R1[9], double R2[9], double P1[12], double P2[12], int roi1[4],
+                       int roi2[4]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,6 +109,14 @@ SYMBOLS = {
     "wass_free": (None, [_vp]),
     "wass_planes_mean_accumulate": (None, [C.POINTER(C.c_double), _i, C.POINTER(C.c_double)]),
     "wass_planes_mean_finish": (None, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
+    "wass_stereo_rectify": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), _i, _i, C.POINTER(C.c_double),
+                                 C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                 C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(_i)]),
+    "wass_init_rectify_map": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), _i, _i, _vp, _vp]),
+    "wass_remap_cubic": (_i, [_vp, _vp, _i, _i, _sz, _vp, _vp, _i, _i, C.POINTER(_i), _vp]),
+    "wass_remap_cubic_dev": (_i, [_vp, _vp, _i, _i, _sz, _vp, _vp, _i, _i, C.POINTER(_i), _vp]),
+    "wass_warp_perspective": (_i, [_vp, _vp, _i, _i, _sz, C.POINTER(C.c_double), _i, _i, C.POINTER(_i), _vp]),
+    "wass_warp_perspective_dev": (_i, [_vp, _vp, _i, _i, _sz, C.POINTER(C.c_double), _i, _i, C.POINTER(_i), _vp]),
 }
 
 _lib = None

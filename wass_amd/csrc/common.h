@@ -124,6 +124,9 @@ struct wass_ctx {
     wass::Buf counters;            // striped atomics of the mesh stages
     wass::Buf dstate;              // device-resident scalar record + radix histogram (mesh.hip DevState)
     wass::Buf scratch;             // mesh stages: gaps / labels / partial sums / packed output
+    wass::Buf rect_tab;            // fixed-point interpolation tables of the rectification resamplers (rectify.hip)
+    bool rect_tab_ready = false;
+    wass::Buf rect_mx, rect_my;    // staging for host-pointer map uploads
     hipEvent_t ev[8] = {};
     hipStream_t side = nullptr, side2 = nullptr;   // checkpoint sweeps run ahead here
     hipEvent_t ev_cost = nullptr, ev_ckpt[4] = {}, ev_cols = nullptr;

@@ -1,11 +1,9 @@
 // rectify.hpp -- the reference's built-in rectification (USE_CUSTOM_STEREORECTIFY=true), host side.
 //
 //   stereoRectifyUndistorted   src/wass_stereo/stereorectify.cpp:57-244
-//   cv::warpPerspective        src/wass_stereo/wass_stereo.cpp:515-516  (INTER_LINEAR, constant 0 border)
 //
-// This is row f1 ("next") of SURVEY.md section 8: it exists so that the CLI can run end to end on workdirs whose
-// rig needs (almost) no resampling; parity with OpenCV's fixed-point warp is tolerance-level, and the default
-// cv::stereoRectify path (USE_CUSTOM_STEREORECTIFY=false) is not implemented.
+// Row f1 of SURVEY.md section 8.  The image resampling (cv::warpPerspective, wass_stereo.cpp:515-516) and the
+// whole cv::stereoRectify path (USE_CUSTOM_STEREORECTIFY=false) are entry points of libwassgpu (csrc/rectify.hip).
 #pragma once
 
 #include <algorithm>
@@ -100,26 +98,6 @@ inline void stereoRectifyUndistorted(const Mat& K0, const Mat& K1, const Mat& R,
     std::sort(xv, xv + 8); std::sort(yv, yv + 8);
     ROI.x = (int)xv[3]; ROI.y = (int)yv[3];                      // implicit double -> int truncation (:240-243)
     ROI.width = (int)(xv[4] - ROI.x); ROI.height = (int)(yv[4] - ROI.y);
-}
-
-// dst(x,y) = src(Hm^-1 (x,y,1)), bilinear with OpenCV's 1/32-pixel coordinate quantisation, zero outside
-inline Image warpPerspective(const Image& src, const Mat& Hm, int W, int H)
-{
-    const Mat M = inv3(Hm);
-    Image dst(W, H, 0);
-    for (int y = 0; y < H; ++y)
-        for (int x = 0; x < W; ++x) {
-            double w = M(2, 0) * x + M(2, 1) * y + M(2, 2);
-            w = w ? 1. / w : 0;
-            const double fx = (M(0, 0) * x + M(0, 1) * y + M(0, 2)) * w, fy = (M(1, 0) * x + M(1, 1) * y + M(1, 2)) * w;
-            const long X = std::lrint(fx * 32), Y = std::lrint(fy * 32);
-            const int sx = (int)(X >> 5), sy = (int)(Y >> 5);
-            const float ax = (float)(X & 31) / 32.f, ay = (float)(Y & 31) / 32.f;
-            auto px = [&](int yy, int xx) -> float { return (xx >= 0 && xx < src.w && yy >= 0 && yy < src.h) ? (float)src.at(yy, xx) : 0.f; };
-            const float v = (1 - ay) * ((1 - ax) * px(sy, sx) + ax * px(sy, sx + 1)) + ay * ((1 - ax) * px(sy + 1, sx) + ax * px(sy + 1, sx + 1));
-            dst.at(y, x) = (uint8_t)std::min(255L, std::max(0L, std::lrint(v)));
-        }
-    return dst;
 }
 
 }  // namespace wasshost

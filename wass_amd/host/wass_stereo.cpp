@@ -7,8 +7,7 @@
 // reference.  There is NO CPU implementation of the hot path here: without a GPU (or
 // without libwassgpu.so) the program fails with exit code -1.
 //
-// Divergences from the reference, all listed in DESIGN.md: only the built-in rectification
-// (USE_CUSTOM_STEREORECTIFY=true) is implemented; DENSE_SCALE must be 1; no JPEG debug renders; the *_s.png
+// Divergences from the reference, all listed in DESIGN.md: DENSE_SCALE must be 1; no JPEG debug renders; the *_s.png
 // previews are skipped (they need a bicubic resize); --measure (interactive GUI) is rejected.
 #include <sys/stat.h>
 #include <sys/time.h>
@@ -43,7 +42,9 @@ struct Env {             // StereoMatchEnv (wass_stereo.cpp:202-335)
     Timer timer;
     std::string workdir;
     Mat K_left, K_right, K0, K1, R, T, Rinv, Tinv, P0, P1, Rpose0, Tpose0, Rpose1, Tpose1, HL, HR, HLi, HRi;
-    Image left, right, left_rect, right_rect, left_crop, right_crop;
+    bool use_custom = true;
+    double rec_R1[9] = {}, rec_R2[9] = {}, rec_P1[12] = {}, rec_P2[12] = {};                 // cv::stereoRectify outputs (:248-251)
+    Image left, right, left_crop, right_crop;
     int left_index = 0, right_index = 1;
     double cam_distance = 1.0, disparity_compensation = 0.0;
     Rect roi_l, roi_r;
@@ -114,15 +115,17 @@ bool load_data(Env& env, const Config& cfg)                                     
     return true;
 }
 
-bool rectify(Env& env, const Config& cfg)                                                 // :447-613
+bool rectify(Env& env, const Config& cfg, wass_ctx* ctx)                                  // :447-613
 {
     WLOG_SCOPE("rectify");
     WLOGI << "rectifying...";
+    bool auto_swap = true, do_swap = false;
     if (std::fabs(env.T(1, 0)) > std::fabs(env.T(0, 0))) { WLOGE << "Vertical stereo not supported"; return false; }
     WLOGI << "Detected stereo setup:";
     WLOGI << (env.T(0, 0) > 0 ? "CAM1 (L) ---------  CAM0 (R)" : "CAM0 (L) ---------  CAM1 (R)");
     if (cfg.get_bool("DISABLE_AUTO_LEFT_RIGHT")) {
-        const bool do_swap = cfg.get_bool("SWAP_LEFT_RIGHT");
+        auto_swap = false;
+        do_swap = cfg.get_bool("SWAP_LEFT_RIGHT");
         WLOGI << "auto left-right detection disabled. Swap left-right? " << (do_swap ? "YES" : "NO");
         if (do_swap) { WLOGI << "swapping left-right images as requested"; swapLeftRight(env); }
     } else if (env.T(0, 0) < 0) {
@@ -130,31 +133,60 @@ bool rectify(Env& env, const Config& cfg)                                       
         swapLeftRight(env);
     }
     const int W = env.left.w, H = env.left.h;
-    if (!cfg.get_bool("USE_CUSTOM_STEREORECTIFY")) {
-        WLOGE << "USE_CUSTOM_STEREORECTIFY=false (cv::stereoRectify + bicubic remap) is not implemented in the MI355X build; "
-                 "set USE_CUSTOM_STEREORECTIFY=true";
-        return false;
+    auto roi_ok = [&](const Rect& r) { return r.x >= 0 && r.y >= 0 && r.width > 0 && r.height > 0 && r.x + r.width <= W && r.y + r.height <= H; };
+    auto gpu = [&](int rc, const char* what) { if (rc != WASS_OK) throw std::runtime_error(std::string(what) + ": " + wass_last_error(ctx)); };
+    env.use_custom = cfg.get_bool("USE_CUSTOM_STEREORECTIFY");
+    if (env.use_custom) {
+        const double ang = cfg.get_double("RECTIFY_ANGLE");
+        WLOGI << "Using WASS custom stereorectify, baseline angle delta=" << ang;
+        const double Tinv[3] = { env.Tinv(0, 0), env.Tinv(1, 0), env.Tinv(2, 0) };
+        Rect roi;
+        stereoRectifyUndistorted(env.K_left, env.K_right, env.Rinv, Tinv, ang, W, H, env.HL, env.HR, roi);
+        env.HLi = inv3(env.HL); env.HRi = inv3(env.HR);
+        save_matrix_txt(path_join(env.workdir, env.left_index == 0 ? "H0_rect.txt" : "H1_rect.txt"), env.HL);
+        save_matrix_txt(path_join(env.workdir, env.left_index == 0 ? "H1_rect.txt" : "H0_rect.txt"), env.HR);
+        env.roi_l = env.roi_r = roi;
+        if (cfg.get_bool("DISABLE_RECTIFY_ROI")) { env.roi_l = env.roi_r = Rect{ 0, 0, W, H }; }
+        if (!roi_ok(env.roi_l)) { WLOGE << "rectification ROI is empty or outside the image"; return false; }
+        // cv::warpPerspective (:515-516) and the ROI .clone() (:526-528) in one GPU pass per camera
+        const int rl[4] = { env.roi_l.x, env.roi_l.y, env.roi_l.width, env.roi_l.height };
+        env.left_crop = Image(rl[2], rl[3]); env.right_crop = Image(rl[2], rl[3]);
+        gpu(wass_warp_perspective(ctx, env.left.px.data(), W, H, (size_t)W, env.HL.d.data(), W, H, rl, env.left_crop.px.data()), "wass_warp_perspective");
+        gpu(wass_warp_perspective(ctx, env.right.px.data(), W, H, (size_t)W, env.HR.d.data(), W, H, rl, env.right_crop.px.data()), "wass_warp_perspective");
+    } else {
+        WLOGI << "Rectifying via cv::stereoRectify";
+        int roi_left[4], roi_right[4];
+        bool rectification_ok = false;
+        do {                                                                               // :539-582
+            const double T3[3] = { env.T(0, 0), env.T(1, 0), env.T(2, 0) };
+            if (wass_stereo_rectify(env.K_left.d.data(), env.K_right.d.data(), W, H, env.R.d.data(), T3, 1.0, env.rec_R1, env.rec_R2, env.rec_P1,
+                                    env.rec_P2, roi_left, roi_right) != WASS_OK) { WLOGE << "stereoRectify failed (zero baseline)"; return false; }
+            if (std::fabs(env.rec_P2[3]) < std::fabs(env.rec_P2[7])) { WLOGE << "vertical stereo not supported"; return false; }
+            if (roi_left[2] == 0 || roi_right[2] == 0 || roi_left[3] == 0 || roi_right[3] == 0) { WLOGE << "the epipole lies inside the image plane"; return false; }
+            if (auto_swap) {
+                if (env.rec_P2[3] < 0) { WLOGI << "auto-swapping left-right images"; swapLeftRight(env); }
+                else rectification_ok = true;
+            } else if (do_swap) {          // sic (:570-575): a requested swap is applied a second time here, i.e. undone
+                WLOGI << "swapping left-right images as requested";
+                swapLeftRight(env);
+                do_swap = false;
+            } else rectification_ok = true;
+        } while (!rectification_ok);
+        const int ymin = std::max(roi_left[1], roi_right[1]);
+        const int ymax = std::min(roi_left[1] + roi_left[3], roi_right[1] + roi_right[3]);
+        env.roi_l = Rect{ roi_left[0], ymin, roi_left[2], ymax - ymin };
+        env.roi_r = Rect{ roi_right[0], ymin, roi_right[2], ymax - ymin };
+        if (env.roi_l.width > env.roi_r.width) env.roi_l.width = env.roi_r.width; else env.roi_r.width = env.roi_l.width;
+        if (!roi_ok(env.roi_l) || !roi_ok(env.roi_r)) { WLOGE << "rectification ROI is empty or outside the image"; return false; }
+        // cv::initUndistortRectifyMap (:600-601), cv::remap INTER_CUBIC (:603-604), ROI .clone() (:606-607)
+        std::vector<float> mx((size_t)W * H), my((size_t)W * H);
+        const int rl[4] = { env.roi_l.x, env.roi_l.y, env.roi_l.width, env.roi_l.height }, rr[4] = { env.roi_r.x, env.roi_r.y, env.roi_r.width, env.roi_r.height };
+        env.left_crop = Image(rl[2], rl[3]); env.right_crop = Image(rr[2], rr[3]);
+        if (wass_init_rectify_map(env.K_left.d.data(), env.rec_R1, env.rec_P1, W, H, mx.data(), my.data()) != WASS_OK) { WLOGE << "singular rectification"; return false; }
+        gpu(wass_remap_cubic(ctx, env.left.px.data(), W, H, (size_t)W, mx.data(), my.data(), W, H, rl, env.left_crop.px.data()), "wass_remap_cubic");
+        if (wass_init_rectify_map(env.K_right.d.data(), env.rec_R2, env.rec_P2, W, H, mx.data(), my.data()) != WASS_OK) { WLOGE << "singular rectification"; return false; }
+        gpu(wass_remap_cubic(ctx, env.right.px.data(), W, H, (size_t)W, mx.data(), my.data(), W, H, rr, env.right_crop.px.data()), "wass_remap_cubic");
     }
-    const double ang = cfg.get_double("RECTIFY_ANGLE");
-    WLOGI << "Using WASS custom stereorectify, baseline angle delta=" << ang;
-    const double Tinv[3] = { env.Tinv(0, 0), env.Tinv(1, 0), env.Tinv(2, 0) };
-    Rect roi;
-    stereoRectifyUndistorted(env.K_left, env.K_right, env.Rinv, Tinv, ang, W, H, env.HL, env.HR, roi);
-    env.HLi = inv3(env.HL); env.HRi = inv3(env.HR);
-    save_matrix_txt(path_join(env.workdir, env.left_index == 0 ? "H0_rect.txt" : "H1_rect.txt"), env.HL);
-    save_matrix_txt(path_join(env.workdir, env.left_index == 0 ? "H1_rect.txt" : "H0_rect.txt"), env.HR);
-    env.left_rect = warpPerspective(env.left, env.HL, W, H);
-    env.right_rect = warpPerspective(env.right, env.HR, W, H);
-    env.roi_l = env.roi_r = roi;
-    if (cfg.get_bool("DISABLE_RECTIFY_ROI")) { env.roi_l = env.roi_r = Rect{ 0, 0, W, H }; }
-    const Rect r = env.roi_l;
-    if (r.x < 0 || r.y < 0 || r.width <= 0 || r.height <= 0 || r.x + r.width > W || r.y + r.height > H) {
-        WLOGE << "rectification ROI is empty or outside the image";
-        return false;
-    }
-    auto crop = [](const Image& src, const Rect& q) { Image o(q.width, q.height); for (int y = 0; y < q.height; ++y) memcpy(&o.px[(size_t)y * q.width], &src.px[(size_t)(q.y + y) * src.w + q.x], q.width); return o; };
-    env.left_crop = crop(env.left_rect, env.roi_l);
-    env.right_crop = crop(env.right_rect, env.roi_r);
     WLOGI << "rectification map generated. Size: " << env.left_crop.w << "x" << env.left_crop.h;
     return true;
 }
@@ -246,16 +278,15 @@ int main(int argc, char* argv[])
             save_matrix_txt(path_join(env.workdir, "Cam1_poseT.txt"), env.Tpose1);
         };
         save_cams();
-        if (!rectify(env, cfg)) return -1;                     // the reference ignores this result (:1897); stricter here
+        const char* dev_env = getenv("WASS_GPU_DEVICE");
+        if (wass_ctx_create(dev_env ? atoi(dev_env) : 0, &ctx) != WASS_OK) { WLOGE << "no usable MI355X GPU / HIP runtime (libwassgpu has no CPU fallback)"; return -1; }
+        if (!rectify(env, cfg, ctx)) { wass_ctx_destroy(ctx); return -1; }   // the reference ignores this result (:1897); stricter here
         env.timer << "Rectification";
         std::cout << "[P|20|100]" << std::endl;
         save_cams();
         WLOG_SCOPE("wass_stereo");
-        if (argc == 4 && std::string("--rectify-only") == argv[3]) { WLOGI << "All done."; return 0; }
-        if (argc == 4 && std::string("--measure") == argv[3]) { WLOGE << "--measure needs the interactive GUI, which this build does not have"; return -1; }
-
-        const char* dev_env = getenv("WASS_GPU_DEVICE");
-        if (wass_ctx_create(dev_env ? atoi(dev_env) : 0, &ctx) != WASS_OK) { WLOGE << "no usable MI355X GPU / HIP runtime (libwassgpu has no CPU fallback)"; return -1; }
+        if (argc == 4 && std::string("--rectify-only") == argv[3]) { WLOGI << "All done."; wass_ctx_destroy(ctx); return 0; }
+        if (argc == 4 && std::string("--measure") == argv[3]) { WLOGE << "--measure needs the interactive GUI, which this build does not have"; wass_ctx_destroy(ctx); return -1; }
 
         // ---- sgbm_dense_stereo (:764-1020)
         WLOG_SCOPE("sgbm_dense_stereo");
@@ -295,7 +326,7 @@ int main(int argc, char* argv[])
 
         // ---- triangulate (:1039-1386)
         WLOG_SCOPE("triangulate");
-        const int W = env.right_rect.w, H = env.right_rect.h, iw = env.left.w, ih = env.left.h;
+        const int W = env.left.w, H = env.left.h, iw = env.left.w, ih = env.left.h;     // rectified images keep the input size
         auto make_mask = [&](const Image& img, const std::string& key, const char* which) {
             std::vector<uint8_t> m((size_t)iw * ih, 1);
             const std::string name = cfg.get_string(key);
@@ -316,8 +347,9 @@ int main(int argc, char* argv[])
         memset(&g, 0, sizeof g);
         auto put = [](double* dst, const Mat& m, int n) { for (int i = 0; i < n; ++i) dst[i] = m.d[i]; };
         put(g.K_left, env.K_left, 9); put(g.K_right, env.K_right, 9); put(g.R, env.R, 9); put(g.T, env.T, 3);
-        g.use_custom = 1;
-        put(g.HLi, env.HLi, 9); put(g.HRi, env.HRi, 9);
+        g.use_custom = env.use_custom ? 1 : 0;
+        if (env.use_custom) { put(g.HLi, env.HLi, 9); put(g.HRi, env.HRi, 9); }
+        else { memcpy(g.R1, env.rec_R1, sizeof g.R1); memcpy(g.R2, env.rec_R2, sizeof g.R2); memcpy(g.P1, env.rec_P1, sizeof g.P1); memcpy(g.P2, env.rec_P2, sizeof g.P2); }
         g.disparity_compensation = env.disparity_compensation;
         g.dense_scale = sp.dense_scale;
         wass_tri_params tp;

@@ -125,6 +125,49 @@ class Context:
                                                              dilate_steps, erode_steps, median_wsize, d_out.data_ptr()))
         return d_out
 
+    # ---- rectification resamplers (wass_stereo.cpp:515-516, 603-604) ----------
+    @staticmethod
+    def _roi(roi):
+        return (C.c_int * 4)(*roi) if roi is not None else None
+
+    def remap_cubic(self, src: np.ndarray, map_x: np.ndarray, map_y: np.ndarray, roi=None) -> np.ndarray:
+        """cv::remap(src, dst, map_x, map_y, INTER_CUBIC); roi = (x, y, w, h) returns only that window."""
+        src = np.ascontiguousarray(src, np.uint8)
+        map_x = np.ascontiguousarray(map_x, np.float32); map_y = np.ascontiguousarray(map_y, np.float32)
+        dh, dw = map_x.shape
+        out = np.empty((roi[3], roi[2]) if roi is not None else (dh, dw), np.uint8)
+        self._check(self._lib.wass_remap_cubic(self._h, src.ctypes.data, src.shape[1], src.shape[0], src.shape[1],
+                                               map_x.ctypes.data, map_y.ctypes.data, dw, dh, self._roi(roi), out.ctypes.data))
+        return out
+
+    def remap_cubic_dev(self, d_src, d_map_x, d_map_y, roi=None, d_out=None):
+        import torch
+        dh, dw = d_map_x.shape
+        if d_out is None:
+            d_out = torch.empty((roi[3], roi[2]) if roi is not None else (dh, dw), dtype=torch.uint8, device=d_src.device)
+        self._check(self._lib.wass_remap_cubic_dev(self._h, d_src.data_ptr(), d_src.shape[1], d_src.shape[0], d_src.stride(0),
+                                                   d_map_x.data_ptr(), d_map_y.data_ptr(), dw, dh, self._roi(roi),
+                                                   d_out.data_ptr()))
+        return d_out
+
+    def warp_perspective(self, src: np.ndarray, H, dw: int, dh: int, roi=None) -> np.ndarray:
+        """cv::warpPerspective(src, dst, H, Size(dw, dh)) (INTER_LINEAR, zero border)."""
+        src = np.ascontiguousarray(src, np.uint8)
+        out = np.empty((roi[3], roi[2]) if roi is not None else (dh, dw), np.uint8)
+        Hc = (C.c_double * 9)(*np.asarray(H, float).ravel())
+        self._check(self._lib.wass_warp_perspective(self._h, src.ctypes.data, src.shape[1], src.shape[0], src.shape[1], Hc,
+                                                    dw, dh, self._roi(roi), out.ctypes.data))
+        return out
+
+    def warp_perspective_dev(self, d_src, H, dw: int, dh: int, roi=None, d_out=None):
+        import torch
+        if d_out is None:
+            d_out = torch.empty((roi[3], roi[2]) if roi is not None else (dh, dw), dtype=torch.uint8, device=d_src.device)
+        Hc = (C.c_double * 9)(*np.asarray(H, float).ravel())
+        self._check(self._lib.wass_warp_perspective_dev(self._h, d_src.data_ptr(), d_src.shape[1], d_src.shape[0],
+                                                        d_src.stride(0), Hc, dw, dh, self._roi(roi), d_out.data_ptr()))
+        return d_out
+
     # ---- triangulate(StereoMatchEnv&) (wass_stereo.cpp:1039-1386) ------------
     def triangulate(self, disp_roi, W, H, roi_l, roi_r, geom: Geom, right_img, left_mask=None, right_mask=None,
                     min_angle_deg=20.0, bbox=None, cam_distance=1.0):
@@ -207,6 +250,30 @@ def planes_mean_finish(acc5):
     out = (C.c_double * 4)(); n = C.c_int()
     lib.wass_planes_mean_finish((C.c_double * 5)(*acc5), out, C.byref(n))
     return np.array(out[:]), int(n.value)
+
+
+def stereo_rectify(K_left, K_right, width: int, height: int, R, T, alpha: float = 1.0) -> dict:
+    """cv::stereoRectify(K_left, 0, K_right, 0, size, R, T, ..., flags=0, alpha, size) (wass_stereo.cpp:541)."""
+    lib = _lib.load()
+    d = lambda a: (C.c_double * len(np.ravel(a)))(*np.asarray(a, float).ravel())  # noqa: E731
+    R1 = (C.c_double * 9)(); R2 = (C.c_double * 9)(); P1 = (C.c_double * 12)(); P2 = (C.c_double * 12)()
+    r1 = (C.c_int * 4)(); r2 = (C.c_int * 4)()
+    rc = lib.wass_stereo_rectify(d(K_left), d(K_right), width, height, d(R), d(T), alpha, R1, R2, P1, P2, r1, r2)
+    if rc != _lib.WASS_OK:
+        raise WassError(rc, "stereo_rectify: invalid rig (zero baseline?)")
+    return dict(R1=np.array(R1[:]).reshape(3, 3), R2=np.array(R2[:]).reshape(3, 3), P1=np.array(P1[:]).reshape(3, 4),
+                P2=np.array(P2[:]).reshape(3, 4), roi1=tuple(r1[:]), roi2=tuple(r2[:]))
+
+
+def init_rectify_map(K, R, P, width: int, height: int):
+    """cv::initUndistortRectifyMap(K, 0, R, P, size, CV_32FC1) (wass_stereo.cpp:600-601) -> (map_x, map_y)."""
+    lib = _lib.load()
+    d = lambda a: (C.c_double * len(np.ravel(a)))(*np.asarray(a, float).ravel())  # noqa: E731
+    mx = np.empty((height, width), np.float32); my = np.empty((height, width), np.float32)
+    rc = lib.wass_init_rectify_map(d(K), d(R), d(P), width, height, mx.ctypes.data, my.ctypes.data)
+    if rc != _lib.WASS_OK:
+        raise WassError(rc, "init_rectify_map: singular P*R")
+    return mx, my
 
 
 class Mesh:
