@@ -157,7 +157,7 @@ int wass_sgm_disparity_dev(wass_ctx* c, const uint8_t* d_right, const uint8_t* d
     const size_t npad = (size_t)d.Wp * d.h;
     const size_t vol = d.cells() * sizeof(uint16_t);
     if ((rc = ensure(c, c->img1, npad)) || (rc = ensure(c, c->img2, npad)) ||
-        (rc = ensure(c, c->bt1, npad * 8)) || (rc = ensure(c, c->bt2, (size_t)d.h * 6 * BT2_COPIES * bt2_pitch(d.Wp) * 2 + 8192)) ||
+        (rc = ensure(c, c->bt1, npad * 8)) || (rc = ensure(c, c->bt2, (size_t)d.h * 6 * bt2_pitch(d.Wp) * 2 + 8192)) ||
         (rc = ensure(c, c->hsum, vol)) || (rc = ensure(c, c->C, vol)) || (rc = ensure(c, c->S, vol)) ||
         (rc = ensure(c, c->sel_d16, (size_t)d.width1 * d.h * 2)) ||
         (rc = ensure(c, c->sel_key, (size_t)d.width1 * d.h * 4)) || (rc = ensure(c, c->raw, npad * 2)))

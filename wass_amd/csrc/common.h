@@ -93,7 +93,7 @@ struct SgmDims {
 };
 
 // pitch (in u16) of one mirrored image-2 plane; the slack absorbs reads of padded disparity slots past the row
-constexpr int BT2_COPIES = 2;     // shifted copies of every image-2 plane (dword-aligned runs for any start index; 4 copies measured slower)
+constexpr int BT2_FRONT = 128;    // u16 elements of slack in front of the first plane (group loads may start a few elements early)
 static inline int bt2_pitch(int Wp) { return (Wp + 1024 + 63) & ~63; }
 
 struct Buf {

@@ -14,6 +14,8 @@
 
 #include <stdlib.h>
 
+#include <algorithm>
+
 namespace wass {
 
 // ---------------------------------------------------------------------------
@@ -64,18 +66,10 @@ __global__ void __launch_bounds__(256) k_prefilter(const uint8_t* __restrict__ i
         o.y = (uint32_t)rlo | ((uint32_t)rhi << 8);
         out1[(size_t)y * Wp + X] = o;
     } else {
-        // every plane is stored BT2_COPIES times, copy k shifted by k elements, so that a lane's run of values can
-        // always be fetched with naturally aligned vector loads (copy = start index mod BT2_COPIES; misaligned
-        // vector loads are legal on gfx950 but slow)
         const int xm = Wp - 1 - X;
-        const unsigned short vals[6] = { (unsigned short)s0, (unsigned short)slo, (unsigned short)shi,
-                                         (unsigned short)r0, (unsigned short)rlo, (unsigned short)rhi };
-        unsigned short* row = out2 + (size_t)y * (6 * BT2_COPIES) * pitch2;
-#pragma unroll
-        for (int pl = 0; pl < 6; ++pl)
-#pragma unroll
-            for (int cpy = 0; cpy < BT2_COPIES; ++cpy)
-                if (xm >= cpy) row[(size_t)(BT2_COPIES * pl + cpy) * pitch2 + xm - cpy] = vals[pl];
+        unsigned short* row = out2 + (size_t)y * 6 * pitch2 + xm;
+        row[0] = (unsigned short)s0; row[pitch2] = (unsigned short)slo; row[2 * (size_t)pitch2] = (unsigned short)shi;
+        row[3 * (size_t)pitch2] = (unsigned short)r0; row[4 * (size_t)pitch2] = (unsigned short)rlo; row[5 * (size_t)pitch2] = (unsigned short)rhi;
     }
 }
 
@@ -89,174 +83,128 @@ int launch_prefilter(wass_ctx* c, const SgmDims& d)
     hipLaunchKernelGGL(k_prefilter<false>, grid, dim3(256), 0, c->stream, (const uint8_t*)c->img1.p, d.Wp, d.h,
                        d.ftzero, (uint2*)c->bt1.p, (unsigned short*)nullptr, 0);
     hipLaunchKernelGGL(k_prefilter<true>, grid, dim3(256), 0, c->stream, (const uint8_t*)c->img2.p, d.Wp, d.h,
-                       d.ftzero, (uint2*)nullptr, (unsigned short*)c->bt2.p, pitch2);
+                       d.ftzero, (uint2*)nullptr, (unsigned short*)c->bt2.p + BT2_FRONT, pitch2);
     WASS_HIP(c, hipGetLastError());
     return WASS_OK;
 }
 
 // ---------------------------------------------------------------------------
-// K2a: hsum[y][x][d] = sum_{i=-SW2..SW2} pix(y, clamp(x+i, 0, width1-1), d)
-// One wave per (row, chunk of XC columns).  Phase 1 computes the BT cost of
-// every column of the chunk plus halo into a wave-private LDS strip, phase 2
-// slides the window over that strip.  No cross-lane traffic at all.
-// ---------------------------------------------------------------------------
-template <int N> struct __attribute__((aligned(4))) UVec { uint32_t v[N]; };   // N dwords, at least dword aligned
+// K2a: hsum[y][x][d] = sum_{i=-SW2..SW2} pix(y, clamp(x+i, 0, width1-1), d), pix = Birchfield-Tomasi cost of
+// the clipped-Sobel channel + (raw channel >> 2).  One wave per (row, chunk of XC columns), lanes = disparities.
+//
+// Consecutive columns X, X+1, ... read image-2 windows that start one element
+// lower each time, so a group of G = 2*NP columns only needs G-1+2*NP consecutive mirrored values per lane.
+// They are kept in two register vectors per plane ("lo" = the NP dwords loaded for this group, "hi" = the lo of
+// the previous group) and the G shifted windows are cut out with v_alignbit -- one NP-dword load per plane and
+// group instead of one per column (4x fewer VMEM instructions and bytes at NP = 2; the per-column version was
+// bound by the texture-address path, not by VALU or HBM).  Chunk starts are shifted by `off` so that every group's
+// load address is a multiple of G elements.  The window ring lives in wave-private LDS, so any WINSIZE works.
+// Groups that touch a replicated border column (first / last chunk of a row) take the per-column path.
+// NP dwords with the natural alignment of the group loads (4*NP bytes, capped at 16) -> one dwordx2/x4 load
+template <int N> struct __attribute__((aligned(((N & -N) * 4) > 16 ? 16 : ((N & -N) * 4)))) AVec { uint32_t v[N]; };
 
 template <int NP>
-__device__ __forceinline__ void bt_cost(const uint2 a1, const unsigned short* __restrict__ m2, int pitch2, int idx,
-                                        us2 (&out)[NP])
+__device__ __forceinline__ void bt_eval(const uint2 a1, const us2 (&v)[6][NP], us2 (&out)[NP])
 {
-    // image-1 values are uniform over the wave
     const us2 us = pk_splat(a1.x & 0xff), us0 = pk_splat((a1.x >> 8) & 0xff), us1 = pk_splat((a1.x >> 16) & 0xff);
     const us2 ur = pk_splat(a1.x >> 24), ur0 = pk_splat(a1.y & 0xff), ur1 = pk_splat((a1.y >> 8) & 0xff);
-    // odd start index -> the copy shifted by one element, at idx-1: the address is always dword aligned
-    const unsigned short* p = m2 + (idx & (BT2_COPIES - 1)) * pitch2 + (idx & ~(BT2_COPIES - 1));
-    const int pp = BT2_COPIES * pitch2;
-    // one NP-dword load per plane (global_load_dwordx2/x3/x4 for NP = 2/3/4)
-    const UVec<NP> a0 = *(const UVec<NP>*)(p), a1v = *(const UVec<NP>*)(p + pp), a2 = *(const UVec<NP>*)(p + 2 * pp);
-    const UVec<NP> a3 = *(const UVec<NP>*)(p + 3 * pp), a4 = *(const UVec<NP>*)(p + 4 * pp), a5 = *(const UVec<NP>*)(p + 5 * pp);
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-        const us2 vs = as_us2(a0.v[j]), vs0 = as_us2(a1v.v[j]), vs1 = as_us2(a2.v[j]);
-        const us2 vr = as_us2(a3.v[j]), vr0 = as_us2(a4.v[j]), vr1 = as_us2(a5.v[j]);
-        // c0 = max(0, u - v1, v0 - u), c1 = max(0, v - u1, u0 - v), cost = min(c0, c1)
+        const us2 vs = v[0][j], vs0 = v[1][j], vs1 = v[2][j], vr = v[3][j], vr0 = v[4][j], vr1 = v[5][j];
         const us2 cs = pk_min(pk_max(pk_subs(us, vs1), pk_subs(vs0, us)), pk_max(pk_subs(vs, us1), pk_subs(us0, vs)));
         const us2 cr = pk_min(pk_max(pk_subs(ur, vr1), pk_subs(vr0, ur)), pk_max(pk_subs(vr, ur1), pk_subs(ur0, vr)));
         out[j] = cs + (cr >> 2);
     }
 }
 
-// LDS strip element: pixel costs are <= 122 + 63 = 185, so an even number of packed pairs is stored as bytes
-// (two pairs per dword) -- half the LDS, twice the resident waves.
-template <int NP> struct StripFmt { static constexpr bool BYTES = (NP % 2) == 0; static constexpr int DW = BYTES ? NP / 2 : NP; };
-
 template <int NP>
-__device__ __forceinline__ void strip_store(uint32_t* __restrict__ strip, int col, int lane, const us2 (&pix)[NP])
+__global__ void __launch_bounds__(256) k_hsum_q(const uint2* __restrict__ bt1, const unsigned short* __restrict__ bt2,
+                                                int pitch2, int Wp, int width1, int minX1, int minD, int SW2, int XC,
+                                                int off, int nchunks, uint32_t* __restrict__ hsum)
 {
-    if constexpr (StripFmt<NP>::BYTES) {
-#pragma unroll
-        for (int j = 0; j < NP / 2; ++j)
-            strip[(col * (NP / 2) + j) * 64 + lane] = __builtin_amdgcn_perm(as_u32(pix[2 * j + 1]), as_u32(pix[2 * j]), 0x06040200u);
-    } else {
-#pragma unroll
-        for (int j = 0; j < NP; ++j) strip[(col * NP + j) * 64 + lane] = as_u32(pix[j]);
-    }
-}
-template <int NP>
-__device__ __forceinline__ void strip_load(const uint32_t* __restrict__ strip, int col, int lane, us2 (&pix)[NP])
-{
-    if constexpr (StripFmt<NP>::BYTES) {
-#pragma unroll
-        for (int j = 0; j < NP / 2; ++j) {
-            const uint32_t w = strip[(col * (NP / 2) + j) * 64 + lane];
-            pix[2 * j] = as_us2(__builtin_amdgcn_perm(0u, w, 0x0c010c00u));
-            pix[2 * j + 1] = as_us2(__builtin_amdgcn_perm(0u, w, 0x0c030c02u));
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < NP; ++j) pix[j] = as_us2(strip[(col * NP + j) * 64 + lane]);
-    }
-}
-
-template <int NP>
-__global__ void __launch_bounds__(64) k_hsum(const uint2* __restrict__ bt1, const unsigned short* __restrict__ bt2,
-                                             int pitch2, int Wp, int width1, int minX1, int minD, int SW2, int XC,
-                                             uint32_t* __restrict__ hsum)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t strip[];   // [(XC + 2*SW2)][StripFmt::DW][64]
-    const int lane = threadIdx.x;
-    const int y = blockIdx.y;
-    const int xs = blockIdx.x * XC;
-    const int xe = min(xs + XC, width1);
-    const int n = xe - xs;
-    const uint2* row1 = bt1 + (size_t)y * Wp;
-    const unsigned short* row2 = bt2 + (size_t)y * (6 * BT2_COPIES) * pitch2;
-    const int dbase = minD + lane * 2 * NP;
-
-    // phase 1: four columns per trip so that their (independent) loads are in flight together
-    const int cols = n + 2 * SW2;
-    for (int i0 = 0; i0 < cols; i0 += 4) {
-        us2 pix[4][NP];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int x = xs - SW2 + min(i0 + q, cols - 1);
-            x = x < 0 ? 0 : (x > width1 - 1 ? width1 - 1 : x);
-            const int X = x + minX1;
-            bt_cost<NP>(row1[X], row2, pitch2, (Wp - 1 - X) + dbase, pix[q]);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (i0 + q < cols) strip_store<NP>(strip, i0 + q, lane, pix[q]);
-    }
-    // phase 2
-    us2 acc[NP], t[NP], u[NP];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) acc[j] = pk_splat(0);
-    for (int i = 0; i < 2 * SW2 + 1; ++i) {
-        strip_load<NP>(strip, i, lane, t);
-#pragma unroll
-        for (int j = 0; j < NP; ++j) acc[j] += t[j];
-    }
-    uint32_t* o = hsum + ((size_t)y * width1 + xs) * (64 * NP) + lane * NP;
-    for (int i = 0; i < n; ++i) {
-        if (i > 0) {
-            strip_load<NP>(strip, i + 2 * SW2, lane, t);
-            strip_load<NP>(strip, i - 1, lane, u);
-#pragma unroll
-            for (int j = 0; j < NP; ++j) acc[j] = acc[j] + t[j] - u[j];
-        }
-#pragma unroll
-        for (int j = 0; j < NP; ++j) o[(size_t)i * (64 * NP) + j] = as_u32(acc[j]);
-    }
-}
-
-// Register-ring variant for a compile-time window: the last WIN pixel-cost vectors live in registers (the loop
-// is unrolled by WIN so the ring index is static), the running sum is updated as each column is produced, and
-// no LDS is touched at all.  Used for the window sizes instantiated below; other sizes take k_hsum.
-template <int NP, int WIN>
-__global__ void __launch_bounds__(256) k_hsum_ring(const uint2* __restrict__ bt1, const unsigned short* __restrict__ bt2,
-                                                   int pitch2, int Wp, int width1, int minX1, int minD, int XC, int nchunks,
-                                                   uint32_t* __restrict__ hsum)
-{
-    constexpr int SW2 = WIN / 2;
+    extern __shared__ __attribute__((aligned(16))) uint32_t ringbuf[];   // [4 waves][WIN][NP][64]
+    constexpr int G = 2 * NP;
     const int lane = threadIdx.x & 63;
-    const int chunk = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int chunk = blockIdx.x * 4 + wv;
     if (chunk >= nchunks) return;
     const int y = blockIdx.y;
-    const int xs = chunk * XC;
-    const int n = min(XC, width1 - xs);
-    const uint2* row1 = bt1 + (size_t)y * Wp;
-    const unsigned short* row2 = bt2 + (size_t)y * (6 * BT2_COPIES) * pitch2;
-    const int dbase = minD + lane * 2 * NP;
-    uint32_t* o = hsum + ((size_t)y * width1 + xs) * (64 * NP) + lane * NP;
+    const int WIN = 2 * SW2 + 1;
+    uint32_t* ring = ringbuf + (size_t)wv * WIN * NP * 64 + lane;
+    const int xs = chunk * XC + off;                        // first output column of the chunk (may be < 0)
+    const int xe = min(xs + XC, width1);
+    const int t0 = xs - SW2;                                // first consumed column; (t0 + minX1) has the group phase
+    const int steps = xe - xs + 2 * SW2;                    // rounded up to whole groups by the loop below
+    const uint2* row1 = bt1 + (size_t)y * Wp + minX1;
+    const unsigned short* row2 = bt2 + (size_t)y * 6 * pitch2;
 
-    us2 ring[WIN][NP], acc[NP];
-#pragma unroll
-    for (int r = 0; r < WIN; ++r)
-#pragma unroll
-        for (int j = 0; j < NP; ++j) ring[r][j] = pk_splat(0);
+    for (int r = 0; r < WIN * NP; ++r) ring[r * 64] = 0;
+    us2 acc[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) acc[j] = pk_splat(0);
-    const int cols = n + 2 * SW2;
-    for (int base = 0; base < cols; base += WIN) {
+
+    // mirrored index of the window start at column t0 is e0 = Wp-1-(t0+minX1)+minD == G-1 (mod G)
+    int b = (Wp - 1 - (t0 + minX1) + minD) - (G - 1) + G * lane;      // this lane's first element of "lo"
+    AVec<NP> hi[6], lo[6];
 #pragma unroll
-        for (int r = 0; r < WIN; ++r) {
-            const int i = base + r;
-            if (i < cols) {                                                  // wave-uniform
-                int x = xs - SW2 + i;
-                x = x < 0 ? 0 : (x > width1 - 1 ? width1 - 1 : x);
-                const int X = x + minX1;
-                us2 pix[NP];
-                bt_cost<NP>(row1[X], row2, pitch2, (Wp - 1 - X) + dbase, pix);
+    for (int p = 0; p < 6; ++p) hi[p] = *(const AVec<NP>*)(row2 + (size_t)p * pitch2 + (b + G));
+    int slot = 0;
+    uint32_t* o = hsum + ((size_t)y * width1 + max(xs, 0)) * (64 * NP) + lane * NP;
+    for (int g0 = 0; g0 < steps; g0 += G, b -= G) {
 #pragma unroll
-                for (int j = 0; j < NP; ++j) { acc[j] = acc[j] + pix[j] - ring[r][j]; ring[r][j] = pix[j]; }
-                if (i >= 2 * SW2) {
-                    uint32_t* oo = o + (size_t)(i - 2 * SW2) * (64 * NP);
+        for (int p = 0; p < 6; ++p) lo[p] = *(const AVec<NP>*)(row2 + (size_t)p * pitch2 + b);
+        const int tg = t0 + g0;
+        const bool fast = tg >= 0 && tg + G - 1 <= width1 - 1;        // wave-uniform
 #pragma unroll
-                    for (int j = 0; j < NP; ++j) oo[j] = as_u32(acc[j]);
+        for (int s = 0; s < G; ++s) {
+            const int t = tg + s;
+            us2 pix[NP];
+            if (fast) {
+                const int oo = G - 1 - s;                             // window offset inside [lo | hi], in elements
+                us2 v[6][NP];
+#pragma unroll
+                for (int p = 0; p < 6; ++p)
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) {
+                        const int q = oo / 2 + j;                     // dword index into the 2*NP-dword concatenation
+                        const uint32_t d0 = q < NP ? lo[p].v[q] : hi[p].v[q - NP];
+                        if (oo & 1) {
+                            const uint32_t d1 = q + 1 < NP ? lo[p].v[q + 1] : hi[p].v[q + 1 - NP];
+                            v[p][j] = as_us2(__builtin_amdgcn_alignbit(d1, d0, 16));
+                        } else {
+                            v[p][j] = as_us2(d0);
+                        }
+                    }
+                bt_eval<NP>(row1[t], v, pix);
+            } else {
+                const int tc = t < 0 ? 0 : (t > width1 - 1 ? width1 - 1 : t);
+                const unsigned short* src = row2 + (Wp - 1 - (tc + minX1) + minD) + G * lane;   // 2-byte aligned only
+                us2 v[6][NP];
+#pragma unroll
+                for (int p = 0; p < 6; ++p) {
+                    AVec<NP> u;
+                    __builtin_memcpy(&u, src + (size_t)p * pitch2, sizeof u);
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) v[p][j] = as_us2(u.v[j]);
                 }
+                bt_eval<NP>(row1[tc], v, pix);
+            }
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                uint32_t* rs = ring + (slot * NP + j) * 64;
+                acc[j] = acc[j] + pix[j] - as_us2(*rs);
+                *rs = as_u32(pix[j]);
+            }
+            slot = slot + 1 == WIN ? 0 : slot + 1;
+            const int xo = t - SW2;                                   // the window centred here is complete now
+            if (g0 + s >= 2 * SW2 && xo >= 0 && xo < xe) {
+#pragma unroll
+                for (int j = 0; j < NP; ++j) o[j] = as_u32(acc[j]);
+                o += 64 * NP;
             }
         }
+#pragma unroll
+        for (int p = 0; p < 6; ++p) hi[p] = lo[p];
     }
 }
 
@@ -338,19 +286,20 @@ __global__ void __launch_bounds__(256) k_vsum(const uint32_t* __restrict__ hsum,
 template <int NP>
 static int launch_cost_np(wass_ctx* c, const SgmDims& d)
 {
-    const int XC = 48;
-    const size_t lds = (size_t)(XC + 2 * d.SW2) * StripFmt<NP>::DW * 64 * sizeof(uint32_t);
-    if (lds > 160 * 1024) return set_err(c, WASS_ERR_UNSUPPORTED, "WINSIZE %d too large for the LDS strip", 2 * d.SW2 + 1);
-    WASS_HIP(c, hipFuncSetAttribute((const void*)k_hsum<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (2 * d.SW2 + 1 == 13 && !getenv("WASS_HSUM_LDS")) {
-        const int XCR = 13 * 8 - 12, nch = (d.width1 + XCR - 1) / XCR;      // 92 columns + 12 halo = 8 trips of 13
-        hipLaunchKernelGGL((k_hsum_ring<NP, 13>), dim3((nch + 3) / 4, d.h), dim3(256), 0, c->stream, (const uint2*)c->bt1.p,
-                           (const unsigned short*)c->bt2.p, bt2_pitch(d.Wp), d.Wp, d.width1, d.minX1, d.minD, XCR, nch,
-                           (uint32_t*)c->hsum.p);
-    } else {
-    dim3 g1((d.width1 + XC - 1) / XC, d.h);
-    hipLaunchKernelGGL(k_hsum<NP>, g1, dim3(64), lds, c->stream, (const uint2*)c->bt1.p, (const unsigned short*)c->bt2.p,
-                       bt2_pitch(d.Wp), d.Wp, d.width1, d.minX1, d.minD, d.SW2, XC, (uint32_t*)c->hsum.p);
+    {
+        constexpr int G = 2 * NP;
+        const int WIN = 2 * d.SW2 + 1;
+        const int XQ = 116 / G * G;                                          // columns per chunk, a multiple of G
+        // chunk starts are shifted left by -off in [0, G) so that (t0 + minX1) == (Wp + minD) (mod G)
+        const int m = (((d.Wp + d.minD - d.minX1 + d.SW2) % G) + G) % G;
+        const int off = m == 0 ? 0 : m - G;
+        const int nch = (d.width1 - off + XQ - 1) / XQ;
+        const size_t ldsq = (size_t)4 * WIN * NP * 64 * sizeof(uint32_t);
+        if (ldsq > 160 * 1024) return set_err(c, WASS_ERR_UNSUPPORTED, "WINSIZE %d too large for the LDS ring", WIN);
+        WASS_HIP(c, hipFuncSetAttribute((const void*)k_hsum_q<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq));
+        hipLaunchKernelGGL((k_hsum_q<NP>), dim3((nch + 3) / 4, d.h), dim3(256), ldsq, c->stream, (const uint2*)c->bt1.p,
+                           (const unsigned short*)c->bt2.p + BT2_FRONT, bt2_pitch(d.Wp), d.Wp, d.width1, d.minX1, d.minD, d.SW2,
+                           XQ, off, nch, (uint32_t*)c->hsum.p);
     }
     const int YSEG = 128;
     const size_t lds2 = (size_t)4 * (2 * d.SW2 + 1) * NP * 64 * sizeof(uint32_t);
