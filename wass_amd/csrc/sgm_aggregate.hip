@@ -46,15 +46,14 @@ __global__ void __launch_bounds__(256) k_sweep(const uint32_t* __restrict__ C, u
     uint32_t* sp = S + pix * vec + lane * NP;
     const us2 P1v = pk_splat(P1), cap = pk_splat(0x7FFF);
 
-    auto finish = [&](const us2 (&L)[NP], const us2 (&sin)[NP], uint32_t* so, long long px) {
-        us2 sv[NP];
+    // finished S of one step; in the last sweep the U vectors of a group are kept for wta_batch
+    auto finish = [&](const us2 (&L)[NP], const us2 (&sin)[NP], uint32_t* so, us2 (&sv)[NP]) {
 #pragma unroll
         for (int j = 0; j < NP; ++j) sv[j] = SMODE == 0 ? pk_min(L[j], cap) : pk_min(pk_adds(sin[j], L[j]), cap);
         if (SMODE != 2 || keepS) {
 #pragma unroll
             for (int j = 0; j < NP; ++j) so[j] = as_u32(sv[j]);
         }
-        if (SMODE == 2) wta_select<NP>(sv, lane, D, minD, uniq, sel_d16 + px, sel_key + px);
     };
 
     PathState<NP> st;
@@ -70,12 +69,14 @@ __global__ void __launch_bounds__(256) k_sweep(const uint32_t* __restrict__ C, u
             load_seg<NP, U, false>(cp + U * step, step, U, cn);
             if (SMODE != 0) load_seg<NP, U, false>(sp + U * step, step, U, sn);
         }
+        us2 fin[U][NP];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             us2 L[NP];
             sgm_step<NP>(st, cb[u], L, P1v, P2);
-            finish(L, sb[u], sp + u * step, pix + u * pixstep);
+            finish(L, sb[u], sp + u * step, fin[u]);
         }
+        if (SMODE == 2) wta_batch<NP, U>(fin, U, lane, D, minD, uniq, sel_d16, sel_key, pix, pixstep);
         copy_seg<NP, U>(cb, cn);
         if (SMODE != 0) copy_seg<NP, U>(sb, sn);
         cp += U * step;
@@ -85,13 +86,18 @@ __global__ void __launch_bounds__(256) k_sweep(const uint32_t* __restrict__ C, u
     if (r > 0) {
         load_seg<NP, U, true>(cp, step, r, cb);
         if (SMODE != 0) load_seg<NP, U, true>(sp, step, r, sb);
+        us2 fin[U][NP];
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) fin[u][j] = cap;
             if (u < r) {
                 us2 L[NP];
                 sgm_step<NP>(st, cb[u], L, P1v, P2);
-                finish(L, sb[u], sp + u * step, pix + u * pixstep);
+                finish(L, sb[u], sp + u * step, fin[u]);
             }
+        }
+        if (SMODE == 2) wta_batch<NP, U>(fin, r, lane, D, minD, uniq, sel_d16, sel_key, pix, pixstep);
     }
 }
 
@@ -151,7 +157,7 @@ __global__ void __launch_bounds__(256) k_ckpt(const uint32_t* __restrict__ C, ui
 // SMODE 3: like 2, but the partial sums of the earlier sweeps arrive in two volumes (S + S2).
 // SMODE 4: like 1 with two inputs: S = S + S2 + Lf + Lb.
 template <int NP, int K, int SMODE>
-__global__ void __launch_bounds__(256) k_pair(const uint32_t* __restrict__ C, uint32_t* __restrict__ S,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_pair(const uint32_t* __restrict__ C, uint32_t* __restrict__ S,
                                               const uint32_t* __restrict__ S2,
                                               uint32_t* __restrict__ ckpt, int width1, int h, int dx, int dy,
                                               int P1, int P2, int nchains, int maxseg, int D, int minD, int uniq,
@@ -178,8 +184,7 @@ __global__ void __launch_bounds__(256) k_pair(const uint32_t* __restrict__ C, ui
 
     // one finished backward step: S handling + optional winner-take-all
     auto finish = [&](const us2 (&lf)[NP], const us2 (&lb)[NP], const us2 (&sin)[NP], const us2 (&sin2)[NP], uint32_t* sp,
-                      long long pix) {
-        us2 sv[NP];
+                      us2 (&sv)[NP]) {
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             const us2 both = pk_adds(lf[j], lb[j]);
@@ -191,7 +196,6 @@ __global__ void __launch_bounds__(256) k_pair(const uint32_t* __restrict__ C, ui
 #pragma unroll
             for (int j = 0; j < NP; ++j) sp[j] = as_u32(sv[j]);
         }
-        if (LAST) wta_select<NP>(sv, lane, D, minD, uniq, sel_d16 + pix, sel_key + pix);
     };
 
     // ---- phase 2: the chain in reverse ------------------------------------------------------------
@@ -215,13 +219,18 @@ __global__ void __launch_bounds__(256) k_pair(const uint32_t* __restrict__ C, ui
 #pragma unroll
         for (int u = 0; u < K; ++u)
             if (u < r) sgm_step<NP>(fw, cb[u], lf[u], P1v, P2);
+        us2 fin[K][NP];
 #pragma unroll
-        for (int u = K - 1; u >= 0; --u)
+        for (int u = K - 1; u >= 0; --u) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) fin[u][j] = cap;
             if (u < r) {
                 us2 L[NP];
                 sgm_step<NP>(bw, cb[u], L, P1v, P2);
-                finish(lf[u], L, sb[u], tb[u], sp + u * step, pix0 + (long long)(F * K + u) * pixstep);
+                finish(lf[u], L, sb[u], tb[u], sp + u * step, fin[u]);
             }
+        }
+        if (LAST) wta_batch<NP, K>(fin, r, lane, D, minD, uniq, sel_d16, sel_key, pix0 + (long long)F * K * pixstep, pixstep);
     }
     if (F == 0) return;
 
@@ -263,13 +272,15 @@ __global__ void __launch_bounds__(256) k_pair(const uint32_t* __restrict__ C, ui
         uint32_t* sp = sp0 + (long long)s * K * step;
         const long long pixs = pix0 + (long long)s * K * pixstep;
         // two independent dependency chains in one block: the scheduler interleaves them
+        us2 fin[K][NP];
 #pragma unroll
         for (int u = 0; u < K; ++u) {
             const int v = K - 1 - u;
             us2 L[NP];
             sgm_step_pair<NP>(fw, cB[u], lB[u], bw, cA[v], L, P1v, P2);
-            finish(lA[v], L, sA[v], tA[v], sp + v * step, pixs + v * pixstep);
+            finish(lA[v], L, sA[v], tA[v], sp + v * step, fin[v]);
         }
+        if (LAST) wta_batch<NP, K>(fin, K, lane, D, minD, uniq, sel_d16, sel_key, pixs, pixstep);
         copy_seg<NP, K>(cA, cB);
         copy_seg<NP, K>(cB, cC);
         copy_seg<NP, K>(lA, lB);
@@ -279,12 +290,14 @@ __global__ void __launch_bounds__(256) k_pair(const uint32_t* __restrict__ C, ui
         for (int j = 0; j < NP; ++j) nvB[j] = nvC[j];
     }
     {                                              // epilogue: backward over segment 0
+        us2 fin[K][NP];
 #pragma unroll
         for (int v = K - 1; v >= 0; --v) {
             us2 L[NP];
             sgm_step<NP>(bw, cA[v], L, P1v, P2);
-            finish(lA[v], L, sA[v], tA[v], sp0 + v * step, pix0 + v * pixstep);
+            finish(lA[v], L, sA[v], tA[v], sp0 + v * step, fin[v]);
         }
+        if (LAST) wta_batch<NP, K>(fin, K, lane, D, minD, uniq, sel_d16, sel_key, pix0, pixstep);
     }
 }
 

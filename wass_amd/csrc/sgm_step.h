@@ -153,54 +153,104 @@ __device__ __forceinline__ void copy_seg(us2 (&dst)[K][NP], const us2 (&src)[K][
 // stay in k_lrcheck).  key = (S << 16) | d reduced with a wave minimum gives the
 // smallest S and, among equals, the smallest d ("first minimum").
 // ---------------------------------------------------------------------------
+// S at a wave-uniform disparity d: the whole lane vector is fetched with NP v_readlane and the half-word is
+// picked on the scalar unit.
 template <int NP>
 __device__ __forceinline__ int s_at(const us2 (&Sv)[NP], int d)
 {
     const int ln = d / (2 * NP), slot = d % (2 * NP);       // wave-uniform
     uint32_t pv = 0;
 #pragma unroll
-    for (int j = 0; j < NP; ++j)
-        if ((slot >> 1) == j) pv = (uint32_t)__builtin_amdgcn_readlane((int)as_u32(Sv[j]), ln);
+    for (int j = 0; j < NP; ++j) {
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)as_u32(Sv[j]), ln);
+        pv = (slot >> 1) == j ? w : pv;
+    }
     return (int)((slot & 1) ? (pv >> 16) : (pv & 0xFFFF));
 }
 
+// trunc(num / den) for |num| < 2^24, 0 < den < 2^24 without the 35-instruction integer-division expansion:
+// float reciprocal estimate, then one correction step each way (the estimate is off by at most one).
+__device__ __forceinline__ int div_small(int num, int den)
+{
+    const int an = num < 0 ? -num : num;
+    int q = (int)((float)an * __builtin_amdgcn_rcpf((float)den));
+    const int r = an - q * den;
+    q += (r >= den) - (r < 0);
+    return num < 0 ? -q : q;
+}
+
+// Winner-take-all for the K finished S vectors of one chain segment, written stage by stage over the K cells so
+// that the K independent reductions / readlanes / scalar tails overlap (one cell at a time the instruction stream
+// is a single dependent chain full of DPP and readlane wait states).  Branch-free; lane u collects the result of
+// cell u and the segment is written with one store per output array.  Cell u lives at pixel pix0 + u*pixstep;
+// only cells u < nvalid are stored.
+template <int NP, int K>
+__device__ __forceinline__ void wta_batch(const us2 (&Sv)[K][NP], int nvalid, int lane, int D, int minD, int uniq,
+                                          int16_t* __restrict__ out_d16, uint32_t* __restrict__ out_key, long long pix0,
+                                          long long pixstep)
+{
+    constexpr int V = 2 * NP;
+    constexpr int ABSENT = 1 << 22;                             // a neighbour that does not exist never passes a test
+    const int dlane = lane * V;
+    // padded slots (d >= D) always hold the saturated 0x7FFF and a larger d than every real slot, so they can
+    // only win the key minimum when every real slot is 0x7FFF too -- and then the smallest (real) d wins anyway
+    uint32_t key[K];
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+        key[u] = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const uint32_t w = as_u32(Sv[u][j]);
+            key[u] = min(key[u], min((w << 16) | (uint32_t)(dlane + 2 * j), (w & 0xFFFF0000u) | (uint32_t)(dlane + 2 * j + 1)));
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < K; ++u) key[u] = wave_min_u32(key[u]);
+    const int q = 100 - uniq;
+    int res_d = 0;
+    uint32_t res_k = 0;
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+        const int minS = (int)(key[u] >> 16);
+        // "if (Sval < minS)" with minS initialised to MAX_COST never fires when every S is MAX_COST
+        const int best = minS >= 32767 ? -1 : (int)(key[u] & 0xFFFF);
+        // uniqueness: some d outside best-1..best+1 with S[d]*(100-uniq) < minS*100.  Count the slots that satisfy
+        // the inequality over the whole vector (ballots, scalar popcounts) and subtract the up to three
+        // neighbours, which are wave-uniform values.
+        const int T = minS * 100;
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int sv = (j & 1) ? Sv[u][j >> 1].y : Sv[u][j >> 1].x;
+            cnt += __builtin_popcountll(__ballot(dlane + j < D && (int)__umul24((uint32_t)sv, (uint32_t)q) < T));
+        }
+        const int am = s_at<NP>(Sv[u], max(best - 1, 0)), cp = s_at<NP>(Sv[u], min(best + 1, D - 1));
+        const int a = best >= 1 ? am : ABSENT, cc = best + 1 < D ? cp : ABSENT;
+        const int near = (a * q < T) + (cc * q < T) + (best >= 0 && minS * q < T);
+        const bool ok = cnt <= near, sub = 0 < best && best < D - 1;
+        const int denom2 = max(a + cc - 2 * minS, 1);
+        const int frac = div_small((a - cc) * 16 + denom2, denom2 * 2);
+        const int out = ok ? (best * 16 + (sub ? frac : 0) + minD * 16) : (minD - 1) * 16;
+        const uint32_t k = ok ? (((uint32_t)minS << 16) | (uint32_t)(best & 0xFFFF)) : 0xFFFFFFFFu;
+        res_d = lane == u ? out : res_d;
+        res_k = lane == u ? k : res_k;
+    }
+    if (lane < nvalid) {
+        const long long px = pix0 + lane * pixstep;
+        out_d16[px] = (int16_t)res_d;
+        out_key[px] = res_k;
+    }
+}
+
+// single-cell form
 template <int NP>
 __device__ __forceinline__ void wta_select(const us2 (&Sv)[NP], int lane, int D, int minD, int uniq,
                                            int16_t* __restrict__ out_d16, uint32_t* __restrict__ out_key)
 {
-    const int dlane = lane * 2 * NP;
-    uint32_t sv[2 * NP];
+    us2 one[1][NP];
 #pragma unroll
-    for (int j = 0; j < NP; ++j) { sv[2 * j] = Sv[j].x; sv[2 * j + 1] = Sv[j].y; }
-    uint32_t key = 0xFFFFFFFFu;
-#pragma unroll
-    for (int j = 0; j < 2 * NP; ++j)
-        if (dlane + j < D) key = min(key, (sv[j] << 16) | (uint32_t)(dlane + j));
-    key = wave_min_u32(key);
-    const int minS = (int)(key >> 16);
-    // "if (Sval < minS)" with minS initialised to MAX_COST never fires when every S is MAX_COST
-    const int best = minS >= 32767 ? -1 : (int)(key & 0xFFFF);
-    bool bad = false;
-#pragma unroll
-    for (int j = 0; j < 2 * NP; ++j) {
-        const int d = dlane + j;
-        if (d < D && (int)sv[j] * (100 - uniq) < minS * 100 && abs(best - d) > 1) bad = true;
-    }
-    const bool reject = __any(bad);
-    int out = (minD - 1) * 16;
-    uint32_t k = 0xFFFFFFFFu;
-    if (!reject) {                                             // wave-uniform
-        int d = best;
-        k = ((uint32_t)minS << 16) | (uint32_t)(best & 0xFFFF);
-        if (0 < d && d < D - 1) {
-            const int a = s_at<NP>(Sv, d - 1), cc = s_at<NP>(Sv, d + 1), b = minS;
-            const int denom2 = max(a + cc - 2 * b, 1);
-            d = d * 16 + ((a - cc) * 16 + denom2) / (denom2 * 2);
-        } else
-            d *= 16;
-        out = d + minD * 16;
-    }
-    if (lane == 0) { *out_d16 = (int16_t)out; *out_key = k; }
+    for (int j = 0; j < NP; ++j) one[0][j] = Sv[j];
+    wta_batch<NP, 1>(one, 1, lane, D, minD, uniq, out_d16, out_key, 0, 0);
 }
 
 
