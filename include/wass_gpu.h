@@ -229,6 +229,12 @@ int wass_mesh_encode_xyzc(wass_ctx* ctx, wass_mesh* m, const double plane[4], vo
  * staging copy) */
 int wass_mesh_encode_xyzc_to(wass_ctx* ctx, wass_mesh* m, const double plane[4], void* dst, size_t capacity,
                              size_t* nbytes);
+/* same, but returns as soon as the size is known: the 148-byte header is complete, the 6*n payload bytes are
+ * being written by a DMA engine on the context's copy stream and are complete after wass_ctx_synchronize().
+ * dst should be pinned host memory.  Lets a sequence driver overlap the PCIe transfer (and the file write of
+ * wass_stereo.cpp:2123) with the next frame. */
+int wass_mesh_encode_xyzc_async(wass_ctx* ctx, wass_mesh* m, const double plane[4], void* dst, size_t capacity,
+                                size_t* nbytes);
 void wass_free(void* p);
 
 /* Coll-1: NaN-aware mean of per-frame planes (np.nanmean of planes.txt,

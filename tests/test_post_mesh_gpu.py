@@ -261,6 +261,14 @@ def test_xyzc_bytes_exact(gpu_ctx, oracle):
     assert buf[:nb].tobytes() == ref
     with pytest.raises(wass_amd.WassError):
         m.encode_xyzc_to(plane, buf.ctypes.data, 200)
+    # asynchronous download into pinned memory: complete after synchronize(); back-to-back encodes reuse the
+    # device-side payload buffer only after the previous download has finished
+    import torch
+    pins = [torch.zeros(148 + 6 * valid.size, dtype=torch.uint8).pin_memory() for _ in range(3)]
+    sizes = [m.encode_xyzc_async(plane, p.data_ptr(), p.numel()) for p in pins]
+    gpu_ctx.synchronize()
+    for p, nb2 in zip(pins, sizes):
+        assert p[:nb2].numpy().tobytes() == ref
     blob2 = m.encode_xyzc(None)
     Rinv = np.frombuffer(blob2[52:124], np.float64).reshape(3, 3)
     np.testing.assert_array_equal(Rinv, np.eye(3))

@@ -106,6 +106,7 @@ SYMBOLS = {
     "wass_RT_from_plane": (None, [C.POINTER(C.c_double)] * 5),
     "wass_mesh_encode_xyzc": (_i, [_vp, _vp, C.POINTER(C.c_double), C.POINTER(_vp), C.POINTER(_sz)]),
     "wass_mesh_encode_xyzc_to": (_i, [_vp, _vp, C.POINTER(C.c_double), _vp, _sz, C.POINTER(_sz)]),
+    "wass_mesh_encode_xyzc_async": (_i, [_vp, _vp, C.POINTER(C.c_double), _vp, _sz, C.POINTER(_sz)]),
     "wass_free": (None, [_vp]),
     "wass_planes_mean_accumulate": (None, [C.POINTER(C.c_double), _i, C.POINTER(C.c_double)]),
     "wass_planes_mean_finish": (None, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),

@@ -98,6 +98,9 @@ int wass_ctx_create(int device_id, wass_ctx** out)
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
     if (hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
+    if (hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
+    if (hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
+    if (hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
     for (auto& e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
     if (hipEventCreateWithFlags(&c->ev_cost, hipEventDisableTiming) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
@@ -105,6 +108,8 @@ int wass_ctx_create(int device_id, wass_ctx** out)
     for (auto& e : c->ev_ckpt)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
     if (ensure(c, c->flags, 64) != WASS_OK) { delete c; return WASS_ERR_NO_MEMORY; }
+    if (hipHostMalloc((void**)&c->h_flags, 64, hipHostMallocDefault) != hipSuccess) { delete c; return WASS_ERR_NO_MEMORY; }
+    c->h_flags[0] = 0;
     *out = c;
     return WASS_OK;
 }
@@ -115,7 +120,7 @@ void wass_ctx_destroy(wass_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (Buf* b : { &c->img1, &c->img2, &c->bt1, &c->bt2, &c->hsum, &c->C, &c->S, &c->S2, &c->halo, &c->ckpt, &c->sel_d16, &c->sel_key, &c->raw,
-                    &c->flags, &c->tmp_in0, &c->tmp_in1, &c->tmp_out, &c->tmp_mask, &c->fA, &c->fB, &c->fC, &c->scratch, &c->counters, &c->dstate, &c->rect_tab, &c->rect_mx, &c->rect_my })
+                    &c->flags, &c->tmp_in0, &c->tmp_in1, &c->tmp_out, &c->tmp_mask, &c->fA, &c->fB, &c->fC, &c->scratch, &c->counters, &c->dstate, &c->rect_tab, &c->rect_mx, &c->rect_my, &c->xyzc })
         release(*b);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_ckpt) if (e) (void)hipEventDestroy(e);
@@ -123,6 +128,10 @@ void wass_ctx_destroy(wass_ctx* c)
     if (c->ev_cols) (void)hipEventDestroy(c->ev_cols);
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     if (c->side2) { (void)hipStreamSynchronize(c->side2); (void)hipStreamDestroy(c->side2); }
+    if (c->copy) { (void)hipStreamSynchronize(c->copy); (void)hipStreamDestroy(c->copy); }
+    if (c->h_flags) (void)hipHostFree(c->h_flags);
+    if (c->ev_pack) (void)hipEventDestroy(c->ev_pack);
+    if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -141,6 +150,7 @@ int wass_ctx_synchronize(wass_ctx* c)
 {
     if (!c) return WASS_ERR_INVALID_ARG;
     WASS_HIP(c, hipStreamSynchronize(c->stream));
+    WASS_HIP(c, hipStreamSynchronize(c->copy));
     return WASS_OK;
 }
 
@@ -184,6 +194,10 @@ int wass_sgm_disparity_dev(wass_ctx* c, const uint8_t* d_right, const uint8_t* d
     WASS_HIP(c, hipEventRecord(c->ev[4], s));
     if ((rc = launch_median_crop(c, d, d_out))) return rc;
     WASS_HIP(c, hipEventRecord(c->ev[5], s));
+    // status word for wass_sgm_last_timings / the host entry point, in stream order (a blocking hipMemcpy on the
+    // null stream would queue behind whatever else the process has in flight)
+    WASS_HIP(c, hipMemcpyAsync(c->h_flags, c->flags.p, 4, hipMemcpyDeviceToHost, s));
+    WASS_HIP(c, hipEventRecord(c->ev[6], s));
     c->last = d; c->have_last = true;
     c->timings.aggregate_launches = nl;
     c->timings_valid = true;
@@ -194,7 +208,7 @@ int wass_sgm_last_timings(wass_ctx* c, wass_sgm_timings* out)
 {
     if (!c || !out) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
     if (!c->timings_valid) return set_err(c, WASS_ERR_INVALID_ARG, "no completed wass_sgm_disparity call");
-    WASS_HIP(c, hipEventSynchronize(c->ev[5]));
+    WASS_HIP(c, hipEventSynchronize(c->ev[6]));
     wass_sgm_timings& t = c->timings;
     WASS_HIP(c, hipEventElapsedTime(&t.prefilter_ms, c->ev[0], c->ev[1]));
     WASS_HIP(c, hipEventElapsedTime(&t.cost_ms, c->ev[1], c->ev[2]));
@@ -202,8 +216,7 @@ int wass_sgm_last_timings(wass_ctx* c, wass_sgm_timings* out)
     WASS_HIP(c, hipEventElapsedTime(&t.select_ms, c->ev[3], c->ev[4]));
     WASS_HIP(c, hipEventElapsedTime(&t.median_ms, c->ev[4], c->ev[5]));
     WASS_HIP(c, hipEventElapsedTime(&t.total_ms, c->ev[0], c->ev[5]));
-    uint32_t fl = 0;
-    WASS_HIP(c, hipMemcpy(&fl, c->flags.p, 4, hipMemcpyDeviceToHost));
+    const uint32_t fl = c->h_flags[0];
     t.cost_overflow = (int)(fl & 1);
     *out = t;
     if (fl & 2) {
@@ -229,9 +242,8 @@ int wass_sgm_disparity(wass_ctx* c, const uint8_t* right, const uint8_t* left, i
                                 (int16_t*)c->tmp_out.p);
     if (rc) return rc;
     WASS_HIP(c, hipMemcpyAsync(disp16_out, c->tmp_out.p, n * 2, hipMemcpyDeviceToHost, c->stream));
-    uint32_t fl = 0;
-    WASS_HIP(c, hipMemcpyAsync(&fl, c->flags.p, 4, hipMemcpyDeviceToHost, c->stream));
     WASS_HIP(c, hipStreamSynchronize(c->stream));
+    const uint32_t fl = c->h_flags[0];
     if (fl & 2) {
         c->halo_dirty = true;
         return set_err(c, WASS_ERR_DEVICE, "aggregation pipeline timed out waiting for a neighbouring strip");

@@ -118,12 +118,16 @@ struct wass_ctx {
     wass::Buf sel_d16, sel_key;    // per (y,x): raw fixed-point disparity / (minS<<16|d)
     wass::Buf raw;                 // padded-width raw disparity [h][Wp] int16
     wass::Buf flags;               // u32[4]: [0] = cost overflow
+    uint32_t* h_flags = nullptr;   // pinned host copy of flags[0], refreshed at the end of every SGM call (stream-ordered)
     wass::Buf tmp_in0, tmp_in1, tmp_out;   // staging for the host-pointer entry points
     wass::Buf tmp_mask;
     wass::Buf fA, fB, fC;          // float32 maps of the disparity clean-up
     wass::Buf counters;            // striped atomics of the mesh stages
     wass::Buf dstate;              // device-resident scalar record + radix histogram (mesh.hip DevState)
     wass::Buf scratch;             // mesh stages: gaps / labels / partial sums / packed output
+    wass::Buf xyzc;                // packed u16 triples of mesh_cam.xyzC (own buffer: downloaded asynchronously)
+    hipStream_t copy = nullptr;    // D2H of the xyzC payload
+    hipEvent_t ev_pack = nullptr, ev_copy = nullptr;
     wass::Buf rect_tab;            // fixed-point interpolation tables of the rectification resamplers (rectify.hip)
     bool rect_tab_ready = false;
     wass::Buf rect_mx, rect_my;    // staging for host-pointer map uploads

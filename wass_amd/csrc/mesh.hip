@@ -1391,7 +1391,7 @@ int wass_mesh_encode_xyzc(wass_ctx* c, wass_mesh* m, const double plane[4], void
     return WASS_OK;
 }
 
-int wass_mesh_encode_xyzc_to(wass_ctx* c, wass_mesh* m, const double plane[4], void* dst, size_t capacity, size_t* nbytes)
+static int encode_xyzc_impl(wass_ctx* c, wass_mesh* m, const double plane[4], void* dst, size_t capacity, size_t* nbytes, bool async)
 {
     if (!c || !m || !dst || !nbytes) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
     WASS_HIP(c, hipSetDevice(c->device));
@@ -1401,13 +1401,16 @@ int wass_mesh_encode_xyzc_to(wass_ctx* c, wass_mesh* m, const double plane[4], v
     memcpy(rt.R, R, sizeof R); memcpy(rt.T, T, sizeof T);
     const size_t n = m->n();
     const unsigned nb = nblk(n);
-    int rc = ensure(c, c->scratch, 64 + (size_t)nb * 4 + 16 + n * 6);
+    int rc = ensure(c, c->scratch, 64 + (size_t)nb * 4 + 16);
     if (rc) return rc;
     if ((rc = ensure(c, c->counters, (size_t)NSLOT * 6 * 8))) return rc;
+    // the packed triples get their own buffer: the download may still be in flight (async form) while the next
+    // frame's stages reuse the scratch area
+    if ((rc = ensure(c, c->xyzc, n * 6 + 16))) return rc;
     unsigned long long* lim = (unsigned long long*)c->counters.p;          // [NSLOT][6] keys
     unsigned int* total = (unsigned int*)c->scratch.p;
     unsigned int* bcnt = (unsigned int*)((char*)c->scratch.p + 64);
-    uint16_t* dq = (uint16_t*)((char*)c->scratch.p + ((64 + (size_t)nb * 4 + 15) & ~(size_t)15));
+    uint16_t* dq = (uint16_t*)c->xyzc.p;
     unsigned long long init[NSLOT * 6];
     for (int i = 0; i < NSLOT; ++i) for (int k = 0; k < 6; ++k) init[i * 6 + k] = k < 3 ? ~0ull : 0ull;
     WASS_HIP(c, hipMemcpyAsync(lim, init, sizeof init, hipMemcpyHostToDevice, c->stream));
@@ -1431,12 +1434,14 @@ int wass_mesh_encode_xyzc_to(wass_ctx* c, wass_mesh* m, const double plane[4], v
         mx[k] = npts ? dunkey(hl[3 + k]) : -1.7976931348623157e308;
         sc[k] = 65535.0 / (mx[k] - mn[k]);
     }
-    if (npts)
-        hipLaunchKernelGGL(k_xyzc_pack, dim3(nb), dim3(256), 0, c->stream, m->valid, m->x, m->y, m->z, n, rt, mn[0], mn[1], mn[2],
-                           sc[0], sc[1], sc[2], (const unsigned int*)bcnt, dq);
     const size_t total_bytes = 148 + (size_t)npts * 6;
     if (total_bytes > capacity)
         return set_err(c, WASS_ERR_INVALID_ARG, "xyzC needs %zu bytes, buffer has %zu", total_bytes, capacity);
+    if (npts) {
+        WASS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_copy, 0));            // a previous download still reading dq
+        hipLaunchKernelGGL(k_xyzc_pack, dim3(nb), dim3(256), 0, c->stream, m->valid, m->x, m->y, m->z, n, rt, mn[0], mn[1], mn[2],
+                           sc[0], sc[1], sc[2], (const unsigned int*)bcnt, dq);
+    }
     unsigned char* buf = (unsigned char*)dst;
     size_t o = 0;
     const uint32_t n32 = npts;
@@ -1446,12 +1451,25 @@ int wass_mesh_encode_xyzc_to(wass_ctx* c, wass_mesh* m, const double plane[4], v
     memcpy(buf + o, Rinv, 72); o += 72;
     memcpy(buf + o, Tinv, 24); o += 24;
     if (npts) {
-        hipError_t e = hipMemcpyAsync(buf + o, dq, (size_t)npts * 6, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) return set_err(c, WASS_ERR_DEVICE, "xyzC download: %s", hipGetErrorString(e));
+        // the download runs on its own stream (a DMA engine), so the next frame's kernels do not wait for PCIe
+        WASS_HIP(c, hipEventRecord(c->ev_pack, c->stream));
+        WASS_HIP(c, hipStreamWaitEvent(c->copy, c->ev_pack, 0));
+        WASS_HIP(c, hipMemcpyAsync(buf + o, dq, (size_t)npts * 6, hipMemcpyDeviceToHost, c->copy));
+        WASS_HIP(c, hipEventRecord(c->ev_copy, c->copy));
+        if (!async) WASS_HIP(c, hipStreamSynchronize(c->copy));
     }
     *nbytes = total_bytes;
     return WASS_OK;
+}
+
+int wass_mesh_encode_xyzc_to(wass_ctx* c, wass_mesh* m, const double plane[4], void* dst, size_t capacity, size_t* nbytes)
+{
+    return encode_xyzc_impl(c, m, plane, dst, capacity, nbytes, false);
+}
+
+int wass_mesh_encode_xyzc_async(wass_ctx* c, wass_mesh* m, const double plane[4], void* dst, size_t capacity, size_t* nbytes)
+{
+    return encode_xyzc_impl(c, m, plane, dst, capacity, nbytes, true);
 }
 
 // np.nanmean over planes.txt rows (wassgridsurface.py:672-678): a row counts if none of its entries is NaN

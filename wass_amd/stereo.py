@@ -357,6 +357,14 @@ class Mesh:
         self.ctx._check(self.ctx._lib.wass_mesh_encode_xyzc_to(self.ctx._h, self._h, pl, dst_ptr, capacity, C.byref(nb)))
         return int(nb.value)
 
+    def encode_xyzc_async(self, plane, dst_ptr: int, capacity: int) -> int:
+        """Like encode_xyzc_to, but the payload is still being copied when this returns; complete after
+        Context.synchronize()."""
+        nb = C.c_size_t()
+        pl = (C.c_double * 4)(*plane) if plane is not None else None
+        self.ctx._check(self.ctx._lib.wass_mesh_encode_xyzc_async(self.ctx._h, self._h, pl, dst_ptr, capacity, C.byref(nb)))
+        return int(nb.value)
+
     def encode_xyzc(self, plane=None) -> bytes:
         buf = C.c_void_p(); nb = C.c_size_t()
         pl = (C.c_double * 4)(*plane) if plane is not None else None
