@@ -154,6 +154,19 @@ int ensure(wass_ctx* c, Buf& b, size_t bytes);
                                  hipGetErrorString(e__), __FILE__, __LINE__);               \
     } while (0)
 
+// Checkpoint regions of the chain families, in launch order.  With 8 paths the column family comes first: its
+// forward checkpoints are produced by the cost stage itself (k_vsum_col walks whole columns top-down, which is
+// exactly that family's forward path), so its pair kernel can start the moment C is complete.
+struct CkptLayout {
+    int K = 8;                       // steps per checkpoint segment
+    int nfam = 0;
+    int dx[4] = {}, dy[4] = {}, smode[4] = {}, nch[4] = {}, mseg[4] = {};
+    size_t off[5] = {};              // byte offsets into c->ckpt
+    bool cols_from_cost = false;     // family 0 is the column family and its checkpoints come from k_vsum_col
+    bool path2_from_cost = false;    // 5-path mode: k_vsum_col has already written S = L_2 (path 2 has no partner)
+};
+CkptLayout ckpt_layout(const SgmDims& d);
+
 // stage launchers (each enqueues on c->stream)
 int launch_prefilter(wass_ctx* c, const SgmDims& d);
 int launch_cost_volume(wass_ctx* c, const SgmDims& d);

@@ -301,6 +301,39 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
     }
 }
 
+CkptLayout ckpt_layout(const SgmDims& d)
+{
+    CkptLayout L;
+    L.K = d.NP <= 2 ? 8 : (d.NP <= 4 ? 4 : 2);
+    auto add = [&](int dx, int dy, int smode) {
+        const int f = L.nfam++;
+        L.dx[f] = dx; L.dy[f] = dy; L.smode[f] = smode;
+        L.nch[f] = dy == 0 ? d.h : (dx == 0 ? d.width1 : d.width1 + d.h - 1);
+        const int maxlen = dy == 0 ? d.width1 : (dx == 0 ? d.h : (d.width1 < d.h ? d.width1 : d.h));
+        L.mseg[f] = (maxlen + L.K - 1) / L.K;
+        const size_t b = (size_t)L.nch[f] * L.mseg[f] * (64 * d.NP) * sizeof(uint32_t);
+        L.off[f + 1] = L.off[f] + ((b + 255) & ~(size_t)255);
+    };
+    // The kernel that carries the winner-take-all goes last and should have the most chains (the WTA adds ~60
+    // instructions per pixel): the anti-diagonals (width1 + h - 1 chains).
+    const char* agg = getenv("WASS_AGG");
+    const bool legacy = agg && (!strcmp(agg, "trio") || !strcmp(agg, "concurrent") || !strcmp(agg, "rowsfirst"));
+    if (d.ndirs == 8 && !legacy) {
+        L.cols_from_cost = true;
+        add(0, 1, 0);                // columns:        paths 2 + 6   (S written)
+        add(1, 0, 1);                // rows:           paths 0 + 4
+        add(1, 1, 1);                // diagonals:      paths 1 + 7
+        add(-1, 1, 2);               // anti-diagonals: paths 3 + 5, winner-take-all fused
+    } else if (d.ndirs == 5 && !legacy) {
+        L.path2_from_cost = true;
+        add(1, 0, 1);                // rows: paths 0 + 4, added to the S = L_2 that the cost stage left behind
+    } else {
+        add(1, 0, 0);                // rows (S written)
+        if (d.ndirs == 8) { add(0, 1, 1); add(1, 1, 1); add(-1, 1, 2); }
+    }
+    return L;
+}
+
 // Pipelined-strip schedule (sgm_trio.hip): paths {0,1,2} and {4,7,6} (MODE_HH) / {4,3} (MODE_SGBM) as two
 // concurrent three-path sweeps writing S and S2; MODE_HH finishes with the anti-diagonal pair {3,5} + fused
 // winner-take-all reading both volumes, MODE_SGBM with a plain S + S2 selection kernel.
@@ -380,26 +413,16 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
     const char* agg = getenv("WASS_AGG");
     if (agg && !strcmp(agg, "trio")) return launch_aggregate_trio<NP>(c, d, n_launches);
     auto nchains = [&](int dx, int dy) { return dy == 0 ? d.h : (dx == 0 ? d.width1 : d.width1 + d.h - 1); };
-    auto maxlen = [&](int dx, int dy) { return dy == 0 ? d.width1 : (dx == 0 ? d.h : (d.width1 < d.h ? d.width1 : d.h)); };
-    auto ckpt_bytes = [&](int dx, int dy) {
-        const size_t b = (size_t)nchains(dx, dy) * ((maxlen(dx, dy) + K - 1) / K) * (64 * NP) * sizeof(uint32_t);
-        return (b + 255) & ~(size_t)255;
-    };
-    // families in launch order; every family has its own checkpoint region so that all checkpoint
-    // sweeps (which only read C) can run ahead on the side stream while the main stream accumulates S
+    // every family has its own checkpoint region so that all checkpoint sweeps (which only read C) can run ahead
+    // on the side stream while the main stream accumulates S
+    const CkptLayout lay = ckpt_layout(d);
+    static_assert(K == (NP <= 2 ? 8 : (NP <= 4 ? 4 : 2)), "ckpt_layout and the kernels must agree on K");
+    const int nf = lay.nfam;
     struct Fam { int dx, dy, smode; };
     Fam fam[4];
-    int nf = 0;
-    // Order: the kernel that carries the winner-take-all goes last and should have the most chains (the WTA adds
-    // ~50 instructions per pixel): the anti-diagonals (width1 + h - 1 chains).
-    fam[nf++] = { 1, 0, 0 };         // rows:           paths 0 + 4   (S written)
-    if (d.ndirs == 8) {
-        fam[nf++] = { 0, 1, 1 };     // columns:        paths 2 + 6
-        fam[nf++] = { 1, 1, 1 };     // diagonals:      paths 1 + 7
-        fam[nf++] = { -1, 1, 2 };    // anti-diagonals: paths 3 + 5, winner-take-all fused
-    }
-    size_t off[5] = { 0 };
-    for (int f = 0; f < nf; ++f) off[f + 1] = off[f] + ckpt_bytes(fam[f].dx, fam[f].dy);
+    size_t off[5];
+    for (int f = 0; f < nf; ++f) { fam[f] = { lay.dx[f], lay.dy[f], lay.smode[f] }; off[f] = lay.off[f]; }
+    off[nf] = lay.off[nf];
     int rc = ensure(c, c->ckpt, off[nf]);
     if (rc) return rc;
 
@@ -407,8 +430,12 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
     WASS_HIP(c, hipStreamWaitEvent(c->side, c->ev_cost, 0));
     WASS_HIP(c, hipStreamWaitEvent(c->side2, c->ev_cost, 0));
     for (int f = 0; f < nf; ++f) {
+        if (f == 0 && lay.cols_from_cost) {         // written by k_vsum_col on the main stream already
+            WASS_HIP(c, hipEventRecord(c->ev_ckpt[f], c->stream));
+            continue;
+        }
         const int dx = fam[f].dx, dy = fam[f].dy;
-        const int nch = nchains(dx, dy), mseg = (maxlen(dx, dy) + K - 1) / K;
+        const int nch = lay.nch[f], mseg = lay.mseg[f];
         static const bool two = getenv("WASS_SIDE_STREAMS") && atoi(getenv("WASS_SIDE_STREAMS")) == 2;
         hipStream_t ss = (two && (f & 1)) ? c->side2 : c->side;
         hipLaunchKernelGGL((k_ckpt<NP, K>), dim3((nch + 3) / 4), dim3(256), 0, ss, C,
@@ -426,9 +453,15 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
         if (rc2) return rc2;
     }
     const uint32_t* S2 = conc ? (const uint32_t*)c->S2.p : (const uint32_t*)S;
+    if (lay.path2_from_cost) {       // path 1 needs no checkpoints: it runs while the row checkpoints are produced
+        const int nch = nchains(1, 1);
+        hipLaunchKernelGGL((k_sweep<NP, 1, U>), dim3((nch + 3) / 4), dim3(256), 0, c->stream, C, S, d.width1, d.h, 1, 1, d.P1, d.P2,
+                           nch, d.D, d.minD, d.uniq, c->debug ? 1 : 0, sd, sk);
+        ++nl;
+    }
     for (int f = 0; f < nf; ++f) {
         const int dx = fam[f].dx, dy = fam[f].dy;
-        const int nch = nchains(dx, dy), mseg = (maxlen(dx, dy) + K - 1) / K;
+        const int nch = lay.nch[f], mseg = lay.mseg[f];
         uint32_t* ck = (uint32_t*)((char*)c->ckpt.p + off[f]);
         const dim3 grid((nch + 3) / 4), block(256);
 #define WASS_PAIR(SMODE, STREAM, SOUT)                                                                       \
@@ -457,10 +490,12 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
                            d.width1, d.h, dx, dy, d.P1, d.P2, nch, d.D, d.minD, d.uniq, c->debug ? 1 : 0, sd, sk); \
         ++nl;                                                                                                \
     } while (0)
-    if (d.ndirs == 5) {              // MODE_SGBM: the three down-going paths have no partner
+    if (d.ndirs == 5 && !lay.path2_from_cost) {   // MODE_SGBM, legacy order: the three down-going paths as plain sweeps
         WASS_SWEEP(1, 0, 1);         // path 2
         WASS_SWEEP(1, 1, 1);         // path 1
         WASS_SWEEP(2, -1, 1);        // path 3, winner-take-all fused
+    } else if (d.ndirs == 5) {
+        WASS_SWEEP(2, -1, 1);        // path 3, winner-take-all fused (paths 2, 1, 0 + 4 are in S by now)
     }
 #undef WASS_SWEEP
     if (n_launches) *n_launches = nl;

@@ -10,7 +10,7 @@
 // (d = 2*NP*lane + j).  One wave therefore reads/writes one contiguous
 // 256*NP-byte vector per pixel -- fully coalesced -- and all arithmetic runs
 // on v_pk_*_u16.  Slots d >= D hold 0xFFFF in C and never win a minimum.
-#include "common.h"
+#include "sgm_step.h"
 
 #include <stdlib.h>
 
@@ -283,6 +283,104 @@ __global__ void __launch_bounds__(256) k_vsum(const uint32_t* __restrict__ hsum,
     if (__any(over) && lane == 0) atomicOr(flags, 1u);
 }
 
+// ---------------------------------------------------------------------------
+// K2b, whole-column form (8-path mode): one wave walks one column from the top row to the bottom row.  That walk
+// IS the forward path of the column chain family (path 2), so the wave runs that recurrence on the cost vectors
+// it has just produced and stores the family's checkpoints (the state after every K rows) -- the separate
+// checkpoint sweep of that family (a full read of C) disappears and its pair kernel can start as soon as C is
+// complete.  Rows entering the window are fetched K ahead.
+// PATH2 (5-path mode, where path 2 has no partner): the path costs themselves are the first contribution to S and
+// are written out (S = L_2), which replaces that path's sweep (a read of C and a read-modify-write of S).
+// ---------------------------------------------------------------------------
+template <int NP, int K, bool PATH2>
+__global__ void __launch_bounds__(256) k_vsum_col(const uint32_t* __restrict__ hsum, int width1, int h, int D, int SH2,
+                                                  int P1, int P2, uint32_t* __restrict__ C, uint32_t* __restrict__ ckpt,
+                                                  int maxseg, uint32_t* __restrict__ S, uint32_t* __restrict__ flags)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t ringbuf[];   // [4 waves][WIN][NP][64]
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x = blockIdx.x * 4 + wv;
+    if (x >= width1) return;
+    const int WIN = 2 * SH2 + 1;
+    uint32_t* ring = ringbuf + (size_t)wv * WIN * NP * 64 + lane;
+    const size_t vec = 64 * NP, rowstride = (size_t)width1 * vec;
+    const uint32_t* hp = hsum + (size_t)x * vec + lane * NP;
+    uint32_t* cp = C + (size_t)x * vec + lane * NP;
+    uint32_t* ck = ckpt + (size_t)x * maxseg * vec + lane * NP;
+    uint32_t* sp = S + (size_t)x * vec + lane * NP;
+    const int dlane = lane * 2 * NP;
+    const us2 lim = pk_splat(32767 - P2), P1v = pk_splat(P1), cap = pk_splat(0x7FFF);
+
+    us2 acc[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) acc[j] = pk_splat(0);
+    for (int k = 0; k < WIN; ++k) {                                   // ring slot k holds row clamp(k - SH2)
+        int yy = k - SH2;
+        yy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const uint32_t v = hp[(size_t)yy * rowstride + j];
+            ring[(k * NP + j) * 64] = v;
+            acc[j] += as_us2(v);
+        }
+    }
+    bool over = false;
+    int slot = 0;                                                     // slot of row clamp(y - SH2): the one leaving next
+    PathState<NP> st;
+    st.reset();
+    const int F = h / K, r = h - F * K;
+    const int ncp = F - (r > 0 ? 0 : 1);                              // checkpoints k_pair reads: end of segments 0..ncp-1
+
+    // rows entering the window while rows yb .. yb+K-1 are finished: min(y + SH2 + 1, h - 1)
+    auto fetch = [&](int yb, us2 (&dst)[K][NP]) {
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            const int ya = min(yb + u + SH2 + 1, h - 1);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) dst[u][j] = as_us2(hp[(size_t)ya * rowstride + j]);
+        }
+    };
+    auto row = [&](int y, const us2 (&in)[NP]) {
+        us2 cv[NP], L[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            us2 v = acc[j];
+            const int d = dlane + 2 * j;
+            if (d < D) over |= (v.x > lim.x); else v.x = 0xFFFF;
+            if (d + 1 < D) over |= (v.y > lim.y); else v.y = 0xFFFF;
+            cv[j] = v;
+            cp[(size_t)y * rowstride + j] = as_u32(v);
+        }
+        sgm_step<NP>(st, cv, L, P1v, P2);
+        if (PATH2) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) sp[(size_t)y * rowstride + j] = as_u32(pk_min(L[j], cap));
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            uint32_t* rs = ring + (slot * NP + j) * 64;
+            acc[j] = acc[j] + in[j] - as_us2(*rs);
+            *rs = as_u32(in[j]);
+        }
+        slot = slot + 1 == WIN ? 0 : slot + 1;
+    };
+
+    us2 nb[K][NP], nn[K][NP];
+    fetch(0, nb);
+    for (int s = 0; s < F; ++s) {
+        if ((s + 1) * K < h) fetch((s + 1) * K, nn);
+#pragma unroll
+        for (int u = 0; u < K; ++u) row(s * K + u, nb[u]);
+        if (!PATH2 && s < ncp) st.store_normalised(ck + (size_t)s * vec);
+        copy_seg<NP, K>(nb, nn);
+    }
+#pragma unroll
+    for (int u = 0; u < K; ++u)
+        if (u < r) row(F * K + u, nb[u]);
+    if (__any(over) && lane == 0) atomicOr(flags, 1u);
+}
+
 template <int NP>
 static int launch_cost_np(wass_ctx* c, const SgmDims& d)
 {
@@ -304,6 +402,25 @@ static int launch_cost_np(wass_ctx* c, const SgmDims& d)
     const int YSEG = 128;
     const size_t lds2 = (size_t)4 * (2 * d.SW2 + 1) * NP * 64 * sizeof(uint32_t);
     if (lds2 > 160 * 1024) return set_err(c, WASS_ERR_UNSUPPORTED, "WINSIZE %d too large for the LDS ring", 2 * d.SW2 + 1);
+    const CkptLayout lay = ckpt_layout(d);
+    if (lay.cols_from_cost || lay.path2_from_cost) {
+        constexpr int K = NP <= 2 ? 8 : (NP <= 4 ? 4 : 2);
+        int rc = ensure(c, c->ckpt, lay.off[lay.nfam]);
+        if (rc) return rc;
+        const dim3 grid((d.width1 + 3) / 4), block(256);
+        if (lay.cols_from_cost) {
+            WASS_HIP(c, hipFuncSetAttribute((const void*)k_vsum_col<NP, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            hipLaunchKernelGGL((k_vsum_col<NP, K, false>), grid, block, lds2, c->stream, (const uint32_t*)c->hsum.p, d.width1, d.h, d.D,
+                               d.SW2, d.P1, d.P2, (uint32_t*)c->C.p, (uint32_t*)((char*)c->ckpt.p + lay.off[0]), lay.mseg[0],
+                               (uint32_t*)c->S.p, (uint32_t*)c->flags.p);
+        } else {
+            WASS_HIP(c, hipFuncSetAttribute((const void*)k_vsum_col<NP, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            hipLaunchKernelGGL((k_vsum_col<NP, K, true>), grid, block, lds2, c->stream, (const uint32_t*)c->hsum.p, d.width1, d.h, d.D,
+                               d.SW2, d.P1, d.P2, (uint32_t*)c->C.p, (uint32_t*)c->ckpt.p, 0, (uint32_t*)c->S.p, (uint32_t*)c->flags.p);
+        }
+        WASS_HIP(c, hipGetLastError());
+        return WASS_OK;
+    }
     WASS_HIP(c, hipFuncSetAttribute((const void*)k_vsum<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     dim3 g2((d.width1 + 3) / 4, (d.h + YSEG - 1) / YSEG);
     hipLaunchKernelGGL(k_vsum<NP>, g2, dim3(256), lds2, c->stream, (const uint32_t*)c->hsum.p, d.width1, d.h, d.D,
