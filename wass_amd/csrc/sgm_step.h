@@ -207,8 +207,16 @@ __device__ __forceinline__ void wta_batch(const us2 (&Sv)[K][NP], int nvalid, in
 #pragma unroll
     for (int u = 0; u < K; ++u) key[u] = wave_min_u32(key[u]);
     const int q = 100 - uniq;
+    // lanes whose slot j is a real disparity (d = lane*V + j < D), as ballot masks
+    unsigned long long inr[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const int nl = (D - j + V - 1) / V;
+        inr[j] = nl >= 64 ? ~0ull : ((1ull << (nl < 0 ? 0 : nl)) - 1ull);
+    }
     int res_d = 0;
     uint32_t res_k = 0;
+    // the scalar tails run cell by cell (few live SGPRs; batching them spills scalars into VGPR lanes)
 #pragma unroll
     for (int u = 0; u < K; ++u) {
         const int minS = (int)(key[u] >> 16);
@@ -221,8 +229,8 @@ __device__ __forceinline__ void wta_batch(const us2 (&Sv)[K][NP], int nvalid, in
         int cnt = 0;
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-            const int sv = (j & 1) ? Sv[u][j >> 1].y : Sv[u][j >> 1].x;
-            cnt += __builtin_popcountll(__ballot(dlane + j < D && (int)__umul24((uint32_t)sv, (uint32_t)q) < T));
+            const uint32_t sv = (j & 1) ? Sv[u][j >> 1].y : Sv[u][j >> 1].x;
+            cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64((int)__umul24(sv, (uint32_t)q) < T) & inr[j]);
         }
         const int am = s_at<NP>(Sv[u], max(best - 1, 0)), cp = s_at<NP>(Sv[u], min(best + 1, D - 1));
         const int a = best >= 1 ? am : ABSENT, cc = best + 1 < D ? cp : ABSENT;
