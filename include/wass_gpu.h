@@ -95,6 +95,8 @@ typedef struct {
     float total_ms;
     int   aggregate_launches;
     int   cost_overflow;  /* 1 if the int16 precondition was violated         */
+    float vsum_ms;        /* part of cost_ms: the vertical block sum, which also
+                             runs path 2 (column checkpoints / S = L_2)       */
 } wass_sgm_timings;
 int wass_sgm_last_timings(wass_ctx* ctx, wass_sgm_timings* out);
 

@@ -32,7 +32,7 @@ class SgmParams(C.Structure):
 class SgmTimings(C.Structure):
     _fields_ = [("prefilter_ms", C.c_float), ("cost_ms", C.c_float), ("aggregate_ms", C.c_float),
                 ("select_ms", C.c_float), ("median_ms", C.c_float), ("total_ms", C.c_float),
-                ("aggregate_launches", C.c_int), ("cost_overflow", C.c_int)]
+                ("aggregate_launches", C.c_int), ("cost_overflow", C.c_int), ("vsum_ms", C.c_float)]
 
 
 class Geom(C.Structure):

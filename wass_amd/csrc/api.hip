@@ -216,6 +216,7 @@ int wass_sgm_last_timings(wass_ctx* c, wass_sgm_timings* out)
     WASS_HIP(c, hipEventElapsedTime(&t.select_ms, c->ev[3], c->ev[4]));
     WASS_HIP(c, hipEventElapsedTime(&t.median_ms, c->ev[4], c->ev[5]));
     WASS_HIP(c, hipEventElapsedTime(&t.total_ms, c->ev[0], c->ev[5]));
+    WASS_HIP(c, hipEventElapsedTime(&t.vsum_ms, c->ev[7], c->ev[2]));
     const uint32_t fl = c->h_flags[0];
     t.cost_overflow = (int)(fl & 1);
     *out = t;

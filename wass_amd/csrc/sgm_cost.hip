@@ -399,6 +399,7 @@ static int launch_cost_np(wass_ctx* c, const SgmDims& d)
                            (const unsigned short*)c->bt2.p + BT2_FRONT, bt2_pitch(d.Wp), d.Wp, d.width1, d.minX1, d.minD, d.SW2,
                            XQ, off, nch, (uint32_t*)c->hsum.p);
     }
+    WASS_HIP(c, hipEventRecord(c->ev[7], c->stream));                        // start of the vertical sum (wass_sgm_timings.vsum_ms)
     const int YSEG = 128;
     const size_t lds2 = (size_t)4 * (2 * d.SW2 + 1) * NP * 64 * sizeof(uint32_t);
     if (lds2 > 160 * 1024) return set_err(c, WASS_ERR_UNSUPPORTED, "WINSIZE %d too large for the LDS ring", 2 * d.SW2 + 1);
