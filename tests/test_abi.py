@@ -36,9 +36,9 @@ def test_binding_covers_header(built):
 
 def test_struct_layout_matches_header():
     from wass_amd import _lib
-    # 12 ints + (pad) + double ; 6 floats + 2 ints
+    # 12 ints + (pad) + double ; 6 floats + 2 ints + 1 float
     assert ctypes.sizeof(_lib.SgmParams) == 56
-    assert ctypes.sizeof(_lib.SgmTimings) == 32
+    assert ctypes.sizeof(_lib.SgmTimings) == 36
 
 
 def test_no_gpu_means_loud_failure(built):
