@@ -493,27 +493,40 @@ __global__ void __launch_bounds__(256) k_ransac_score(const uint8_t* __restrict_
     }
     __syncthreads();
     double px[PTS], py[PTS], pz[PTS];
-    bool pv[PTS];
+    unsigned long long vmask[PTS];                                // lanes of this wave whose point k exists and is valid
     const size_t base = (size_t)blockIdx.x * 256 * PTS + threadIdx.x;
+    bool any = false;
 #pragma unroll
     for (int k = 0; k < PTS; ++k) {
         const size_t i = base + (size_t)k * 256;
-        pv[k] = i < n && valid[i];
-        px[k] = pv[k] ? X[i] : 0.0; py[k] = pv[k] ? Y[i] : 0.0; pz[k] = pv[k] ? Z[i] : 0.0;
+        const bool pv = i < n && valid[i];
+        px[k] = pv ? X[i] : 0.0; py[k] = pv ? Y[i] : 0.0; pz[k] = pv ? Z[i] : 0.0;
+        vmask[k] = __builtin_amdgcn_ballot_w64(pv);
+        any |= pv;
     }
-    bool any = false;
-#pragma unroll
-    for (int k = 0; k < PTS; ++k) any |= pv[k];
     if (__syncthreads_or(any)) {
+        // Branch-free inner loop: invalid points are computed and masked out of the ballot; the next plane is
+        // fetched from LDS while the current one is scored; lane (r & 63) collects the count of round r and the
+        // wave adds 64 rounds to the block totals with one LDS atomic instruction.
+        const int lane = threadIdx.x & 63;
+        unsigned int mine = 0;
+        double a = pl[0], b = pl[1], c = pl[2], d = pl[3];
         for (int r = 0; r < rounds; ++r) {
-            const double a = pl[r * 4], b = pl[r * 4 + 1], c = pl[r * 4 + 2], d = pl[r * 4 + 3];
+            const int rn = r + 1 < rounds ? r + 1 : r;
+            const double an = pl[rn * 4], bn = pl[rn * 4 + 1], cn = pl[rn * 4 + 2], dn = pl[rn * 4 + 3];
             unsigned int cnt = 0;
 #pragma unroll
             for (int k = 0; k < PTS; ++k) {
-                const bool in = pv[k] && fabs((a * px[k] + b * py[k] + c * pz[k]) + d) < thr;
-                cnt += (unsigned)__popcll(__ballot(in));
+                const bool in = fabs((a * px[k] + b * py[k] + c * pz[k]) + d) < thr;
+                cnt += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(in) & vmask[k]);
             }
-            if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&lc[r], cnt);
+            mine += lane == (r & 63) ? cnt : 0u;
+            if ((r & 63) == 63 || r == rounds - 1) {              // wave-uniform
+                const int rr = (r & ~63) + lane;
+                if (rr <= r && mine) atomicAdd(&lc[rr], mine);
+                mine = 0;
+            }
+            a = an; b = bn; c = cn; d = dn;
         }
     }
     __syncthreads();
@@ -1221,7 +1234,7 @@ int wass_mesh_ransac_plane(wass_ctx* c, wass_mesh* m, const int32_t* uv, int rou
     WASS_HIP(c, hipMemsetAsync(counts, 0, (size_t)rounds * 8, c->stream));
     hipLaunchKernelGGL(k_ransac_planes, dim3((rounds + 63) / 64), dim3(64), 0, c->stream, m->valid, m->x, m->y, m->z, m->w,
                        (const int32_t*)duv, rounds, cand);
-    constexpr int PTS = 4;
+    constexpr int PTS = 8;
     const size_t lds = (size_t)rounds * (32 + 4);
     if (lds > 64 * 1024) return set_err(c, WASS_ERR_UNSUPPORTED, "PLANE_RANSAC_ROUNDS %d too large (max 1800)", rounds);
     hipLaunchKernelGGL(k_ransac_score<PTS>, dim3((unsigned)((n + 256 * PTS - 1) / (256 * PTS))), dim3(256), lds, c->stream,
@@ -1321,7 +1334,7 @@ int wass_mesh_fit_plane(wass_ctx* c, wass_mesh* m, const int32_t* uv, int rounds
     double* part = (double*)((char*)c->scratch.p + cand_bytes);
     unsigned long long* kept1 = (unsigned long long*)c->counters.p;            // [NSLOT]
     unsigned long long* kept2 = kept1 + NSLOT;
-    constexpr int PTS = 4;
+    constexpr int PTS = 8;
     const size_t lds = (size_t)rounds * (32 + 4);
     if (lds > 64 * 1024) return set_err(c, WASS_ERR_UNSUPPORTED, "PLANE_RANSAC_ROUNDS %d too large (max 1800)", rounds);
     hipStream_t s = c->stream;
