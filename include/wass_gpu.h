@@ -271,6 +271,14 @@ int wass_remap_cubic(wass_ctx* ctx, const uint8_t* src, int sw, int sh, size_t s
 int wass_remap_cubic_dev(wass_ctx* ctx, const uint8_t* d_src, int sw, int sh, size_t src_stride,
                          const float* d_map_x, const float* d_map_y, int dw, int dh, const int roi[4],
                          uint8_t* d_dst);
+/* Row f2: cv::undistort(src, dst, K, dist) of wass_prepare (src/wass_prepare/wass_prepare.cpp:268): new camera
+ * matrix = K, INTER_LINEAR, BORDER_CONSTANT 0, stripe-wise 1/32-pixel fixed-point maps.  dist = n_dist
+ * coefficients in OpenCV order k1 k2 p1 p2 [k3 [k4 k5 k6 [s1 s2 s3 s4]]] (n_dist = 4, 5, 8 or 12; the tilt
+ * model is not supported).  dst is w x h, tightly packed. */
+int wass_undistort(wass_ctx* ctx, const uint8_t* src, int w, int h, size_t src_stride, const double K[9],
+                   const double* dist, int n_dist, uint8_t* dst);
+int wass_undistort_dev(wass_ctx* ctx, const uint8_t* d_src, int w, int h, size_t src_stride, const double K[9],
+                       const double* dist, int n_dist, uint8_t* d_dst);
 /* cv::warpPerspective(src, dst, H, Size(dw,dh)) with the default INTER_LINEAR / BORDER_CONSTANT 0
  * (wass_stereo.cpp:515-516); H maps source to destination pixels (it is inverted internally). */
 int wass_warp_perspective(wass_ctx* ctx, const uint8_t* src, int sw, int sh, size_t src_stride, const double H[9],

@@ -296,3 +296,13 @@ def stereo_rectify(K1, K2, w, h, R, T, alpha=1.0):
         raise ValueError("zero baseline")
     return dict(R1=np.array(R1[:]).reshape(3, 3), R2=np.array(R2[:]).reshape(3, 3), P1=np.array(P1[:]).reshape(3, 4),
                 P2=np.array(P2[:]).reshape(3, 4), roi1=tuple(r1[:]), roi2=tuple(r2[:]))
+
+
+def undistort(src, K, dist):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros_like(src)
+    rc = lib().orc_undistort(_p(src, C.c_uint8), src.shape[1], src.shape[0], C.c_size_t(src.shape[1]), _d(K), _d(dist), len(dist),
+                             _p(dst, C.c_uint8))
+    if rc:
+        raise ValueError("unsupported distortion model")
+    return dst

@@ -378,3 +378,56 @@ int orc_stereo_rectify(const double K1[9], const double K2[9], int W, int H, con
     }
     return 0;
 }
+
+/* cv::undistort(src, dst, K, dist) as called by wass_prepare (src/wass_prepare/wass_prepare.cpp:268): new camera
+ * matrix = K, INTER_LINEAR, BORDER_CONSTANT 0.  Restated from OpenCV 4.5.5 imgproc/undistort.dispatch.cpp:
+ * the image is processed in stripes of max(1, 4096 / cols) rows; each stripe builds CV_16SC2 + CV_16UC1
+ * fixed-point maps with initUndistortRectifyMap (R = I, principal point shifted by the stripe origin) and remaps.
+ * dist holds n = 4, 5, 8 or 12 coefficients (k1 k2 p1 p2 [k3 [k4 k5 k6 [s1 s2 s3 s4]]]); the tilt model is not
+ * restated. */
+int orc_undistort(const uint8_t* src, int w, int h, size_t ss, const double K[9], const double* dist, int n, uint8_t* dst)
+{
+    double k[12] = { 0 }, A[9], Ar[9], ir[9];
+    const double fx = K[0], fy = K[4], u0 = K[2], v0 = K[5];
+    int16_t* tab;
+    int stripe0, y0, i, j;
+    if (!(n == 4 || n == 5 || n == 8 || n == 12)) return -1;
+    for (i = 0; i < n; ++i) k[i] = dist[i];
+    {
+        /* OpenCV's order: k1 k2 p1 p2 k3 k4 k5 k6 s1 s2 s3 s4 */
+    }
+    memcpy(A, K, sizeof A);
+    tab = (int16_t*)malloc(sizeof(int16_t) * ORC_TAB * ORC_TAB * 4);
+    orc_inter_tab(2, tab);
+    stripe0 = 4096 / (w > 1 ? w : 1);
+    if (stripe0 < 1) stripe0 = 1;
+    if (stripe0 > h) stripe0 = h;
+    for (y0 = 0; y0 < h; y0 += stripe0) {
+        const int stripe = stripe0 < h - y0 ? stripe0 : h - y0;
+        memcpy(Ar, A, sizeof Ar);
+        Ar[5] = A[5] - y0;
+        if (!inv3(Ar, ir)) { free(tab); return -1; }
+        for (i = 0; i < stripe; ++i) {
+            double _x = i * ir[1] + ir[2], _y = i * ir[4] + ir[5], _w = i * ir[7] + ir[8];
+            for (j = 0; j < w; ++j, _x += ir[0], _y += ir[3], _w += ir[6]) {
+                double ww = 1. / _w, x = _x * ww, y = _y * ww;
+                double x2 = x * x, y2 = y * y;
+                double r2 = x2 + y2, _2xy = 2 * x * y;
+                double kr = (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2) / (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2);
+                double xd = (x * kr + k[2] * _2xy + k[3] * (r2 + 2 * x2) + k[8] * r2 + k[9] * r2 * r2);
+                double yd = (y * kr + k[2] * (r2 + 2 * y2) + k[3] * _2xy + k[10] * r2 + k[11] * r2 * r2);
+                double u = fx * xd + u0, v = fy * yd + v0;               /* identity tilt, invProj = 1 */
+                double fu = u * 32, fv = v * 32;
+                int iu, iv, a;
+                fu = fu < -2147483648.0 ? -2147483648.0 : (fu > 2147483647.0 ? 2147483647.0 : fu);
+                fv = fv < -2147483648.0 ? -2147483648.0 : (fv > 2147483647.0 ? 2147483647.0 : fv);
+                iu = (int)lrint(fu);
+                iv = (int)lrint(fv);
+                a = (iv & 31) * 32 + (iu & 31);
+                dst[(size_t)(y0 + i) * w + j] = tap_sum(src, w, h, ss, (int16_t)(iu >> 5), (int16_t)(iv >> 5), tab + a * 4, 2);
+            }
+        }
+    }
+    free(tab);
+    return 0;
+}

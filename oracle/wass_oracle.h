@@ -163,6 +163,9 @@ void orc_remap_cubic(const uint8_t* src, int sw, int sh, size_t src_stride, cons
 /* cv::initUndistortRectifyMap, zero distortion, CV_32FC1 (wass_stereo.cpp:600-601) */
 int orc_init_rectify_map(const double K[9], const double R[9], const double P[12], int w, int h, float* map_x,
                          float* map_y);
+/* cv::undistort(src, dst, K, dist) with INTER_LINEAR (wass_prepare.cpp:268), row f2; n = 4, 5, 8 or 12 coefficients */
+int orc_undistort(const uint8_t* src, int w, int h, size_t src_stride, const double K[9], const double* dist, int n,
+                  uint8_t* dst);
 /* cv::stereoRectify flags=0 (wass_stereo.cpp:541) */
 int orc_stereo_rectify(const double K1[9], const double K2[9], int W, int H, const double R[9], const double T[3],
                        double alpha, double R1[9], double R2[9], double P1[12], double P2[12], int roi1[4],

@@ -142,3 +142,34 @@ def test_oracle_warp_perspective_properties(oracle):
     got = oracle.warp_perspective(img, Hs, 90, 50).astype(int)
     exp = (img[:, :-1].astype(int) + img[:, 1:].astype(int) + 1) >> 1
     assert np.abs(got[:, 1:] - exp).max() <= 1
+
+
+def test_oracle_undistort_properties(oracle):
+    """Row f2: cv::undistort of wass_prepare.cpp:268 (restated, unpinned): zero distortion is the identity; a
+    distorted smooth image agrees with a float64 evaluation of the Brown model + bilinear interpolation at the
+    1/32-quantised position to within one grey level."""
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (70, 90), dtype=np.uint8)
+    K = np.array([[80., 0, 44.5], [0, 82., 35.5], [0, 0, 1]])
+    np.testing.assert_array_equal(oracle.undistort(img, K, [0, 0, 0, 0, 0]), img)
+    yy, xx = np.mgrid[0:70, 0:90]
+    smooth = (127 + 60 * np.sin(xx / 6.0) + 50 * np.cos(yy / 5.0)).astype(np.uint8)
+    for dist in ([-0.25, 0.08, 0.002, -0.001, 0.01], [-0.2, 0.05, 0.001, -0.002], [0.1, -0.02, 0, 0, 0.003, 0.01, -0.005, 0.001],
+                 [-0.2, 0.05, 0.001, -0.002, 0.01, 0.0, 0.0, 0.0, 0.002, -0.001, 0.0015, 0.0005]):
+        got = oracle.undistort(smooth, K, dist).astype(np.int64)
+        k = list(dist) + [0.0] * (12 - len(dist))
+        x = (xx - K[0, 2]) / K[0, 0]; y = (yy - K[1, 2]) / K[1, 1]
+        r2 = x * x + y * y
+        kr = (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2) / (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2)
+        xd = x * kr + k[2] * 2 * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2
+        yd = y * kr + k[2] * (r2 + 2 * y * y) + k[3] * 2 * x * y + k[10] * r2 + k[11] * r2 * r2
+        u = np.rint((K[0, 0] * xd + K[0, 2]) * 32) / 32; v = np.rint((K[1, 1] * yd + K[1, 2]) * 32) / 32
+        iu = np.floor(u).astype(int); iv = np.floor(v).astype(int); fu = u - iu; fv = v - iv
+        P = np.pad(smooth.astype(np.float64), 2)
+        at = lambda r, c: P[np.clip(r + 2, 0, 73), np.clip(c + 2, 0, 93)]  # noqa: E731
+        ref = (1 - fv) * ((1 - fu) * at(iv, iu) + fu * at(iv, iu + 1)) + fv * ((1 - fu) * at(iv + 1, iu) + fu * at(iv + 1, iu + 1))
+        inside = (iu >= 0) & (iu < 89) & (iv >= 0) & (iv < 69)
+        assert inside.mean() > 0.8
+        assert np.abs(got - np.rint(ref))[inside].max() <= 1
+    with pytest.raises(ValueError):
+        oracle.undistort(img, K, [0.1] * 14)                      # tilt model is not restated

@@ -65,6 +65,29 @@ def test_warp_perspective_parity(gpu_ctx, oracle, sw, sh, dw, dh):
     np.testing.assert_array_equal(gpu_ctx.warp_perspective(img, np.eye(3), sw, sh), img)
 
 
+@pytest.mark.parametrize("w,h", [(90, 70), (333, 41), (2049, 9), (5000, 5)])
+def test_undistort_parity(gpu_ctx, oracle, w, h):
+    """Row f2: cv::undistort (wass_prepare.cpp:268), bit-exact against the oracle; widths on both sides of the
+    4096-pixel stripe rule (several rows per stripe / one row per stripe)."""
+    rng = np.random.default_rng(w)
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    K = np.array([[0.9 * w, 0, w / 2 - 0.3], [0, 0.92 * w, h / 2 + 0.2], [0, 0, 1]])
+    for dist in ([0, 0, 0, 0, 0], [-0.25, 0.08, 0.002, -0.001, 0.01], [-0.2, 0.05, 0.001, -0.002],
+                 [0.1, -0.02, 0, 0, 0.003, 0.01, -0.005, 0.001],
+                 [-0.2, 0.05, 0.001, -0.002, 0.01, 0.0, 0.0, 0.0, 0.002, -0.001, 0.0015, 0.0005], [3.0, -8.0, 0.1, 0.1, 5.0]):
+        np.testing.assert_array_equal(gpu_ctx.undistort(img, K, dist), oracle.undistort(img, K, dist))
+    with pytest.raises(wass_amd.WassError):
+        gpu_ctx.undistort(img, K, [0.1] * 14)
+
+
+def test_undistort_fullsize(gpu_ctx, oracle):
+    w, h = 2456, 2058
+    img = synth.make_pair(w, h, 256, frame_idx=2)[0]
+    K = synth.rig_geometry(w, h)["K_left"]
+    dist = [-0.12, 0.03, 0.0005, -0.0007, 0.002]
+    np.testing.assert_array_equal(gpu_ctx.undistort(img, K, dist), oracle.undistort(img, K, dist))
+
+
 def test_resampler_argument_errors(gpu_ctx):
     img = np.zeros((10, 12), np.uint8)
     with pytest.raises(wass_amd.WassError):

@@ -116,6 +116,8 @@ SYMBOLS = {
     "wass_init_rectify_map": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), _i, _i, _vp, _vp]),
     "wass_remap_cubic": (_i, [_vp, _vp, _i, _i, _sz, _vp, _vp, _i, _i, C.POINTER(_i), _vp]),
     "wass_remap_cubic_dev": (_i, [_vp, _vp, _i, _i, _sz, _vp, _vp, _i, _i, C.POINTER(_i), _vp]),
+    "wass_undistort": (_i, [_vp, _vp, _i, _i, _sz, C.POINTER(C.c_double), C.POINTER(C.c_double), _i, _vp]),
+    "wass_undistort_dev": (_i, [_vp, _vp, _i, _i, _sz, C.POINTER(C.c_double), C.POINTER(C.c_double), _i, _vp]),
     "wass_warp_perspective": (_i, [_vp, _vp, _i, _i, _sz, C.POINTER(C.c_double), _i, _i, C.POINTER(_i), _vp]),
     "wass_warp_perspective_dev": (_i, [_vp, _vp, _i, _i, _sz, C.POINTER(C.c_double), _i, _i, C.POINTER(_i), _vp]),
 }

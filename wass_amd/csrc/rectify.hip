@@ -180,6 +180,32 @@ __global__ __launch_bounds__(256) void k_remap_cubic(const uint8_t* __restrict__
     dst[(size_t)ty * ow + tx] = sample_cubic(src, sw, sh, ss, sx, sy, tab + TAB_CUB_OFF + (size_t)a * 16);
 }
 
+// cv::undistort: normalised coordinates per column / per row come from the host (the column sequence is an
+// accumulated sum in OpenCV, the row value depends on the stripe the row belongs to); the distortion polynomial,
+// the 1/32-pixel quantisation and the bilinear taps run here, one thread per pixel.
+struct Dist12 { double k[12]; };
+__global__ __launch_bounds__(256) void k_undistort(const uint8_t* __restrict__ src, int w, int h, size_t ss,
+                                                   const double* __restrict__ xs, const double* __restrict__ ys, Dist12 D,
+                                                   double fx, double fy, double u0, double v0, uint8_t* __restrict__ dst,
+                                                   const short* __restrict__ tab)
+{
+    const int tx = blockIdx.x * 64 + threadIdx.x, ty = blockIdx.y * 4 + threadIdx.y;
+    if (tx >= w || ty >= h) return;
+    const double* k = D.k;
+    const double x = xs[tx], y = ys[ty];
+    const double x2 = x * x, y2 = y * y;
+    const double r2 = x2 + y2, _2xy = 2 * x * y;
+    const double kr = (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2) / (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2);
+    const double xd = (x * kr + k[2] * _2xy + k[3] * (r2 + 2 * x2) + k[8] * r2 + k[9] * r2 * r2);
+    const double yd = (y * kr + k[2] * (r2 + 2 * y2) + k[3] * _2xy + k[10] * r2 + k[11] * r2 * r2);
+    const double u = fx * xd + u0, v = fy * yd + v0;
+    const int iu = __double2int_rn(fmax(-2147483648.0, fmin(2147483647.0, u * 32)));
+    const int iv = __double2int_rn(fmax(-2147483648.0, fmin(2147483647.0, v * 32)));
+    const int a = (iv & (TAB - 1)) * TAB + (iu & (TAB - 1));
+    dst[(size_t)ty * w + tx] = sample_linear(src, w, h, ss, (int)(short)(iu >> INTER_BITS), (int)(short)(iv >> INTER_BITS),
+                                             tab + TAB_LIN_OFF + (size_t)a * 4);
+}
+
 // ---------------------------------------------------------------- small host linear algebra (row-major 3x3)
 static void mul33(const double* a, const double* b, double* o)
 {
@@ -352,11 +378,70 @@ static int resample_host(wass_ctx* c, bool cubic, const uint8_t* src, int sw, in
     return WASS_OK;
 }
 
+static int undistort_dev(wass_ctx* c, const uint8_t* d_src, int w, int h, size_t ss, const double* K, const double* dist, int n,
+                         uint8_t* d_dst)
+{
+    if (!c) return WASS_ERR_INVALID_ARG;
+    if (!d_src || !d_dst || !K || (!dist && n) || w <= 0 || h <= 0 || ss < (size_t)w) return set_err(c, WASS_ERR_INVALID_ARG, "bad argument");
+    if (!(n == 0 || n == 4 || n == 5 || n == 8 || n == 12))
+        return set_err(c, WASS_ERR_UNSUPPORTED, "%d distortion coefficients (4, 5, 8 or 12 supported; no tilt model)", n);
+    if (w > 32767 || h > 32767) return set_err(c, WASS_ERR_UNSUPPORTED, "images larger than 32767 px are not supported");
+    Dist12 D;
+    for (int i = 0; i < 12; ++i) D.k[i] = i < n ? dist[i] : 0.0;
+    // normalised coordinates exactly as initUndistortRectifyMap produces them inside cv::undistort's stripes
+    std::vector<double> xy((size_t)w + h);
+    int stripe0 = std::min(std::max(1, 4096 / std::max(w, 1)), h);
+    for (int y0 = 0; y0 < h; y0 += stripe0) {
+        const int stripe = std::min(stripe0, h - y0);
+        double Ar[9], ir[9];
+        memcpy(Ar, K, sizeof Ar);
+        Ar[5] = K[5] - y0;
+        if (!inv33(Ar, ir)) return set_err(c, WASS_ERR_INVALID_ARG, "singular camera matrix");
+        if (ir[1] != 0 || ir[3] != 0 || ir[6] != 0 || ir[7] != 0 || ir[8] != 1)
+            return set_err(c, WASS_ERR_UNSUPPORTED, "camera matrix with skew is not supported");
+        if (y0 == 0) {
+            double _x = ir[2];
+            for (int j = 0; j < w; ++j, _x += ir[0]) xy[j] = _x * (1. / 1.);
+        }
+        for (int i = 0; i < stripe; ++i) xy[(size_t)w + y0 + i] = (i * ir[4] + ir[5]) * (1. / 1.);
+    }
+    int rc = ensure_tables(c);
+    if (rc) return rc;
+    if ((rc = ensure(c, c->rect_mx, xy.size() * sizeof(double)))) return rc;
+    WASS_HIP(c, hipMemcpyAsync(c->rect_mx.p, xy.data(), xy.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    WASS_HIP(c, hipStreamSynchronize(c->stream));          // xy is pageable and about to go out of scope
+    const double* dxy = (const double*)c->rect_mx.p;
+    hipLaunchKernelGGL(k_undistort, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, c->stream, d_src, w, h, ss, dxy, dxy + w, D,
+                       K[0], K[4], K[2], K[5], d_dst, (const short*)c->rect_tab.p);
+    WASS_HIP(c, hipGetLastError());
+    return WASS_OK;
+}
+
 }  // namespace wass
 
 using namespace wass;
 
 extern "C" {
+
+int wass_undistort_dev(wass_ctx* c, const uint8_t* d_src, int w, int h, size_t ss, const double K[9], const double* dist, int n_dist,
+                       uint8_t* d_dst)
+{
+    return undistort_dev(c, d_src, w, h, ss, K, dist, n_dist, d_dst);
+}
+
+int wass_undistort(wass_ctx* c, const uint8_t* src, int w, int h, size_t ss, const double K[9], const double* dist, int n_dist, uint8_t* dst)
+{
+    if (!c) return WASS_ERR_INVALID_ARG;
+    if (!src || !dst || w <= 0 || h <= 0 || ss < (size_t)w) return set_err(c, WASS_ERR_INVALID_ARG, "bad argument");
+    const size_t n = (size_t)w * h;
+    int rc;
+    if ((rc = ensure(c, c->tmp_in0, n)) || (rc = ensure(c, c->tmp_in1, n))) return rc;
+    WASS_HIP(c, hipMemcpy2DAsync(c->tmp_in0.p, (size_t)w, src, ss, (size_t)w, (size_t)h, hipMemcpyHostToDevice, c->stream));
+    if ((rc = undistort_dev(c, (const uint8_t*)c->tmp_in0.p, w, h, (size_t)w, K, dist, n_dist, (uint8_t*)c->tmp_in1.p))) return rc;
+    WASS_HIP(c, hipMemcpyAsync(dst, c->tmp_in1.p, n, hipMemcpyDeviceToHost, c->stream));
+    WASS_HIP(c, hipStreamSynchronize(c->stream));
+    return WASS_OK;
+}
 
 int wass_remap_cubic_dev(wass_ctx* c, const uint8_t* d_src, int sw, int sh, size_t ss, const float* d_mx, const float* d_my, int dw, int dh,
                          const int roi[4], uint8_t* d_dst)

@@ -150,6 +150,17 @@ class Context:
                                                    d_out.data_ptr()))
         return d_out
 
+    def undistort(self, src: np.ndarray, K, dist) -> np.ndarray:
+        """cv::undistort(src, dst, K, dist) of wass_prepare (wass_prepare.cpp:268)."""
+        src = np.ascontiguousarray(src, np.uint8)
+        out = np.empty_like(src)
+        Kc = (C.c_double * 9)(*np.asarray(K, float).ravel())
+        dist = np.asarray(dist, float).ravel()
+        dc = (C.c_double * max(len(dist), 1))(*dist)
+        self._check(self._lib.wass_undistort(self._h, src.ctypes.data, src.shape[1], src.shape[0], src.shape[1], Kc, dc, len(dist),
+                                             out.ctypes.data))
+        return out
+
     def warp_perspective(self, src: np.ndarray, H, dw: int, dh: int, roi=None) -> np.ndarray:
         """cv::warpPerspective(src, dst, H, Size(dw, dh)) (INTER_LINEAR, zero border)."""
         src = np.ascontiguousarray(src, np.uint8)
