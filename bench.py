@@ -123,19 +123,28 @@ def main():
         # wass_stereo.cpp main(): clean-up -> triangulate -> z-gap / biggest component -> RANSAC -> crop ->
         # refine -> crop -> mesh_cam.xyzC (defaults of SURVEY.md Appendix C, RANDOM_SEED=12345)
         ctx.disparity_postprocess_dev(out, params, 1, 2, 0, dispf)
-        mesh, n = ctx.triangulate_dev(dispf, w, h, roi, roi, geom, dr, None, burned[i % 2], 20.0, None, 1.0)
-        mesh.remove_outliers(99.0)
+        mesh, _ = ctx.triangulate_dev(dispf, w, h, roi, roi, geom, dr, None, burned[i % 2], 20.0, None, 1.0, count=False)
         uv = wass_amd.ransac_sample(w, h, 400, 12345)
-        res = mesh.fit_plane(uv, 1.0, 1.5)
-        found, pl = bool(res.found), np.array(res.plane[:])
-        # the payload download overlaps the next frame (DMA engine on the context's copy stream); the closing
-        # barrier of the timed region waits for the last one
-        nbytes = mesh.encode_xyzc_async(pl if found else None, xyzc_host.data_ptr(), xyzc_host.numel())
-        planes.append(pl if found else np.full(4, np.nan))
-        npts_hist.append(n); nbytes_hist.append(nbytes)
+        collect(slot)                      # the previous frame of this context: its record and file image are complete
+        # z-gap / biggest component -> RANSAC -> crop -> refine -> crop -> mesh_cam.xyzC, all decisions on the device,
+        # no host synchronisation; the file image is downloaded by the context's copy stream while the next frame runs
+        mesh.finish_frame_async(uv, xyzc_host.data_ptr(), xyzc_host.numel(), 99.0, 1.0, 1.5)
         mesh.close()
+        pending[slot] = True
+
+    pending = [False] * nslot
+
+    def collect(slot):
+        if not pending[slot]:
+            return
+        fr = ctxs[slot].frame_result()
+        pl = np.array(fr.plane[:]) if fr.found and fr.refine_ok else np.full(4, np.nan)
+        planes.append(pl); npts_hist.append(int(fr.n_points)); nbytes_hist.append(int(fr.xyzc_bytes))
+        pending[slot] = False
 
     def barrier():
+        for s_ in range(nslot):
+            collect(s_)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()

@@ -157,7 +157,9 @@ typedef struct wass_mesh wass_mesh;
  * rectified frames.  roi_* = {x, y, width, height}.  right_img: the undistorted
  * RIGHT image (env.right, img_w x img_h) sampled for the point grey value
  * (:1342).  left_mask/right_mask: 0/1 images of the originals' size or NULL
- * (= all ones) (:1057-1093).  Host pointers; *_dev takes device pointers. */
+ * (= all ones) (:1057-1093).  Host pointers; *_dev takes device pointers.
+ * n_pts may be NULL for the *_dev form: the point count is then not read back
+ * and the call does not synchronise with the host. */
 int wass_triangulate(wass_ctx* ctx, const float* disp_roi, int W, int H,
                      const int roi_l[4], const int roi_r[4], const wass_geom* g,
                      const uint8_t* right_img, int img_w, int img_h,
@@ -220,6 +222,26 @@ typedef struct {
 } wass_plane_result;
 int wass_mesh_fit_plane(wass_ctx* ctx, wass_mesh* m, const int32_t* uv_triplets, int rounds, double ransac_thr,
                         const wass_refine_params* rp, double max_distance, wass_plane_result* out);
+/* Everything main() does with the mesh after triangulation (wass_stereo.cpp:2046-2123: z-gap percentile, biggest
+ * component, RANSAC plane, crop, refine, crop, mesh_cam.xyzC) enqueued WITHOUT a host synchronisation: all
+ * decisions are taken on the device (RANSAC failure -> nothing cropped, identity R|T in the header, like
+ * wass_mesh_encode_xyzc(plane = NULL)).  dst receives the file image (148-byte header + 6 bytes per point; it must
+ * hold 148 + 6*width*height bytes, pinned memory recommended) through the context's copy stream.
+ * wass_ctx_frame_result() waits for that download and reports what the stage-by-stage calls would have returned;
+ * the number of valid bytes in dst is result.xyzc_bytes.  One frame may be pending per context. */
+typedef struct {
+    double   zgap;  uint64_t n_gaps, component_size;
+    int      found, refine_ok;      /* refine_ok == 0 with found == 1: fewer than 3 refinement inliers (the
+                                       stage-by-stage call returns WASS_ERR_TOO_FEW_POINTS)                     */
+    double   ransac_plane[4];  uint64_t ransac_inliers;
+    double   plane[4];         uint64_t refine_inliers, kept_after_ransac_crop, kept_final;
+    uint64_t n_points, xyzc_bytes;
+} wass_frame_result;
+int wass_mesh_finish_frame_async(wass_ctx* ctx, wass_mesh* m, double percentile, const int32_t* uv_triplets, int rounds,
+                                 double ransac_thr, const wass_refine_params* rp, double max_distance, void* dst,
+                                 size_t capacity);
+int wass_ctx_frame_result(wass_ctx* ctx, wass_frame_result* out);
+
 /* RT_from_plane (:1044-1069); pure host math */
 void wass_RT_from_plane(const double plane[4], double R[9], double T[3], double Rinv[9], double Tinv[3]);
 /* save_as_xyz_compressed (:377-460): returns the exact bytes of mesh_cam.xyzC

@@ -311,6 +311,51 @@ def test_fused_calls_equal_step_by_step(gpu_ctx, oracle, seed):
     assert np.isnan(ze) and ne == 0 and se == 0
 
 
+@pytest.mark.parametrize("seed", [0, 3])
+def test_async_frame_tail_equals_stage_by_stage(gpu_ctx, oracle, seed):
+    """wass_mesh_finish_frame_async (no host synchronisation, every decision and the xyzC header on the device):
+    same numbers and the same file bytes as the stage-by-stage calls; also the RANSAC-failure and empty cases."""
+    import torch
+    valid, p3d, _ = _cloud(seed=seed)
+    h, w = valid.shape
+    uv = wass_amd.ransac_sample(w, h, 400, 12345)
+    a = gpu_ctx.mesh_upload(valid, p3d)
+    zg, ng, sz = a.remove_outliers(99.0)
+    res = a.fit_plane(uv, 1.0, 1.5)
+    ref_bytes = a.encode_xyzc(np.array(res.plane[:]))
+    pin = torch.zeros(148 + 6 * w * h, dtype=torch.uint8).pin_memory()
+    for rep in range(2):                                     # twice: buffers and events are reused across frames
+        b = gpu_ctx.mesh_upload(valid, p3d)
+        b.finish_frame_async(uv, pin.data_ptr(), pin.numel())
+        b.close()                                            # the mesh may be released right after the enqueue
+        fr = gpu_ctx.frame_result()
+        assert (fr.zgap, fr.n_gaps, fr.component_size) == (zg, ng, sz)
+        assert fr.found == res.found and fr.refine_ok == 1 and fr.ransac_inliers == res.ransac_inliers
+        np.testing.assert_array_equal(np.array(fr.ransac_plane[:]), np.array(res.ransac_plane[:]))
+        np.testing.assert_array_equal(np.array(fr.plane[:]), np.array(res.plane[:]))
+        assert (fr.kept_after_ransac_crop, fr.refine_inliers, fr.kept_final) == (res.kept_after_ransac_crop, res.refine_inliers, res.kept_final)
+        assert fr.xyzc_bytes == len(ref_bytes) and fr.n_points == (len(ref_bytes) - 148) // 6
+        assert pin[:fr.xyzc_bytes].numpy().tobytes() == ref_bytes
+    # RANSAC failure: nothing cropped, NaN plane, identity R|T in the header -- the bytes of encode_xyzc(None)
+    v2 = valid.copy(); v2[:] = 0; v2[:6, :6] = 1
+    m2 = gpu_ctx.mesh_upload(v2, p3d)
+    m2.remove_outliers(99.0)
+    ref2 = m2.encode_xyzc(None)
+    m3 = gpu_ctx.mesh_upload(v2, p3d)
+    m3.finish_frame_async(uv, pin.data_ptr(), pin.numel())
+    fr = gpu_ctx.frame_result()
+    assert not fr.found and np.isnan(np.array(fr.plane[:])).all()
+    assert pin[:fr.xyzc_bytes].numpy().tobytes() == ref2
+    # empty mesh: zero points, the reference's +-DBL_MAX limits
+    e = gpu_ctx.mesh_upload(np.zeros((9, 11), np.uint8), np.zeros((9, 11, 3)))
+    ref3 = e.encode_xyzc(None)
+    e.finish_frame_async(wass_amd.ransac_sample(11, 9, 8, 1), pin.data_ptr(), pin.numel())
+    fr = gpu_ctx.frame_result()
+    assert fr.n_points == 0 and pin[:148].numpy().tobytes() == ref3
+    with pytest.raises(wass_amd.WassError):
+        a.finish_frame_async(uv, pin.data_ptr(), 1000)         # needs room for every grid point
+
+
 def test_planes_mean(oracle):
     import os
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "planes_txt.npz"))

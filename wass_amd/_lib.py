@@ -35,6 +35,14 @@ class SgmTimings(C.Structure):
                 ("aggregate_launches", C.c_int), ("cost_overflow", C.c_int), ("vsum_ms", C.c_float)]
 
 
+class FrameResult(C.Structure):
+    """wass_frame_result"""
+    _fields_ = [("zgap", C.c_double), ("n_gaps", C.c_uint64), ("component_size", C.c_uint64), ("found", C.c_int),
+                ("refine_ok", C.c_int), ("ransac_plane", C.c_double * 4), ("ransac_inliers", C.c_uint64),
+                ("plane", C.c_double * 4), ("refine_inliers", C.c_uint64), ("kept_after_ransac_crop", C.c_uint64),
+                ("kept_final", C.c_uint64), ("n_points", C.c_uint64), ("xyzc_bytes", C.c_uint64)]
+
+
 class Geom(C.Structure):
     """wass_geom"""
     _fields_ = [("K_left", C.c_double * 9), ("K_right", C.c_double * 9), ("R", C.c_double * 9), ("T", C.c_double * 3),
@@ -107,6 +115,8 @@ SYMBOLS = {
     "wass_mesh_encode_xyzc": (_i, [_vp, _vp, C.POINTER(C.c_double), C.POINTER(_vp), C.POINTER(_sz)]),
     "wass_mesh_encode_xyzc_to": (_i, [_vp, _vp, C.POINTER(C.c_double), _vp, _sz, C.POINTER(_sz)]),
     "wass_mesh_encode_xyzc_async": (_i, [_vp, _vp, C.POINTER(C.c_double), _vp, _sz, C.POINTER(_sz)]),
+    "wass_mesh_finish_frame_async": (_i, [_vp, _vp, C.c_double, _vp, _i, C.c_double, C.POINTER(RefineParams), C.c_double, _vp, _sz]),
+    "wass_ctx_frame_result": (_i, [_vp, C.POINTER(FrameResult)]),
     "wass_free": (None, [_vp]),
     "wass_planes_mean_accumulate": (None, [C.POINTER(C.c_double), _i, C.POINTER(C.c_double)]),
     "wass_planes_mean_finish": (None, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),

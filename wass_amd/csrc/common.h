@@ -126,6 +126,9 @@ struct wass_ctx {
     wass::Buf dstate;              // device-resident scalar record + radix histogram (mesh.hip DevState)
     wass::Buf scratch;             // mesh stages: gaps / labels / partial sums / packed output
     wass::Buf xyzc;                // packed u16 triples of mesh_cam.xyzC (own buffer: downloaded asynchronously)
+    wass::Buf limits;              // striped min/max keys of the frame tail
+    void* h_frame = nullptr;       // pinned: device state record of the last wass_mesh_finish_frame_async
+    bool frame_pending = false;
     hipStream_t copy = nullptr;    // D2H of the xyzC payload
     hipEvent_t ev_pack = nullptr, ev_copy = nullptr;
     wass::Buf rect_tab;            // fixed-point interpolation tables of the rectification resamplers (rectify.hip)

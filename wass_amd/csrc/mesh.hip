@@ -376,6 +376,11 @@ struct DevState {
     double wsum, centroid[3], ninl;
     double plane[4];                                      // refined plane
     int refine_ok, pad1;
+    // host-sync-free frame tail (wass_mesh_finish_frame_async): everything the xyzC encoder needs, decided on the device
+    double rtR[9], rtT[3], rtRinv[9], rtTinv[3];
+    double mn[3], sc[3];
+    unsigned int npts, have_plane;
+    unsigned long long kept1, kept2;
 };
 
 // z gaps computed on the fly (no gap array): histogram of one 11-bit digit of the fp64 bit patterns that match the
@@ -786,9 +791,9 @@ __global__ void __launch_bounds__(256) k_block_counts(const uint8_t* __restrict_
     const int c = __syncthreads_count(i < n && valid[i]);
     if (threadIdx.x == 0) blockcnt[blockIdx.x] = (unsigned)c;
 }
-__global__ void __launch_bounds__(256) k_xyzc_limits(const uint8_t* __restrict__ valid, const double* __restrict__ X,
-                                                     const double* __restrict__ Y, const double* __restrict__ Z, size_t n,
-                                                     RTDev rt, unsigned long long* __restrict__ lim /* [NSLOT][6] keys */)
+__device__ __forceinline__ void xyzc_limits_body(const uint8_t* __restrict__ valid, const double* __restrict__ X,
+                                                 const double* __restrict__ Y, const double* __restrict__ Z, size_t n,
+                                                 const RTDev& rt, unsigned long long* __restrict__ lim /* [NSLOT][6] keys */)
 {
     unsigned long long mn[3] = { ~0ull, ~0ull, ~0ull }, mx[3] = { 0, 0, 0 };
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -819,6 +824,12 @@ __global__ void __launch_bounds__(256) k_xyzc_limits(const uint8_t* __restrict__
         }
     }
 }
+__global__ void __launch_bounds__(256) k_xyzc_limits(const uint8_t* __restrict__ valid, const double* __restrict__ X,
+                                                     const double* __restrict__ Y, const double* __restrict__ Z, size_t n,
+                                                     RTDev rt, unsigned long long* __restrict__ lim)
+{
+    xyzc_limits_body(valid, X, Y, Z, n, rt, lim);
+}
 // exclusive scan of the per-block counts (single block; nblocks <= ~25k at full size)
 __global__ void __launch_bounds__(1024) k_scan_blocks(unsigned int* __restrict__ cnt, int nb, unsigned int* __restrict__ total)
 {
@@ -842,11 +853,10 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(unsigned int* __restrict__
     }
     if (threadIdx.x == 0) *total = carry;
 }
-__global__ void __launch_bounds__(256) k_xyzc_pack(const uint8_t* __restrict__ valid, const double* __restrict__ X,
-                                                   const double* __restrict__ Y, const double* __restrict__ Z, size_t n,
-                                                   RTDev rt, double mnx, double mny, double mnz, double sx, double sy,
-                                                   double sz, const unsigned int* __restrict__ blockoff,
-                                                   uint16_t* __restrict__ out)
+__device__ __forceinline__ void xyzc_pack_body(const uint8_t* __restrict__ valid, const double* __restrict__ X,
+                                               const double* __restrict__ Y, const double* __restrict__ Z, size_t n,
+                                               const RTDev& rt, double mnx, double mny, double mnz, double sx, double sy,
+                                               double sz, const unsigned int* __restrict__ blockoff, uint16_t* __restrict__ out)
 {
     __shared__ unsigned int wsum[4];
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -867,6 +877,14 @@ __global__ void __launch_bounds__(256) k_xyzc_pack(const uint8_t* __restrict__ v
         out[(size_t)off * 3 + 1] = (uint16_t)((t[1] - mny) * sy);
         out[(size_t)off * 3 + 2] = (uint16_t)((t[2] - mnz) * sz);
     }
+}
+__global__ void __launch_bounds__(256) k_xyzc_pack(const uint8_t* __restrict__ valid, const double* __restrict__ X,
+                                                   const double* __restrict__ Y, const double* __restrict__ Z, size_t n,
+                                                   RTDev rt, double mnx, double mny, double mnz, double sx, double sy,
+                                                   double sz, const unsigned int* __restrict__ blockoff,
+                                                   uint16_t* __restrict__ out)
+{
+    xyzc_pack_body(valid, X, Y, Z, n, rt, mnx, mny, mnz, sx, sy, sz, blockoff, out);
 }
 
 __global__ void __launch_bounds__(256) k_interleave(const double* __restrict__ X, const double* __restrict__ Y,
@@ -995,8 +1013,10 @@ int wass_triangulate_dev(wass_ctx* c, const float* d_disp, int W, int H, const i
     unsigned long long hc = 0;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { wass_mesh_destroy(m); return set_err(c, WASS_ERR_DEVICE, "triangulate: %s", hipGetErrorString(e)); }
-    if ((rc = counters_sum(c, cnt, &hc))) { wass_mesh_destroy(m); return rc; }
-    if (n_pts) *n_pts = hc;
+    if (n_pts) {                                 // the count is the only reason to synchronise here
+        if ((rc = counters_sum(c, cnt, &hc))) { wass_mesh_destroy(m); return rc; }
+        *n_pts = hc;
+    }
     *out = m;
     return WASS_OK;
 }
@@ -1104,6 +1124,87 @@ int wass_mesh_zgap_percentile(wass_ctx* c, wass_mesh* m, double percentile, doub
 }
 
 // the device-resident scalar record of this context
+// RT_from_plane (PovMesh.cpp:1044-1069), one body for the host entry point and the device-side frame tail
+__host__ __device__ inline void rt_from_plane(const double plane[4], double R[9], double T[3], double Rinv[9], double Tinv[3])
+{
+    const double a = plane[0], b = plane[1], cc = plane[2], d = plane[3];
+    const double q = (1 - cc) / (a * a + b * b);
+    R[0] = 1 - a * a * q; R[1] = -a * b * q; R[2] = -a;
+    R[3] = -a * b * q; R[4] = 1 - b * b * q; R[5] = -b;
+    R[6] = a; R[7] = b; R[8] = cc;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rinv[i * 3 + j] = R[j * 3 + i];
+    T[0] = 0; T[1] = 0; T[2] = d;
+    const double mT[3] = { -T[0], -T[1], -T[2] };
+    for (int i = 0; i < 3; i++) Tinv[i] = Rinv[i * 3] * mT[0] + Rinv[i * 3 + 1] * mT[1] + Rinv[i * 3 + 2] * mT[2];
+}
+
+// frame tail, step 1: the plane that main() would pass to save_as_xyz_compressed (wass_stereo.cpp:2108-2123)
+__global__ void k_frame_rt(DevState* __restrict__ ds, const unsigned long long* __restrict__ kept /* [2][NSLOT] */)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    const bool have = ds->ransac_found && ds->refine_ok;
+    ds->have_plane = have ? 1u : 0u;
+    if (have) {
+        rt_from_plane(ds->plane, ds->rtR, ds->rtT, ds->rtRinv, ds->rtTinv);
+    } else {
+        for (int i = 0; i < 9; ++i) ds->rtR[i] = ds->rtRinv[i] = (i % 4 == 0) ? 1.0 : 0.0;
+        for (int i = 0; i < 3; ++i) ds->rtT[i] = ds->rtTinv[i] = 0.0;
+    }
+    unsigned long long k1 = 0, k2 = 0;
+    for (int i = 0; i < NSLOT; ++i) { k1 += kept[i]; k2 += kept[NSLOT + i]; }
+    ds->kept1 = k1; ds->kept2 = k2;
+}
+__global__ void __launch_bounds__(256) k_xyzc_limits_dev(const uint8_t* __restrict__ valid, const double* __restrict__ X,
+                                                         const double* __restrict__ Y, const double* __restrict__ Z, size_t n,
+                                                         const DevState* __restrict__ ds, unsigned long long* __restrict__ lim)
+{
+    RTDev rt;
+    for (int i = 0; i < 9; ++i) rt.R[i] = ds->rtR[i];
+    for (int i = 0; i < 3; ++i) rt.T[i] = ds->rtT[i];
+    xyzc_limits_body(valid, X, Y, Z, n, rt, lim);
+}
+// frame tail: limits -> scale factors, and the 148-byte header of the file image (PovMesh.cpp:417-436)
+__global__ void k_frame_header(DevState* __restrict__ ds, const unsigned long long* __restrict__ lim, const unsigned int* __restrict__ total,
+                               unsigned char* __restrict__ img)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    unsigned long long hl[6] = { ~0ull, ~0ull, ~0ull, 0, 0, 0 };
+    for (int i = 0; i < NSLOT; ++i)
+        for (int k = 0; k < 3; ++k) {
+            if (lim[i * 6 + k] < hl[k]) hl[k] = lim[i * 6 + k];
+            if (lim[i * 6 + 3 + k] > hl[3 + k]) hl[3 + k] = lim[i * 6 + 3 + k];
+        }
+    const unsigned int npts = *total;
+    double mx[3];
+    for (int k = 0; k < 3; ++k) {
+        ds->mn[k] = npts ? dunkey(hl[k]) : 1.7976931348623157e308;
+        mx[k] = npts ? dunkey(hl[3 + k]) : -1.7976931348623157e308;
+        ds->sc[k] = 65535.0 / (mx[k] - ds->mn[k]);
+    }
+    ds->npts = npts;
+    // header: u32 n, f64 scale[3], f64 min[3], f64 Rinv[9], f64 Tinv[3] -- doubles sit at offset 4 (mod 8): word stores
+    unsigned int* w = (unsigned int*)img;
+    w[0] = npts;
+    auto put = [&](int word, double v) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        w[word] = (unsigned int)b; w[word + 1] = (unsigned int)(b >> 32);
+    };
+    for (int k = 0; k < 3; ++k) put(1 + 2 * k, ds->sc[k]);
+    for (int k = 0; k < 3; ++k) put(7 + 2 * k, ds->mn[k]);
+    for (int k = 0; k < 9; ++k) put(13 + 2 * k, ds->rtRinv[k]);
+    for (int k = 0; k < 3; ++k) put(31 + 2 * k, ds->rtTinv[k]);
+}
+__global__ void __launch_bounds__(256) k_xyzc_pack_dev(const uint8_t* __restrict__ valid, const double* __restrict__ X,
+                                                       const double* __restrict__ Y, const double* __restrict__ Z, size_t n,
+                                                       const DevState* __restrict__ ds, const unsigned int* __restrict__ blockoff,
+                                                       uint16_t* __restrict__ out)
+{
+    RTDev rt;
+    for (int i = 0; i < 9; ++i) rt.R[i] = ds->rtR[i];
+    for (int i = 0; i < 3; ++i) rt.T[i] = ds->rtT[i];
+    xyzc_pack_body(valid, X, Y, Z, n, rt, ds->mn[0], ds->mn[1], ds->mn[2], ds->sc[0], ds->sc[1], ds->sc[2], blockoff, out);
+}
+
 static int dstate(wass_ctx* c, DevState** ds)
 {
     int rc = ensure(c, c->dstate, sizeof(DevState) + 2048 * 4);
@@ -1161,10 +1262,8 @@ int wass_mesh_keep_biggest_component(wass_ctx* c, wass_mesh* m, double zgap, uin
 
 // wass_stereo.cpp:2046-2050 as one call: compute_zgap_percentile + cluster_biggest_connected_component with every
 // intermediate decision taken on the device (6 radix-select passes, component choice) and one read-back at the end.
-int wass_mesh_remove_outliers(wass_ctx* c, wass_mesh* m, double percentile, double* zgap_out, uint64_t* n_gaps, uint64_t* size_out)
+static int enqueue_remove_outliers(wass_ctx* c, wass_mesh* m, double percentile, DevState** dsp)
 {
-    if (!c || !m) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
-    WASS_HIP(c, hipSetDevice(c->device));
     DevState* ds = nullptr;
     int rc = dstate(c, &ds);
     if (rc) return rc;
@@ -1172,6 +1271,7 @@ int wass_mesh_remove_outliers(wass_ctx* c, wass_mesh* m, double percentile, doub
     DevState init;
     memset(&init, 0, sizeof init);
     init.sel_hi_shift = 64;
+    WASS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_copy, 0));            // the copy stream may still be reading the last frame's record
     WASS_HIP(c, hipMemcpyAsync(ds, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
     WASS_HIP(c, hipMemsetAsync(hist, 0, 2048 * 4, c->stream));
     for (int pass = 0; pass < 6; ++pass) {
@@ -1181,6 +1281,17 @@ int wass_mesh_remove_outliers(wass_ctx* c, wass_mesh* m, double percentile, doub
         hipLaunchKernelGGL(k_radix_pick, dim3(1), dim3(256), 0, c->stream, hist, pass, shift, nbits, percentile, ds);
     }
     if ((rc = enqueue_ccl(c, m, ds))) return rc;
+    *dsp = ds;
+    return WASS_OK;
+}
+
+int wass_mesh_remove_outliers(wass_ctx* c, wass_mesh* m, double percentile, double* zgap_out, uint64_t* n_gaps, uint64_t* size_out)
+{
+    if (!c || !m) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    WASS_HIP(c, hipSetDevice(c->device));
+    DevState* ds = nullptr;
+    int rc = enqueue_remove_outliers(c, m, percentile, &ds);
+    if (rc) return rc;
     DevState h;
     WASS_HIP(c, hipMemcpyAsync(&h, ds, sizeof h, hipMemcpyDeviceToHost, c->stream));
     WASS_HIP(c, hipStreamSynchronize(c->stream));
@@ -1312,10 +1423,10 @@ int wass_mesh_refine_plane(wass_ctx* c, wass_mesh* m, const wass_refine_params* 
 
 // wass_stereo.cpp:2062-2107 as one call: ransac_find_plane -> crop_plane(ransac_thr) -> refine_plane ->
 // crop_plane(max_distance); candidate choice, centroid and the 3x3 eigen-solve run on the device, one read-back.
-int wass_mesh_fit_plane(wass_ctx* c, wass_mesh* m, const int32_t* uv, int rounds, double ransac_thr, const wass_refine_params* rp,
-                        double max_distance, wass_plane_result* out)
+static int enqueue_fit_plane(wass_ctx* c, wass_mesh* m, const int32_t* uv, int rounds, double ransac_thr, const wass_refine_params* rp,
+                             double max_distance, DevState** dsp, unsigned long long** keptp)
 {
-    if (!c || !m || !uv || !rp || !out || rounds <= 0) return set_err(c, WASS_ERR_INVALID_ARG, "bad argument");
+    if (!c || !m || !uv || !rp || rounds <= 0) return set_err(c, WASS_ERR_INVALID_ARG, "bad argument");
     for (int r = 0; r < rounds * 3; ++r)
         if (uv[2 * r] < 0 || uv[2 * r] >= m->w || uv[2 * r + 1] < 0 || uv[2 * r + 1] >= m->h)
             return set_err(c, WASS_ERR_INVALID_ARG, "sample %d outside the mesh grid", r / 3);
@@ -1361,9 +1472,23 @@ int wass_mesh_fit_plane(wass_ctx* c, wass_mesh* m, const int32_t* uv, int rounds
     hipLaunchKernelGGL(k_refine_finish, dim3(1), dim3(64), 0, s, (const double*)part, NB, ds);
     hipLaunchKernelGGL(k_crop_plane_dev, dim3(2048), dim3(256), 0, s, m->valid, m->x, m->y, m->z, n, (const double*)ds->plane,
                        (const int*)&ds->refine_ok, max_distance, kept2);
+    WASS_HIP(c, hipGetLastError());
+    *dsp = ds;
+    *keptp = kept1;
+    return WASS_OK;
+}
+
+int wass_mesh_fit_plane(wass_ctx* c, wass_mesh* m, const int32_t* uv, int rounds, double ransac_thr, const wass_refine_params* rp,
+                        double max_distance, wass_plane_result* out)
+{
+    if (!out) return set_err(c, WASS_ERR_INVALID_ARG, "bad argument");
+    DevState* ds = nullptr;
+    unsigned long long* kept1 = nullptr;
+    int rc = enqueue_fit_plane(c, m, uv, rounds, ransac_thr, rp, max_distance, &ds, &kept1);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
     DevState h;
     unsigned long long hk[2 * NSLOT];
-    WASS_HIP(c, hipGetLastError());
     WASS_HIP(c, hipMemcpyAsync(&h, ds, sizeof h, hipMemcpyDeviceToHost, s));
     WASS_HIP(c, hipMemcpyAsync(hk, kept1, sizeof hk, hipMemcpyDeviceToHost, s));
     WASS_HIP(c, hipStreamSynchronize(s));
@@ -1379,17 +1504,77 @@ int wass_mesh_fit_plane(wass_ctx* c, wass_mesh* m, const int32_t* uv, int rounds
     return WASS_OK;
 }
 
+// The whole mesh tail of main() (wass_stereo.cpp:2046-2123) enqueued without a single host synchronisation: every
+// decision (percentile, component, best candidate, found / not found, refined plane, R|T, limits, point count) is
+// taken on the device, the file image (header included) is assembled in HBM and downloaded on the copy stream.
+int wass_mesh_finish_frame_async(wass_ctx* c, wass_mesh* m, double percentile, const int32_t* uv, int rounds, double ransac_thr,
+                                 const wass_refine_params* rp, double max_distance, void* dst, size_t capacity)
+{
+    if (!c || !m || !dst) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    WASS_HIP(c, hipSetDevice(c->device));
+    const size_t n = m->n();
+    if (capacity < 148 + n * 6)
+        return set_err(c, WASS_ERR_INVALID_ARG, "the asynchronous form needs room for every grid point: %zu bytes", 148 + n * 6);
+    if (!c->h_frame && hipHostMalloc((void**)&c->h_frame, sizeof(DevState) + 64, hipHostMallocDefault) != hipSuccess)
+        return set_err(c, WASS_ERR_NO_MEMORY, "hipHostMalloc failed");
+    DevState* ds = nullptr;
+    unsigned long long* kept1 = nullptr;
+    int rc;
+    if ((rc = enqueue_remove_outliers(c, m, percentile, &ds))) return rc;
+    if ((rc = enqueue_fit_plane(c, m, uv, rounds, ransac_thr, rp, max_distance, &ds, &kept1))) return rc;
+    const unsigned nb = nblk(n);
+    if ((rc = ensure(c, c->xyzc, 148 + n * 6 + 16))) return rc;
+    // block counts live behind the candidate area of the scratch buffer, which enqueue_fit_plane sized; grow if needed
+    const size_t need = 64 + (size_t)nb * 4 + 16;
+    if (c->scratch.cap < need && (rc = ensure(c, c->scratch, need))) return rc;
+    hipStream_t s = c->stream;
+    hipLaunchKernelGGL(k_frame_rt, dim3(1), dim3(64), 0, s, ds, (const unsigned long long*)kept1);
+    unsigned long long init[NSLOT * 6];
+    for (int i = 0; i < NSLOT; ++i) for (int k = 0; k < 6; ++k) init[i * 6 + k] = k < 3 ? ~0ull : 0ull;
+    if ((rc = ensure(c, c->limits, sizeof init))) return rc;
+    unsigned long long* lim = (unsigned long long*)c->limits.p;            // [NSLOT][6] keys
+    WASS_HIP(c, hipMemcpyAsync(lim, init, sizeof init, hipMemcpyHostToDevice, s));
+    unsigned int* total = (unsigned int*)c->scratch.p;
+    unsigned int* bcnt = (unsigned int*)((char*)c->scratch.p + 64);
+    unsigned char* img = (unsigned char*)c->xyzc.p;
+    WASS_HIP(c, hipStreamWaitEvent(s, c->ev_copy, 0));                    // a previous download still reading the image
+    hipLaunchKernelGGL(k_xyzc_limits_dev, dim3(1024), dim3(256), 0, s, m->valid, m->x, m->y, m->z, n, (const DevState*)ds, lim);
+    hipLaunchKernelGGL(k_block_counts, dim3(nb), dim3(256), 0, s, m->valid, n, bcnt);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, bcnt, (int)nb, total);
+    hipLaunchKernelGGL(k_frame_header, dim3(1), dim3(64), 0, s, ds, (const unsigned long long*)lim, (const unsigned int*)total, img);
+    hipLaunchKernelGGL(k_xyzc_pack_dev, dim3(nb), dim3(256), 0, s, m->valid, m->x, m->y, m->z, n, (const DevState*)ds,
+                       (const unsigned int*)bcnt, (uint16_t*)(img + 148));
+    WASS_HIP(c, hipGetLastError());
+    WASS_HIP(c, hipEventRecord(c->ev_pack, s));
+    WASS_HIP(c, hipStreamWaitEvent(c->copy, c->ev_pack, 0));
+    WASS_HIP(c, hipMemcpyAsync(c->h_frame, ds, sizeof(DevState), hipMemcpyDeviceToHost, c->copy));
+    WASS_HIP(c, hipMemcpyAsync(dst, img, 148 + n * 6, hipMemcpyDeviceToHost, c->copy));
+    WASS_HIP(c, hipEventRecord(c->ev_copy, c->copy));
+    c->frame_pending = true;
+    return WASS_OK;
+}
+
+int wass_ctx_frame_result(wass_ctx* c, wass_frame_result* out)
+{
+    if (!c || !out) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    if (!c->frame_pending) return set_err(c, WASS_ERR_INVALID_ARG, "no wass_mesh_finish_frame_async call to wait for");
+    WASS_HIP(c, hipEventSynchronize(c->ev_copy));
+    const DevState& h = *(const DevState*)c->h_frame;
+    memset(out, 0, sizeof *out);
+    out->zgap = h.zgap; out->n_gaps = h.sel_total; out->component_size = h.ccl_best >> 32;
+    out->found = h.ransac_found; out->refine_ok = h.refine_ok;
+    out->ransac_inliers = h.ransac_best;
+    for (int k = 0; k < 4; ++k) { out->ransac_plane[k] = h.ransac_plane[k]; out->plane[k] = h.ransac_found && h.refine_ok ? h.plane[k] : NAN; }
+    if (h.ransac_found) { out->kept_after_ransac_crop = h.kept1; out->kept_final = h.kept2; out->refine_inliers = (uint64_t)(h.ninl + 0.5); }
+    out->n_points = h.npts;
+    out->xyzc_bytes = 148 + (uint64_t)h.npts * 6;
+    if (h.sel_fail == 2) return set_err(c, WASS_ERR_DEVICE, "radix select lost its rank (internal error)");
+    return WASS_OK;
+}
+
 void wass_RT_from_plane(const double plane[4], double R[9], double T[3], double Rinv[9], double Tinv[3])
 {
-    const double a = plane[0], b = plane[1], cc = plane[2], d = plane[3];
-    const double q = (1 - cc) / (a * a + b * b);
-    R[0] = 1 - a * a * q; R[1] = -a * b * q; R[2] = -a;
-    R[3] = -a * b * q; R[4] = 1 - b * b * q; R[5] = -b;
-    R[6] = a; R[7] = b; R[8] = cc;
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rinv[i * 3 + j] = R[j * 3 + i];
-    T[0] = 0; T[1] = 0; T[2] = d;
-    const double mT[3] = { -T[0], -T[1], -T[2] };
-    for (int i = 0; i < 3; i++) Tinv[i] = Rinv[i * 3] * mT[0] + Rinv[i * 3 + 1] * mT[1] + Rinv[i * 3 + 2] * mT[2];
+    rt_from_plane(plane, R, T, Rinv, Tinv);
 }
 
 int wass_mesh_encode_xyzc(wass_ctx* c, wass_mesh* m, const double plane[4], void** bytes, size_t* nbytes)

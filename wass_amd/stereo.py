@@ -125,6 +125,12 @@ class Context:
                                                              dilate_steps, erode_steps, median_wsize, d_out.data_ptr()))
         return d_out
 
+    def frame_result(self):
+        """Wait for the frame enqueued by Mesh.finish_frame_async and return its wass_frame_result."""
+        res = _lib.FrameResult()
+        self._check(self._lib.wass_ctx_frame_result(self._h, C.byref(res)))
+        return res
+
     # ---- rectification resamplers (wass_stereo.cpp:515-516, 603-604) ----------
     @staticmethod
     def _roi(roi):
@@ -198,15 +204,18 @@ class Context:
         return Mesh(self, h), int(n.value)
 
     def triangulate_dev(self, d_disp_roi, W, H, roi_l, roi_r, geom: Geom, d_right_img, d_left_mask=None,
-                        d_right_mask=None, min_angle_deg=20.0, bbox=None, cam_distance=1.0):
+                        d_right_mask=None, min_angle_deg=20.0, bbox=None, cam_distance=1.0, count=True):
+        """count=False skips the point count (and with it the only host synchronisation of this call); the
+        returned count is then None."""
         ih, iw = d_right_img.shape
         tp = TriParams(min_angle_deg, (C.c_double * 4)(*(bbox or (0, 0, iw, ih))), cam_distance)
         h = C.c_void_p(); n = C.c_uint64()
         self._check(self._lib.wass_triangulate_dev(
             self._h, d_disp_roi.data_ptr(), W, H, (C.c_int * 4)(*roi_l), (C.c_int * 4)(*roi_r), C.byref(geom),
             d_right_img.data_ptr(), iw, ih, d_left_mask.data_ptr() if d_left_mask is not None else None,
-            d_right_mask.data_ptr() if d_right_mask is not None else None, C.byref(tp), C.byref(h), C.byref(n)))
-        return Mesh(self, h), int(n.value)
+            d_right_mask.data_ptr() if d_right_mask is not None else None, C.byref(tp), C.byref(h),
+            C.byref(n) if count else None))
+        return Mesh(self, h), (int(n.value) if count else None)
 
     def mesh_upload(self, valid, p3d, gray=None):
         valid = np.ascontiguousarray(valid, np.uint8)
@@ -341,6 +350,16 @@ class Mesh:
         self.ctx._check(self.ctx._lib.wass_mesh_fit_plane(self.ctx._h, self._h, uv.ctypes.data, len(uv), ransac_thr,
                                                           C.byref(rp), max_distance, C.byref(res)))
         return res
+
+    def finish_frame_async(self, uv, dst_ptr: int, capacity: int, percentile=99.0, ransac_thr=1.0, max_distance=1.5,
+                           xmin=-9999., xmax=9999., ymin=-9999., ymax=9999., refine_max_distance=70.0, weight_by_distance=True,
+                           central_third_only=False) -> None:
+        """remove_outliers -> fit_plane -> xyzC encode + download, enqueued without a host synchronisation
+        (wass_stereo.cpp:2046-2123); Context.frame_result() waits and reports."""
+        uv = np.ascontiguousarray(uv, np.int32)
+        rp = RefineParams(xmin, xmax, ymin, ymax, refine_max_distance, int(weight_by_distance), int(central_third_only))
+        self.ctx._check(self.ctx._lib.wass_mesh_finish_frame_async(self.ctx._h, self._h, percentile, uv.ctypes.data, len(uv),
+                                                                   ransac_thr, C.byref(rp), max_distance, dst_ptr, capacity))
 
     def ransac_plane(self, uv, thr: float):
         uv = np.ascontiguousarray(uv, np.int32)
