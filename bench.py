@@ -35,11 +35,12 @@ CONFIGS = {
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-def cpu_baseline(w: int, D: int, ndirs: int, budget_rows: int = 192):
-    """Time the CPU oracle (scalar C restatement, 1 thread) on a bounded band of the same workload."""
+def cpu_baseline(w: int, h_full: int, D: int, ndirs: int, budget_cells: float = 1.0e9):
+    """Time the CPU oracle (scalar C restatement, 1 thread) on a bounded band of the same workload: same width and
+    disparity range, as many rows as ~15 s of CPU work allow (about 1e9 pixel-disparity cells)."""
     from oracle import oracle as O
     from wass_amd import synth
-    h = budget_rows
+    h = int(min(h_full, max(64, budget_cells // (w * D))))
     right, left = synth.make_pair(w, h, D, frame_idx=1000)
     p = O.wass_params(D, mode=ndirs)
     t0 = time.perf_counter()
@@ -47,7 +48,9 @@ def cpu_baseline(w: int, D: int, ndirs: int, budget_rows: int = 192):
     dt = time.perf_counter() - t0
     mdisp = w * h * D / 1e6 / dt
     return {"value": round(mdisp, 2), "unit": "Mdisp/s", "cores": 1, "kind": "port",
-            "sample": f"{w}x{h} band of the workload, D={D}, {ndirs}-path, scalar C oracle, 1 thread, {dt:.1f}s"}
+            "pairs_per_sec_equivalent": round(mdisp * 1e6 / (w * h_full * D), 4),
+            "sample": f"{w}x{h} band of the {w}x{h_full} workload, D={D}, {ndirs}-path SGBM stage (a1-a6), scalar C oracle, "
+                      f"1 thread, {dt:.1f}s"}
 
 
 def measured_traffic(config: str, ndirs: int):
@@ -231,7 +234,7 @@ def main():
             "cost_overflow": int(overflow),
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(w, D, args.ndirs)
+            line["cpu_baseline"] = cpu_baseline(w, h, D, args.ndirs)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
