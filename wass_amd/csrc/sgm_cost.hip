@@ -145,23 +145,44 @@ __global__ void __launch_bounds__(256) k_hsum_q(const uint2* __restrict__ bt1, c
 
     // mirrored index of the window start at column t0 is e0 = Wp-1-(t0+minX1)+minD == G-1 (mod G)
     int b = (Wp - 1 - (t0 + minX1) + minD) - (G - 1) + G * lane;      // this lane's first element of "lo"
-    AVec<NP> hi[6], lo[6];
+    AVec<NP> hi[6], lo[6], nx[6];
 #pragma unroll
-    for (int p = 0; p < 6; ++p) hi[p] = *(const AVec<NP>*)(row2 + (size_t)p * pitch2 + (b + G));
+    for (int p = 0; p < 6; ++p) {
+        hi[p] = *(const AVec<NP>*)(row2 + (size_t)p * pitch2 + (b + G));
+        lo[p] = *(const AVec<NP>*)(row2 + (size_t)p * pitch2 + b);
+    }
     int slot = 0;
     uint32_t* o = hsum + ((size_t)y * width1 + max(xs, 0)) * (64 * NP) + lane * NP;
+    // one finished pixel-cost vector: slide the window, write the column whose window is complete now
+    auto emit = [&](const us2 (&pix)[NP], int i, int t) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            uint32_t* rs = ring + (slot * NP + j) * 64;
+            acc[j] = acc[j] + pix[j] - as_us2(*rs);
+            *rs = as_u32(pix[j]);
+        }
+        slot = slot + 1 == WIN ? 0 : slot + 1;
+        const int xo = t - SW2;
+        if (i >= 2 * SW2 && xo >= 0 && xo < xe) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) o[j] = as_u32(acc[j]);
+            o += 64 * NP;
+        }
+    };
     for (int g0 = 0; g0 < steps; g0 += G, b -= G) {
+        // the next group's vectors are requested before this group is evaluated (the loads of a group used to be
+        // waited for right where they were issued)
 #pragma unroll
-        for (int p = 0; p < 6; ++p) lo[p] = *(const AVec<NP>*)(row2 + (size_t)p * pitch2 + b);
+        for (int p = 0; p < 6; ++p) nx[p] = *(const AVec<NP>*)(row2 + (size_t)p * pitch2 + (b - G));
         const int tg = t0 + g0;
-        const bool fast = tg >= 0 && tg + G - 1 <= width1 - 1;        // wave-uniform
+        if (tg >= 0 && tg + G - 1 <= width1 - 1) {                     // wave-uniform: the whole group is inside the row
+            uint2 a1[G];
 #pragma unroll
-        for (int s = 0; s < G; ++s) {
-            const int t = tg + s;
-            us2 pix[NP];
-            if (fast) {
+            for (int s = 0; s < G; ++s) a1[s] = row1[tg + s];          // uniform addresses: one scalar load each
+#pragma unroll
+            for (int s = 0; s < G; ++s) {
                 const int oo = G - 1 - s;                             // window offset inside [lo | hi], in elements
-                us2 v[6][NP];
+                us2 v[6][NP], pix[NP];
 #pragma unroll
                 for (int p = 0; p < 6; ++p)
 #pragma unroll
@@ -175,11 +196,15 @@ __global__ void __launch_bounds__(256) k_hsum_q(const uint2* __restrict__ bt1, c
                             v[p][j] = as_us2(d0);
                         }
                     }
-                bt_eval<NP>(row1[t], v, pix);
-            } else {
+                bt_eval<NP>(a1[s], v, pix);
+                emit(pix, g0 + s, tg + s);
+            }
+        } else {                                                       // a replicated border column: per-column loads
+            for (int s = 0; s < G; ++s) {
+                const int t = tg + s;
                 const int tc = t < 0 ? 0 : (t > width1 - 1 ? width1 - 1 : t);
                 const unsigned short* src = row2 + (Wp - 1 - (tc + minX1) + minD) + G * lane;   // 2-byte aligned only
-                us2 v[6][NP];
+                us2 v[6][NP], pix[NP];
 #pragma unroll
                 for (int p = 0; p < 6; ++p) {
                     AVec<NP> u;
@@ -188,23 +213,11 @@ __global__ void __launch_bounds__(256) k_hsum_q(const uint2* __restrict__ bt1, c
                     for (int j = 0; j < NP; ++j) v[p][j] = as_us2(u.v[j]);
                 }
                 bt_eval<NP>(row1[tc], v, pix);
-            }
-#pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                uint32_t* rs = ring + (slot * NP + j) * 64;
-                acc[j] = acc[j] + pix[j] - as_us2(*rs);
-                *rs = as_u32(pix[j]);
-            }
-            slot = slot + 1 == WIN ? 0 : slot + 1;
-            const int xo = t - SW2;                                   // the window centred here is complete now
-            if (g0 + s >= 2 * SW2 && xo >= 0 && xo < xe) {
-#pragma unroll
-                for (int j = 0; j < NP; ++j) o[j] = as_u32(acc[j]);
-                o += 64 * NP;
+                emit(pix, g0 + s, t);
             }
         }
 #pragma unroll
-        for (int p = 0; p < 6; ++p) hi[p] = lo[p];
+        for (int p = 0; p < 6; ++p) { hi[p] = lo[p]; lo[p] = nx[p]; }
     }
 }
 
