@@ -379,12 +379,58 @@ __global__ void __launch_bounds__(256) k_vsum_col(const uint32_t* __restrict__ h
         slot = slot + 1 == WIN ? 0 : slot + 1;
     };
 
+    // K rows at a time with the three dependent pieces decoupled: (a) the K vectors leaving the window are read from
+    // the LDS ring back to back, (b) the K cost vectors are finished and stored, (c) the path recurrence runs over
+    // them.  Needs K distinct ring slots, i.e. K <= WIN; narrower windows take the row-by-row form.
+    auto group = [&](int y0, const us2 (&in)[K][NP]) {
+        us2 old[K][NP], cv[K][NP];
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            int sl = slot + u;
+            sl = sl >= WIN ? sl - WIN : sl;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) old[u][j] = as_us2(ring[(sl * NP + j) * 64]);
+        }
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            int sl = slot + u;
+            sl = sl >= WIN ? sl - WIN : sl;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                us2 v = acc[j];
+                const int d = dlane + 2 * j;
+                if (d < D) over |= (v.x > lim.x); else v.x = 0xFFFF;
+                if (d + 1 < D) over |= (v.y > lim.y); else v.y = 0xFFFF;
+                cv[u][j] = v;
+                cp[(size_t)(y0 + u) * rowstride + j] = as_u32(v);
+                acc[j] = acc[j] + in[u][j] - old[u][j];
+                ring[(sl * NP + j) * 64] = as_u32(in[u][j]);
+            }
+        }
+        slot += K;
+        slot = slot >= WIN ? slot - WIN : slot;
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            us2 L[NP];
+            sgm_step<NP>(st, cv[u], L, P1v, P2);
+            if (PATH2) {
+#pragma unroll
+                for (int j = 0; j < NP; ++j) sp[(size_t)(y0 + u) * rowstride + j] = as_u32(pk_min(L[j], cap));
+            }
+        }
+    };
+
     us2 nb[K][NP], nn[K][NP];
     fetch(0, nb);
+    const bool batched = K <= WIN;
     for (int s = 0; s < F; ++s) {
         if ((s + 1) * K < h) fetch((s + 1) * K, nn);
+        if (batched) {
+            group(s * K, nb);
+        } else {
 #pragma unroll
-        for (int u = 0; u < K; ++u) row(s * K + u, nb[u]);
+            for (int u = 0; u < K; ++u) row(s * K + u, nb[u]);
+        }
         if (!PATH2 && s < ncp) st.store_normalised(ck + (size_t)s * vec);
         copy_seg<NP, K>(nb, nn);
     }
