@@ -46,6 +46,10 @@ CASES = [
     (700, 20, 640, 5, 13, 1, 0),      # NP = 5: the WASS default MAX_DISPARITY
     (40, 300, 16, 8, 13, 1, 0),       # tall and narrow: long columns, short rows
     (33, 29, 16, 8, 3, 1, 0),         # tiny
+    (900, 12, 768, 8, 13, 1, 0),      # NP = 6
+    (1100, 10, 1024, 5, 13, 1, 0),    # NP = 8: the largest supported MAX_DISPARITY
+    (257, 33, 96, 8, 11, 1, 0),       # (wider windows leave the int16 range of A.7 on textured input)
+    (75, 41, 32, 5, 11, 3, 0),        # odd width, minD = 3, window wider than a checkpoint segment is tall
 ]
 
 
