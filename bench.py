@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--ndirs", type=int, default=8, choices=(5, 8))
     ap.add_argument("--config", default="B", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tail-overlap", action="store_true",
+                    help="run the post-SGM stages on the SGM stream instead of the context's tail stream")
     ap.add_argument("--inflight", type=int, default=1,
                     help="frames in flight per GPU (each on its own context/stream/scratch, one host thread each)")
     ap.add_argument("--stage", default="full", choices=("full", "sgm"),
@@ -103,13 +105,18 @@ def main():
     nslot = max(1, args.inflight)
     ctxs = [wass_amd.Context(local_rank) for _ in range(nslot)]
     ctx = ctxs[0]
+    tail_overlap = args.stage == "full" and not args.no_tail_overlap
+    for c_ in ctxs:
+        c_.set_tail_overlap(tail_overlap)
 
     # two different resident frames per rank, alternated, so no step can reuse a previous result
     frames = []
     for k in range(2):
         r, l = synth.make_pair(w, h, D, frame_idx=rank * 16 + k)
         frames.append((torch.from_numpy(r).to(dev), torch.from_numpy(l).to(dev)))
-    outs = [torch.empty((h, w), dtype=torch.int16, device=dev) for _ in range(nslot)]
+    # two disparity buffers per context, alternated: with tail overlap the clean-up of frame i still reads its
+    # disparity while the SGM stage of frame i+1 writes the next one
+    outs = [[torch.empty((h, w), dtype=torch.int16, device=dev) for _ in range(2)] for _ in range(nslot)]
     dispfs = [torch.empty((h, w), dtype=torch.float32, device=dev) for _ in range(nslot)]
     geom = wass_amd.make_geom(synth.rig_geometry(w, h))
     roi = (0, 0, w, h)
@@ -118,7 +125,7 @@ def main():
     xyzc_hosts = [torch.empty(148 + 6 * w * h, dtype=torch.uint8, pin_memory=True) for _ in range(nslot)]   # mesh_cam.xyzC
 
     def step(i, slot=0):
-        ctx, out, dispf, xyzc_host = ctxs[slot], outs[slot], dispfs[slot], xyzc_hosts[slot]
+        ctx, out, dispf, xyzc_host = ctxs[slot], outs[slot][(i // nslot) % 2], dispfs[slot], xyzc_hosts[slot]
         dr, dl = frames[i % 2]
         ctx.sgm_disparity_dev(dr, dl, params, out)
         if args.stage == "sgm":
@@ -217,7 +224,7 @@ def main():
                                    + ("+ disparity clean-up + triangulation + z-gap/CC + RANSAC plane + refine + xyzC encode"
                                       if args.stage == "full" else "(a1-a6 only)") + ", frame-parallel over ranks",
                        "width": w, "height": h, "num_disp": D, "ndirs": args.ndirs, "pairs_per_rank": args.steps,
-                       "stage": args.stage, "frames_in_flight": nslot},
+                       "stage": args.stage, "frames_in_flight": nslot, "tail_overlap": tail_overlap},
             "roofline": {"bound": "hbm", "kernel": "path aggregation family (k_ckpt + k_pair [+ k_sweep]), all launches of one frame",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),

@@ -86,6 +86,7 @@ SYMBOLS = {
     "wass_ctx_stream": (_vp, [_vp]),
     "wass_ctx_synchronize": (_i, [_vp]),
     "wass_ctx_set_debug": (_i, [_vp, _i]),
+    "wass_ctx_set_tail_overlap": (_i, [_vp, _i]),
     "wass_sgm_disparity": (_i, [_vp, _vp, _vp, _i, _i, _sz, C.POINTER(SgmParams), _vp]),
     "wass_sgm_disparity_dev": (_i, [_vp, _vp, _vp, _i, _i, _sz, C.POINTER(SgmParams), _vp]),
     "wass_sgm_last_timings": (_i, [_vp, C.POINTER(SgmTimings)]),

@@ -99,6 +99,7 @@ int wass_ctx_create(int device_id, wass_ctx** out)
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
     if (hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
     if (hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
+    if (hipStreamCreateWithFlags(&c->tail, hipStreamNonBlocking) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
     if (hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
     if (hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
     for (auto& e : c->ev)
@@ -129,6 +130,7 @@ void wass_ctx_destroy(wass_ctx* c)
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     if (c->side2) { (void)hipStreamSynchronize(c->side2); (void)hipStreamDestroy(c->side2); }
     if (c->copy) { (void)hipStreamSynchronize(c->copy); (void)hipStreamDestroy(c->copy); }
+    if (c->tail) { (void)hipStreamSynchronize(c->tail); (void)hipStreamDestroy(c->tail); }
     if (c->h_flags) (void)hipHostFree(c->h_flags);
     if (c->h_frame) (void)hipHostFree(c->h_frame);
     if (c->ev_pack) (void)hipEventDestroy(c->ev_pack);
@@ -151,7 +153,17 @@ int wass_ctx_synchronize(wass_ctx* c)
 {
     if (!c) return WASS_ERR_INVALID_ARG;
     WASS_HIP(c, hipStreamSynchronize(c->stream));
+    WASS_HIP(c, hipStreamSynchronize(c->tail));
     WASS_HIP(c, hipStreamSynchronize(c->copy));
+    return WASS_OK;
+}
+
+int wass_ctx_set_tail_overlap(wass_ctx* c, int on)
+{
+    if (!c) return WASS_ERR_INVALID_ARG;
+    WASS_HIP(c, hipStreamSynchronize(c->stream));          // switching streams mid-flight would drop the ordering
+    WASS_HIP(c, hipStreamSynchronize(c->tail));
+    c->tail_overlap = on != 0;
     return WASS_OK;
 }
 

@@ -130,6 +130,12 @@ struct wass_ctx {
     void* h_frame = nullptr;       // pinned: device state record of the last wass_mesh_finish_frame_async
     bool frame_pending = false;
     hipStream_t copy = nullptr;    // D2H of the xyzC payload
+    // Everything after the SGM call (disparity clean-up, triangulation, mesh stages: post.hip, mesh.hip) is enqueued on
+    // ts(): the main stream, or -- with tail overlap on -- a second stream that waits for the last SGM call, so that
+    // this string of small, latency-bound kernels runs underneath the next frame's bandwidth-bound SGM stage.
+    hipStream_t tail = nullptr;
+    bool tail_overlap = false;
+    hipStream_t ts() const { return tail_overlap ? tail : stream; }
     hipEvent_t ev_pack = nullptr, ev_copy = nullptr;
     wass::Buf rect_tab;            // fixed-point interpolation tables of the rectification resamplers (rectify.hip)
     bool rect_tab_ready = false;

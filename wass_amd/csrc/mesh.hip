@@ -946,14 +946,14 @@ static int counters_reset(wass_ctx* c, unsigned long long** cnt)
     int rc = ensure(c, c->counters, (size_t)NSLOT * 6 * 8);
     if (rc) return rc;
     *cnt = (unsigned long long*)c->counters.p;
-    WASS_HIP(c, hipMemsetAsync(*cnt, 0, (size_t)NSLOT * 8, c->stream));
+    WASS_HIP(c, hipMemsetAsync(*cnt, 0, (size_t)NSLOT * 8, c->ts()));
     return WASS_OK;
 }
 static int counters_sum(wass_ctx* c, const unsigned long long* cnt, unsigned long long* out)
 {
     unsigned long long h[NSLOT];
-    WASS_HIP(c, hipMemcpyAsync(h, cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    WASS_HIP(c, hipStreamSynchronize(c->stream));
+    WASS_HIP(c, hipMemcpyAsync(h, cnt, sizeof h, hipMemcpyDeviceToHost, c->ts()));
+    WASS_HIP(c, hipStreamSynchronize(c->ts()));
     unsigned long long s = 0;
     for (int i = 0; i < NSLOT; ++i) s += h[i];
     *out = s;
@@ -1007,7 +1007,7 @@ int wass_triangulate_dev(wass_ctx* c, const float* d_disp, int W, int H, const i
     unsigned long long* cnt = nullptr;
     if ((rc = counters_reset(c, &cnt))) { wass_mesh_destroy(m); return rc; }
     dim3 grid(4096);
-    hipLaunchKernelGGL(k_triangulate, grid, dim3(256), 0, c->stream, d_disp, W, H, roi_l[0], roi_r[0], roi_r[1], m->w, m->h,
+    hipLaunchKernelGGL(k_triangulate, grid, dim3(256), 0, c->ts(), d_disp, W, H, roi_l[0], roi_r[0], roi_r[1], m->w, m->h,
                        gd, d_right_img, img_w, img_h, d_lmask, d_rmask, tp->min_angle_deg, tp->bbox[0], tp->bbox[1],
                        tp->bbox[2], tp->bbox[3], tp->cam_distance, m->valid, m->x, m->y, m->z, m->gray, cnt);
     unsigned long long hc = 0;
@@ -1032,10 +1032,10 @@ int wass_triangulate(wass_ctx* c, const float* disp, int W, int H, const int roi
     if ((rc = ensure(c, c->fC, nd * 4)) || (rc = ensure(c, c->tmp_in0, ni)) ||
         (lmask && (rc = ensure(c, c->tmp_in1, ni))) || (rmask && (rc = ensure(c, c->tmp_mask, ni))))
         return rc;
-    WASS_HIP(c, hipMemcpyAsync(c->fC.p, disp, nd * 4, hipMemcpyHostToDevice, c->stream));
-    WASS_HIP(c, hipMemcpyAsync(c->tmp_in0.p, right_img, ni, hipMemcpyHostToDevice, c->stream));
-    if (lmask) WASS_HIP(c, hipMemcpyAsync(c->tmp_in1.p, lmask, ni, hipMemcpyHostToDevice, c->stream));
-    if (rmask) WASS_HIP(c, hipMemcpyAsync(c->tmp_mask.p, rmask, ni, hipMemcpyHostToDevice, c->stream));
+    WASS_HIP(c, hipMemcpyAsync(c->fC.p, disp, nd * 4, hipMemcpyHostToDevice, c->ts()));
+    WASS_HIP(c, hipMemcpyAsync(c->tmp_in0.p, right_img, ni, hipMemcpyHostToDevice, c->ts()));
+    if (lmask) WASS_HIP(c, hipMemcpyAsync(c->tmp_in1.p, lmask, ni, hipMemcpyHostToDevice, c->ts()));
+    if (rmask) WASS_HIP(c, hipMemcpyAsync(c->tmp_mask.p, rmask, ni, hipMemcpyHostToDevice, c->ts()));
     return wass_triangulate_dev(c, (const float*)c->fC.p, W, H, roi_l, roi_r, g, (const uint8_t*)c->tmp_in0.p, img_w, img_h,
                                 lmask ? (const uint8_t*)c->tmp_in1.p : nullptr, rmask ? (const uint8_t*)c->tmp_mask.p : nullptr,
                                 tp, out, n_pts);
@@ -1046,15 +1046,15 @@ int wass_mesh_download(wass_ctx* c, const wass_mesh* m, uint8_t* valid, double* 
     if (!c || !m) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
     WASS_HIP(c, hipSetDevice(c->device));
     const size_t n = m->n();
-    if (valid) WASS_HIP(c, hipMemcpyAsync(valid, m->valid, n, hipMemcpyDeviceToHost, c->stream));
-    if (gray) WASS_HIP(c, hipMemcpyAsync(gray, m->gray, n, hipMemcpyDeviceToHost, c->stream));
+    if (valid) WASS_HIP(c, hipMemcpyAsync(valid, m->valid, n, hipMemcpyDeviceToHost, c->ts()));
+    if (gray) WASS_HIP(c, hipMemcpyAsync(gray, m->gray, n, hipMemcpyDeviceToHost, c->ts()));
     if (p3d) {
         int rc = ensure(c, c->scratch, n * 24);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_interleave, dim3(nblk(n)), dim3(256), 0, c->stream, m->x, m->y, m->z, n, (double*)c->scratch.p);
-        WASS_HIP(c, hipMemcpyAsync(p3d, c->scratch.p, n * 24, hipMemcpyDeviceToHost, c->stream));
+        hipLaunchKernelGGL(k_interleave, dim3(nblk(n)), dim3(256), 0, c->ts(), m->x, m->y, m->z, n, (double*)c->scratch.p);
+        WASS_HIP(c, hipMemcpyAsync(p3d, c->scratch.p, n * 24, hipMemcpyDeviceToHost, c->ts()));
     }
-    WASS_HIP(c, hipStreamSynchronize(c->stream));
+    WASS_HIP(c, hipStreamSynchronize(c->ts()));
     return WASS_OK;
 }
 
@@ -1068,13 +1068,13 @@ int wass_mesh_upload(wass_ctx* c, int width, int height, const uint8_t* valid, c
     if (rc) return rc;
     const size_t n = m->n();
     if ((rc = ensure(c, c->scratch, n * 24))) { wass_mesh_destroy(m); return rc; }
-    hipError_t e = hipMemcpyAsync(m->valid, valid, n, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = gray ? hipMemcpyAsync(m->gray, gray, n, hipMemcpyHostToDevice, c->stream)
-                                  : hipMemsetAsync(m->gray, 0, n, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(c->scratch.p, p3d, n * 24, hipMemcpyHostToDevice, c->stream);
+    hipError_t e = hipMemcpyAsync(m->valid, valid, n, hipMemcpyHostToDevice, c->ts());
+    if (e == hipSuccess) e = gray ? hipMemcpyAsync(m->gray, gray, n, hipMemcpyHostToDevice, c->ts())
+                                  : hipMemsetAsync(m->gray, 0, n, c->ts());
+    if (e == hipSuccess) e = hipMemcpyAsync(c->scratch.p, p3d, n * 24, hipMemcpyHostToDevice, c->ts());
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_deinterleave, dim3(nblk(n)), dim3(256), 0, c->stream, (const double*)c->scratch.p, n, m->x, m->y, m->z);
-        e = hipStreamSynchronize(c->stream);
+        hipLaunchKernelGGL(k_deinterleave, dim3(nblk(n)), dim3(256), 0, c->ts(), (const double*)c->scratch.p, n, m->x, m->y, m->z);
+        e = hipStreamSynchronize(c->ts());
     }
     if (e != hipSuccess) { wass_mesh_destroy(m); return set_err(c, WASS_ERR_DEVICE, "mesh upload: %s", hipGetErrorString(e)); }
     *out = m;
@@ -1092,7 +1092,7 @@ int wass_mesh_zgap_percentile(wass_ctx* c, wass_mesh* m, double percentile, doub
     unsigned int* hist = (unsigned int*)(gaps + ng);
     unsigned long long* cnt = nullptr;
     if ((rc = counters_reset(c, &cnt))) return rc;
-    hipLaunchKernelGGL(k_zgaps, dim3((m->w + 255) / 256, m->h), dim3(256), 0, c->stream, m->valid, m->z, m->w, m->h, gaps, cnt);
+    hipLaunchKernelGGL(k_zgaps, dim3((m->w + 255) / 256, m->h), dim3(256), 0, c->ts(), m->valid, m->z, m->w, m->h, gaps, cnt);
     unsigned long long total = 0;
     if ((rc = counters_sum(c, cnt, &total))) return rc;
     if (n_gaps) *n_gaps = total;
@@ -1105,11 +1105,11 @@ int wass_mesh_zgap_percentile(wass_ctx* c, wass_mesh* m, double percentile, doub
     int hi_shift = 64;
     for (int pass = 0; pass < 6; ++pass) {
         const int shift = pass < 5 ? 64 - 11 * (pass + 1) : 0;      // 53,42,31,20,9,0 (last digit: 9 bits)
-        WASS_HIP(c, hipMemsetAsync(hist, 0, 2048 * 4, c->stream));
-        hipLaunchKernelGGL(k_radix_hist, dim3(1024), dim3(256), 0, c->stream, (const unsigned long long*)gaps, ng, shift,
+        WASS_HIP(c, hipMemsetAsync(hist, 0, 2048 * 4, c->ts()));
+        hipLaunchKernelGGL(k_radix_hist, dim3(1024), dim3(256), 0, c->ts(), (const unsigned long long*)gaps, ng, shift,
                            pass < 5 ? 2047u : 511u, hi_shift, prefix, hist);
-        WASS_HIP(c, hipMemcpyAsync(hh.data(), hist, 2048 * 4, hipMemcpyDeviceToHost, c->stream));
-        WASS_HIP(c, hipStreamSynchronize(c->stream));
+        WASS_HIP(c, hipMemcpyAsync(hh.data(), hist, 2048 * 4, hipMemcpyDeviceToHost, c->ts()));
+        WASS_HIP(c, hipStreamSynchronize(c->ts()));
         const int nb = pass < 5 ? 2048 : 512;
         int b = 0;
         for (; b < nb; ++b) { if (k < hh[b]) break; k -= hh[b]; }
@@ -1225,17 +1225,17 @@ static int enqueue_ccl(wass_ctx* c, wass_mesh* m, DevState* ds)
     unsigned int* mincm = size + n;
     unsigned long long* best = &ds->ccl_best;
     const dim3 blk(256), g1(nblk(n));
-    WASS_HIP(c, hipMemsetAsync(best, 0, 8, c->stream));
-    hipLaunchKernelGGL(k_ccl_init, g1, blk, 0, c->stream, m->valid, m->z, m->w, (int)n, (const double*)&ds->zgap, parent, size, mincm);
-    hipLaunchKernelGGL(k_ccl_merge, g1, blk, 0, c->stream, m->valid, m->z, m->w, (int)n, (const double*)&ds->zgap, parent);
-    hipLaunchKernelGGL(k_ccl_flatten, g1, blk, 0, c->stream, (int)n, parent);
-    hipLaunchKernelGGL(k_ccl_count, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, c->stream, (int)n, m->w, m->h,
+    WASS_HIP(c, hipMemsetAsync(best, 0, 8, c->ts()));
+    hipLaunchKernelGGL(k_ccl_init, g1, blk, 0, c->ts(), m->valid, m->z, m->w, (int)n, (const double*)&ds->zgap, parent, size, mincm);
+    hipLaunchKernelGGL(k_ccl_merge, g1, blk, 0, c->ts(), m->valid, m->z, m->w, (int)n, (const double*)&ds->zgap, parent);
+    hipLaunchKernelGGL(k_ccl_flatten, g1, blk, 0, c->ts(), (int)n, parent);
+    hipLaunchKernelGGL(k_ccl_count, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, c->ts(), (int)n, m->w, m->h,
                        (const int*)parent, size, mincm);
-    hipLaunchKernelGGL(k_ccl_best, g1, blk, 0, c->stream, (int)n, (const int*)parent, (const unsigned int*)size,
+    hipLaunchKernelGGL(k_ccl_best, g1, blk, 0, c->ts(), (int)n, (const int*)parent, (const unsigned int*)size,
                        (const unsigned int*)mincm, best);
     // no valid point at all: best stays 0 and no root key can equal it (sizes are >= 1) -> nothing kept, as in the
     // reference where extract_component(0) then matches no point
-    hipLaunchKernelGGL(k_ccl_keep, g1, blk, 0, c->stream, m->valid, (int)n, (const int*)parent, (const unsigned int*)size,
+    hipLaunchKernelGGL(k_ccl_keep, g1, blk, 0, c->ts(), m->valid, (int)n, (const int*)parent, (const unsigned int*)size,
                        (const unsigned int*)mincm, (const unsigned long long*)best);
     WASS_HIP(c, hipGetLastError());
     return WASS_OK;
@@ -1248,13 +1248,13 @@ int wass_mesh_keep_biggest_component(wass_ctx* c, wass_mesh* m, double zgap, uin
     DevState* ds = nullptr;
     int rc = dstate(c, &ds);
     if (rc) return rc;
-    WASS_HIP(c, hipMemcpyAsync(&ds->zgap, &zgap, 8, hipMemcpyHostToDevice, c->stream));
-    WASS_HIP(c, hipStreamSynchronize(c->stream));       // zgap lives on the caller's stack
+    WASS_HIP(c, hipMemcpyAsync(&ds->zgap, &zgap, 8, hipMemcpyHostToDevice, c->ts()));
+    WASS_HIP(c, hipStreamSynchronize(c->ts()));       // zgap lives on the caller's stack
     if ((rc = enqueue_ccl(c, m, ds))) return rc;
     if (size_out) {
         unsigned long long hb = 0;
-        WASS_HIP(c, hipMemcpyAsync(&hb, &ds->ccl_best, 8, hipMemcpyDeviceToHost, c->stream));
-        WASS_HIP(c, hipStreamSynchronize(c->stream));
+        WASS_HIP(c, hipMemcpyAsync(&hb, &ds->ccl_best, 8, hipMemcpyDeviceToHost, c->ts()));
+        WASS_HIP(c, hipStreamSynchronize(c->ts()));
         *size_out = hb >> 32;
     }
     return WASS_OK;
@@ -1271,14 +1271,14 @@ static int enqueue_remove_outliers(wass_ctx* c, wass_mesh* m, double percentile,
     DevState init;
     memset(&init, 0, sizeof init);
     init.sel_hi_shift = 64;
-    WASS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_copy, 0));            // the copy stream may still be reading the last frame's record
-    WASS_HIP(c, hipMemcpyAsync(ds, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
-    WASS_HIP(c, hipMemsetAsync(hist, 0, 2048 * 4, c->stream));
+    WASS_HIP(c, hipStreamWaitEvent(c->ts(), c->ev_copy, 0));            // the copy stream may still be reading the last frame's record
+    WASS_HIP(c, hipMemcpyAsync(ds, &init, sizeof init, hipMemcpyHostToDevice, c->ts()));
+    WASS_HIP(c, hipMemsetAsync(hist, 0, 2048 * 4, c->ts()));
     for (int pass = 0; pass < 6; ++pass) {
         const int shift = pass < 5 ? 64 - 11 * (pass + 1) : 0, nbits = pass < 5 ? 11 : 9;
-        hipLaunchKernelGGL(k_gap_hist, dim3(2048), dim3(256), 0, c->stream, m->valid, m->z, m->w, m->h, shift, (1u << nbits) - 1u,
+        hipLaunchKernelGGL(k_gap_hist, dim3(2048), dim3(256), 0, c->ts(), m->valid, m->z, m->w, m->h, shift, (1u << nbits) - 1u,
                            (const DevState*)ds, hist);
-        hipLaunchKernelGGL(k_radix_pick, dim3(1), dim3(256), 0, c->stream, hist, pass, shift, nbits, percentile, ds);
+        hipLaunchKernelGGL(k_radix_pick, dim3(1), dim3(256), 0, c->ts(), hist, pass, shift, nbits, percentile, ds);
     }
     if ((rc = enqueue_ccl(c, m, ds))) return rc;
     *dsp = ds;
@@ -1293,8 +1293,8 @@ int wass_mesh_remove_outliers(wass_ctx* c, wass_mesh* m, double percentile, doub
     int rc = enqueue_remove_outliers(c, m, percentile, &ds);
     if (rc) return rc;
     DevState h;
-    WASS_HIP(c, hipMemcpyAsync(&h, ds, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    WASS_HIP(c, hipStreamSynchronize(c->stream));
+    WASS_HIP(c, hipMemcpyAsync(&h, ds, sizeof h, hipMemcpyDeviceToHost, c->ts()));
+    WASS_HIP(c, hipStreamSynchronize(c->ts()));
     if (h.sel_fail == 2) return set_err(c, WASS_ERR_DEVICE, "radix select lost its rank (internal error)");
     if (zgap_out) *zgap_out = h.zgap;
     if (n_gaps) *n_gaps = h.sel_total;
@@ -1341,20 +1341,20 @@ int wass_mesh_ransac_plane(wass_ctx* c, wass_mesh* m, const int32_t* uv, int rou
     PlaneCand* cand = (PlaneCand*)c->scratch.p;
     unsigned long long* counts = (unsigned long long*)(cand + rounds);
     int32_t* duv = (int32_t*)(counts + rounds);
-    WASS_HIP(c, hipMemcpyAsync(duv, uv, (size_t)rounds * 24, hipMemcpyHostToDevice, c->stream));
-    WASS_HIP(c, hipMemsetAsync(counts, 0, (size_t)rounds * 8, c->stream));
-    hipLaunchKernelGGL(k_ransac_planes, dim3((rounds + 63) / 64), dim3(64), 0, c->stream, m->valid, m->x, m->y, m->z, m->w,
+    WASS_HIP(c, hipMemcpyAsync(duv, uv, (size_t)rounds * 24, hipMemcpyHostToDevice, c->ts()));
+    WASS_HIP(c, hipMemsetAsync(counts, 0, (size_t)rounds * 8, c->ts()));
+    hipLaunchKernelGGL(k_ransac_planes, dim3((rounds + 63) / 64), dim3(64), 0, c->ts(), m->valid, m->x, m->y, m->z, m->w,
                        (const int32_t*)duv, rounds, cand);
     constexpr int PTS = 8;
     const size_t lds = (size_t)rounds * (32 + 4);
     if (lds > 64 * 1024) return set_err(c, WASS_ERR_UNSUPPORTED, "PLANE_RANSAC_ROUNDS %d too large (max 1800)", rounds);
-    hipLaunchKernelGGL(k_ransac_score<PTS>, dim3((unsigned)((n + 256 * PTS - 1) / (256 * PTS))), dim3(256), lds, c->stream,
+    hipLaunchKernelGGL(k_ransac_score<PTS>, dim3((unsigned)((n + 256 * PTS - 1) / (256 * PTS))), dim3(256), lds, c->ts(),
                        m->valid, m->x, m->y, m->z, n, (const PlaneCand*)cand, rounds, thr, counts);
     std::vector<PlaneCand> hc(rounds);
     std::vector<unsigned long long> hn(rounds);
-    WASS_HIP(c, hipMemcpyAsync(hc.data(), cand, (size_t)rounds * sizeof(PlaneCand), hipMemcpyDeviceToHost, c->stream));
-    WASS_HIP(c, hipMemcpyAsync(hn.data(), counts, (size_t)rounds * 8, hipMemcpyDeviceToHost, c->stream));
-    WASS_HIP(c, hipStreamSynchronize(c->stream));
+    WASS_HIP(c, hipMemcpyAsync(hc.data(), cand, (size_t)rounds * sizeof(PlaneCand), hipMemcpyDeviceToHost, c->ts()));
+    WASS_HIP(c, hipMemcpyAsync(hn.data(), counts, (size_t)rounds * 8, hipMemcpyDeviceToHost, c->ts()));
+    WASS_HIP(c, hipStreamSynchronize(c->ts()));
     unsigned long long best = 0;
     double bn[3] = { 0, 0, 0 }, bd = 0;
     for (int r = 0; r < rounds; ++r)          // first strictly better candidate wins (:750-755)
@@ -1372,7 +1372,7 @@ int wass_mesh_crop_plane(wass_ctx* c, wass_mesh* m, const double plane[4], doubl
     unsigned long long* cnt = nullptr;
     int rc = counters_reset(c, &cnt);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_crop_plane, dim3(2048), dim3(256), 0, c->stream, m->valid, m->x, m->y, m->z, m->n(), plane[0],
+    hipLaunchKernelGGL(k_crop_plane, dim3(2048), dim3(256), 0, c->ts(), m->valid, m->x, m->y, m->z, m->n(), plane[0],
                        plane[1], plane[2], plane[3], thr, cnt);
     unsigned long long hk = 0;
     if ((rc = counters_sum(c, cnt, &hk))) return rc;
@@ -1396,18 +1396,18 @@ int wass_mesh_refine_plane(wass_ctx* c, wass_mesh* m, const wass_refine_params* 
     if (rc) return rc;
     double* part = (double*)c->scratch.p;
     std::vector<double> hp((size_t)NB * 6);
-    hipLaunchKernelGGL(k_refine_moments, dim3(NB), dim3(256), 0, c->stream, m->valid, m->x, m->y, m->z, m->w, m->n(), rd, part);
-    WASS_HIP(c, hipMemcpyAsync(hp.data(), part, (size_t)NB * 5 * 8, hipMemcpyDeviceToHost, c->stream));
-    WASS_HIP(c, hipStreamSynchronize(c->stream));
+    hipLaunchKernelGGL(k_refine_moments, dim3(NB), dim3(256), 0, c->ts(), m->valid, m->x, m->y, m->z, m->w, m->n(), rd, part);
+    WASS_HIP(c, hipMemcpyAsync(hp.data(), part, (size_t)NB * 5 * 8, hipMemcpyDeviceToHost, c->ts()));
+    WASS_HIP(c, hipStreamSynchronize(c->ts()));
     double mom[5];
     sum_partials_host<5>(hp.data(), NB, mom);
     if (n_inliers) *n_inliers = (uint64_t)(mom[0] + 0.5);
     if (mom[0] < 3 || !(mom[1] > 0)) return set_err(c, WASS_ERR_TOO_FEW_POINTS, "plane refinement has %g inliers", mom[0]);
     const double cx = mom[2] / mom[1], cy = mom[3] / mom[1], cz = mom[4] / mom[1];
-    hipLaunchKernelGGL(k_refine_cov, dim3(NB), dim3(256), 0, c->stream, m->valid, m->x, m->y, m->z, m->w, m->n(), rd, cx, cy, cz,
+    hipLaunchKernelGGL(k_refine_cov, dim3(NB), dim3(256), 0, c->ts(), m->valid, m->x, m->y, m->z, m->w, m->n(), rd, cx, cy, cz,
                        part);
-    WASS_HIP(c, hipMemcpyAsync(hp.data(), part, (size_t)NB * 6 * 8, hipMemcpyDeviceToHost, c->stream));
-    WASS_HIP(c, hipStreamSynchronize(c->stream));
+    WASS_HIP(c, hipMemcpyAsync(hp.data(), part, (size_t)NB * 6 * 8, hipMemcpyDeviceToHost, c->ts()));
+    WASS_HIP(c, hipStreamSynchronize(c->ts()));
     double s[6];
     sum_partials_host<6>(hp.data(), NB, s);
     const double A[9] = { s[0], s[1], s[2], s[1], s[3], s[4], s[2], s[4], s[5] };
@@ -1448,7 +1448,7 @@ static int enqueue_fit_plane(wass_ctx* c, wass_mesh* m, const int32_t* uv, int r
     constexpr int PTS = 8;
     const size_t lds = (size_t)rounds * (32 + 4);
     if (lds > 64 * 1024) return set_err(c, WASS_ERR_UNSUPPORTED, "PLANE_RANSAC_ROUNDS %d too large (max 1800)", rounds);
-    hipStream_t s = c->stream;
+    hipStream_t s = c->ts();
     WASS_HIP(c, hipMemcpyAsync(duv, uv, (size_t)rounds * 24, hipMemcpyHostToDevice, s));
     WASS_HIP(c, hipMemsetAsync(counts, 0, (size_t)rounds * 8, s));
     WASS_HIP(c, hipMemsetAsync(kept1, 0, (size_t)2 * NSLOT * 8, s));
@@ -1486,7 +1486,7 @@ int wass_mesh_fit_plane(wass_ctx* c, wass_mesh* m, const int32_t* uv, int rounds
     unsigned long long* kept1 = nullptr;
     int rc = enqueue_fit_plane(c, m, uv, rounds, ransac_thr, rp, max_distance, &ds, &kept1);
     if (rc) return rc;
-    hipStream_t s = c->stream;
+    hipStream_t s = c->ts();
     DevState h;
     unsigned long long hk[2 * NSLOT];
     WASS_HIP(c, hipMemcpyAsync(&h, ds, sizeof h, hipMemcpyDeviceToHost, s));
@@ -1527,7 +1527,7 @@ int wass_mesh_finish_frame_async(wass_ctx* c, wass_mesh* m, double percentile, c
     // block counts live behind the candidate area of the scratch buffer, which enqueue_fit_plane sized; grow if needed
     const size_t need = 64 + (size_t)nb * 4 + 16;
     if (c->scratch.cap < need && (rc = ensure(c, c->scratch, need))) return rc;
-    hipStream_t s = c->stream;
+    hipStream_t s = c->ts();
     hipLaunchKernelGGL(k_frame_rt, dim3(1), dim3(64), 0, s, ds, (const unsigned long long*)kept1);
     unsigned long long init[NSLOT * 6];
     for (int i = 0; i < NSLOT; ++i) for (int k = 0; k < 6; ++k) init[i * 6 + k] = k < 3 ? ~0ull : 0ull;
@@ -1611,15 +1611,15 @@ static int encode_xyzc_impl(wass_ctx* c, wass_mesh* m, const double plane[4], vo
     uint16_t* dq = (uint16_t*)c->xyzc.p;
     unsigned long long init[NSLOT * 6];
     for (int i = 0; i < NSLOT; ++i) for (int k = 0; k < 6; ++k) init[i * 6 + k] = k < 3 ? ~0ull : 0ull;
-    WASS_HIP(c, hipMemcpyAsync(lim, init, sizeof init, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_xyzc_limits, dim3(1024), dim3(256), 0, c->stream, m->valid, m->x, m->y, m->z, n, rt, lim);
-    hipLaunchKernelGGL(k_block_counts, dim3(nb), dim3(256), 0, c->stream, m->valid, n, bcnt);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, c->stream, bcnt, (int)nb, total);
+    WASS_HIP(c, hipMemcpyAsync(lim, init, sizeof init, hipMemcpyHostToDevice, c->ts()));
+    hipLaunchKernelGGL(k_xyzc_limits, dim3(1024), dim3(256), 0, c->ts(), m->valid, m->x, m->y, m->z, n, rt, lim);
+    hipLaunchKernelGGL(k_block_counts, dim3(nb), dim3(256), 0, c->ts(), m->valid, n, bcnt);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, c->ts(), bcnt, (int)nb, total);
     unsigned long long hs[NSLOT * 6], hl[6] = { ~0ull, ~0ull, ~0ull, 0, 0, 0 };
     unsigned int npts = 0;
-    WASS_HIP(c, hipMemcpyAsync(hs, lim, sizeof hs, hipMemcpyDeviceToHost, c->stream));
-    WASS_HIP(c, hipMemcpyAsync(&npts, total, 4, hipMemcpyDeviceToHost, c->stream));
-    WASS_HIP(c, hipStreamSynchronize(c->stream));
+    WASS_HIP(c, hipMemcpyAsync(hs, lim, sizeof hs, hipMemcpyDeviceToHost, c->ts()));
+    WASS_HIP(c, hipMemcpyAsync(&npts, total, 4, hipMemcpyDeviceToHost, c->ts()));
+    WASS_HIP(c, hipStreamSynchronize(c->ts()));
     for (int i = 0; i < NSLOT; ++i)
         for (int k = 0; k < 3; ++k) {
             if (hs[i * 6 + k] < hl[k]) hl[k] = hs[i * 6 + k];
@@ -1636,8 +1636,8 @@ static int encode_xyzc_impl(wass_ctx* c, wass_mesh* m, const double plane[4], vo
     if (total_bytes > capacity)
         return set_err(c, WASS_ERR_INVALID_ARG, "xyzC needs %zu bytes, buffer has %zu", total_bytes, capacity);
     if (npts) {
-        WASS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_copy, 0));            // a previous download still reading dq
-        hipLaunchKernelGGL(k_xyzc_pack, dim3(nb), dim3(256), 0, c->stream, m->valid, m->x, m->y, m->z, n, rt, mn[0], mn[1], mn[2],
+        WASS_HIP(c, hipStreamWaitEvent(c->ts(), c->ev_copy, 0));            // a previous download still reading dq
+        hipLaunchKernelGGL(k_xyzc_pack, dim3(nb), dim3(256), 0, c->ts(), m->valid, m->x, m->y, m->z, n, rt, mn[0], mn[1], mn[2],
                            sc[0], sc[1], sc[2], (const unsigned int*)bcnt, dq);
     }
     unsigned char* buf = (unsigned char*)dst;
@@ -1650,7 +1650,7 @@ static int encode_xyzc_impl(wass_ctx* c, wass_mesh* m, const double plane[4], vo
     memcpy(buf + o, Tinv, 24); o += 24;
     if (npts) {
         // the download runs on its own stream (a DMA engine), so the next frame's kernels do not wait for PCIe
-        WASS_HIP(c, hipEventRecord(c->ev_pack, c->stream));
+        WASS_HIP(c, hipEventRecord(c->ev_pack, c->ts()));
         WASS_HIP(c, hipStreamWaitEvent(c->copy, c->ev_pack, 0));
         WASS_HIP(c, hipMemcpyAsync(buf + o, dq, (size_t)npts * 6, hipMemcpyDeviceToHost, c->copy));
         WASS_HIP(c, hipEventRecord(c->ev_copy, c->copy));

@@ -110,6 +110,7 @@ extern "C" int wass_disparity_postprocess_dev(wass_ctx* c, const int16_t* d_disp
                                               int median_wsize, float* d_out)
 {
     if (!c || !d_disp16 || !p || !d_out || w <= 0 || h <= 0) return set_err(c, WASS_ERR_INVALID_ARG, "bad argument");
+    if (c->tail_overlap && c->have_last) WASS_HIP(c, hipStreamWaitEvent(c->tail, c->ev[6], 0));   // the SGM call that produced d_disp16
     if (p->dense_scale != 1.0) return set_err(c, WASS_ERR_UNSUPPORTED, "DENSE_SCALE != 1.0 is not supported");
     if (median_wsize >= 3 && median_wsize != 3 && median_wsize != 5)
         return set_err(c, WASS_ERR_UNSUPPORTED, "MEDIAN_FILTER_WSIZE must be 0, 3 or 5 for float maps (cv::medianBlur)");
@@ -119,7 +120,7 @@ extern "C" int wass_disparity_postprocess_dev(wass_ctx* c, const int16_t* d_disp
     if ((rc = ensure(c, c->fA, n * 4)) || (rc = ensure(c, c->fB, n * 4))) return rc;
     float* a = (float*)c->fA.p;
     float* b = (float*)c->fB.p;
-    hipStream_t s = c->stream;
+    hipStream_t s = c->ts();
     const dim3 grid2((w + 255) / 256, h), blk(256);
     const int off = p->disp_offset > 0 ? p->disp_offset : 0;    // :803-808
     hipLaunchKernelGGL(k_convert, dim3((unsigned)((n + 255) / 256)), blk, 0, s, d_disp16, n, p->min_disp, p->num_disp,
@@ -149,11 +150,11 @@ extern "C" int wass_disparity_postprocess(wass_ctx* c, const int16_t* disp16, in
     const size_t n = (size_t)w * h;
     int rc;
     if ((rc = ensure(c, c->tmp_out, n * 2)) || (rc = ensure(c, c->fC, n * 4))) return rc;
-    WASS_HIP(c, hipMemcpyAsync(c->tmp_out.p, disp16, n * 2, hipMemcpyHostToDevice, c->stream));
+    WASS_HIP(c, hipMemcpyAsync(c->tmp_out.p, disp16, n * 2, hipMemcpyHostToDevice, c->ts()));
     rc = wass_disparity_postprocess_dev(c, (const int16_t*)c->tmp_out.p, w, h, p, dilate_steps, erode_steps, median_wsize,
                                         (float*)c->fC.p);
     if (rc) return rc;
-    WASS_HIP(c, hipMemcpyAsync(out, c->fC.p, n * 4, hipMemcpyDeviceToHost, c->stream));
-    WASS_HIP(c, hipStreamSynchronize(c->stream));
+    WASS_HIP(c, hipMemcpyAsync(out, c->fC.p, n * 4, hipMemcpyDeviceToHost, c->ts()));
+    WASS_HIP(c, hipStreamSynchronize(c->ts()));
     return WASS_OK;
 }

@@ -57,6 +57,10 @@ class Context:
     def synchronize(self):
         self._check(self._lib.wass_ctx_synchronize(self._h))
 
+    def set_tail_overlap(self, on: bool = True):
+        """Run everything after the SGM call on a second stream (see wass_ctx_set_tail_overlap)."""
+        self._check(self._lib.wass_ctx_set_tail_overlap(self._h, int(on)))
+
     def set_debug(self, on: bool = True):
         """Keep intermediates that production never writes (the finished S volume) for sgm_debug_fetch."""
         self._check(self._lib.wass_ctx_set_debug(self._h, int(on)))
