@@ -105,6 +105,9 @@ typedef struct {
                              runs path 2 (column checkpoints / S = L_2)       */
 } wass_sgm_timings;
 int wass_sgm_last_timings(wass_ctx* ctx, wass_sgm_timings* out);
+/* the call before the last one: lets a pipelined driver read frame n's stage times after frame n+1 has been
+ * enqueued, without waiting for frame n+1 */
+int wass_sgm_prev_timings(wass_ctx* ctx, wass_sgm_timings* out);
 
 /* Test hooks: copy intermediates of the last wass_sgm_disparity call to host.
  * C/S are [h][width1][num_disp] int16 with width1 = w + max(disp_offset,0) -

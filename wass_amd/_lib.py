@@ -90,6 +90,7 @@ SYMBOLS = {
     "wass_sgm_disparity": (_i, [_vp, _vp, _vp, _i, _i, _sz, C.POINTER(SgmParams), _vp]),
     "wass_sgm_disparity_dev": (_i, [_vp, _vp, _vp, _i, _i, _sz, C.POINTER(SgmParams), _vp]),
     "wass_sgm_last_timings": (_i, [_vp, C.POINTER(SgmTimings)]),
+    "wass_sgm_prev_timings": (_i, [_vp, C.POINTER(SgmTimings)]),
     "wass_sgm_debug_fetch": (_i, [_vp, _vp, _vp, _vp]),
     "wass_disparity_postprocess": (_i, [_vp, _vp, _i, _i, C.POINTER(SgmParams), _i, _i, _i, _vp]),
     "wass_disparity_postprocess_dev": (_i, [_vp, _vp, _i, _i, C.POINTER(SgmParams), _i, _i, _i, _vp]),

@@ -102,15 +102,16 @@ int wass_ctx_create(int device_id, wass_ctx** out)
     if (hipStreamCreateWithFlags(&c->tail, hipStreamNonBlocking) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
     if (hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
     if (hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
-    for (auto& e : c->ev)
-        if (hipEventCreate(&e) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
+    for (auto& set : c->evs)
+        for (auto& e : set)
+            if (hipEventCreate(&e) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
     if (hipEventCreateWithFlags(&c->ev_cost, hipEventDisableTiming) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
     if (hipEventCreateWithFlags(&c->ev_cols, hipEventDisableTiming) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
     for (auto& e : c->ev_ckpt)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
     if (ensure(c, c->flags, 64) != WASS_OK) { delete c; return WASS_ERR_NO_MEMORY; }
     if (hipHostMalloc((void**)&c->h_flags, 64, hipHostMallocDefault) != hipSuccess) { delete c; return WASS_ERR_NO_MEMORY; }
-    c->h_flags[0] = 0;
+    c->h_flags[0] = c->h_flags[4] = 0;
     *out = c;
     return WASS_OK;
 }
@@ -123,7 +124,7 @@ void wass_ctx_destroy(wass_ctx* c)
     for (Buf* b : { &c->img1, &c->img2, &c->bt1, &c->bt2, &c->hsum, &c->C, &c->S, &c->S2, &c->halo, &c->ckpt, &c->sel_d16, &c->sel_key, &c->raw,
                     &c->flags, &c->tmp_in0, &c->tmp_in1, &c->tmp_out, &c->tmp_mask, &c->fA, &c->fB, &c->fC, &c->scratch, &c->counters, &c->dstate, &c->rect_tab, &c->rect_mx, &c->rect_my, &c->xyzc, &c->limits })
         release(*b);
-    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& set : c->evs) for (auto& e : set) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_ckpt) if (e) (void)hipEventDestroy(e);
     if (c->ev_cost) (void)hipEventDestroy(c->ev_cost);
     if (c->ev_cols) (void)hipEventDestroy(c->ev_cols);
@@ -188,6 +189,8 @@ int wass_sgm_disparity_dev(wass_ctx* c, const uint8_t* d_right, const uint8_t* d
 
     hipStream_t s = c->stream;
     c->timings_valid = false;
+    const int set = (int)(c->nsgm & 1);
+    c->ev = c->evs[set];
     WASS_HIP(c, hipEventRecord(c->ev[0], s));
     // wass_stereo.cpp:820-831: zero images, left at column D+off-comp, right at column D
     WASS_HIP(c, hipMemsetAsync(c->img1.p, 0, npad, s));
@@ -209,35 +212,53 @@ int wass_sgm_disparity_dev(wass_ctx* c, const uint8_t* d_right, const uint8_t* d
     WASS_HIP(c, hipEventRecord(c->ev[5], s));
     // status word for wass_sgm_last_timings / the host entry point, in stream order (a blocking hipMemcpy on the
     // null stream would queue behind whatever else the process has in flight)
-    WASS_HIP(c, hipMemcpyAsync(c->h_flags, c->flags.p, 4, hipMemcpyDeviceToHost, s));
+    WASS_HIP(c, hipMemcpyAsync(c->h_flags + 4 * set, c->flags.p, 4, hipMemcpyDeviceToHost, s));
     WASS_HIP(c, hipEventRecord(c->ev[6], s));
     c->last = d; c->have_last = true;
-    c->timings.aggregate_launches = nl;
+    c->launches[set] = nl;
+    c->nsgm++;
     c->timings_valid = true;
     return WASS_OK;
 }
 
-int wass_sgm_last_timings(wass_ctx* c, wass_sgm_timings* out)
+// timings of SGM call number `call` (0-based), which must be one of the last two
+static int read_timings(wass_ctx* c, unsigned long long call, wass_sgm_timings* out)
 {
-    if (!c || !out) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
-    if (!c->timings_valid) return set_err(c, WASS_ERR_INVALID_ARG, "no completed wass_sgm_disparity call");
-    WASS_HIP(c, hipEventSynchronize(c->ev[6]));
-    wass_sgm_timings& t = c->timings;
-    WASS_HIP(c, hipEventElapsedTime(&t.prefilter_ms, c->ev[0], c->ev[1]));
-    WASS_HIP(c, hipEventElapsedTime(&t.cost_ms, c->ev[1], c->ev[2]));
-    WASS_HIP(c, hipEventElapsedTime(&t.aggregate_ms, c->ev[2], c->ev[3]));
-    WASS_HIP(c, hipEventElapsedTime(&t.select_ms, c->ev[3], c->ev[4]));
-    WASS_HIP(c, hipEventElapsedTime(&t.median_ms, c->ev[4], c->ev[5]));
-    WASS_HIP(c, hipEventElapsedTime(&t.total_ms, c->ev[0], c->ev[5]));
-    WASS_HIP(c, hipEventElapsedTime(&t.vsum_ms, c->ev[7], c->ev[2]));
-    const uint32_t fl = c->h_flags[0];
+    const int set = (int)(call & 1);
+    hipEvent_t* ev = c->evs[set];
+    WASS_HIP(c, hipEventSynchronize(ev[6]));
+    wass_sgm_timings t = {};
+    WASS_HIP(c, hipEventElapsedTime(&t.prefilter_ms, ev[0], ev[1]));
+    WASS_HIP(c, hipEventElapsedTime(&t.cost_ms, ev[1], ev[2]));
+    WASS_HIP(c, hipEventElapsedTime(&t.aggregate_ms, ev[2], ev[3]));
+    WASS_HIP(c, hipEventElapsedTime(&t.select_ms, ev[3], ev[4]));
+    WASS_HIP(c, hipEventElapsedTime(&t.median_ms, ev[4], ev[5]));
+    WASS_HIP(c, hipEventElapsedTime(&t.total_ms, ev[0], ev[5]));
+    WASS_HIP(c, hipEventElapsedTime(&t.vsum_ms, ev[7], ev[2]));
+    const uint32_t fl = c->h_flags[4 * set];
     t.cost_overflow = (int)(fl & 1);
+    t.aggregate_launches = c->launches[set];
+    c->timings = t;
     *out = t;
     if (fl & 2) {
         c->halo_dirty = true;
         return set_err(c, WASS_ERR_DEVICE, "aggregation pipeline timed out waiting for a neighbouring strip");
     }
     return WASS_OK;
+}
+
+int wass_sgm_last_timings(wass_ctx* c, wass_sgm_timings* out)
+{
+    if (!c || !out) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    if (!c->timings_valid || c->nsgm == 0) return set_err(c, WASS_ERR_INVALID_ARG, "no completed wass_sgm_disparity call");
+    return read_timings(c, c->nsgm - 1, out);
+}
+
+int wass_sgm_prev_timings(wass_ctx* c, wass_sgm_timings* out)
+{
+    if (!c || !out) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    if (c->nsgm < 2) return set_err(c, WASS_ERR_INVALID_ARG, "fewer than two wass_sgm_disparity calls so far");
+    return read_timings(c, c->nsgm - 2, out);
 }
 
 int wass_sgm_disparity(wass_ctx* c, const uint8_t* right, const uint8_t* left, int w, int h, size_t pitch,
@@ -257,7 +278,7 @@ int wass_sgm_disparity(wass_ctx* c, const uint8_t* right, const uint8_t* left, i
     if (rc) return rc;
     WASS_HIP(c, hipMemcpyAsync(disp16_out, c->tmp_out.p, n * 2, hipMemcpyDeviceToHost, c->stream));
     WASS_HIP(c, hipStreamSynchronize(c->stream));
-    const uint32_t fl = c->h_flags[0];
+    const uint32_t fl = c->h_flags[4 * (int)((c->nsgm - 1) & 1)];
     if (fl & 2) {
         c->halo_dirty = true;
         return set_err(c, WASS_ERR_DEVICE, "aggregation pipeline timed out waiting for a neighbouring strip");

@@ -140,7 +140,12 @@ struct wass_ctx {
     wass::Buf rect_tab;            // fixed-point interpolation tables of the rectification resamplers (rectify.hip)
     bool rect_tab_ready = false;
     wass::Buf rect_mx, rect_my;    // staging for host-pointer map uploads
-    hipEvent_t ev[8] = {};
+    // stage events of the SGM call, two sets used alternately so that the timings of call n can be read after call
+    // n+1 has been enqueued (a lagging reader never stalls the pipeline)
+    hipEvent_t evs[2][8] = {};
+    hipEvent_t* ev = evs[0];       // set of the last call
+    unsigned long long nsgm = 0;   // SGM calls so far
+    int launches[2] = {};
     hipStream_t side = nullptr, side2 = nullptr;   // checkpoint sweeps run ahead here
     hipEvent_t ev_cost = nullptr, ev_ckpt[4] = {}, ev_cols = nullptr;
     wass::SgmDims last = {};

@@ -91,9 +91,12 @@ class Context:
         self._check(rc)
         return d_out
 
-    def sgm_timings(self) -> SgmTimings:
+    def sgm_timings(self, previous: bool = False) -> SgmTimings:
+        """Stage times of the last SGM call (previous=True: of the call before it, which a pipelined driver can
+        read without waiting for the frame it has just enqueued)."""
         t = SgmTimings()
-        self._check(self._lib.wass_sgm_last_timings(self._h, C.byref(t)))
+        f = self._lib.wass_sgm_prev_timings if previous else self._lib.wass_sgm_last_timings
+        self._check(f(self._h, C.byref(t)))
         return t
 
     def sgm_debug_fetch(self, w: int, h: int, params: SgmParams, want=("C", "S", "raw")):
