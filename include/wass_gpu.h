@@ -49,8 +49,9 @@ int wass_ctx_synchronize(wass_ctx* ctx);
 /* Two-stage pipelining inside one context.  on != 0: every stage after the SGM call (wass_disparity_postprocess*,
  * wass_triangulate*, wass_mesh_*) is enqueued on a second stream that waits for the last wass_sgm_disparity_dev
  * call, so the tail of frame i (small, latency-bound kernels and the PCIe download) runs underneath the SGM stage
- * of frame i+1.  The caller keeps the disparity buffer of frame i alive until its tail has run (two buffers,
- * alternated).  wass_ctx_synchronize waits for both streams. */
+ * of frame i+1.  Reusing one disparity buffer for every frame is safe (the SGM call waits for the previous
+ * frame's clean-up to have read it before its last kernel writes it); alternating two avoids that wait.
+ * wass_ctx_synchronize waits for both streams. */
 int wass_ctx_set_tail_overlap(wass_ctx* ctx, int on);
 /* test mode: keep intermediates (the finished S volume) that production never writes to HBM */
 int wass_ctx_set_debug(wass_ctx* ctx, int on);

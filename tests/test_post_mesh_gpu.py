@@ -407,3 +407,46 @@ def test_full_chain_small(gpu_ctx, oracle):
     # the plane must be the synthetic sea plane: affine disparity <=> planar surface
     assert n > 0.7 * w * h and best > 0.8 * n
     assert len(blob) == 148 + 6 * int(v_got.sum())
+
+
+def test_pipelined_frames_equal_serial_frames(oracle):
+    """wass_ctx_set_tail_overlap: the post-SGM stages of frame i run on the tail stream underneath the SGM stage of
+    frame i+1.  Same planes and the same mesh_cam.xyzC bytes as the serial order, with one disparity buffer reused
+    for every frame (ordering enforced by the library) and with two alternating ones."""
+    import torch
+    w, h, D = 320, 240, 64
+    dev = torch.device("cuda", 0)
+    p = default_sgm_params(D, ndirs=8)
+    geom = wass_amd.make_geom(synth.rig_geometry(w, h))
+    roi = (0, 0, w, h)
+    uv = wass_amd.ransac_sample(w, h, 400, 12345)
+    frames = [tuple(torch.from_numpy(a).to(dev) for a in synth.make_pair(w, h, D, frame_idx=k)) for k in range(5)]
+
+    def run(overlap, nbuf):
+        ctx = wass_amd.Context(0)
+        ctx.set_tail_overlap(overlap)
+        outs = [torch.empty((h, w), dtype=torch.int16, device=dev) for _ in range(nbuf)]
+        dispf = torch.empty((h, w), dtype=torch.float32, device=dev)
+        pins = [torch.zeros(148 + 6 * w * h, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        res = []
+        for i, (dr, dl) in enumerate(frames):
+            out = outs[i % nbuf]
+            ctx.sgm_disparity_dev(dr, dl, p, out)
+            ctx.disparity_postprocess_dev(out, p, 1, 2, 0, dispf)
+            mesh, _ = ctx.triangulate_dev(dispf, w, h, roi, roi, geom, dr, None, None, 20.0, None, 1.0, count=False)
+            if i > 0:
+                fr = ctx.frame_result()
+                res.append((np.array(fr.plane[:]), pins[(i - 1) % 2][:fr.xyzc_bytes].numpy().tobytes()))
+            mesh.finish_frame_async(uv, pins[i % 2].data_ptr(), pins[i % 2].numel())
+            mesh.close()
+        fr = ctx.frame_result()
+        res.append((np.array(fr.plane[:]), pins[(len(frames) - 1) % 2][:fr.xyzc_bytes].numpy().tobytes()))
+        ctx.close()
+        return res
+
+    serial = run(False, 1)
+    assert len({b for _, b in serial}) == len(frames)          # five different frames, five different files
+    for variant in (run(True, 1), run(True, 2)):
+        for (pa, ba), (pb, bb) in zip(serial, variant):
+            np.testing.assert_array_equal(pa, pb)
+            assert ba == bb

@@ -100,6 +100,7 @@ int wass_ctx_create(int device_id, wass_ctx** out)
     if (hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
     if (hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
     if (hipStreamCreateWithFlags(&c->tail, hipStreamNonBlocking) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
+    if (hipEventCreateWithFlags(&c->ev_post, hipEventDisableTiming) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
     if (hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
     if (hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
     for (auto& set : c->evs)
@@ -132,6 +133,7 @@ void wass_ctx_destroy(wass_ctx* c)
     if (c->side2) { (void)hipStreamSynchronize(c->side2); (void)hipStreamDestroy(c->side2); }
     if (c->copy) { (void)hipStreamSynchronize(c->copy); (void)hipStreamDestroy(c->copy); }
     if (c->tail) { (void)hipStreamSynchronize(c->tail); (void)hipStreamDestroy(c->tail); }
+    if (c->ev_post) (void)hipEventDestroy(c->ev_post);
     if (c->h_flags) (void)hipHostFree(c->h_flags);
     if (c->h_frame) (void)hipHostFree(c->h_frame);
     if (c->ev_pack) (void)hipEventDestroy(c->ev_pack);
@@ -208,6 +210,9 @@ int wass_sgm_disparity_dev(wass_ctx* c, const uint8_t* d_right, const uint8_t* d
     WASS_HIP(c, hipEventRecord(c->ev[3], s));
     if ((rc = launch_select(c, d))) return rc;
     WASS_HIP(c, hipEventRecord(c->ev[4], s));
+    // with tail overlap the previous frame's clean-up may still be reading the caller's disparity buffer if the
+    // caller does not alternate two of them; its first kernel is the only reader
+    if (c->tail_overlap) WASS_HIP(c, hipStreamWaitEvent(s, c->ev_post, 0));
     if ((rc = launch_median_crop(c, d, d_out))) return rc;
     WASS_HIP(c, hipEventRecord(c->ev[5], s));
     // status word for wass_sgm_last_timings / the host entry point, in stream order (a blocking hipMemcpy on the

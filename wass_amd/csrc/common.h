@@ -134,6 +134,7 @@ struct wass_ctx {
     // ts(): the main stream, or -- with tail overlap on -- a second stream that waits for the last SGM call, so that
     // this string of small, latency-bound kernels runs underneath the next frame's bandwidth-bound SGM stage.
     hipStream_t tail = nullptr;
+    hipEvent_t ev_post = nullptr;  // the clean-up on the tail stream has read the disparity of the last SGM call
     bool tail_overlap = false;
     hipStream_t ts() const { return tail_overlap ? tail : stream; }
     hipEvent_t ev_pack = nullptr, ev_copy = nullptr;

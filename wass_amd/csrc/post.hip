@@ -125,6 +125,8 @@ extern "C" int wass_disparity_postprocess_dev(wass_ctx* c, const int16_t* d_disp
     const int off = p->disp_offset > 0 ? p->disp_offset : 0;    // :803-808
     hipLaunchKernelGGL(k_convert, dim3((unsigned)((n + 255) / 256)), blk, 0, s, d_disp16, n, p->min_disp, p->num_disp,
                        off, 1.0 / p->dense_scale, a);
+    // d_disp16 has been consumed: the next SGM call may overwrite it (it waits for this before its last kernel)
+    if (c->tail_overlap) WASS_HIP(c, hipEventRecord(c->ev_post, s));
     for (int k = 1; k <= dilate_steps; ++k) {
         hipLaunchKernelGGL(k_dilate_zero, grid2, blk, 0, s, (const float*)a, b, w, h);
         float* t = a; a = b; b = t;
