@@ -51,8 +51,7 @@ __global__ void __launch_bounds__(256) k_sweep(const uint32_t* __restrict__ C, u
 #pragma unroll
         for (int j = 0; j < NP; ++j) sv[j] = SMODE == 0 ? pk_min(L[j], cap) : pk_min(pk_adds(sin[j], L[j]), cap);
         if (SMODE != 2 || keepS) {
-#pragma unroll
-            for (int j = 0; j < NP; ++j) so[j] = as_u32(sv[j]);
+            st_stream_vec<NP>(so, sv);
         }
     };
 
@@ -193,8 +192,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
             sv[j] = pk_min(acc, cap);
         }
         if (!LAST || keepS) {
-#pragma unroll
-            for (int j = 0; j < NP; ++j) sp[j] = as_u32(sv[j]);
+            st_stream_vec<NP>(sp, sv);
         }
     };
 
@@ -212,8 +210,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
         fw.reset();
         if (F > 0) {
             us2 nv[NP];
-#pragma unroll
-            for (int j = 0; j < NP; ++j) nv[j] = as_us2(ck[(long long)(F - 1) * vec + j]);
+            ld_stream_vec<NP>(ck + (long long)(F - 1) * vec, nv);
             fw.load_normalised(nv);
         }
 #pragma unroll
@@ -251,12 +248,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
         fw.reset();
         if (s >= 1) {
             us2 nv[NP];
-#pragma unroll
-            for (int j = 0; j < NP; ++j) nv[j] = as_us2(ck[(long long)(s - 1) * vec + j]);
+            ld_stream_vec<NP>(ck + (long long)(s - 1) * vec, nv);
             fw.load_normalised(nv);
         }
 #pragma unroll
-        for (int j = 0; j < NP; ++j) nvB[j] = s >= 2 ? as_us2(ck[(long long)(s - 2) * vec + j]) : pk_splat(0);
+        for (int j = 0; j < NP; ++j) nvB[j] = s >= 2 ? as_us2(ld_stream(ck + (long long)(s - 2) * vec + j)) : pk_splat(0);
 #pragma unroll
         for (int u = 0; u < K; ++u) sgm_step<NP>(fw, cA[u], lA[u], P1v, P2);
     }
@@ -266,7 +262,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
         if (SMODE != 0) load_seg<NP, K, false>(sp0 + (long long)(s - 1) * K * step, step, K, sB);
         if (TWO) load_seg<NP, K, false>(tp0 + (long long)(s - 1) * K * step, step, K, tB);
 #pragma unroll
-        for (int j = 0; j < NP; ++j) nvC[j] = s >= 3 ? as_us2(ck[(long long)(s - 3) * vec + j]) : pk_splat(0);
+        for (int j = 0; j < NP; ++j) nvC[j] = s >= 3 ? as_us2(ld_stream(ck + (long long)(s - 3) * vec + j)) : pk_splat(0);
         PathState<NP> fw;
         fw.load_normalised(nvB);                   // zeros when s-1 == 0
         uint32_t* sp = sp0 + (long long)s * K * step;

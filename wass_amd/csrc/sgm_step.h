@@ -11,6 +11,87 @@ namespace wass {
 // scalar takes its cross-lane reduction off the critical path of the next step:
 //   L'(d) = C(d) + min(L(d), min(L(d-1), L(d+1)) + P1, m + P2) - m,   m' = min_d L'
 // (same value as the normalised form in the header comment; only L - m matters).
+// Streamed once per kernel, far larger than any cache: non-temporal hints measured +3..6 % on this access pattern
+// (scripts/micro/nt.hip).  WASS_NT=0 at build time keeps the plain forms for comparison.
+#ifndef WASS_NT
+#define WASS_NT 1
+#endif
+__device__ __forceinline__ uint32_t ld_stream(const uint32_t* p)
+{
+#if WASS_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void st_stream(uint32_t* p, uint32_t v)
+{
+#if WASS_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+// NP consecutive dwords of one lane (address aligned to 4*NP bytes) as the widest vector accesses that alignment allows
+typedef uint32_t wass_u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t wass_u32x4 __attribute__((ext_vector_type(4)));
+template <int NP>
+__device__ __forceinline__ void ld_stream_vec(const uint32_t* __restrict__ p, us2 (&dst)[NP])
+{
+    if constexpr (NP % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < NP; j += 4) {
+#if WASS_NT
+            const wass_u32x4 v = __builtin_nontemporal_load((const wass_u32x4*)(p + j));
+#else
+            const wass_u32x4 v = *(const wass_u32x4*)(p + j);
+#endif
+            dst[j] = as_us2(v.x); dst[j + 1] = as_us2(v.y); dst[j + 2] = as_us2(v.z); dst[j + 3] = as_us2(v.w);
+        }
+    } else if constexpr (NP % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < NP; j += 2) {
+#if WASS_NT
+            const wass_u32x2 v = __builtin_nontemporal_load((const wass_u32x2*)(p + j));
+#else
+            const wass_u32x2 v = *(const wass_u32x2*)(p + j);
+#endif
+            dst[j] = as_us2(v.x); dst[j + 1] = as_us2(v.y);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) dst[j] = as_us2(ld_stream(p + j));
+    }
+}
+template <int NP>
+__device__ __forceinline__ void st_stream_vec(uint32_t* __restrict__ p, const us2 (&src)[NP])
+{
+    if constexpr (NP % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < NP; j += 4) {
+            wass_u32x4 v = { as_u32(src[j]), as_u32(src[j + 1]), as_u32(src[j + 2]), as_u32(src[j + 3]) };
+#if WASS_NT
+            __builtin_nontemporal_store(v, (wass_u32x4*)(p + j));
+#else
+            *(wass_u32x4*)(p + j) = v;
+#endif
+        }
+    } else if constexpr (NP % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < NP; j += 2) {
+            wass_u32x2 v = { as_u32(src[j]), as_u32(src[j + 1]) };
+#if WASS_NT
+            __builtin_nontemporal_store(v, (wass_u32x2*)(p + j));
+#else
+            *(wass_u32x2*)(p + j) = v;
+#endif
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) st_stream(p + j, as_u32(src[j]));
+    }
+}
+
 template <int NP>
 struct PathState {
     us2 L[NP];
@@ -29,8 +110,10 @@ struct PathState {
     __device__ __forceinline__ void store_normalised(uint32_t* __restrict__ p) const
     {
         const us2 mv = pk_splat(m);
+        us2 n[NP];
 #pragma unroll
-        for (int j = 0; j < NP; ++j) p[j] = as_u32(L[j] - mv);
+        for (int j = 0; j < NP; ++j) n[j] = L[j] - mv;
+        st_stream_vec<NP>(p, n);
     }
     __device__ __forceinline__ void load_normalised(const us2 (&v)[NP])
     {
@@ -133,8 +216,7 @@ __device__ __forceinline__ void load_seg(const uint32_t* __restrict__ p, long lo
 #pragma unroll
     for (int u = 0; u < K; ++u)
         if (!GUARD || u < len) {
-#pragma unroll
-            for (int j = 0; j < NP; ++j) dst[u][j] = as_us2(p[u * step + j]);
+            ld_stream_vec<NP>(p + u * step, dst[u]);
         }
 }
 
