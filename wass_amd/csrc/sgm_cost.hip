@@ -164,8 +164,7 @@ __global__ void __launch_bounds__(256) k_hsum_q(const uint2* __restrict__ bt1, c
         slot = slot + 1 == WIN ? 0 : slot + 1;
         const int xo = t - SW2;
         if (i >= 2 * SW2 && xo >= 0 && xo < xe) {
-#pragma unroll
-            for (int j = 0; j < NP; ++j) o[j] = as_u32(acc[j]);
+            st_stream_vec<NP>(o, acc);
             o += 64 * NP;
         }
     };
@@ -350,8 +349,7 @@ __global__ void __launch_bounds__(256) k_vsum_col(const uint32_t* __restrict__ h
 #pragma unroll
         for (int u = 0; u < K; ++u) {
             const int ya = min(yb + u + SH2 + 1, h - 1);
-#pragma unroll
-            for (int j = 0; j < NP; ++j) dst[u][j] = as_us2(hp[(size_t)ya * rowstride + j]);
+            ld_stream_vec<NP>(hp + (size_t)ya * rowstride, dst[u]);
         }
     };
     auto row = [&](int y, const us2 (&in)[NP]) {
@@ -402,10 +400,10 @@ __global__ void __launch_bounds__(256) k_vsum_col(const uint32_t* __restrict__ h
                 if (d < D) over |= (v.x > lim.x); else v.x = 0xFFFF;
                 if (d + 1 < D) over |= (v.y > lim.y); else v.y = 0xFFFF;
                 cv[u][j] = v;
-                cp[(size_t)(y0 + u) * rowstride + j] = as_u32(v);
                 acc[j] = acc[j] + in[u][j] - old[u][j];
                 ring[(sl * NP + j) * 64] = as_u32(in[u][j]);
             }
+            st_stream_vec<NP>(cp + (size_t)(y0 + u) * rowstride, cv[u]);
         }
         slot += K;
         slot = slot >= WIN ? slot - WIN : slot;
@@ -414,8 +412,10 @@ __global__ void __launch_bounds__(256) k_vsum_col(const uint32_t* __restrict__ h
             us2 L[NP];
             sgm_step<NP>(st, cv[u], L, P1v, P2);
             if (PATH2) {
+                us2 s2[NP];
 #pragma unroll
-                for (int j = 0; j < NP; ++j) sp[(size_t)(y0 + u) * rowstride + j] = as_u32(pk_min(L[j], cap));
+                for (int j = 0; j < NP; ++j) s2[j] = pk_min(L[j], cap);
+                st_stream_vec<NP>(sp + (size_t)(y0 + u) * rowstride, s2);
             }
         }
     };
