@@ -133,6 +133,53 @@ def test_rectify_only_is_identity_for_the_ideal_rig(cli, tmp_path):
     assert "load_data [info ] image 0 loaded, Size: 160x120" in open(os.path.join(wd, "wass_stereo_log.txt")).read()
 
 
+def _read_png_gray(path):
+    blob = open(path, "rb").read()
+    assert blob[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w, h = 8, b"", 0, 0
+    while pos < len(blob):
+        n, t = struct.unpack(">I4s", blob[pos:pos + 8])
+        d = blob[pos + 8:pos + 8 + n]
+        assert zlib.crc32(t + d) & 0xFFFFFFFF == struct.unpack(">I", blob[pos + 8 + n:pos + 12 + n])[0]
+        if t == b"IHDR":
+            w, h, depth, ctype = struct.unpack(">IIBB", d[:10]); assert (depth, ctype) == (8, 0)
+        elif t == b"IDAT":
+            idat += d
+        pos += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, w + 1)
+    assert (raw[:, 0] == 0).all()                                # filter type 0 on every row
+    return raw[:, 1:]
+
+
+def test_scaled_previews_are_written(cli, tmp_path):
+    """SAVE_INPUT_SCALE (default 0.3): 0000000{0,1}_s.png = cv::resize(INTER_CUBIC) of the inputs, K{0,1}_small.txt,
+    scale.txt (wass_stereo.cpp:401-434).  Written by load_data, i.e. before the GPU is needed."""
+    w, h, D = 200, 150, 32
+    wd, cfg, right, left, rig = make_workdir(str(tmp_path), w, h, D)
+    run(cli, cfg, wd)                                            # exit code depends on whether a GPU is present
+    for name, img in (("00000000_s.png", left), ("00000001_s.png", right)):
+        got = _read_png_gray(os.path.join(wd, name)).astype(int)
+        assert got.shape == (int(h * 0.3), int(w * 0.3))
+        # float64 Keys (a = -0.75) interpolation at the same sample positions, replicated border
+        nh, nw = got.shape
+
+        def taps(n_out, n_in):
+            f = (np.arange(n_out) + 0.5) * (n_in / n_out) - 0.5
+            i0 = np.floor(f).astype(int); t = f - i0
+            A = -0.75
+            wts = np.stack([((A * (t + 1) - 5 * A) * (t + 1) + 8 * A) * (t + 1) - 4 * A, ((A + 2) * t - (A + 3)) * t * t + 1,
+                            ((A + 2) * (1 - t) - (A + 3)) * (1 - t) * (1 - t) + 1], 0)
+            wts = np.vstack([wts, 1 - wts.sum(0)])
+            idx = np.clip(i0[None, :] + np.arange(-1, 3)[:, None], 0, n_in - 1)
+            return idx, wts
+        ix, wx = taps(nw, w); iy, wy = taps(nh, h)
+        tmp = (img.astype(float)[:, ix] * wx[None]).sum(1)       # [h, nw]
+        ref = (tmp[iy] * wy[:, :, None]).sum(0)                  # [nh, nw]
+        assert np.abs(got - np.clip(np.rint(ref), 0, 255)).max() <= 1
+    assert abs(float(open(os.path.join(wd, "scale.txt")).read()) - 0.3) < 1e-12
+    assert os.path.exists(os.path.join(wd, "K0_small.txt")) and os.path.exists(os.path.join(wd, "K1_small.txt"))
+
+
 def test_no_gpu_is_a_loud_failure(cli, tmp_path):
     import torch
     if torch.cuda.is_available():

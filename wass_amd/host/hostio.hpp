@@ -199,6 +199,73 @@ inline Image read_png_gray(const std::string& filename)
     return img;
 }
 
+// cv::resize(src, dst, Size(nw, nh), 0, 0, INTER_CUBIC) for CV_8UC1 (wass_stereo.cpp:413,416), restated from OpenCV
+// 4.5.5 imgproc/resize.cpp (unpinned): source position (d + 0.5) * scale - 0.5 in float, Keys a = -0.75 weights as
+// int16 * 2^11, replicated borders, horizontal pass to int32 rows, vertical pass (sum + 2^21) >> 22.  (OpenCV's SIMD
+// vertical pass rounds in float and can differ from this scalar form by one grey level.)
+inline Image resize_cubic(const Image& src, int nw, int nh)
+{
+    auto coeffs = [](float x, short* c) {
+        const float A = -0.75f;
+        float f[4];
+        f[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+        f[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+        f[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+        f[3] = 1.f - f[0] - f[1] - f[2];
+        for (int k = 0; k < 4; ++k) { const long r = lrintf(f[k] * 2048.f); c[k] = (short)(r < -32768 ? -32768 : (r > 32767 ? 32767 : r)); }
+    };
+    auto clip = [](int v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); };
+    Image dst(nw, nh);
+    if (src.empty() || nw <= 0 || nh <= 0) return dst;
+    const double sx = (double)src.w / nw, sy = (double)src.h / nh;
+    std::vector<int> xo((size_t)nw * 4);
+    std::vector<short> xa((size_t)nw * 4);
+    for (int dx = 0; dx < nw; ++dx) {
+        float fx = (float)((dx + 0.5) * sx - 0.5);
+        const int ix = (int)std::floor(fx);
+        fx -= ix;
+        coeffs(fx, &xa[(size_t)dx * 4]);
+        for (int k = 0; k < 4; ++k) xo[(size_t)dx * 4 + k] = clip(ix - 1 + k, src.w);
+    }
+    std::vector<int> rows[4];
+    int have[4] = { -1, -1, -1, -1 };
+    for (auto& r : rows) r.resize(nw);
+    for (int dy = 0; dy < nh; ++dy) {
+        float fy = (float)((dy + 0.5) * sy - 0.5);
+        const int iy = (int)std::floor(fy);
+        fy -= iy;
+        short b[4];
+        coeffs(fy, b);
+        const int* R[4];
+        for (int k = 0; k < 4; ++k) {
+            const int yy = clip(iy - 1 + k, src.h);
+            int slot = -1;
+            for (int q = 0; q < 4; ++q) if (have[q] == yy) slot = q;
+            if (slot < 0) {                                   // a row not in the small cache: horizontal pass
+                slot = 0;
+                for (int q = 0; q < 4; ++q) {                 // evict a row this output line does not need
+                    bool needed = false;
+                    for (int kk = 0; kk < 4; ++kk) needed |= have[q] == clip(iy - 1 + kk, src.h);
+                    if (!needed) { slot = q; break; }
+                }
+                have[slot] = yy;
+                const uint8_t* S = &src.px[(size_t)yy * src.w];
+                for (int dx = 0; dx < nw; ++dx) {
+                    const int* o = &xo[(size_t)dx * 4];
+                    const short* a = &xa[(size_t)dx * 4];
+                    rows[slot][dx] = S[o[0]] * a[0] + S[o[1]] * a[1] + S[o[2]] * a[2] + S[o[3]] * a[3];
+                }
+            }
+            R[k] = rows[slot].data();
+        }
+        for (int dx = 0; dx < nw; ++dx) {
+            const int v = (R[0][dx] * b[0] + R[1][dx] * b[1] + R[2][dx] * b[2] + R[3][dx] * b[3] + (1 << 21)) >> 22;
+            dst.at(dy, dx) = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    }
+    return dst;
+}
+
 inline bool write_png_gray(const std::string& filename, const Image& img)
 {
     std::vector<uint8_t> raw((size_t)(img.w + 1) * img.h);

@@ -7,8 +7,8 @@
 // reference.  There is NO CPU implementation of the hot path here: without a GPU (or
 // without libwassgpu.so) the program fails with exit code -1.
 //
-// Divergences from the reference, all listed in DESIGN.md: DENSE_SCALE must be 1; no JPEG debug renders; the *_s.png
-// previews are skipped (they need a bicubic resize); --measure (interactive GUI) is rejected.
+// Divergences from the reference, all listed in DESIGN.md: DENSE_SCALE must be 1; no JPEG debug renders;
+// --measure (interactive GUI) is rejected.
 #include <sys/stat.h>
 #include <sys/time.h>
 
@@ -102,9 +102,16 @@ bool load_data(Env& env, const Config& cfg)                                     
     }
     if (env.left.w != env.right.w || env.left.h != env.right.h) { WLOGE << "left and right images differ in size"; return false; }
     const double sis = cfg.get_double("SAVE_INPUT_SCALE");
-    if (sis < 1.0) {                                                                      // :401-434 (previews skipped)
-        const size_t nw = (size_t)(env.left.w * sis);
+    if (sis < 1.0) {                                                                      // :401-434
+        const size_t nw = (size_t)(env.left.w * sis), nh = (size_t)(env.left.h * sis);
         const double scale = (double)nw / (double)env.left.w;
+        WLOGI << "original size: " << env.left.w << "x" << env.left.h;
+        WLOGI << "  scaled size: " << nw << "x" << nh;
+        WLOGI << "        scale: " << scale;
+        if (nw > 0 && nh > 0) {
+            write_png_gray(path_join(env.workdir, "00000000_s.png"), resize_cubic(env.left, (int)nw, (int)nh));
+            write_png_gray(path_join(env.workdir, "00000001_s.png"), resize_cubic(env.right, (int)nw, (int)nh));
+        }
         Mat k0 = scaled(env.K_left, scale), k1 = scaled(env.K_right, scale);
         k0(2, 2) = 1; k1(2, 2) = 1;
         save_matrix_txt(path_join(env.workdir, "K0_small.txt"), k0);
