@@ -182,6 +182,8 @@ struct CkptLayout {
 };
 CkptLayout ckpt_layout(const SgmDims& d);
 
+void mesh_pool_purge(const void* owner);      // mesh.hip: parked mesh allocations of a context that is going away
+
 // stage launchers (each enqueues on c->stream)
 int launch_prefilter(wass_ctx* c, const SgmDims& d);
 int launch_cost_volume(wass_ctx* c, const SgmDims& d);

@@ -24,6 +24,7 @@ struct wass_mesh {
     uint8_t* gray = nullptr;
     size_t bytes = 0;
     int device = 0;
+    const void* owner = nullptr;   // the context whose stream orders every use of this allocation
     size_t n() const { return (size_t)w * h; }
 };
 
@@ -901,23 +902,32 @@ __global__ void __launch_bounds__(256) k_deinterleave(const double* __restrict__
 }
 
 // hipMalloc / hipFree cost milliseconds and synchronise the device, so destroyed meshes park their allocation in a
-// small process-wide pool and the next frame of the same size takes it back.
-struct PoolEntry { void* p; size_t bytes; int device; };
-static PoolEntry g_pool[4];
+// small pool and the next frame of the same size takes it back.  A mesh is destroyed when its last use has been
+// ENQUEUED, not when it has run, so an allocation only ever goes back to the context that owned it: that context's
+// stream orders the old kernels before the new ones.  (Another context would start writing while they still run.)
+struct PoolEntry { void* p; size_t bytes; int device; const void* owner; };
+static PoolEntry g_pool[8];
 static std::mutex g_pool_mu;
-static void* pool_take(size_t bytes, int device)
+static void* pool_take(size_t bytes, int device, const void* owner)
 {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     for (auto& e : g_pool)
-        if (e.p && e.bytes == bytes && e.device == device) { void* p = e.p; e.p = nullptr; return p; }
+        if (e.p && e.bytes == bytes && e.device == device && e.owner == owner) { void* p = e.p; e.p = nullptr; return p; }
     return nullptr;
 }
-static bool pool_give(void* p, size_t bytes, int device)
+static bool pool_give(void* p, size_t bytes, int device, const void* owner)
 {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     for (auto& e : g_pool)
-        if (!e.p) { e.p = p; e.bytes = bytes; e.device = device; return true; }
+        if (!e.p) { e.p = p; e.bytes = bytes; e.device = device; e.owner = owner; return true; }
     return false;
+}
+// called by wass_ctx_destroy (after the context's streams have drained)
+void mesh_pool_purge(const void* owner)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (auto& e : g_pool)
+        if (e.p && e.owner == owner) { (void)hipFree(e.p); e.p = nullptr; }
 }
 
 static int mesh_alloc(wass_ctx* c, int w, int h, wass_mesh** out)
@@ -928,8 +938,8 @@ static int mesh_alloc(wass_ctx* c, int w, int h, wass_mesh** out)
     const size_t n = m->n();
     // one allocation: x | y | z | valid | gray
     const size_t bytes = n * 8 * 3 + ((n + 255) & ~(size_t)255) * 2;
-    m->bytes = bytes; m->device = c->device;
-    void* base = pool_take(bytes, c->device);
+    m->bytes = bytes; m->device = c->device; m->owner = c;
+    void* base = pool_take(bytes, c->device, c);
     if (!base && hipMalloc(&base, bytes) != hipSuccess) { delete m; return set_err(c, WASS_ERR_NO_MEMORY, "hipMalloc(%zu) failed", bytes); }
     m->x = (double*)base; m->y = m->x + n; m->z = m->y + n;
     m->valid = (uint8_t*)(m->z + n);
@@ -969,7 +979,7 @@ extern "C" {
 void wass_mesh_destroy(wass_mesh* m)
 {
     if (!m) return;
-    if (m->x && !pool_give(m->x, m->bytes, m->device)) { (void)hipSetDevice(m->device); (void)hipFree(m->x); }
+    if (m->x && !pool_give(m->x, m->bytes, m->device, m->owner)) { (void)hipSetDevice(m->device); (void)hipFree(m->x); }
     delete m;
 }
 
