@@ -25,7 +25,7 @@
 namespace wass {
 
 // One path, every chain.  SMODE 0: S = L_r (first path)   1: S += L_r   2: last path -- S is read, finished in
-// registers and handed to wta_select (stored only if keepS).  Loads of the next U steps are in flight while the
+// registers and handed to wta_batch (stored only if keepS).  Loads of the next U steps are in flight while the
 // current U steps compute.
 template <int NP, int SMODE, int U>
 __global__ void __launch_bounds__(256) k_sweep(const uint32_t* __restrict__ C, uint32_t* __restrict__ S,
@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256) k_sweep(const uint32_t* __restrict__ C, u
 //            registers, run the backward path over the same registers, and
 //            add both to S.
 // SMODE 0: S = Lf+Lb (first family)   1: S += Lf+Lb   2: last family -- S is
-// read, finished in registers and handed to wta_select; it is stored only if
+// read, finished in registers and handed to wta_batch; it is stored only if
 // keepS (debug fetch).
 // ---------------------------------------------------------------------------
 // Phase 1 of a chain-family pair: the forward path over every chain, keeping only the (normalised)

@@ -40,7 +40,7 @@ __device__ __forceinline__ int raw_at(const uint8_t* img, int Wp, int X, int y, 
 }
 
 // MIRROR = false: image 1 (the reference image of the match): one 8-byte record per pixel
-//   {sobel v, lo, hi, raw v, lo, hi} -- read wave-uniformly by k_hsum.
+//   {sobel v, lo, hi, raw v, lo, hi} -- read wave-uniformly by k_hsum_q.
 // MIRROR = true: image 2: six u16 planes per row, [y][plane][Wp + pad], stored MIRRORED in x
 //   (index Wp-1-X), so that the values a lane needs for consecutive disparities d, d+1, ... at
 //   column X (image-2 columns X-d, X-d-1, ...) are consecutive, ascending u16 in memory and arrive

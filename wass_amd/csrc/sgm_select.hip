@@ -1,5 +1,5 @@
 // sgm_select.hip -- K4b (right-view disparity + left-right check; the per-pixel winner-take-all is fused into
-// the last aggregation kernel, sgm_step.h: wta_select) and K5 (3x3 median of the int16 map + crop).
+// the last aggregation kernel, sgm_step.h: wta_batch) and K5 (3x3 median of the int16 map + crop).
 //
 // Replaces the per-row tail of OpenCV's computeDisparitySGBM and the
 // medianBlur in StereoSGBMImpl::compute, reached
