@@ -20,7 +20,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the fp64 geometry kernels must round like the reference's
 # plain x86-64 build (no FMA contraction) to keep inlier counts bit-identical.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
-         "-Wno-unused-function", "-fgpu-rdc" if False else "-fno-gpu-rdc"]
+         "-Wno-unused-function", "-fno-gpu-rdc"] + os.environ.get("WASS_EXTRA_FLAGS", "").split()
 
 
 def _newer(src: str, dst: str, deps) -> bool:

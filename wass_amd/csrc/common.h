@@ -172,6 +172,19 @@ int ensure(wass_ctx* c, Buf& b, size_t bytes);
 // Checkpoint regions of the chain families, in launch order.  With 8 paths the column family comes first: its
 // forward checkpoints are produced by the cost stage itself (k_vsum_col walks whole columns top-down, which is
 // exactly that family's forward path), so its pair kernel can start the moment C is complete.
+// steps per checkpoint segment (and unroll depth of the sweeps) for NP packed pairs per lane: bounded by the register
+// budget of k_pair, which keeps 7 * K * NP vectors live
+#ifndef WASS_K_SMALL
+#define WASS_K_SMALL 8
+#endif
+#ifndef WASS_K_MID
+#define WASS_K_MID 4
+#endif
+#ifndef WASS_K_BIG
+#define WASS_K_BIG 2
+#endif
+constexpr int ckpt_k(int NP) { return NP <= 2 ? WASS_K_SMALL : (NP <= 4 ? WASS_K_MID : WASS_K_BIG); }
+
 struct CkptLayout {
     int K = 8;                       // steps per checkpoint segment
     int nfam = 0;

@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
 CkptLayout ckpt_layout(const SgmDims& d)
 {
     CkptLayout L;
-    L.K = d.NP <= 2 ? 8 : (d.NP <= 4 ? 4 : 2);
+    L.K = ckpt_k(d.NP);
     auto add = [&](int dx, int dy, int smode) {
         const int f = L.nfam++;
         L.dx[f] = dx; L.dy[f] = dy; L.smode[f] = smode;
@@ -336,7 +336,7 @@ CkptLayout ckpt_layout(const SgmDims& d)
 template <int NP>
 static int launch_aggregate_trio(wass_ctx* c, const SgmDims& d, int* n_launches)
 {
-    constexpr int K = NP <= 2 ? 8 : (NP <= 4 ? 4 : 2);
+    constexpr int K = ckpt_k(NP);
     const uint32_t* C = (const uint32_t*)c->C.p;
     uint32_t* S = (uint32_t*)c->S.p;
     int rc;
@@ -396,8 +396,8 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
     // Path numbering of Appendix A.4: pass 1 = 0:(-1,0) 1:(-1,-1) 2:(0,-1) 3:(+1,-1), then 4:(+1,0);
     // MODE_HH adds 5:(-1,+1) 6:(0,+1) 7:(+1,+1).  (dx,dy) below is the direction of travel = -r.
     // Opposite paths share their chains: rows {0,4}, columns {2,6}, diagonals {1,7}, anti-diagonals {3,5}.
-    constexpr int U = NP <= 2 ? 8 : (NP <= 4 ? 4 : 2);
-    constexpr int K = NP <= 2 ? 8 : (NP <= 4 ? 4 : 2);
+    constexpr int U = ckpt_k(NP);
+    constexpr int K = ckpt_k(NP);
     const uint32_t* C = (const uint32_t*)c->C.p;
     uint32_t* S = (uint32_t*)c->S.p;
     int16_t* sd = (int16_t*)c->sel_d16.p;
@@ -412,7 +412,6 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
     // every family has its own checkpoint region so that all checkpoint sweeps (which only read C) can run ahead
     // on the side stream while the main stream accumulates S
     const CkptLayout lay = ckpt_layout(d);
-    static_assert(K == (NP <= 2 ? 8 : (NP <= 4 ? 4 : 2)), "ckpt_layout and the kernels must agree on K");
     const int nf = lay.nfam;
     struct Fam { int dx, dy, smode; };
     Fam fam[4];

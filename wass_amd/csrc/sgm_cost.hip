@@ -464,7 +464,7 @@ static int launch_cost_np(wass_ctx* c, const SgmDims& d)
     if (lds2 > 160 * 1024) return set_err(c, WASS_ERR_UNSUPPORTED, "WINSIZE %d too large for the LDS ring", 2 * d.SW2 + 1);
     const CkptLayout lay = ckpt_layout(d);
     if (lay.cols_from_cost || lay.path2_from_cost) {
-        constexpr int K = NP <= 2 ? 8 : (NP <= 4 ? 4 : 2);
+        constexpr int K = ckpt_k(NP);
         int rc = ensure(c, c->ckpt, lay.off[lay.nfam]);
         if (rc) return rc;
         const dim3 grid((d.width1 + 3) / 4), block(256);
