@@ -159,3 +159,30 @@ def test_pipelined_strip_schedule_is_bit_exact(gpu_ctx, oracle, ndirs, monkeypat
         disp, st, Co, So, rawo = oracle.sgbm_compute(R, L, _oracle_params(oracle, p), dump=True)
         np.testing.assert_array_equal(Sg, So)
         np.testing.assert_array_equal(got, disp[:, D:D + w])
+
+
+def test_random_parameter_sets_match_the_oracle(gpu_ctx, oracle):
+    """SGBM parameters away from the WASS defaults (uniqueness ratio, disp12MaxDiff, pre-filter cap, P1/P2, window,
+    minimum disparity, path count), drawn at random: final fixed-point disparity bit-exact against the oracle."""
+    rng = np.random.default_rng(20260928)
+    done = 0
+    for trial in range(40):
+        w, h = int(rng.integers(40, 180)), int(rng.integers(12, 70))
+        D = int(rng.choice([16, 32, 48, 64, 96, 144]))
+        win = int(rng.choice([3, 5, 7, 9, 11, 13]))
+        mind = int(rng.integers(0, 4))
+        p = default_sgm_params(D, ndirs=int(rng.choice([5, 8])), win=win, min_disp=mind)
+        p.P1 = int(rng.integers(1, 40)) * win
+        p.P2 = p.P1 + int(rng.integers(1, 400)) * win
+        p.uniq_ratio = int(rng.choice([0, 1, 5, 10, 15, 40]))
+        p.disp12_max_diff = int(rng.choice([-1, 0, 1, 2, 5]))
+        p.prefilter_cap = int(rng.choice([5, 15, 31, 60, 63]))
+        right, left = synth.make_pair(w, h, D, frame_idx=1000 + trial)
+        ref, st = oracle.dense_disparity16(right, left, _oracle_params(oracle, p))
+        if st.overflow:
+            continue                                              # outside the int16 range where the reference is defined
+        got = gpu_ctx.sgm_disparity(right, left, p)
+        np.testing.assert_array_equal(got, ref, err_msg=f"trial {trial}: {w}x{h} D={D} win={win} minD={mind} P1={p.P1} P2={p.P2} "
+                                                         f"uniq={p.uniq_ratio} d12={p.disp12_max_diff} cap={p.prefilter_cap} ndirs={p.ndirs}")
+        done += 1
+    assert done >= 25
