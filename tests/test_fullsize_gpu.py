@@ -35,6 +35,16 @@ def test_config_b_5path_bit_exact_vs_oracle(gpu_ctx, oracle, pair_b):
     np.testing.assert_array_equal(gpu_ctx.disparity_postprocess(got, p), oracle.disparity_postprocess(ref, 1, 256))
 
 
+def test_config_b_8path_bit_exact_vs_oracle(gpu_ctx, oracle, pair_b):
+    """The benchmark workload itself (2456x2058, D=256, 8 paths = MODE_HH): every disparity equals the oracle's."""
+    right, left = pair_b
+    p = default_sgm_params(256, ndirs=8)
+    got = gpu_ctx.sgm_disparity(right, left, p)
+    ref, st = oracle.dense_disparity16(right, left, _oracle_params(oracle, p))
+    assert not st.overflow
+    np.testing.assert_array_equal(got, ref)
+
+
 def _flip_property(ctx, right, left, D):
     p = default_sgm_params(D, ndirs=8)
     a = ctx.sgm_disparity(right, left, p)
