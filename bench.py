@@ -114,47 +114,30 @@ def main():
     for k in range(2):
         r, l = synth.make_pair(w, h, D, frame_idx=rank * 16 + k)
         frames.append((torch.from_numpy(r).to(dev), torch.from_numpy(l).to(dev)))
-    # two disparity buffers per context, alternated: with tail overlap the clean-up of frame i still reads its
-    # disparity while the SGM stage of frame i+1 writes the next one
-    outs = [[torch.empty((h, w), dtype=torch.int16, device=dev) for _ in range(2)] for _ in range(nslot)]
-    dispfs = [torch.empty((h, w), dtype=torch.float32, device=dev) for _ in range(nslot)]
     geom = wass_amd.make_geom(synth.rig_geometry(w, h))
-    roi = (0, 0, w, h)
     burned = [(fr[0] <= 254).to(torch.uint8) for fr in frames]      # DISCARD_BURNED_AREAS masks (right image)
     planes, npts_hist, nbytes_hist = [], [], []
-    xyzc_hosts = [torch.empty(148 + 6 * w * h, dtype=torch.uint8, pin_memory=True) for _ in range(nslot)]   # mesh_cam.xyzC
+    # wass_stereo.cpp main() per frame: SGM -> clean-up -> triangulate -> z-gap / biggest component -> RANSAC -> crop ->
+    # refine -> crop -> mesh_cam.xyzC (defaults of SURVEY.md Appendix C, RANDOM_SEED=12345), as wass_amd.batch.FramePipeline
+    # enqueues it: no host synchronisation inside a frame, the previous frame's output is collected while this one runs
+    from wass_amd.batch import FramePipeline
+    pipes = [FramePipeline(c_, w, h, params, geom, tail_overlap=tail_overlap) for c_ in ctxs] if args.stage == "full" else []
+    sgm_out = [torch.empty((h, w), dtype=torch.int16, device=dev) for _ in range(nslot)]
+
+    def keep(o):
+        if o is not None:
+            planes.append(o.plane); npts_hist.append(o.n_points); nbytes_hist.append(len(o.xyzc))
 
     def step(i, slot=0):
-        ctx, out, dispf, xyzc_host = ctxs[slot], outs[slot][(i // nslot) % 2], dispfs[slot], xyzc_hosts[slot]
         dr, dl = frames[i % 2]
-        ctx.sgm_disparity_dev(dr, dl, params, out)
         if args.stage == "sgm":
-            return
-        # wass_stereo.cpp main(): clean-up -> triangulate -> z-gap / biggest component -> RANSAC -> crop ->
-        # refine -> crop -> mesh_cam.xyzC (defaults of SURVEY.md Appendix C, RANDOM_SEED=12345)
-        ctx.disparity_postprocess_dev(out, params, 1, 2, 0, dispf)
-        mesh, _ = ctx.triangulate_dev(dispf, w, h, roi, roi, geom, dr, None, burned[i % 2], 20.0, None, 1.0, count=False)
-        uv = wass_amd.ransac_sample(w, h, 400, 12345)
-        collect(slot)                      # the previous frame of this context: its record and file image are complete
-        # z-gap / biggest component -> RANSAC -> crop -> refine -> crop -> mesh_cam.xyzC, all decisions on the device,
-        # no host synchronisation; the file image is downloaded by the context's copy stream while the next frame runs
-        mesh.finish_frame_async(uv, xyzc_host.data_ptr(), xyzc_host.numel(), 99.0, 1.0, 1.5)
-        mesh.close()
-        pending[slot] = True
-
-    pending = [False] * nslot
-
-    def collect(slot):
-        if not pending[slot]:
-            return
-        fr = ctxs[slot].frame_result()
-        pl = np.array(fr.plane[:]) if fr.found and fr.refine_ok else np.full(4, np.nan)
-        planes.append(pl); npts_hist.append(int(fr.n_points)); nbytes_hist.append(int(fr.xyzc_bytes))
-        pending[slot] = False
+            ctxs[slot].sgm_disparity_dev(dr, dl, params, sgm_out[slot])
+        else:
+            keep(pipes[slot].submit(dr, dl, d_right_image=dr, d_right_mask=burned[i % 2]))
 
     def barrier():
-        for s_ in range(nslot):
-            collect(s_)
+        for p_ in pipes:
+            keep(p_.flush())
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()

@@ -450,3 +450,40 @@ def test_pipelined_frames_equal_serial_frames(oracle):
         for (pa, ba), (pb, bb) in zip(serial, variant):
             np.testing.assert_array_equal(pa, pb)
             assert ba == bb
+
+
+def test_frame_pipeline_matches_stage_by_stage(gpu_ctx, oracle):
+    """wass_amd.batch.FramePipeline (what bench.py and a sequence driver run): every frame's plane and file bytes equal
+    the stage-by-stage chain on a second context, outputs arrive one frame late and in order."""
+    import torch
+    from wass_amd.batch import FramePipeline
+    w, h, D = 320, 240, 64
+    dev = torch.device("cuda", 0)
+    p = default_sgm_params(D, ndirs=5)
+    geom = wass_amd.make_geom(synth.rig_geometry(w, h))
+    roi = (0, 0, w, h)
+    frames = [tuple(torch.from_numpy(a).to(dev) for a in synth.make_pair(w, h, D, frame_idx=30 + k)) for k in range(4)]
+    masks = [(fr[0] <= 254).to(torch.uint8) for fr in frames]
+    uv = wass_amd.ransac_sample(w, h, 400, 12345)
+    ref = []
+    for (dr, dl), m in zip(frames, masks):
+        d16 = gpu_ctx.sgm_disparity_dev(dr, dl, p)
+        f = gpu_ctx.disparity_postprocess_dev(d16, p, 1, 2, 0)
+        mesh, _ = gpu_ctx.triangulate_dev(f, w, h, roi, roi, geom, dr, None, m, 20.0, None, 1.0)
+        mesh.remove_outliers(99.0)
+        res = mesh.fit_plane(uv, 1.0, 1.5)
+        ref.append((np.array(res.plane[:]), mesh.encode_xyzc(np.array(res.plane[:]))))
+    with wass_amd.Context(0) as ctx2:
+        pipe = FramePipeline(ctx2, w, h, p, geom)
+        outs = []
+        for (dr, dl), m in zip(frames, masks):
+            o = pipe.submit(dr, dl, d_right_mask=m)
+            if o is not None:
+                outs.append((o.index, o.plane.copy(), o.xyzc.tobytes()))
+        o = pipe.flush()
+        outs.append((o.index, o.plane.copy(), o.xyzc.tobytes()))
+        assert pipe.flush() is None
+    assert [i for i, _, _ in outs] == [0, 1, 2, 3]
+    for (_, pl, by), (rpl, rby) in zip(outs, ref):
+        np.testing.assert_array_equal(pl, rpl)
+        assert by == rby

@@ -18,6 +18,85 @@ import numpy as np
 from . import stereo
 
 
+class FrameOutput:
+    """What one frame leaves behind: the refined plane (NaNs when RANSAC or the refinement failed, as plane.txt
+    has them), the bytes of mesh_cam.xyzC (a view of the pipeline's pinned buffer: valid until two more frames
+    have been submitted) and the stage-by-stage numbers of wass_frame_result."""
+
+    def __init__(self, index, result, xyzc):
+        self.index, self.result, self.xyzc = index, result, xyzc
+        ok = bool(result.found and result.refine_ok)
+        self.plane = np.array(result.plane[:]) if ok else np.full(4, np.nan)
+        self.n_points = int(result.n_points)
+
+
+class FramePipeline:
+    """Frames back to back on one context without host round-trips (the GPU counterpart of one wasscli worker).
+
+    submit() enqueues a whole frame -- SGM on the context's main stream, disparity clean-up, triangulation, outlier
+    removal, plane fit and the xyzC encoder on its tail stream, the file image on its copy stream -- and returns the
+    output of the PREVIOUS frame, whose download has finished while this one was being enqueued.  flush() returns the
+    last one.  Inputs are rectified crops resident in HBM (torch uint8 CUDA tensors); stage parameters are the
+    defaults of wass_stereo unless given.
+    """
+
+    def __init__(self, ctx: "stereo.Context", width: int, height: int, params, geom, roi_l=None, roi_r=None,
+                 dilate_steps=1, erode_steps=2, median_wsize=0, min_angle_deg=20.0, zgap_percentile=99.0,
+                 ransac_rounds=400, random_seed=12345, ransac_thr=1.0, plane_max_distance=1.5, refine=None,
+                 tail_overlap=True):
+        import torch
+        self.ctx, self.w, self.h, self.params, self.geom = ctx, width, height, params, geom
+        self.roi_l = tuple(roi_l) if roi_l is not None else (0, 0, width, height)
+        self.roi_r = tuple(roi_r) if roi_r is not None else (0, 0, width, height)
+        self.dilate, self.erode, self.median, self.min_angle = dilate_steps, erode_steps, median_wsize, min_angle_deg
+        self.pct, self.rounds, self.seed = zgap_percentile, ransac_rounds, random_seed
+        self.ransac_thr, self.max_distance, self.refine = ransac_thr, plane_max_distance, dict(refine or {})
+        dev = torch.device("cuda", ctx.device_id)
+        # two disparity buffers, alternated: the clean-up of frame i reads one while the SGM stage of frame i+1 writes
+        # the other; two pinned file images, alternated: frame i's is read by the caller while frame i+1's is written
+        self._disp16 = [torch.empty((height, width), dtype=torch.int16, device=dev) for _ in range(2)]
+        self._dispf = torch.empty((height, width), dtype=torch.float32, device=dev)
+        mw, mh = self.roi_r[2], self.roi_r[3]
+        self._host = [torch.empty(148 + 6 * mw * mh, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+        # wass_stereo seeds rand() once per process = once per frame (wass_stereo.cpp:1864-1872), so every frame of a
+        # sequence draws the same RANSAC triplets for a given grid size: draw them once
+        self._uv = stereo.ransac_sample(mw, mh, ransac_rounds, random_seed)
+        self._n = 0
+        self._pending = None
+        ctx.set_tail_overlap(tail_overlap)
+
+    def submit(self, d_right, d_left, d_right_image=None, d_left_mask=None, d_right_mask=None):
+        """d_right/d_left: rectified crops; d_right_image: the undistorted right image sampled for the point colour
+        (defaults to d_right); masks: 0/1 uint8 images of the originals' size or None."""
+        ctx, k = self.ctx, self._n & 1
+        out = self._disp16[k]
+        ctx.sgm_disparity_dev(d_right, d_left, self.params, out)
+        ctx.disparity_postprocess_dev(out, self.params, self.dilate, self.erode, self.median, self._dispf)
+        img = d_right_image if d_right_image is not None else d_right
+        mesh, _ = ctx.triangulate_dev(self._dispf, self.w, self.h, self.roi_l, self.roi_r, self.geom, img, d_left_mask,
+                                      d_right_mask, self.min_angle, None, 1.0, count=False)
+        prev = self._collect()
+        host = self._host[k]
+        mesh.finish_frame_async(self._uv, host.data_ptr(), host.numel(), self.pct, self.ransac_thr, self.max_distance,
+                                **self.refine)
+        mesh.close()
+        self._pending = (self._n, host)
+        self._n += 1
+        return prev
+
+    def _collect(self):
+        if self._pending is None:
+            return None
+        idx, host = self._pending
+        fr = self.ctx.frame_result()
+        self._pending = None
+        return FrameOutput(idx, fr, host[:int(fr.xyzc_bytes)].numpy())
+
+    def flush(self):
+        """Wait for the last submitted frame."""
+        return self._collect()
+
+
 def shard(n_frames: int, rank: int, world: int) -> list[int]:
     """Frame indices owned by `rank` (round-robin, like wasscli's work queue)."""
     return list(range(rank, n_frames, world))

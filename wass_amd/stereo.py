@@ -246,12 +246,16 @@ def make_geom(g: dict, use_custom=False, disparity_compensation=0.0, dense_scale
     return G
 
 
+_rand_lock = __import__("threading").Lock()          # libc rand() has process-wide state
+
+
 def ransac_sample(width: int, height: int, rounds: int, seed: int) -> np.ndarray:
     """srand(seed) + the reference's sampling loop (PovMesh.cpp:680-691)."""
     lib = _lib.load()
-    C.CDLL(None).srand(C.c_uint(seed))
     uv = np.empty((rounds, 6), np.int32)
-    rc = lib.wass_ransac_sample(width, height, rounds, uv.ctypes.data)
+    with _rand_lock:
+        C.CDLL(None).srand(C.c_uint(seed))
+        rc = lib.wass_ransac_sample(width, height, rounds, uv.ctypes.data)
     if rc != 0:
         raise WassError(rc, "wass_ransac_sample failed")
     return uv
