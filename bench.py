@@ -71,8 +71,8 @@ def measured_traffic(config: str, ndirs: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--ndirs", type=int, default=8, choices=(5, 8))
     ap.add_argument("--config", default="B", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
