@@ -34,6 +34,16 @@ def test_binding_covers_header(built):
     _lib.load()
 
 
+def test_header_is_plain_c99(tmp_path):
+    """The boundary is a C ABI: the header must compile as C99 with no C++ or HIP types in it."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include "wass_gpu.h"\nint main(void) { wass_sgm_params p; wass_frame_result r; (void)p; (void)r; '
+                   'return wass_version() == 0; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           "-fsyntax-only", str(src)])
+
+
 def test_struct_layout_matches_header():
     from wass_amd import _lib
     # 12 ints + (pad) + double ; 6 floats + 2 ints + 1 float
