@@ -44,6 +44,23 @@ def test_header_is_plain_c99(tmp_path):
                            "-fsyntax-only", str(src)])
 
 
+def test_ctypes_struct_sizes_match_the_compiled_header(tmp_path):
+    """Every struct crossing the boundary: sizeof in C == ctypes.sizeof of its Python mirror."""
+    import subprocess
+    from wass_amd import _lib
+    pairs = [("wass_sgm_params", _lib.SgmParams), ("wass_sgm_timings", _lib.SgmTimings), ("wass_geom", _lib.Geom),
+             ("wass_tri_params", _lib.TriParams), ("wass_refine_params", _lib.RefineParams),
+             ("wass_plane_result", _lib.PlaneResult), ("wass_frame_result", _lib.FrameResult)]
+    src = tmp_path / "sizes.c"
+    body = "".join(f'printf("%zu\\n", sizeof({c}));' for c, _ in pairs)
+    src.write_text(f'#include <stdio.h>\n#include "wass_gpu.h"\nint main(void) {{ {body} return 0; }}\n')
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    for (cname, py), sz in zip(pairs, sizes):
+        assert ctypes.sizeof(py) == sz, cname
+
+
 def test_struct_layout_matches_header():
     from wass_amd import _lib
     # 12 ints + (pad) + double ; 6 floats + 2 ints + 1 float
