@@ -95,23 +95,23 @@ int wass_ctx_create(int device_id, wass_ctx** out)
     wass_ctx* c = new (std::nothrow) wass_ctx();
     if (!c) return WASS_ERR_NO_MEMORY;
     c->device = device_id;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
-    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
-    if (hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
-    if (hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
-    if (hipStreamCreateWithFlags(&c->tail, hipStreamNonBlocking) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
-    if (hipEventCreateWithFlags(&c->ev_post, hipEventDisableTiming) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
-    if (hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
-    if (hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
+    if (hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
+    if (hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
+    if (hipStreamCreateWithFlags(&c->tail, hipStreamNonBlocking) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
+    if (hipEventCreateWithFlags(&c->ev_post, hipEventDisableTiming) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
+    if (hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
+    if (hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
     for (auto& set : c->evs)
         for (auto& e : set)
-            if (hipEventCreate(&e) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
-    if (hipEventCreateWithFlags(&c->ev_cost, hipEventDisableTiming) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
-    if (hipEventCreateWithFlags(&c->ev_cols, hipEventDisableTiming) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
+            if (hipEventCreate(&e) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
+    if (hipEventCreateWithFlags(&c->ev_cost, hipEventDisableTiming) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
+    if (hipEventCreateWithFlags(&c->ev_cols, hipEventDisableTiming) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
     for (auto& e : c->ev_ckpt)
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return WASS_ERR_DEVICE; }
-    if (ensure(c, c->flags, 64) != WASS_OK) { delete c; return WASS_ERR_NO_MEMORY; }
-    if (hipHostMalloc((void**)&c->h_flags, 64, hipHostMallocDefault) != hipSuccess) { delete c; return WASS_ERR_NO_MEMORY; }
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
+    if (ensure(c, c->flags, 64) != WASS_OK) { wass_ctx_destroy(c); return WASS_ERR_NO_MEMORY; }
+    if (hipHostMalloc((void**)&c->h_flags, 64, hipHostMallocDefault) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_NO_MEMORY; }
     c->h_flags[0] = c->h_flags[4] = 0;
     *out = c;
     return WASS_OK;
@@ -121,10 +121,10 @@ void wass_ctx_destroy(wass_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->tail) (void)hipStreamSynchronize(c->tail);
     mesh_pool_purge(c);
-    for (Buf* b : { &c->img1, &c->img2, &c->bt1, &c->bt2, &c->hsum, &c->C, &c->S, &c->S2, &c->halo, &c->ckpt, &c->sel_d16, &c->sel_key, &c->raw,
+    for (Buf* b : { &c->img1, &c->img2, &c->bt1, &c->bt2, &c->hsum, &c->C, &c->S, &c->S2, &c->halo, &c->ckpt, &c->edges, &c->sel_d16, &c->sel_key, &c->raw,
                     &c->flags, &c->tmp_in0, &c->tmp_in1, &c->tmp_out, &c->tmp_mask, &c->fA, &c->fB, &c->fC, &c->scratch, &c->counters, &c->dstate, &c->rect_tab, &c->rect_mx, &c->rect_my, &c->xyzc, &c->limits })
         release(*b);
     for (auto& set : c->evs) for (auto& e : set) if (e) (void)hipEventDestroy(e);
@@ -186,7 +186,9 @@ int wass_sgm_disparity_dev(wass_ctx* c, const uint8_t* d_right, const uint8_t* d
     const size_t vol = d.cells() * sizeof(uint16_t);
     if ((rc = ensure(c, c->img1, npad)) || (rc = ensure(c, c->img2, npad)) ||
         (rc = ensure(c, c->bt1, npad * 8)) || (rc = ensure(c, c->bt2, (size_t)d.h * 6 * bt2_pitch(d.Wp) * 2 + 8192)) ||
-        (rc = ensure(c, c->hsum, vol)) || (rc = ensure(c, c->C, vol)) || (rc = ensure(c, c->S, vol)) ||
+        (rc = ensure(c, c->hsum, vol)) || (rc = ensure(c, c->C, vol)) ||
+        (!tile_schedule_enabled() && (rc = ensure(c, c->S, vol))) ||      // the tile schedule keeps S in LDS
+
         (rc = ensure(c, c->sel_d16, (size_t)d.width1 * d.h * 2)) ||
         (rc = ensure(c, c->sel_key, (size_t)d.width1 * d.h * 4)) || (rc = ensure(c, c->raw, npad * 2)))
         return rc;
@@ -208,7 +210,7 @@ int wass_sgm_disparity_dev(wass_ctx* c, const uint8_t* d_right, const uint8_t* d
     if ((rc = launch_cost_volume(c, d))) return rc;
     WASS_HIP(c, hipEventRecord(c->ev[2], s));
     int nl = 0;
-    if ((rc = launch_aggregate(c, d, &nl))) return rc;
+    if ((rc = tile_schedule_enabled() ? launch_aggregate_tile(c, d, &nl) : launch_aggregate(c, d, &nl))) return rc;
     WASS_HIP(c, hipEventRecord(c->ev[3], s));
     if ((rc = launch_select(c, d))) return rc;
     WASS_HIP(c, hipEventRecord(c->ev[4], s));

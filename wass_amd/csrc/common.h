@@ -112,6 +112,7 @@ struct wass_ctx {
     wass::Buf bt1, bt2;            // BT interval records: bt1 8 B/pixel; bt2 six mirrored u16 planes per row
     wass::Buf hsum, C, S;          // u16 volumes [h][width1][Dp]
     wass::Buf ckpt;                // forward-path checkpoints of k_pair (1/K of a volume)
+    wass::Buf edges;               // tile schedule: states with which every path enters every tile (sgm_tile.hip)
     wass::Buf S2;                  // second partial-sum volume (pipelined-strip schedule)
     wass::Buf halo;                // boundary vectors handed between neighbouring strips (two sweeps)
     bool halo_dirty = false;       // a time-out left the halo buffer in an unknown state
@@ -194,6 +195,19 @@ struct CkptLayout {
     bool path2_from_cost = false;    // 5-path mode: k_vsum_col has already written S = L_2 (path 2 has no partner)
 };
 CkptLayout ckpt_layout(const SgmDims& d);
+
+// Tile-fused schedule (sgm_tile.hip, tile_geom.h).  Tile edge length for NP packed pairs per lane: the cost tile and the S
+// tile, T*T vectors of 256*NP bytes each, share the 160 KiB of LDS of one CU; one wave per tile row.
+constexpr int tile_size(int NP) { return NP <= 2 ? 12 : (NP <= 4 ? 8 : (NP <= 6 ? 7 : 6)); }
+struct EdgeLayout {
+    int T = 0, ntx = 0, nty = 0;
+    bool has[4][2] = {};             // [family][0 forward / 1 backward]: is the path aggregated at all?
+    size_t off_row[4][2] = {}, off_col[4][2] = {};   // byte offsets into c->edges ((size_t)-1: no such array)
+    size_t total = 0;
+};
+EdgeLayout edge_layout(const SgmDims& d);
+bool tile_schedule_enabled();        // WASS_AGG=tile
+int launch_aggregate_tile(wass_ctx* c, const SgmDims& d, int* n_launches);
 
 void mesh_pool_purge(const void* owner);      // mesh.hip: parked mesh allocations of a context that is going away
 

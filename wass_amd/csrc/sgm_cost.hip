@@ -11,6 +11,7 @@
 // 256*NP-byte vector per pixel -- fully coalesced -- and all arithmetic runs
 // on v_pk_*_u16.  Slots d >= D hold 0xFFFF in C and never win a minimum.
 #include "sgm_step.h"
+#include "tile_geom.h"
 
 #include <stdlib.h>
 
@@ -304,7 +305,9 @@ __global__ void __launch_bounds__(256) k_vsum(const uint32_t* __restrict__ hsum,
 // PATH2 (5-path mode, where path 2 has no partner): the path costs themselves are the first contribution to S and
 // are written out (S = L_2), which replaces that path's sweep (a read of C and a read-modify-write of S).
 // ---------------------------------------------------------------------------
-template <int NP, int K, bool PATH2>
+// ET > 0 (tile-fused schedule, sgm_tile.hip): instead of the checkpoints the wave stores the state with which path 2
+// enters every tile row (tile edge ET), i.e. it is that path's k_edge_sweep.
+template <int NP, int K, bool PATH2, int ET>
 __global__ void __launch_bounds__(256) k_vsum_col(const uint32_t* __restrict__ hsum, int width1, int h, int D, int SH2,
                                                   int P1, int P2, uint32_t* __restrict__ C, uint32_t* __restrict__ ckpt,
                                                   int maxseg, uint32_t* __restrict__ S, uint32_t* __restrict__ flags)
@@ -319,8 +322,16 @@ __global__ void __launch_bounds__(256) k_vsum_col(const uint32_t* __restrict__ h
     const size_t vec = 64 * NP, rowstride = (size_t)width1 * vec;
     const uint32_t* hp = hsum + (size_t)x * vec + lane * NP;
     uint32_t* cp = C + (size_t)x * vec + lane * NP;
-    uint32_t* ck = ckpt + (size_t)x * maxseg * vec + lane * NP;
+    uint32_t* ck = ET > 0 ? ckpt + (size_t)x * vec + lane * NP       // row-edge array of path 2: [tile row][x]
+                          : ckpt + (size_t)x * maxseg * vec + lane * NP;
     uint32_t* sp = S + (size_t)x * vec + lane * NP;
+    // the state after row y enters the next tile row at y + 1
+    auto edge = [&](const PathState<NP>& s_, int y) {
+        if (ET > 0) {
+            const int ny = y + 1;
+            if (ny < h && ny % (ET > 0 ? ET : 1) == 0) s_.store_normalised(ck + (size_t)(ny / (ET > 0 ? ET : 1)) * rowstride);
+        }
+    };
     const int dlane = lane * 2 * NP;
     const us2 lim = pk_splat(32767 - P2), P1v = pk_splat(P1), cap = pk_splat(0x7FFF);
 
@@ -364,6 +375,7 @@ __global__ void __launch_bounds__(256) k_vsum_col(const uint32_t* __restrict__ h
             cp[(size_t)y * rowstride + j] = as_u32(v);
         }
         sgm_step<NP>(st, cv, L, P1v, P2);
+        edge(st, y);
         if (PATH2) {
 #pragma unroll
             for (int j = 0; j < NP; ++j) sp[(size_t)y * rowstride + j] = as_u32(pk_min(L[j], cap));
@@ -411,6 +423,7 @@ __global__ void __launch_bounds__(256) k_vsum_col(const uint32_t* __restrict__ h
         for (int u = 0; u < K; ++u) {
             us2 L[NP];
             sgm_step<NP>(st, cv[u], L, P1v, P2);
+            edge(st, y0 + u);
             if (PATH2) {
                 us2 s2[NP];
 #pragma unroll
@@ -431,7 +444,7 @@ __global__ void __launch_bounds__(256) k_vsum_col(const uint32_t* __restrict__ h
 #pragma unroll
             for (int u = 0; u < K; ++u) row(s * K + u, nb[u]);
         }
-        if (!PATH2 && s < ncp) st.store_normalised(ck + (size_t)s * vec);
+        if (ET == 0 && !PATH2 && s < ncp) st.store_normalised(ck + (size_t)s * vec);
         copy_seg<NP, K>(nb, nn);
     }
 #pragma unroll
@@ -462,6 +475,20 @@ static int launch_cost_np(wass_ctx* c, const SgmDims& d)
     const int YSEG = 128;
     const size_t lds2 = (size_t)4 * (2 * d.SW2 + 1) * NP * 64 * sizeof(uint32_t);
     if (lds2 > 160 * 1024) return set_err(c, WASS_ERR_UNSUPPORTED, "WINSIZE %d too large for the LDS ring", 2 * d.SW2 + 1);
+    if (tile_schedule_enabled()) {
+        // the column walk doubles as the edge sweep of path 2 (forward column path) in both path modes
+        constexpr int K = ckpt_k(NP);
+        constexpr int T = tile_size(NP);
+        const EdgeLayout el = edge_layout(d);
+        int rc = ensure(c, c->edges, el.total);
+        if (rc) return rc;
+        WASS_HIP(c, hipFuncSetAttribute((const void*)k_vsum_col<NP, K, false, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        hipLaunchKernelGGL((k_vsum_col<NP, K, false, T>), dim3((d.width1 + 3) / 4), dim3(256), lds2, c->stream, (const uint32_t*)c->hsum.p,
+                           d.width1, d.h, d.D, d.SW2, d.P1, d.P2, (uint32_t*)c->C.p,
+                           (uint32_t*)((char*)c->edges.p + el.off_row[FAM_COLS][0]), 0, (uint32_t*)nullptr, (uint32_t*)c->flags.p);
+        WASS_HIP(c, hipGetLastError());
+        return WASS_OK;
+    }
     const CkptLayout lay = ckpt_layout(d);
     if (lay.cols_from_cost || lay.path2_from_cost) {
         constexpr int K = ckpt_k(NP);
@@ -469,13 +496,13 @@ static int launch_cost_np(wass_ctx* c, const SgmDims& d)
         if (rc) return rc;
         const dim3 grid((d.width1 + 3) / 4), block(256);
         if (lay.cols_from_cost) {
-            WASS_HIP(c, hipFuncSetAttribute((const void*)k_vsum_col<NP, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-            hipLaunchKernelGGL((k_vsum_col<NP, K, false>), grid, block, lds2, c->stream, (const uint32_t*)c->hsum.p, d.width1, d.h, d.D,
+            WASS_HIP(c, hipFuncSetAttribute((const void*)k_vsum_col<NP, K, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            hipLaunchKernelGGL((k_vsum_col<NP, K, false, 0>), grid, block, lds2, c->stream, (const uint32_t*)c->hsum.p, d.width1, d.h, d.D,
                                d.SW2, d.P1, d.P2, (uint32_t*)c->C.p, (uint32_t*)((char*)c->ckpt.p + lay.off[0]), lay.mseg[0],
                                (uint32_t*)c->S.p, (uint32_t*)c->flags.p);
         } else {
-            WASS_HIP(c, hipFuncSetAttribute((const void*)k_vsum_col<NP, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-            hipLaunchKernelGGL((k_vsum_col<NP, K, true>), grid, block, lds2, c->stream, (const uint32_t*)c->hsum.p, d.width1, d.h, d.D,
+            WASS_HIP(c, hipFuncSetAttribute((const void*)k_vsum_col<NP, K, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            hipLaunchKernelGGL((k_vsum_col<NP, K, true, 0>), grid, block, lds2, c->stream, (const uint32_t*)c->hsum.p, d.width1, d.h, d.D,
                                d.SW2, d.P1, d.P2, (uint32_t*)c->C.p, (uint32_t*)c->ckpt.p, 0, (uint32_t*)c->S.p, (uint32_t*)c->flags.p);
         }
         WASS_HIP(c, hipGetLastError());

@@ -264,12 +264,11 @@ __device__ __forceinline__ int div_small(int num, int den)
 // Winner-take-all for the K finished S vectors of one chain segment, written stage by stage over the K cells so
 // that the K independent reductions / readlanes / scalar tails overlap (one cell at a time the instruction stream
 // is a single dependent chain full of DPP and readlane wait states).  Branch-free; lane u collects the result of
-// cell u and the segment is written with one store per output array.  Cell u lives at pixel pix0 + u*pixstep;
-// only cells u < nvalid are stored.
+// cell u (res_d: fixed-point disparity, res_k: (minS << 16) | d or ~0 for a rejected pixel), so that a batch is
+// written with one store per output array.
 template <int NP, int K>
-__device__ __forceinline__ void wta_batch(const us2 (&Sv)[K][NP], int nvalid, int lane, int D, int minD, int uniq,
-                                          int16_t* __restrict__ out_d16, uint32_t* __restrict__ out_key, long long pix0,
-                                          long long pixstep)
+__device__ __forceinline__ void wta_batch_eval(const us2 (&Sv)[K][NP], int lane, int D, int minD, int uniq, int& res_d,
+                                               uint32_t& res_k)
 {
     constexpr int V = 2 * NP;
     constexpr int ABSENT = 1 << 22;                             // a neighbour that does not exist never passes a test
@@ -296,8 +295,8 @@ __device__ __forceinline__ void wta_batch(const us2 (&Sv)[K][NP], int nvalid, in
         const int nl = (D - j + V - 1) / V;
         inr[j] = nl >= 64 ? ~0ull : ((1ull << (nl < 0 ? 0 : nl)) - 1ull);
     }
-    int res_d = 0;
-    uint32_t res_k = 0;
+    res_d = 0;
+    res_k = 0;
     // the scalar tails run cell by cell (few live SGPRs; batching them spills scalars into VGPR lanes)
 #pragma unroll
     for (int u = 0; u < K; ++u) {
@@ -325,6 +324,17 @@ __device__ __forceinline__ void wta_batch(const us2 (&Sv)[K][NP], int nvalid, in
         res_d = lane == u ? out : res_d;
         res_k = lane == u ? k : res_k;
     }
+}
+
+// ... for cells that lie on an arithmetic progression of pixels (one chain segment)
+template <int NP, int K>
+__device__ __forceinline__ void wta_batch(const us2 (&Sv)[K][NP], int nvalid, int lane, int D, int minD, int uniq,
+                                          int16_t* __restrict__ out_d16, uint32_t* __restrict__ out_key, long long pix0,
+                                          long long pixstep)
+{
+    int res_d;
+    uint32_t res_k;
+    wta_batch_eval<NP, K>(Sv, lane, D, minD, uniq, res_d, res_k);
     if (lane < nvalid) {
         const long long px = pix0 + lane * pixstep;
         out_d16[px] = (int16_t)res_d;
