@@ -82,7 +82,25 @@ def main():
                     help="frames in flight per GPU (each on its own context/stream/scratch, one host thread each)")
     ap.add_argument("--stage", default="full", choices=("full", "sgm"),
                     help="full = a1-a20 (SGBM, clean-up, triangulation, plane fit, xyzC); sgm = a1-a6 only")
+    ap.add_argument("--allow-shared-gpu", action="store_true",
+                    help="let several ranks share one GPU (rank r uses device r %% device_count): only for exercising the "
+                         "multi-rank path on a single-GPU box; throughput numbers are then meaningless")
     args = ap.parse_args()
+
+    # --gpus N without a launcher: become the launcher (one rank per GPU under torch.distributed.run, rendezvous on
+    # 127.0.0.1).  Under a launcher WORLD_SIZE must agree with --gpus: a silent 1-rank run of an N-GPU request is an error.
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            import socket
+            import subprocess
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                port = so.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            sys.exit(subprocess.call(cmd))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
 
     import torch
     import wass_amd
@@ -92,18 +110,31 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        sys.exit("bench.py: no GPU visible (libwassgpu has no CPU path)")
+    if local_rank >= ndev:
+        if not args.allow_shared_gpu:
+            sys.exit(f"bench.py: rank {rank} needs GPU {local_rank} but only {ndev} device(s) are visible "
+                     f"(--allow-shared-gpu runs the ranks on shared devices, for functional tests only)")
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        # RCCL refuses two ranks on one device; the functional single-GPU test of the multi-rank path uses gloo
+        backend = "gloo" if (args.allow_shared_gpu and world > ndev) else "nccl"
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
+        world = dist.get_world_size()                    # what the process group actually has, not what the env said
+    dev = torch.device("cuda", dev_index)
+    coll_dev = dev if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")
 
     w, h, D = CONFIGS[args.config]
     params = wass_amd.default_sgm_params(D, ndirs=args.ndirs)
     nslot = max(1, args.inflight)
-    ctxs = [wass_amd.Context(local_rank) for _ in range(nslot)]
+    ctxs = [wass_amd.Context(dev_index) for _ in range(nslot)]
     ctx = ctxs[0]
     tail_overlap = args.stage == "full" and not args.no_tail_overlap
     for c_ in ctxs:
@@ -177,13 +208,18 @@ def main():
     elapsed = time.perf_counter() - t0
     # Coll-1: sequence mean plane = NaN-aware mean over every rank's frames (5 doubles all-reduced over RCCL)
     acc = wass_amd.planes_mean_accumulate(np.array(planes).reshape(-1, 4)) if planes else np.zeros(5)
+    rank_rates = [args.steps / elapsed]
     if dist is not None:
-        acc_t = torch.tensor(acc, dtype=torch.float64, device=dev)
+        acc_t = torch.tensor(acc, dtype=torch.float64, device=coll_dev)
         dist.all_reduce(acc_t, op=dist.ReduceOp.SUM)
         acc = acc_t.cpu().numpy()
     mean_plane, n_planes = wass_amd.planes_mean_finish(acc)
     if dist is not None:
-        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        mine = torch.tensor([args.steps / elapsed], dtype=torch.float64, device=coll_dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rank_rates = [float(t.item()) for t in allr]
+        el = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
     overflow = ctx.sgm_timings().cost_overflow
@@ -206,6 +242,9 @@ def main():
             "metric": "stereo_pairs_per_sec", "value": round(pairs_s, 4), "unit": "pairs/s",
             "mdisp_per_sec": round(pairs_s * cells / 1e6, 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ranks": {"world_size_from_process_group": world, "backend": (dist.get_backend() if dist is not None else None),
+                      "pairs_per_sec_per_rank": [round(x, 3) for x in rank_rates],
+                      "shared_gpu": bool(args.allow_shared_gpu and world > ndev)},
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16", "data": "synthetic",

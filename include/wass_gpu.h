@@ -278,6 +278,17 @@ void wass_free(void* p);
 void wass_planes_mean_accumulate(const double* planes, int n, double acc5[5]);
 void wass_planes_mean_finish(const double acc5[5], double mean_out[4], int* n_valid);
 
+/* Coll-1 as a collective: one rank per GPU (one process per GPU, one context per process).  Rank 0 draws an id
+ * (ncclGetUniqueId, 128 bytes) and hands it to the other ranks by whatever means the launcher has (pipe, file, env);
+ * every rank then calls wass_coll_init and, once per sequence, wass_coll_allreduce_sum_f64 on the acc5 of
+ * wass_planes_mean_accumulate -- an RCCL all-reduce (ncclSum, fp64) over xGMI on the context's stream, in place on
+ * host values, followed by wass_planes_mean_finish.  librccl is loaded on first use; WASS_ERR_DEVICE if it is
+ * missing.  Replaces: the shared output/planes.txt of cli/wasscli/wasscli.py:320,341-343 as the means of agreeing
+ * on the sequence's mean plane.  The communicator is destroyed with the context. */
+int wass_coll_unique_id(unsigned char id_out[128]);
+int wass_coll_init(wass_ctx* ctx, int rank, int world, const unsigned char id[128]);
+int wass_coll_allreduce_sum_f64(wass_ctx* ctx, double* values, int count /* <= 64 */);
+
 /* ---- rectification: rectify() of wass_stereo.cpp:447-613 ------------------------
  * Rig-constant host math (no GPU work, usable without a context): */
 

@@ -1,0 +1,139 @@
+"""The C++ sequence driver wass_stereo_batch (replacement for wasscli's fan-out, cli/wasscli/wasscli.py:305-364).
+
+CPU: the driver's own logic -- sharding over worker processes, the gather through pipes, planes.txt bytes and the
+NaN-aware mean -- on workdirs that are already finished (--skip-existing reads plane.txt back), against the golden
+planes_txt.npz (numpy nanmean semantics of wassgridsurface.py:672-678).
+GPU: real frames through persistent contexts, compared with one wass_stereo process per frame; Coll-1 over RCCL.
+"""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from test_cli import make_workdir
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def exes():
+    from wass_amd import build
+    cli = build.build_host()
+    return cli, build.BATCH
+
+
+def _finished_workdir(root, i, line):
+    wd = os.path.join(root, "%06d_wd" % i)
+    os.makedirs(wd)
+    with open(os.path.join(wd, "plane.txt"), "w") as f:
+        f.write(line + "\n" if "nan" in line else "".join(v + "\n" for v in line.split()))
+    open(os.path.join(wd, "mesh_cam.xyzC"), "wb").write(b"\0" * 148)
+    return wd
+
+
+def test_usage(exes):
+    r = subprocess.run([exes[1]], capture_output=True, text=True)
+    assert r.returncode == 0 and "Usage:" in r.stdout
+
+
+@pytest.mark.parametrize("workers", [1, 2, 3])
+def test_planes_txt_and_mean_from_finished_workdirs(exes, tmp_path, workers):
+    g = np.load(os.path.join(GOLD, "planes_txt.npz"))
+    lines = str(g["text"]).strip().split("\n")
+    out = tmp_path / "output"
+    out.mkdir()
+    for i, l in enumerate(lines):
+        _finished_workdir(str(out), i, l)
+    cfg = tmp_path / "cfg.txt"
+    cfg.write_text("MAX_DISPARITY=64\n")
+    r = subprocess.run([exes[1], str(cfg), "--sequence", str(out), "--gpus", "1", "--procs-per-gpu", str(workers), "--skip-existing"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert (out / "planes.txt").read_text() == str(g["text"])          # byte for byte, frame order
+    mean = np.array([float(x) for x in (out / "planes_mean.txt").read_text().split()])
+    np.testing.assert_allclose(mean, g["nanmean"], rtol=1e-15)
+    assert f"mean plane over {int(g['n_valid'])} frame(s)" in r.stdout
+    for i in range(len(lines)):
+        assert f"[frame {i}]" in r.stdout
+
+
+def test_failed_frame_is_reported_and_left_out(exes, tmp_path):
+    out = tmp_path / "output"
+    out.mkdir()
+    _finished_workdir(str(out), 0, "0.1 0.2 0.3 -4")
+    os.makedirs(out / "000001_wd")                                       # unfinished and unprocessable (no inputs, no GPU needed to fail)
+    _finished_workdir(str(out), 2, "0.3 0.2 0.1 -6")
+    cfg = tmp_path / "cfg.txt"
+    cfg.write_text("MAX_DISPARITY=64\n")
+    r = subprocess.run([exes[1], str(cfg), "--sequence", str(out), "--procs-per-gpu", "2", "--skip-existing"], capture_output=True, text=True)
+    assert r.returncode == 255
+    assert (out / "planes.txt").read_text() == "0.1 0.2 0.3 -4\n0.3 0.2 0.1 -6\n"
+    assert "[frame 1]" in r.stdout and "rc=-1" in r.stdout
+    np.testing.assert_allclose([float(x) for x in (out / "planes_mean.txt").read_text().split()], [0.2, 0.2, 0.2, -5.0], rtol=1e-15)
+
+
+@pytest.mark.gpu
+def test_batch_equals_one_process_per_frame(exes, tmp_path):
+    cli, batch = exes
+    w, h, D = 320, 240, 64
+    seq_a, seq_b = tmp_path / "a", tmp_path / "b"
+    cfg = None
+    for i in range(3):
+        t = tmp_path / f"mk{i}"
+        t.mkdir()
+        wd, cfg_i, *_ = make_workdir(str(t), w, h, D, frame=i)
+        for seq in (seq_a, seq_b):
+            shutil.copytree(wd, seq / ("%06d_wd" % i))
+        cfg = cfg_i
+    for i in range(3):                                                   # the reference's way: one process per frame
+        r = subprocess.run([cli, cfg, str(seq_a / ("%06d_wd" % i))], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout
+    r = subprocess.run([batch, cfg, "--sequence", str(seq_b), "--gpus", "1", "--procs-per-gpu", "2"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    expect = ""
+    for i in range(3):
+        for name in ("mesh_cam.xyzC", "plane.txt", "P0cam.txt", "Cam1_poseT.txt", "plane_refinement_inliers.xyz"):
+            a = (seq_a / ("%06d_wd" % i) / name).read_bytes()
+            assert a == (seq_b / ("%06d_wd" % i) / name).read_bytes(), f"frame {i}: {name} differs"
+        expect += " ".join((seq_a / ("%06d_wd" % i) / "plane.txt").read_text().split("\n")).strip() + "\n"
+    assert (seq_b / "planes.txt").read_text() == expect
+    planes = np.array([[float(x) for x in l.split()] for l in expect.strip().split("\n")])
+    np.testing.assert_allclose([float(x) for x in (seq_b / "planes_mean.txt").read_text().split()], np.nanmean(planes, axis=0), rtol=1e-14)
+    # the same sequence again: nothing is recomputed
+    r2 = subprocess.run([batch, cfg, "--sequence", str(seq_b), "--skip-existing"], capture_output=True, text=True)
+    assert r2.returncode == 0 and (seq_b / "planes.txt").read_text() == expect
+
+
+@pytest.mark.gpu
+def test_rccl_allreduce_through_the_c_abi(gpu_ctx):
+    """Coll-1 over RCCL on one rank (the multi-rank case needs one GPU per rank): unique id, communicator, all-reduce."""
+    import ctypes as C
+    from wass_amd import _lib
+    lib = _lib.load()
+    uid = (C.c_ubyte * 128)()
+    assert lib.wass_coll_unique_id(uid) == 0
+    assert lib.wass_coll_init(gpu_ctx._h, 0, 1, uid) == 0, gpu_ctx._lib.wass_last_error(gpu_ctx._h).decode()
+    acc = (C.c_double * 5)(1.5, -2.0, 3.25, -11.0, 4.0)
+    assert lib.wass_coll_allreduce_sum_f64(gpu_ctx._h, acc, 5) == 0, gpu_ctx._lib.wass_last_error(gpu_ctx._h).decode()
+    assert list(acc) == [1.5, -2.0, 3.25, -11.0, 4.0]
+
+
+@pytest.mark.gpu
+def test_bench_runs_two_ranks_or_fails_loudly():
+    """python bench.py --gpus 2 on a one-GPU box must never be a silent one-rank run."""
+    import json
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "A",
+                        "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and "only 1 device(s) are visible" in (r.stdout + r.stderr)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "A",
+                        "--no-cpu-baseline", "--allow-shared-gpu"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks"]["world_size_from_process_group"] == 2
+    assert len(line["ranks"]["pairs_per_sec_per_rank"]) == 2 and line["planes_averaged"] == 4

@@ -122,6 +122,9 @@ SYMBOLS = {
     "wass_free": (None, [_vp]),
     "wass_planes_mean_accumulate": (None, [C.POINTER(C.c_double), _i, C.POINTER(C.c_double)]),
     "wass_planes_mean_finish": (None, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
+    "wass_coll_unique_id": (_i, [_vp]),
+    "wass_coll_init": (_i, [_vp, _i, _i, _vp]),
+    "wass_coll_allreduce_sum_f64": (_i, [_vp, C.POINTER(C.c_double), _i]),
     "wass_stereo_rectify": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), _i, _i, C.POINTER(C.c_double),
                                  C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                  C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(_i)]),

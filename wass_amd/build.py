@@ -47,7 +47,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if failed:
         raise RuntimeError("hipcc failed for: " + ", ".join(failed))
     if force or procs or not os.path.exists(SO):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO, *objs]
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO, *objs, "-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
@@ -57,20 +57,22 @@ def build(force: bool = False, verbose: bool = False) -> str:
 HOST_DIR = os.path.join(_HERE, "host")
 BIN_DIR = os.path.join(_HERE, "bin")
 CLI = os.path.join(BIN_DIR, "wass_stereo")
+BATCH = os.path.join(BIN_DIR, "wass_stereo_batch")
 
 
 def build_host(force: bool = False, verbose: bool = False) -> str:
     """The drop-in wass_stereo executable: plain C++17 (g++) above the C ABI, linked against libwassgpu.so."""
     build(force=False)
     os.makedirs(BIN_DIR, exist_ok=True)
-    src = os.path.join(HOST_DIR, "wass_stereo.cpp")
     deps = sorted(glob.glob(os.path.join(HOST_DIR, "*.hpp"))) + [os.path.join(_HERE, "..", "include", "wass_gpu.h"), SO]
-    if force or _newer(src, CLI, deps):
-        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", "-Wno-unused-function", src, "-o", CLI,
-               "-L" + _HERE, "-lwassgpu", "-lz", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath-link," + "/opt/rocm/lib"]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+    for name, exe in (("wass_stereo.cpp", CLI), ("wass_stereo_batch.cpp", BATCH)):
+        src = os.path.join(HOST_DIR, name)
+        if force or _newer(src, exe, deps):
+            cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", "-Wno-unused-function", src, "-o", exe,
+                   "-L" + _HERE, "-lwassgpu", "-lz", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath-link," + "/opt/rocm/lib"]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
     return CLI
 
 

@@ -150,6 +150,9 @@ struct wass_ctx {
     int launches[2] = {};
     hipStream_t side = nullptr, side2 = nullptr;   // checkpoint sweeps run ahead here
     hipEvent_t ev_cost = nullptr, ev_ckpt[4] = {}, ev_cols = nullptr;
+    void* coll_comm = nullptr;     // ncclComm_t of wass_coll_init (coll.hip); coll_buf: 64 doubles of HBM for the all-reduce
+    void* coll_buf = nullptr;
+    int coll_world = 0;
     wass::SgmDims last = {};
     bool have_last = false;
     bool debug = false;            // keep the finished S volume for wass_sgm_debug_fetch
@@ -209,6 +212,7 @@ EdgeLayout edge_layout(const SgmDims& d);
 bool tile_schedule_enabled();        // WASS_AGG=tile
 int launch_aggregate_tile(wass_ctx* c, const SgmDims& d, int* n_launches);
 
+void coll_release(wass_ctx* c);               // coll.hip
 void mesh_pool_purge(const void* owner);      // mesh.hip: parked mesh allocations of a context that is going away
 
 // stage launchers (each enqueues on c->stream)

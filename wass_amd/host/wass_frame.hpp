@@ -1,0 +1,504 @@
+// wass_frame.hpp -- one frame of the reference's wass_stereo stage (/root/reference/src/wass_stereo/wass_stereo.cpp:1833-2147,
+// everything main() does once argv has been checked), calling libwassgpu through its C ABI.  Shared by the drop-in
+// executable (wass_stereo.cpp: one frame per process, as wasscli launches it) and by the sequence driver
+// (wass_stereo_batch.cpp: one process per GPU, one persistent context, many frames).
+//
+// Same argv, exit codes, config format, workdir inputs/outputs, stdout progress markers and log format as the
+// reference.  There is NO CPU implementation of the hot path here: without a GPU (or
+// without libwassgpu.so) the program fails with exit code -1.
+//
+// Divergences from the reference, all listed in DESIGN.md: DENSE_SCALE must be 1; no JPEG debug renders;
+// --measure (interactive GUI) is rejected.
+#pragma once
+
+#include <sys/stat.h>
+#include <sys/time.h>
+
+#include <cstdlib>
+#include <ctime>
+
+#include "../../include/wass_gpu.h"
+#include "config.hpp"
+#include "hostio.hpp"
+#include "rectify.hpp"
+
+using namespace wasshost;
+
+#ifndef WASS_AMD_VERSION
+#define WASS_AMD_VERSION "1.26-mi355x"
+#endif
+
+namespace wassframe {
+
+struct Timer {           // cvlab::HiresTimer (src/wass_lib/hires_timer.cpp:76-131)
+    double t0 = 0, tend = 0;
+    std::vector<std::pair<double, std::string>> events;
+    static double now() { timeval tv; gettimeofday(&tv, nullptr); return (double)tv.tv_sec + (double)tv.tv_usec / 1e6; }
+    void start() { t0 = now(); }
+    double elapsed() const { return (tend > 0 ? tend : now()) - t0; }
+    void stop() { tend = now(); }
+    void operator<<(const std::string& name) { events.emplace_back(elapsed(), name); }
+};
+
+struct Env {             // StereoMatchEnv (wass_stereo.cpp:202-335)
+    Timer timer;
+    std::string workdir;
+    Mat K_left, K_right, K0, K1, R, T, Rinv, Tinv, P0, P1, Rpose0, Tpose0, Rpose1, Tpose1, HL, HR, HLi, HRi;
+    bool use_custom = true;
+    double rec_R1[9] = {}, rec_R2[9] = {}, rec_P1[12] = {}, rec_P2[12] = {};                 // cv::stereoRectify outputs (:248-251)
+    Image left, right, left_crop, right_crop;
+    int left_index = 0, right_index = 1;
+    double cam_distance = 1.0, disparity_compensation = 0.0;
+    Rect roi_l, roi_r;
+};
+
+std::string path_join(const std::string& a, const std::string& b) { return a.empty() || a.back() == '/' ? a + b : a + "/" + b; }
+bool exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+
+Mat stack_RT(const Mat& R, const Mat& T) { Mat m(3, 4); for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) m(i, j) = R(i, j); m(i, 3) = T(i, 0); } return m; }
+void invert_RT(Mat& R, Mat& T) { R = transpose(R); T = scaled(matmul(R, T), -1.0); }     // :196-200
+void computeP(Env& e) { e.P0 = matmul(e.K0, stack_RT(e.Rpose0, e.Tpose0)); e.P1 = matmul(e.K1, stack_RT(e.Rpose1, e.Tpose1)); }
+
+void swapLeftRight(Env& e)                                                                // :264-297
+{
+    std::swap(e.left_index, e.right_index);
+    std::swap(e.left, e.right);
+    std::swap(e.K_left, e.K_right);
+    std::swap(e.R, e.Rinv);
+    std::swap(e.T, e.Tinv);
+    std::swap(e.Rpose0, e.Rpose1);
+    std::swap(e.Tpose0, e.Tpose1);
+    invert_RT(e.Rpose0, e.Tpose0);
+    invert_RT(e.Rpose1, e.Tpose1);
+    computeP(e);
+}
+
+bool load_data(Env& env, const Config& cfg)                                               // :337-445
+{
+    WLOG_SCOPE("load_data");
+    env.R = load_matrix_xml(path_join(env.workdir, "ext_R.xml"));
+    if (env.R.rows != 3 || env.R.cols != 3) { WLOGE << "invalid extrinsic rotation matrix (ext_R.xml)"; return false; }
+    env.T = load_matrix_xml(path_join(env.workdir, "ext_T.xml"));
+    if (env.T.cols != 1 || env.T.rows != 3) { WLOGE << "invalid extrinsic translation vector (ext_T.xml)"; return false; }
+    env.Rinv = env.R; env.Tinv = env.T;
+    invert_RT(env.Rinv, env.Tinv);
+    const double cur = std::sqrt(env.T(0, 0) * env.T(0, 0) + env.T(1, 0) * env.T(1, 0) + env.T(2, 0) * env.T(2, 0));
+    for (int i = 0; i < 3; ++i) { env.T(i, 0) = env.T(i, 0) / cur * env.cam_distance; env.Tinv(i, 0) = env.Tinv(i, 0) / cur * env.cam_distance; }
+    env.Rpose0 = Mat::eye(3); env.Tpose0 = Mat(3, 1);
+    env.Rpose1 = env.R; env.Tpose1 = env.T;
+    env.K0 = load_matrix_xml(path_join(env.workdir, "intrinsics_00000000.xml"));
+    env.K1 = load_matrix_xml(path_join(env.workdir, "intrinsics_00000001.xml"));
+    if (env.K0.rows != 3 || env.K0.cols != 3 || env.K1.rows != 3 || env.K1.cols != 3) { WLOGE << "invalid intrinsics"; return false; }
+    env.K_left = env.K0; env.K_right = env.K1;
+    computeP(env);
+    try {
+        env.left = read_png_gray(path_join(env.workdir, "undistorted/00000000.png"));
+        env.left_index = 0;
+        WLOGI << "image 0 loaded, Size: " << env.left.w << "x" << env.left.h;
+        env.right = read_png_gray(path_join(env.workdir, "undistorted/00000001.png"));
+        env.right_index = 1;
+        WLOGI << "image 1 loaded, Size: " << env.right.w << "x" << env.right.h;
+    } catch (const std::exception& e) {
+        WLOGE << "unable to load input images: " << e.what();
+        return false;
+    }
+    if (env.left.w != env.right.w || env.left.h != env.right.h) { WLOGE << "left and right images differ in size"; return false; }
+    const double sis = cfg.get_double("SAVE_INPUT_SCALE");
+    if (sis < 1.0) {                                                                      // :401-434
+        const size_t nw = (size_t)(env.left.w * sis), nh = (size_t)(env.left.h * sis);
+        const double scale = (double)nw / (double)env.left.w;
+        WLOGI << "original size: " << env.left.w << "x" << env.left.h;
+        WLOGI << "  scaled size: " << nw << "x" << nh;
+        WLOGI << "        scale: " << scale;
+        if (nw > 0 && nh > 0) {
+            write_png_gray(path_join(env.workdir, "00000000_s.png"), resize_cubic(env.left, (int)nw, (int)nh));
+            write_png_gray(path_join(env.workdir, "00000001_s.png"), resize_cubic(env.right, (int)nw, (int)nh));
+        }
+        Mat k0 = scaled(env.K_left, scale), k1 = scaled(env.K_right, scale);
+        k0(2, 2) = 1; k1(2, 2) = 1;
+        save_matrix_txt(path_join(env.workdir, "K0_small.txt"), k0);
+        save_matrix_txt(path_join(env.workdir, "K1_small.txt"), k1);
+        std::ofstream ofs(path_join(env.workdir, "scale.txt").c_str());
+        ofs.precision(16); ofs << std::scientific << scale;
+    }
+    return true;
+}
+
+bool rectify(Env& env, const Config& cfg, wass_ctx* ctx)                                  // :447-613
+{
+    WLOG_SCOPE("rectify");
+    WLOGI << "rectifying...";
+    bool auto_swap = true, do_swap = false;
+    if (std::fabs(env.T(1, 0)) > std::fabs(env.T(0, 0))) { WLOGE << "Vertical stereo not supported"; return false; }
+    WLOGI << "Detected stereo setup:";
+    WLOGI << (env.T(0, 0) > 0 ? "CAM1 (L) ---------  CAM0 (R)" : "CAM0 (L) ---------  CAM1 (R)");
+    if (cfg.get_bool("DISABLE_AUTO_LEFT_RIGHT")) {
+        auto_swap = false;
+        do_swap = cfg.get_bool("SWAP_LEFT_RIGHT");
+        WLOGI << "auto left-right detection disabled. Swap left-right? " << (do_swap ? "YES" : "NO");
+        if (do_swap) { WLOGI << "swapping left-right images as requested"; swapLeftRight(env); }
+    } else if (env.T(0, 0) < 0) {
+        WLOGI << "auto-swapping left-right images";
+        swapLeftRight(env);
+    }
+    const int W = env.left.w, H = env.left.h;
+    auto roi_ok = [&](const Rect& r) { return r.x >= 0 && r.y >= 0 && r.width > 0 && r.height > 0 && r.x + r.width <= W && r.y + r.height <= H; };
+    auto gpu = [&](int rc, const char* what) { if (rc != WASS_OK) throw std::runtime_error(std::string(what) + ": " + wass_last_error(ctx)); };
+    env.use_custom = cfg.get_bool("USE_CUSTOM_STEREORECTIFY");
+    if (env.use_custom) {
+        const double ang = cfg.get_double("RECTIFY_ANGLE");
+        WLOGI << "Using WASS custom stereorectify, baseline angle delta=" << ang;
+        const double Tinv[3] = { env.Tinv(0, 0), env.Tinv(1, 0), env.Tinv(2, 0) };
+        Rect roi;
+        stereoRectifyUndistorted(env.K_left, env.K_right, env.Rinv, Tinv, ang, W, H, env.HL, env.HR, roi);
+        env.HLi = inv3(env.HL); env.HRi = inv3(env.HR);
+        save_matrix_txt(path_join(env.workdir, env.left_index == 0 ? "H0_rect.txt" : "H1_rect.txt"), env.HL);
+        save_matrix_txt(path_join(env.workdir, env.left_index == 0 ? "H1_rect.txt" : "H0_rect.txt"), env.HR);
+        env.roi_l = env.roi_r = roi;
+        if (cfg.get_bool("DISABLE_RECTIFY_ROI")) { env.roi_l = env.roi_r = Rect{ 0, 0, W, H }; }
+        if (!roi_ok(env.roi_l)) { WLOGE << "rectification ROI is empty or outside the image"; return false; }
+        // cv::warpPerspective (:515-516) and the ROI .clone() (:526-528) in one GPU pass per camera
+        const int rl[4] = { env.roi_l.x, env.roi_l.y, env.roi_l.width, env.roi_l.height };
+        env.left_crop = Image(rl[2], rl[3]); env.right_crop = Image(rl[2], rl[3]);
+        gpu(wass_warp_perspective(ctx, env.left.px.data(), W, H, (size_t)W, env.HL.d.data(), W, H, rl, env.left_crop.px.data()), "wass_warp_perspective");
+        gpu(wass_warp_perspective(ctx, env.right.px.data(), W, H, (size_t)W, env.HR.d.data(), W, H, rl, env.right_crop.px.data()), "wass_warp_perspective");
+    } else {
+        WLOGI << "Rectifying via cv::stereoRectify";
+        int roi_left[4], roi_right[4];
+        bool rectification_ok = false;
+        do {                                                                               // :539-582
+            const double T3[3] = { env.T(0, 0), env.T(1, 0), env.T(2, 0) };
+            if (wass_stereo_rectify(env.K_left.d.data(), env.K_right.d.data(), W, H, env.R.d.data(), T3, 1.0, env.rec_R1, env.rec_R2, env.rec_P1,
+                                    env.rec_P2, roi_left, roi_right) != WASS_OK) { WLOGE << "stereoRectify failed (zero baseline)"; return false; }
+            if (std::fabs(env.rec_P2[3]) < std::fabs(env.rec_P2[7])) { WLOGE << "vertical stereo not supported"; return false; }
+            if (roi_left[2] == 0 || roi_right[2] == 0 || roi_left[3] == 0 || roi_right[3] == 0) { WLOGE << "the epipole lies inside the image plane"; return false; }
+            if (auto_swap) {
+                if (env.rec_P2[3] < 0) { WLOGI << "auto-swapping left-right images"; swapLeftRight(env); }
+                else rectification_ok = true;
+            } else if (do_swap) {          // sic (:570-575): a requested swap is applied a second time here, i.e. undone
+                WLOGI << "swapping left-right images as requested";
+                swapLeftRight(env);
+                do_swap = false;
+            } else rectification_ok = true;
+        } while (!rectification_ok);
+        const int ymin = std::max(roi_left[1], roi_right[1]);
+        const int ymax = std::min(roi_left[1] + roi_left[3], roi_right[1] + roi_right[3]);
+        env.roi_l = Rect{ roi_left[0], ymin, roi_left[2], ymax - ymin };
+        env.roi_r = Rect{ roi_right[0], ymin, roi_right[2], ymax - ymin };
+        if (env.roi_l.width > env.roi_r.width) env.roi_l.width = env.roi_r.width; else env.roi_r.width = env.roi_l.width;
+        if (!roi_ok(env.roi_l) || !roi_ok(env.roi_r)) { WLOGE << "rectification ROI is empty or outside the image"; return false; }
+        // cv::initUndistortRectifyMap (:600-601), cv::remap INTER_CUBIC (:603-604), ROI .clone() (:606-607)
+        std::vector<float> mx((size_t)W * H), my((size_t)W * H);
+        const int rl[4] = { env.roi_l.x, env.roi_l.y, env.roi_l.width, env.roi_l.height }, rr[4] = { env.roi_r.x, env.roi_r.y, env.roi_r.width, env.roi_r.height };
+        env.left_crop = Image(rl[2], rl[3]); env.right_crop = Image(rr[2], rr[3]);
+        if (wass_init_rectify_map(env.K_left.d.data(), env.rec_R1, env.rec_P1, W, H, mx.data(), my.data()) != WASS_OK) { WLOGE << "singular rectification"; return false; }
+        gpu(wass_remap_cubic(ctx, env.left.px.data(), W, H, (size_t)W, mx.data(), my.data(), W, H, rl, env.left_crop.px.data()), "wass_remap_cubic");
+        if (wass_init_rectify_map(env.K_right.d.data(), env.rec_R2, env.rec_P2, W, H, mx.data(), my.data()) != WASS_OK) { WLOGE << "singular rectification"; return false; }
+        gpu(wass_remap_cubic(ctx, env.right.px.data(), W, H, (size_t)W, mx.data(), my.data(), W, H, rr, env.right_crop.px.data()), "wass_remap_cubic");
+    }
+    WLOGI << "rectification map generated. Size: " << env.left_crop.w << "x" << env.left_crop.h;
+    return true;
+}
+
+void show_time_stats(const Timer& t)                                                       // render.hpp:175-191
+{
+    WLOGI << "+----------------------------+-------------------+";
+    WLOGI << "|   Task                     |   Time (seconds)  |";
+    WLOGI << "+----------------------------+-------------------+";
+    double last = 0.0;
+    for (const auto& e : t.events) {
+        std::ostringstream os; os << "| " << std::setw(25) << e.second << "  |" << std::setw(18) << (e.first - last) << " |";
+        WLOGI << os.str();
+        last = e.first;
+    }
+    WLOGI << "+----------------------------+-------------------+";
+    { std::ostringstream os; os << "| " << std::setw(25) << "TOTAL" << "  |" << std::setw(18) << t.elapsed() << " |"; WLOGI << os.str(); }
+    WLOGI << "+----------------------------+-------------------+";
+}
+
+int save_configuration(const Config& cfg, const std::string& filename)                    // :1776-1794
+{
+    WLOG_SCOPE("wass_stereo");
+    WLOGI << "Writing " << filename;
+    std::ofstream ofs(filename);
+    if (!ofs.is_open()) { WLOGE << "Unable to open " << filename << " for write"; return -1; }
+    ofs << cfg.to_config_string();
+    ofs.close();
+    WLOGI << "Done!";
+    return 0;
+}
+
+struct GpuError : std::runtime_error { using std::runtime_error::runtime_error; };
+void gpu_check(wass_ctx* ctx, int rc, const char* what, bool allow_overflow = false)
+{
+    if (rc == WASS_OK || (allow_overflow && rc == WASS_ERR_COST_OVERFLOW)) return;
+    throw GpuError(std::string(what) + ": " + wass_last_error(ctx));
+}
+
+
+struct FrameSummary {
+    int have_plane = 0;           // 1: plane.txt holds a refined plane, 0: "nan nan nan nan" (RANSAC failed) or the frame failed
+    double plane[4] = { 0, 0, 0, 0 };
+    unsigned long long n_points = 0;
+};
+
+// Everything wass_stereo does with one workdir.  *ctxp may hold a live context (sequence driver); if it is null one is
+// created on `device` at the point where the reference would first need the GPU and handed back to the caller, who
+// destroys it.  mode: nullptr, "--rectify-only" or "--measure".  Returns the process exit code of wass_stereo (0 / -1).
+inline int wass_run_frame(const char* config_path, const std::string& workdir, const char* mode, int device, wass_ctx** ctxp,
+                          FrameSummary* summary)
+{
+    Env env;
+    env.workdir = workdir;
+    Config cfg;
+    register_wass_stereo_options(cfg);
+    setup_logger(path_join(env.workdir, "wass_stereo_log.txt"));
+    WLOG_SCOPE("wass_stereo");
+    {
+        WLOGI << "Loading configuration file " << config_path;
+        std::ifstream ifs(config_path);
+        if (!ifs.is_open()) { WLOGE << "Unable to load " << config_path; return -1; }
+        try { cfg.load(ifs); } catch (const std::runtime_error& er) { WLOGE << er.what(); return -1; }
+        if (save_configuration(cfg, path_join(env.workdir, "stereo_config.txt")) != 0) WLOGE << "Unable to save stereo configuration file";
+    }
+    if (cfg.get_int("RANDOM_SEED") == -1) srand((unsigned int)time(0));
+    else { srand(cfg.get_int("RANDOM_SEED")); WLOGI << "random seed set to: " << cfg.get_int("RANDOM_SEED"); }
+
+    wass_ctx* ctx = *ctxp;
+    wass_mesh* mesh = nullptr;
+    int ret = 0;
+    try {
+        WLOGI << "Reconstructing " << env.workdir;
+        env.timer.start();
+        env.cam_distance = 1.0;
+        if (!load_data(env, cfg)) return -1;
+        env.timer << "Data load";
+        std::cout << "[P|10|100]" << std::endl;
+        auto save_cams = [&]() {
+            save_matrix_txt(path_join(env.workdir, "P0cam.txt"), env.P0);
+            save_matrix_txt(path_join(env.workdir, "P1cam.txt"), env.P1);
+            save_matrix_txt(path_join(env.workdir, "Cam0_poseR.txt"), env.Rpose0);
+            save_matrix_txt(path_join(env.workdir, "Cam0_poseT.txt"), env.Tpose0);
+            save_matrix_txt(path_join(env.workdir, "Cam1_poseR.txt"), env.Rpose1);
+            save_matrix_txt(path_join(env.workdir, "Cam1_poseT.txt"), env.Tpose1);
+        };
+        save_cams();
+        const char* dev_env = getenv("WASS_GPU_DEVICE");
+        if (!ctx) {
+            if (wass_ctx_create(dev_env ? atoi(dev_env) : device, &ctx) != WASS_OK) { WLOGE << "no usable MI355X GPU / HIP runtime (libwassgpu has no CPU fallback)"; return -1; }
+            *ctxp = ctx;
+        }
+        if (!rectify(env, cfg, ctx)) return -1;   // the reference ignores this result (:1897); stricter here
+        env.timer << "Rectification";
+        std::cout << "[P|20|100]" << std::endl;
+        save_cams();
+        WLOG_SCOPE("wass_stereo");
+        if (mode && std::string("--rectify-only") == mode) { WLOGI << "All done."; return 0; }
+        if (mode && std::string("--measure") == mode) { WLOGE << "--measure needs the interactive GUI, which this build does not have"; return -1; }
+
+        // ---- sgbm_dense_stereo (:764-1020)
+        WLOG_SCOPE("sgbm_dense_stereo");
+        wass_sgm_params sp;
+        sp.min_disp = cfg.get_int("MIN_DISPARITY");
+        sp.num_disp = cfg.get_int("MAX_DISPARITY");
+        sp.win = cfg.get_int("WINSIZE");
+        sp.P1 = cfg.get_int("DENSE_P1_MULT") * sp.win * sp.win;
+        sp.P2 = cfg.get_int("DENSE_P2_MULT") * sp.win * sp.win;
+        sp.uniq_ratio = cfg.get_int("DENSE_UNIQUENESS_RATIO");
+        sp.disp12_max_diff = cfg.get_int("DENSE_DISP12MAXDIFF");
+        sp.prefilter_cap = cfg.get_int("DENSE_PREFILTER_CAP");
+        sp.speckle_win = cfg.get_int("DENSE_SPECKLE_WINDOW_SIZE");
+        sp.speckle_range = cfg.get_int("DENSE_SPECKLE_RANGE");
+        sp.ndirs = cfg.get_int("DENSE_PATHS");
+        sp.disp_offset = cfg.get_int("DISPARITY_OFFSET");
+        sp.dense_scale = cfg.get_double("DENSE_SCALE");
+        if (cfg.get_int("DENSE_DISPARITY_BIGGEST_COMPONENT_THRESHOLD") > 0)
+            throw std::runtime_error("DENSE_DISPARITY_BIGGEST_COMPONENT_THRESHOLD > 0 is not supported");
+        WLOGI << "Disparity offset: " << sp.disp_offset << " px";
+        env.disparity_compensation = sp.disp_offset > 0 ? 0 : -sp.disp_offset;
+        const int cw = env.right_crop.w, ch = env.right_crop.h;
+        std::vector<int16_t> disp16((size_t)cw * ch);
+        WLOGI << "computing dense disparity map... (may take a while)";
+        const int rc = wass_sgm_disparity(ctx, env.right_crop.px.data(), env.left_crop.px.data(), cw, ch, (size_t)cw, &sp, disp16.data());
+        gpu_check(ctx, rc, "wass_sgm_disparity", true);
+        if (rc == WASS_ERR_COST_OVERFLOW) WLOGE << "matching costs exceeded the int16 range; the disparity is outside the reference's defined behaviour";
+        std::vector<float> dispf((size_t)cw * ch);
+        const int dil = cfg.get_int("DISP_DILATE_STEPS"), ero = cfg.get_int("DISP_EROSION_STEPS");
+        if (dil > 0) WLOGI << "applying dilate filter (" << dil << " steps)"; else WLOGI << "dilate filter skipped.";
+        if (ero > 0) WLOGI << "applying erode filter (" << ero << " steps)"; else WLOGI << "erode filter skipped.";
+        gpu_check(ctx, wass_disparity_postprocess(ctx, disp16.data(), cw, ch, &sp, dil, ero, cfg.get_int("MEDIAN_FILTER_WSIZE"), dispf.data()),
+                  "wass_disparity_postprocess");
+        WLOGI << "dense stereo completed successfully";
+        env.timer << "Dense Stereo";
+        std::cout << "[P|40|100]" << std::endl;
+
+        // ---- triangulate (:1039-1386)
+        WLOG_SCOPE("triangulate");
+        const int W = env.left.w, H = env.left.h, iw = env.left.w, ih = env.left.h;     // rectified images keep the input size
+        auto make_mask = [&](const Image& img, const std::string& key, const char* which) {
+            std::vector<uint8_t> m((size_t)iw * ih, 1);
+            const std::string name = cfg.get_string(key);
+            if (name != "none") {
+                const std::string fn = path_join(env.workdir, name);
+                WLOGI << "Loading " << fn << " as " << which << " camera mask";
+                try {
+                    const Image aux = read_png_gray(fn);
+                    if (aux.w == iw && aux.h == ih) for (size_t i = 0; i < m.size(); ++i) m[i] = aux.px[i] > 0 ? 1 : 0;   // threshold(0.5)
+                    else WLOGE << "not found or invalid image.";
+                } catch (const std::exception&) { WLOGE << "not found or invalid image."; }
+            }
+            if (cfg.get_bool("DISCARD_BURNED_AREAS")) for (size_t i = 0; i < m.size(); ++i) if (img.px[i] > 254) m[i] = 0;
+            return m;
+        };
+        const std::vector<uint8_t> lmask = make_mask(env.left, "LEFT_MASK_IMAGE", "left"), rmask = make_mask(env.right, "RIGHT_MASK_IMAGE", "right");
+        wass_geom g;
+        memset(&g, 0, sizeof g);
+        auto put = [](double* dst, const Mat& m, int n) { for (int i = 0; i < n; ++i) dst[i] = m.d[i]; };
+        put(g.K_left, env.K_left, 9); put(g.K_right, env.K_right, 9); put(g.R, env.R, 9); put(g.T, env.T, 3);
+        g.use_custom = env.use_custom ? 1 : 0;
+        if (env.use_custom) { put(g.HLi, env.HLi, 9); put(g.HRi, env.HRi, 9); }
+        else { memcpy(g.R1, env.rec_R1, sizeof g.R1); memcpy(g.R2, env.rec_R2, sizeof g.R2); memcpy(g.P1, env.rec_P1, sizeof g.P1); memcpy(g.P2, env.rec_P2, sizeof g.P2); }
+        g.disparity_compensation = env.disparity_compensation;
+        g.dense_scale = sp.dense_scale;
+        wass_tri_params tp;
+        tp.min_angle_deg = cfg.get_double("TRIANG_MIN_ANGLE");
+        tp.bbox[0] = 0; tp.bbox[1] = 0; tp.bbox[2] = iw; tp.bbox[3] = ih;
+        if (cfg.get_double("TRIANG_BBOX_TOP") >= 0 && cfg.get_double("TRIANG_BBOX_LEFT") >= 0 && cfg.get_double("TRIANG_BBOX_BOTTOM") >= 0 &&
+            cfg.get_double("TRIANG_BBOX_RIGHT") >= 0) {
+            tp.bbox[0] = cfg.get_double("TRIANG_BBOX_LEFT"); tp.bbox[1] = cfg.get_double("TRIANG_BBOX_TOP");
+            tp.bbox[2] = cfg.get_double("TRIANG_BBOX_RIGHT"); tp.bbox[3] = cfg.get_double("TRIANG_BBOX_BOTTOM");
+        }
+        tp.cam_distance = env.cam_distance;
+        const int roi_l[4] = { env.roi_l.x, env.roi_l.y, env.roi_l.width, env.roi_l.height };
+        const int roi_r[4] = { env.roi_r.x, env.roi_r.y, env.roi_r.width, env.roi_r.height };
+        WLOGI << "triangulating disparity map";
+        uint64_t n_pts = 0;
+        gpu_check(ctx, wass_triangulate(ctx, dispf.data(), W, H, roi_l, roi_r, &g, env.right.px.data(), iw, ih, lmask.data(), rmask.data(), &tp, &mesh, &n_pts),
+                  "wass_triangulate");
+        WLOGI << "... 100%";
+        WLOGI << n_pts << " valid points found";
+        if (summary) summary->n_points = n_pts;
+        env.timer << "Triangulation";
+        std::cout << "[P|60|100]" << std::endl;
+        WLOG_SCOPE("wass_stereo");
+        if ((long long)n_pts < cfg.get_int("MIN_TRIANGULATED_POINTS")) { WLOGE << "Too few points triangulated, aborting"; throw GpuError("too few points"); }
+
+        // ---- outlier removal (:2046-2050)
+        double pct = 0; uint64_t ngaps = 0, csize = 0;
+        gpu_check(ctx, wass_mesh_zgap_percentile(ctx, mesh, cfg.get_double("ZGAP_PERCENTILE"), &pct, &ngaps), "wass_mesh_zgap_percentile");
+        env.timer << "Z-gap stats";
+        gpu_check(ctx, wass_mesh_keep_biggest_component(ctx, mesh, pct, &csize), "wass_mesh_keep_biggest_component");
+        WLOG_SCOPE("cluster");
+        WLOGI << "biggest component size: " << csize << " (px)";
+        env.timer << "Outlier removal";
+        std::cout << "[P|80|100]" << std::endl;
+        WLOG_SCOPE("wass_stereo");
+
+        const int mw = roi_r[2], mh = roi_r[3];
+        std::vector<uint8_t> hv, hg; std::vector<double> hp;
+        auto download = [&]() { hv.resize((size_t)mw * mh); hg.resize(hv.size()); hp.resize(hv.size() * 3); gpu_check(ctx, wass_mesh_download(ctx, mesh, hv.data(), hp.data(), hg.data()), "wass_mesh_download"); };
+        if (cfg.get_bool("SAVE_FULL_MESH")) {
+            download();
+            if (!save_ply_points(path_join(env.workdir, "mesh_full.ply"), hv, hp, hg)) { WLOGE << "unable to save mesh data."; throw GpuError("write failed"); }
+        }
+
+        // ---- plane (:2062-2107)
+        WLOGI << "estimating best fitting plane...";
+        const int rounds = cfg.get_int("PLANE_RANSAC_ROUNDS");
+        std::vector<int32_t> uv((size_t)std::max(rounds, 1) * 6);
+        if (rounds <= 0 || wass_ransac_sample(mw, mh, rounds, uv.data()) != WASS_OK) throw std::runtime_error("invalid PLANE_RANSAC_ROUNDS / mesh size");
+        double plane[4] = { 0, 0, 0, 0 };
+        uint64_t best = 0; int found = 0;
+        gpu_check(ctx, wass_mesh_ransac_plane(ctx, mesh, uv.data(), rounds, cfg.get_double("PLANE_RANSAC_THRESHOLD"), plane, &best, &found), "wass_mesh_ransac_plane");
+        WLOG_SCOPE("ransac_find_plane");
+        WLOGI << rounds << " ransac rounds, " << best << " best inliers";
+        WLOGI << "ransac plane coeffs: " << plane[0] << " " << plane[1] << " " << plane[2] << " " << plane[3];
+        WLOG_SCOPE("wass_stereo");
+        bool have_plane = false;
+        if (found) {
+            env.timer << "Plane fitting";
+            std::cout << "[P|90|100]" << std::endl;
+            WLOGI << "refining plane";
+            uint64_t kept = 0, ninl = 0;
+            gpu_check(ctx, wass_mesh_crop_plane(ctx, mesh, plane, cfg.get_double("PLANE_RANSAC_THRESHOLD"), &kept), "wass_mesh_crop_plane");
+            wass_refine_params rp;
+            rp.xmin = cfg.get_double("PLANE_REFINE_XMIN"); rp.xmax = cfg.get_double("PLANE_REFINE_XMAX");
+            rp.ymin = cfg.get_double("PLANE_REFINE_YMIN"); rp.ymax = cfg.get_double("PLANE_REFINE_YMAX");
+            rp.max_distance = cfg.get_double("PLANE_REFINEMENT_MAX_DISTANCE");
+            rp.weight_by_distance = cfg.get_bool("PLANE_WEIGHT_PROPORTIONAL_TO_DISTANCE");
+            rp.central_third_only = cfg.get_bool("PLANE_USE_CENTRAL_THIRD_ONLY");
+            gpu_check(ctx, wass_mesh_refine_plane(ctx, mesh, &rp, plane, &ninl), "wass_mesh_refine_plane");
+            WLOG_SCOPE("refine_plane");
+            WLOGI << "refinement inliers (after cropping): " << ninl;
+            WLOGI << "estimated plane coeffs: " << plane[0] << " " << plane[1] << " " << plane[2] << " " << plane[3];
+            WLOG_SCOPE("wass_stereo");
+            {   // plane_refinement_inliers.xyz: every 10th refinement inlier in raster order (:2077-2085)
+                download();
+                const int umin = rp.central_third_only ? mw / 4 : 0, umax = rp.central_third_only ? mw * 3 / 4 : mw - 1;
+                const int vmin = rp.central_third_only ? mh / 4 : 0, vmax = rp.central_third_only ? mh * 2 / 3 : mh - 1;
+                std::ofstream ofs(path_join(env.workdir, "plane_refinement_inliers.xyz").c_str());
+                size_t k = 0;
+                for (int v = vmin; v <= vmax; ++v)
+                    for (int u = umin; u <= umax; ++u) {
+                        const size_t i = (size_t)v * mw + u;
+                        if (!hv[i]) continue;
+                        const double* p = &hp[3 * i];
+                        if (p[0] > rp.xmin && p[0] < rp.xmax && p[1] > rp.ymin && p[1] < rp.ymax && std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) < rp.max_distance) {
+                            if (k % 10 == 0) ofs << p[0] << " " << p[1] << " " << p[2] << std::endl;
+                            ++k;
+                        }
+                    }
+            }
+            gpu_check(ctx, wass_mesh_crop_plane(ctx, mesh, plane, cfg.get_double("PLANE_MAX_DISTANCE"), &kept), "wass_mesh_crop_plane");
+            WLOG_SCOPE("crop_plane");
+            WLOGI << "number of points after plane cropping: " << kept;
+            WLOG_SCOPE("wass_stereo");
+            env.timer << "Plane refinement";
+            std::ofstream ofs(path_join(env.workdir, "plane.txt").c_str());
+            ofs << std::setprecision(20);
+            for (int i = 0; i < 4; ++i) ofs << plane[i] << std::endl;
+            have_plane = true;
+            if (summary) { summary->have_plane = 1; for (int i = 0; i < 4; ++i) summary->plane[i] = plane[i]; }
+        } else {
+            WLOGE << "ransac failed. I'll continue anyway but plane data won't be available!";
+            std::ofstream ofs(path_join(env.workdir, "plane.txt").c_str());
+            ofs << "nan nan nan nan" << std::endl;
+        }
+
+        // ---- export (:2110-2135)
+        WLOGI << "Exporting point cloud data";
+        if (cfg.get_bool("SAVE_AS_PLY")) {
+            download();
+            if (!save_ply_points(path_join(env.workdir, "mesh.ply"), hv, hp, hg)) { WLOGE << "unable to save mesh data."; throw GpuError("write failed"); }
+        }
+        if (cfg.get_bool("SAVE_COMPRESSED")) {
+            WLOG_SCOPE("save_as_xyz_compressed");
+            WLOGI << "saving mesh as compressed xyz file...";
+            void* bytes = nullptr; size_t nb = 0;
+            gpu_check(ctx, wass_mesh_encode_xyzc(ctx, mesh, have_plane ? plane : nullptr, &bytes, &nb), "wass_mesh_encode_xyzc");
+            std::ofstream ofs(path_join(env.workdir, "mesh_cam.xyzC").c_str(), std::ios::binary);
+            const bool ok = !ofs.fail() && ofs.write((const char*)bytes, (std::streamsize)nb).good();
+            wass_free(bytes);
+            if (!ok) { WLOGE << "unable to save mesh data"; throw GpuError("write failed"); }
+            WLOGI << "total data size: " << ((double)nb / 1E6) << " MB";
+            WLOG_SCOPE("wass_stereo");
+        } else {
+            download();
+            if (!save_xyz_binary(path_join(env.workdir, "mesh_cam.xyzbin"), hv, hp)) { WLOGE << "unable to save mesh data"; throw GpuError("write failed"); }
+        }
+        env.timer.stop();
+        std::cout << "[P|100|100]" << std::endl;
+        show_time_stats(env.timer);
+        WLOGI << "All done.";
+    } catch (const GpuError& e) {
+        WLOGE << e.what();
+        ret = -1;
+    } catch (const std::runtime_error& e) {
+        WLOGE << e.what();
+        ret = -1;
+    }
+    if (mesh) wass_mesh_destroy(mesh);
+    return ret;
+}
+
+}  // namespace wassframe

@@ -1,0 +1,228 @@
+// wass_stereo_batch.cpp -- sequence driver: the MI355X replacement for wasscli's process fan-out
+// (/root/reference/cli/wasscli/wasscli.py:305-364).
+//
+//   wass_stereo_batch <config_file> <workdir_0> <workdir_1> ... [--gpus G] [--procs-per-gpu P] [--out <dir>] [--verbose]
+//                     [--skip-existing]
+//   wass_stereo_batch <config_file> --sequence <output_dir> [...]      (every <output_dir>/NNNNNN_wd, in order)
+//
+// The reference starts one wass_stereo process per frame, NUM_PARALLEL_PROCESSES at a time, and appends each
+// successful frame's plane.txt to output/planes.txt (:341-343); the gridding stage later takes np.nanmean of that file
+// (gridding/wassgridsurface/wassgridsurface.py:672-678).  Here: one worker PROCESS per GPU (frames are independent, so
+// frame i goes to worker i mod G and no image data ever crosses GPUs), each with ONE persistent libwassgpu context
+// -- HIP start-up and the 5-8 GB of scratch HBM are paid once per worker, not once per frame -- running exactly the
+// per-frame code of the drop-in wass_stereo (wass_frame.hpp), so every workdir receives the same files.  The only
+// exchange is Coll-1: [sum a, sum b, sum c, sum d, n_valid] over the workers' planes, all-reduced over RCCL/xGMI when
+// every worker owns a GPU of its own (wass_coll_*), and the per-frame records that the parent collects through pipes to
+// write planes.txt in FRAME order (wasscli writes it in completion order) and planes_mean.txt.
+// --skip-existing: the workdir is the checkpoint: a frame whose plane.txt and mesh_cam.xyzC /
+// mesh_cam.xyzbin exist is not recomputed, its plane is read back from plane.txt.
+#include <dirent.h>
+#include <fcntl.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <algorithm>
+
+#include "wass_frame.hpp"
+
+using namespace wassframe;
+
+namespace {
+
+struct Record {            // worker -> parent, one per frame
+    int index, rc, have_plane;
+    double plane[4];
+    double seconds;
+    unsigned long long n_points;
+};
+struct Tail {              // worker -> parent, once: what the worker's all-reduce returned
+    int magic, used_rccl, n_valid;
+    double mean[4];
+};
+
+bool write_all(int fd, const void* p, size_t n)
+{
+    const char* c = (const char*)p;
+    while (n) { const ssize_t k = write(fd, c, n); if (k <= 0) return false; c += k; n -= (size_t)k; }
+    return true;
+}
+bool read_all(int fd, void* p, size_t n)
+{
+    char* c = (char*)p;
+    while (n) { const ssize_t k = read(fd, c, n); if (k <= 0) return false; c += k; n -= (size_t)k; }
+    return true;
+}
+double now() { timeval tv; gettimeofday(&tv, nullptr); return (double)tv.tv_sec + (double)tv.tv_usec / 1e6; }
+
+// plane.txt of a finished frame: four lines, or the single line "nan nan nan nan" (wass_stereo.cpp:2092-2107)
+bool read_plane_txt(const std::string& wd, FrameSummary& fs)
+{
+    std::ifstream f(path_join(wd, "plane.txt").c_str());
+    if (!f.is_open()) return false;
+    std::string tok[4];
+    for (auto& t : tok) if (!(f >> t)) return false;
+    fs.have_plane = 1;
+    for (int k = 0; k < 4; ++k) {
+        if (tok[k] == "nan" || tok[k] == "-nan") { fs.have_plane = 0; break; }
+        fs.plane[k] = atof(tok[k].c_str());
+    }
+    return true;
+}
+
+int worker(int rank, int world, int device, bool distinct_gpus, const unsigned char* uid, const char* cfg,
+           const std::vector<std::string>& wds, bool verbose, bool skip_existing, int fd)
+{
+    if (!verbose) {                       // per-frame logs still go to <workdir>/wass_stereo_log.txt
+        const int nul = open("/dev/null", O_WRONLY);
+        if (nul >= 0) { dup2(nul, 1); close(nul); }
+    }
+    wass_ctx* ctx = nullptr;
+    double acc[5] = { 0, 0, 0, 0, 0 };
+    for (size_t i = (size_t)rank; i < wds.size(); i += (size_t)world) {
+        Record r = {};
+        r.index = (int)i;
+        const double t0 = now();
+        FrameSummary fs;
+        if (skip_existing && (exists(path_join(wds[i], "mesh_cam.xyzC")) || exists(path_join(wds[i], "mesh_cam.xyzbin"))) &&
+            read_plane_txt(wds[i], fs))
+            r.rc = 0;
+        else
+            r.rc = exists(wds[i]) ? wass_run_frame(cfg, wds[i], nullptr, device, &ctx, &fs) : -1;
+        r.seconds = now() - t0;
+        r.have_plane = r.rc == 0 && fs.have_plane;
+        r.n_points = fs.n_points;
+        for (int k = 0; k < 4; ++k) r.plane[k] = r.have_plane ? fs.plane[k] : std::nan("");
+        if (r.rc == 0) wass_planes_mean_accumulate(r.plane, 1, acc);     // NaN planes are skipped (nanmean)
+        if (!write_all(fd, &r, sizeof r)) return 2;
+    }
+    Tail t = {};
+    t.magic = 0x57415353;
+    if (world > 1 && distinct_gpus) {
+        // Coll-1 over RCCL: needs a context (a worker with no frames creates one just for the collective)
+        if (!ctx && wass_ctx_create(device, &ctx) != WASS_OK) return 3;
+        if (wass_coll_init(ctx, rank, world, uid) != WASS_OK || wass_coll_allreduce_sum_f64(ctx, acc, 5) != WASS_OK) {
+            std::cerr << "worker " << rank << ": RCCL all-reduce failed: " << wass_last_error(ctx) << std::endl;
+            return 4;
+        }
+        t.used_rccl = 1;
+        wass_planes_mean_finish(acc, t.mean, &t.n_valid);
+    }
+    if (!write_all(fd, &t, sizeof t)) return 2;
+    if (ctx) wass_ctx_destroy(ctx);
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char* argv[])
+{
+    if (argc < 3) {
+        std::cout << "Usage:\n  wass_stereo_batch <config_file> <workdir>... [--gpus G] [--procs-per-gpu P] [--out <dir>] [--verbose] [--skip-existing]\n"
+                     "  wass_stereo_batch <config_file> --sequence <output_dir> [--gpus G] ...\n";
+        return argc == 1 ? 0 : -1;
+    }
+    const char* cfg = argv[1];
+    std::vector<std::string> wds;
+    std::string outdir;
+    int gpus = 1, ppg = 1;
+    bool verbose = false, skip_existing = false;
+    for (int i = 2; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a == "--gpus" && i + 1 < argc) gpus = atoi(argv[++i]);
+        else if (a == "--procs-per-gpu" && i + 1 < argc) ppg = atoi(argv[++i]);
+        else if (a == "--out" && i + 1 < argc) outdir = argv[++i];
+        else if (a == "--verbose") verbose = true;
+        else if (a == "--skip-existing") skip_existing = true;
+        else if (a == "--sequence" && i + 1 < argc) {
+            const std::string root = argv[++i];
+            if (outdir.empty()) outdir = root;
+            std::vector<std::string> found;
+            if (DIR* d = opendir(root.c_str())) {
+                while (dirent* e = readdir(d)) {
+                    const std::string n = e->d_name;
+                    if (n.size() == 9 && n.compare(6, 3, "_wd") == 0 && std::all_of(n.begin(), n.begin() + 6, ::isdigit)) found.push_back(n);
+                }
+                closedir(d);
+            }
+            std::sort(found.begin(), found.end());
+            for (const auto& n : found) wds.push_back(path_join(root, n));
+        } else if (a.rfind("--", 0) == 0) { std::cerr << "unknown option " << a << std::endl; return -1; }
+        else wds.push_back(a);
+    }
+    if (gpus < 1 || ppg < 1 || wds.empty()) { std::cerr << "Invalid arguments" << std::endl; return -1; }
+    { std::ifstream ifs(cfg); if (!ifs.is_open()) { std::cerr << "Unable to load " << cfg << std::endl; return -1; } }
+    if (outdir.empty()) outdir = ".";
+    const int world = gpus * ppg;
+    const bool distinct = ppg == 1;
+    unsigned char uid[128] = {};
+    if (world > 1 && distinct && wass_coll_unique_id(uid) != WASS_OK) {
+        std::cerr << "RCCL is not available (wass_coll_unique_id failed); planes will be reduced by the parent process" << std::endl;
+        return -1;
+    }
+
+    std::cout << "wass_stereo_batch: " << wds.size() << " frame(s), " << world << " worker process(es) on " << gpus << " GPU(s)" << std::endl;
+    const double t0 = now();
+    std::vector<pid_t> pids(world);
+    std::vector<int> fds(world);
+    for (int r = 0; r < world; ++r) {          // fork BEFORE any HIP call in this process: every worker initialises its own runtime
+        int pfd[2];
+        if (pipe(pfd) != 0) { perror("pipe"); return -1; }
+        const pid_t pid = fork();
+        if (pid < 0) { perror("fork"); return -1; }
+        if (pid == 0) {
+            close(pfd[0]);
+            for (int q = 0; q < r; ++q) close(fds[q]);
+            _exit(worker(r, world, r / ppg, distinct, uid, cfg, wds, verbose, skip_existing, pfd[1]));
+        }
+        close(pfd[1]);
+        pids[r] = pid; fds[r] = pfd[0];
+    }
+    std::vector<Record> recs(wds.size());
+    std::vector<char> got(wds.size(), 0);
+    std::vector<Tail> tails(world);
+    bool ok = true;
+    for (int r = 0; r < world; ++r) {
+        const size_t mine = (wds.size() + world - 1 - r) / world;
+        for (size_t k = 0; k < mine; ++k) {
+            Record rec;
+            if (!read_all(fds[r], &rec, sizeof rec) || rec.index < 0 || (size_t)rec.index >= wds.size()) { ok = false; break; }
+            recs[rec.index] = rec; got[rec.index] = 1;
+            std::cout << "[frame " << rec.index << "] " << wds[rec.index] << "  rc=" << rec.rc << "  " << rec.seconds << " s  "
+                      << rec.n_points << " pts" << (rec.have_plane ? "" : "  (no plane)") << std::endl;
+        }
+        if (!read_all(fds[r], &tails[r], sizeof(Tail)) || tails[r].magic != 0x57415353) ok = false;
+        close(fds[r]);
+        int st = 0;
+        waitpid(pids[r], &st, 0);
+        if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) { std::cerr << "worker " << r << " failed (status " << st << ")" << std::endl; ok = false; }
+    }
+    // planes.txt as wasscli builds it: the lines of plane.txt joined by single blanks, successful frames only (:341-343)
+    std::ofstream fpl(path_join(outdir, "planes.txt").c_str());
+    double acc[5] = { 0, 0, 0, 0, 0 };
+    int nfail = 0;
+    for (size_t i = 0; i < wds.size(); ++i) {
+        if (!got[i] || recs[i].rc != 0) { ++nfail; continue; }
+        std::ifstream fin(path_join(wds[i], "plane.txt").c_str());
+        std::string line, joined;
+        while (std::getline(fin, line)) { if (!joined.empty()) joined += " "; joined += line; }
+        fpl << joined << "\n";
+        wass_planes_mean_accumulate(recs[i].plane, 1, acc);
+    }
+    double mean[4]; int nvalid = 0;
+    wass_planes_mean_finish(acc, mean, &nvalid);
+    if (world > 1 && distinct && ok) {         // what the workers agreed on over RCCL must be what the parent sees
+        for (int r = 0; r < world; ++r)
+            if (!tails[r].used_rccl || tails[r].n_valid != nvalid) { std::cerr << "RCCL mean plane disagrees with the gathered planes" << std::endl; ok = false; }
+        for (int k = 0; k < 4 && ok; ++k) mean[k] = tails[0].mean[k];
+    }
+    {
+        std::ofstream fm(path_join(outdir, "planes_mean.txt").c_str());
+        fm << std::setprecision(20);
+        for (int k = 0; k < 4; ++k) fm << mean[k] << std::endl;
+    }
+    const double dt = now() - t0;
+    std::cout << "mean plane over " << nvalid << " frame(s): " << std::setprecision(12) << mean[0] << " " << mean[1] << " " << mean[2] << " " << mean[3]
+              << (world > 1 && distinct ? "  (RCCL all-reduce)" : "") << std::endl;
+    std::cout << wds.size() - nfail << "/" << wds.size() << " frame(s) ok in " << dt << " s (" << (wds.size() / dt) << " frames/s)" << std::endl;
+    return ok && nfail == 0 ? 0 : -1;
+}
