@@ -46,6 +46,10 @@ const char* wass_last_error(const wass_ctx* ctx);
 /* raw hipStream_t of the context (for callers that enqueue their own work) */
 void* wass_ctx_stream(wass_ctx* ctx);
 int wass_ctx_synchronize(wass_ctx* ctx);
+/* The "_dev" entry points read caller-owned device buffers on the context's own (non-blocking) streams.  A caller
+ * that produced those buffers on another stream calls this first: it orders all work enqueued on the context from now
+ * on after everything already enqueued on producer_stream (a hipStream_t; NULL = the legacy default stream). */
+int wass_ctx_wait_for_stream(wass_ctx* ctx, void* producer_stream);
 /* Two-stage pipelining inside one context.  on != 0: every stage after the SGM call (wass_disparity_postprocess*,
  * wass_triangulate*, wass_mesh_*) is enqueued on a second stream that waits for the last wass_sgm_disparity_dev
  * call, so the tail of frame i (small, latency-bound kernels and the PCIe download) runs underneath the SGM stage
@@ -246,6 +250,10 @@ typedef struct {
     double   ransac_plane[4];  uint64_t ransac_inliers;
     double   plane[4];         uint64_t refine_inliers, kept_after_ransac_crop, kept_final;
     uint64_t n_points, xyzc_bytes;
+    /* status of the wass_sgm_disparity_dev call that produced the frame's disparity (the asynchronous SGM entry point
+     * cannot return it): 1 = block cost + P2 left the int16 range where the reference is defined (the synchronous call
+     * returns WASS_ERR_COST_OVERFLOW), -1 = unknown (the disparity did not come from this context's last two calls) */
+    int      sgm_cost_overflow, sgm_timeout;
 } wass_frame_result;
 int wass_mesh_finish_frame_async(wass_ctx* ctx, wass_mesh* m, double percentile, const int32_t* uv_triplets, int rounds,
                                  double ransac_thr, const wass_refine_params* rp, double max_distance, void* dst,

@@ -85,3 +85,74 @@ def test_wass_default_640_disparities_band(gpu_ctx, oracle):
         ref, st = oracle.dense_disparity16(right, left, _oracle_params(oracle, p))
         assert not st.overflow
         np.testing.assert_array_equal(got, ref)
+
+
+def test_config_b_full_chain_vs_oracle(oracle, pair_b):
+    """Config D's single-GPU content at full size: the whole path a1-a20 on a 2456x2058, D=256 frame (5 paths, the
+    reference's MODE_SGBM) through the pipelined, host-sync-free frame chain that bench.py and the sequence driver
+    run (wass_amd.batch.FramePipeline), against the oracle chain stage by stage -- 5 M points through the radix
+    select (PovMesh.cpp:888-926), the union-find (:929-987), RANSAC scoring (:665-777), crop / refine (:780-815,
+    :581-660) and the xyzC encoder (:377-460)."""
+    import torch
+    import wass_amd
+    from wass_amd.batch import FramePipeline
+    w, h, D = 2456, 2058, 256
+    right, left = pair_b
+    p = default_sgm_params(D, ndirs=5)
+    rig = synth.rig_geometry(w, h)
+    roi = (0, 0, w, h)
+    mask = (right <= 254).astype(np.uint8)
+    dev = torch.device("cuda", 0)
+    with wass_amd.Context(0) as ctx:
+        pipe = FramePipeline(ctx, w, h, p, wass_amd.make_geom(rig))
+        dr, dl, dm = torch.from_numpy(right).to(dev), torch.from_numpy(left).to(dev), torch.from_numpy(mask).to(dev)
+        assert pipe.submit(dr, dl, d_right_mask=dm) is None
+        out = pipe.flush()
+        res, blob = out.result, out.xyzc.tobytes()
+    assert out.cost_overflow == 0 and out.sgm_timeout == 0
+    # oracle chain
+    od16, st = oracle.dense_disparity16(right, left, _oracle_params(oracle, p))
+    assert not st.overflow
+    of = oracle.disparity_postprocess(od16, 1, D)
+    on, ov, op3, og = oracle.triangulate(of, roi, roi, oracle.make_geom(rig), right, None, mask)
+    ozg, ongaps = oracle.zgap_percentile(ov, op3, 99.0)
+    ov, osize = oracle.keep_biggest_component(ov, op3, ozg)
+    uv = wass_amd.ransac_sample(w, h, 400, 12345)
+    ok, opl, obest, _ = oracle.ransac_plane(ov, op3, uv, 1.0)
+    assert ok and res.found
+    ov, okept1 = oracle.crop_plane(ov, op3, opl, 1.0)
+    opl2, oninl, _ = oracle.refine_plane(ov, op3)
+    ov, okept2 = oracle.crop_plane(ov, op3, opl2, 1.5)
+    # exact: counts and order statistics
+    assert res.n_gaps == ongaps and res.zgap == ozg
+    assert res.component_size == osize
+    assert res.ransac_inliers == obest and res.kept_after_ransac_crop == okept1
+    np.testing.assert_array_equal(np.array(res.ransac_plane[:]), opl)
+    assert res.refine_inliers == oninl
+    # refined plane: sums over 4.7 M points in a different (tree) order: 1e-9 absolute on a unit normal / |d| ~ 11
+    np.testing.assert_allclose(np.array(res.plane[:]), opl2, rtol=0, atol=1e-9)
+    assert abs(int(res.kept_final) - int(okept2)) <= 2               # a point within 1e-9 of the 1.5 threshold may flip
+    assert res.n_points == res.kept_final and len(blob) == 148 + 6 * res.n_points
+    # file bytes: the oracle encoder fed with the GPU's plane must give the GPU's bytes (identical inputs -> identical
+    # quantisation); with its own plane (1e-9 away) it may differ in the last bit of a few coordinates
+    if int(res.kept_final) == int(okept2):
+        ref_blob = oracle.encode_xyzc(ov, op3, np.array(res.plane[:]))
+        assert len(ref_blob) == len(blob)
+        a = np.frombuffer(blob, np.uint8); b = np.frombuffer(ref_blob, np.uint8)
+        ndiff = int((a[148:].reshape(-1, 6) != b[148:].reshape(-1, 6)).any(axis=1).sum())
+        assert ndiff <= 2, f"{ndiff} points quantise differently"
+        np.testing.assert_allclose(np.frombuffer(blob[4:148], np.float64), np.frombuffer(ref_blob[4:148], np.float64), rtol=1e-12, atol=1e-12)
+
+
+def test_config_e_band_sgm_and_cleanup_vs_oracle(gpu_ctx, oracle):
+    """Config E geometry (3840 wide, D=512, NP=4) on a 600-row band the oracle finishes in half a minute: SGM 5- and
+    8-path and the disparity clean-up a7-a9, bit-exact."""
+    w, h, D = 3840, 600, 512
+    right, left = synth.make_pair(w, h, D, frame_idx=6)
+    for nd in (5, 8):
+        p = default_sgm_params(D, ndirs=nd)
+        got = gpu_ctx.sgm_disparity(right, left, p)
+        ref, st = oracle.dense_disparity16(right, left, _oracle_params(oracle, p))
+        assert not st.overflow
+        np.testing.assert_array_equal(got, ref)
+    np.testing.assert_array_equal(gpu_ctx.disparity_postprocess(got, p), oracle.disparity_postprocess(ref, 1, D))

@@ -40,7 +40,8 @@ class FrameResult(C.Structure):
     _fields_ = [("zgap", C.c_double), ("n_gaps", C.c_uint64), ("component_size", C.c_uint64), ("found", C.c_int),
                 ("refine_ok", C.c_int), ("ransac_plane", C.c_double * 4), ("ransac_inliers", C.c_uint64),
                 ("plane", C.c_double * 4), ("refine_inliers", C.c_uint64), ("kept_after_ransac_crop", C.c_uint64),
-                ("kept_final", C.c_uint64), ("n_points", C.c_uint64), ("xyzc_bytes", C.c_uint64)]
+                ("kept_final", C.c_uint64), ("n_points", C.c_uint64), ("xyzc_bytes", C.c_uint64),
+                ("sgm_cost_overflow", C.c_int), ("sgm_timeout", C.c_int)]
 
 
 class Geom(C.Structure):
@@ -122,6 +123,7 @@ SYMBOLS = {
     "wass_free": (None, [_vp]),
     "wass_planes_mean_accumulate": (None, [C.POINTER(C.c_double), _i, C.POINTER(C.c_double)]),
     "wass_planes_mean_finish": (None, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
+    "wass_ctx_wait_for_stream": (_i, [_vp, _vp]),
     "wass_coll_unique_id": (_i, [_vp]),
     "wass_coll_init": (_i, [_vp, _i, _i, _vp]),
     "wass_coll_allreduce_sum_f64": (_i, [_vp, C.POINTER(C.c_double), _i]),

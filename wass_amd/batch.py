@@ -28,6 +28,10 @@ class FrameOutput:
         ok = bool(result.found and result.refine_ok)
         self.plane = np.array(result.plane[:]) if ok else np.full(4, np.nan)
         self.n_points = int(result.n_points)
+        # 1: the frame's block costs left the int16 range in which the reference is defined; the
+        # synchronous entry point reports the same condition as WASS_ERR_COST_OVERFLOW
+        self.cost_overflow = int(result.sgm_cost_overflow)
+        self.sgm_timeout = int(result.sgm_timeout)
 
 
 class FramePipeline:
@@ -36,7 +40,9 @@ class FramePipeline:
     submit() enqueues a whole frame -- SGM on the context's main stream, disparity clean-up, triangulation, outlier
     removal, plane fit and the xyzC encoder on its tail stream, the file image on its copy stream -- and returns the
     output of the PREVIOUS frame, whose download has finished while this one was being enqueued.  flush() returns the
-    last one.  Inputs are rectified crops resident in HBM (torch uint8 CUDA tensors); stage parameters are the
+    last one.  Lifetime contract: the tail of frame i keeps reading d_right_image and the masks while frame i+1 is
+    being prepared, so the caller must leave every input of frame i untouched until submit() of frame i+2 has
+    returned (or flush()); ordering against the stream that produced the inputs is handled here.  Inputs are rectified crops resident in HBM (torch uint8 CUDA tensors); stage parameters are the
     defaults of wass_stereo unless given.
     """
 
@@ -68,8 +74,11 @@ class FramePipeline:
     def submit(self, d_right, d_left, d_right_image=None, d_left_mask=None, d_right_mask=None):
         """d_right/d_left: rectified crops; d_right_image: the undistorted right image sampled for the point colour
         (defaults to d_right); masks: 0/1 uint8 images of the originals' size or None."""
+        import torch
         ctx, k = self.ctx, self._n & 1
         out = self._disp16[k]
+        # the inputs were produced on torch's current stream; the context runs on streams of its own
+        ctx.wait_for_stream(torch.cuda.current_stream(ctx.device_id).cuda_stream)
         ctx.sgm_disparity_dev(d_right, d_left, self.params, out)
         ctx.disparity_postprocess_dev(out, self.params, self.dilate, self.erode, self.median, self._dispf)
         img = d_right_image if d_right_image is not None else d_right

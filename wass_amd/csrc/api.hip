@@ -139,6 +139,9 @@ void wass_ctx_destroy(wass_ctx* c)
     if (c->ev_post) (void)hipEventDestroy(c->ev_post);
     if (c->h_flags) (void)hipHostFree(c->h_flags);
     if (c->h_frame) (void)hipHostFree(c->h_frame);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
+    if (c->ev_producer) (void)hipEventDestroy(c->ev_producer);
     if (c->ev_pack) (void)hipEventDestroy(c->ev_pack);
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -161,6 +164,17 @@ int wass_ctx_synchronize(wass_ctx* c)
     WASS_HIP(c, hipStreamSynchronize(c->stream));
     WASS_HIP(c, hipStreamSynchronize(c->tail));
     WASS_HIP(c, hipStreamSynchronize(c->copy));
+    return WASS_OK;
+}
+
+int wass_ctx_wait_for_stream(wass_ctx* c, void* producer_stream)
+{
+    if (!c) return WASS_ERR_INVALID_ARG;
+    WASS_HIP(c, hipSetDevice(c->device));
+    if (!c->ev_producer) WASS_HIP(c, hipEventCreateWithFlags(&c->ev_producer, hipEventDisableTiming));
+    WASS_HIP(c, hipEventRecord(c->ev_producer, (hipStream_t)producer_stream));
+    WASS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_producer, 0));
+    WASS_HIP(c, hipStreamWaitEvent(c->tail, c->ev_producer, 0));
     return WASS_OK;
 }
 

@@ -130,6 +130,11 @@ struct wass_ctx {
     wass::Buf limits;              // striped min/max keys of the frame tail
     void* h_frame = nullptr;       // pinned: device state record of the last wass_mesh_finish_frame_async
     bool frame_pending = false;
+    unsigned long long frame_sgm_call = 0;   // 1-based index of the SGM call whose disparity the pending frame was built from
+    void* h_stage = nullptr;       // pinned source images of the frame tail's small H2D copies (mesh.hip host_stage)
+    hipEvent_t ev_stage = nullptr;
+    hipEvent_t ev_producer = nullptr; // wass_ctx_wait_for_stream
+    bool stage_uv_busy = false;
     hipStream_t copy = nullptr;    // D2H of the xyzC payload
     // Everything after the SGM call (disparity clean-up, triangulation, mesh stages: post.hip, mesh.hip) is enqueued on
     // ts(): the main stream, or -- with tail overlap on -- a second stream that waits for the last SGM call, so that

@@ -1272,17 +1272,40 @@ int wass_mesh_keep_biggest_component(wass_ctx* c, wass_mesh* m, double zgap, uin
 
 // wass_stereo.cpp:2046-2050 as one call: compute_zgap_percentile + cluster_biggest_connected_component with every
 // intermediate decision taken on the device (6 radix-select passes, component choice) and one read-back at the end.
+// Pinned, context-owned source images of the small host-to-device copies of the sync-free frame tail.  An asynchronous
+// copy from pageable or stack memory is only safe if the runtime happens to stage it before returning; these copies
+// are enqueued and never waited for, so their sources must outlive the call: [DevState init | limits init | uv samples].
+constexpr size_t STAGE_UV_OFF = 4096 + NSLOT * 6 * 8;
+constexpr size_t STAGE_BYTES = STAGE_UV_OFF + 1800 * 24;      // PLANE_RANSAC_ROUNDS <= 1800 (LDS limit of k_ransac_score)
+static int host_stage(wass_ctx* c, unsigned char** out)
+{
+    static_assert(sizeof(DevState) <= 4096, "DevState init image");
+    if (!c->h_stage) {
+        if (hipHostMalloc((void**)&c->h_stage, STAGE_BYTES, hipHostMallocDefault) != hipSuccess)
+            return set_err(c, WASS_ERR_NO_MEMORY, "hipHostMalloc failed");
+        unsigned char* p = (unsigned char*)c->h_stage;
+        DevState init;
+        memset(&init, 0, sizeof init);
+        init.sel_hi_shift = 64;
+        memcpy(p, &init, sizeof init);
+        unsigned long long* lim = (unsigned long long*)(p + 4096);
+        for (int i = 0; i < NSLOT; ++i) for (int k = 0; k < 6; ++k) lim[i * 6 + k] = k < 3 ? ~0ull : 0ull;
+        if (hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming) != hipSuccess) return set_err(c, WASS_ERR_DEVICE, "hipEventCreate failed");
+    }
+    *out = (unsigned char*)c->h_stage;
+    return WASS_OK;
+}
+
 static int enqueue_remove_outliers(wass_ctx* c, wass_mesh* m, double percentile, DevState** dsp)
 {
     DevState* ds = nullptr;
     int rc = dstate(c, &ds);
     if (rc) return rc;
     unsigned int* hist = (unsigned int*)(ds + 1);
-    DevState init;
-    memset(&init, 0, sizeof init);
-    init.sel_hi_shift = 64;
+    unsigned char* stage = nullptr;
+    if ((rc = host_stage(c, &stage))) return rc;
     WASS_HIP(c, hipStreamWaitEvent(c->ts(), c->ev_copy, 0));            // the copy stream may still be reading the last frame's record
-    WASS_HIP(c, hipMemcpyAsync(ds, &init, sizeof init, hipMemcpyHostToDevice, c->ts()));
+    WASS_HIP(c, hipMemcpyAsync(ds, stage, sizeof(DevState), hipMemcpyHostToDevice, c->ts()));
     WASS_HIP(c, hipMemsetAsync(hist, 0, 2048 * 4, c->ts()));
     for (int pass = 0; pass < 6; ++pass) {
         const int shift = pass < 5 ? 64 - 11 * (pass + 1) : 0, nbits = pass < 5 ? 11 : 9;
@@ -1459,7 +1482,16 @@ static int enqueue_fit_plane(wass_ctx* c, wass_mesh* m, const int32_t* uv, int r
     const size_t lds = (size_t)rounds * (32 + 4);
     if (lds > 64 * 1024) return set_err(c, WASS_ERR_UNSUPPORTED, "PLANE_RANSAC_ROUNDS %d too large (max 1800)", rounds);
     hipStream_t s = c->ts();
-    WASS_HIP(c, hipMemcpyAsync(duv, uv, (size_t)rounds * 24, hipMemcpyHostToDevice, s));
+    {   // the caller's sample array may be pageable and short-lived: go through the pinned stage (the previous frame's
+        // copy out of it was enqueued a whole frame ago; wait for it before overwriting)
+        unsigned char* stage = nullptr;
+        if ((rc = host_stage(c, &stage))) return rc;
+        if (c->stage_uv_busy) WASS_HIP(c, hipEventSynchronize(c->ev_stage));
+        memcpy(stage + STAGE_UV_OFF, uv, (size_t)rounds * 24);
+        WASS_HIP(c, hipMemcpyAsync(duv, stage + STAGE_UV_OFF, (size_t)rounds * 24, hipMemcpyHostToDevice, s));
+        WASS_HIP(c, hipEventRecord(c->ev_stage, s));
+        c->stage_uv_busy = true;
+    }
     WASS_HIP(c, hipMemsetAsync(counts, 0, (size_t)rounds * 8, s));
     WASS_HIP(c, hipMemsetAsync(kept1, 0, (size_t)2 * NSLOT * 8, s));
     hipLaunchKernelGGL(k_ransac_planes, dim3((rounds + 63) / 64), dim3(64), 0, s, m->valid, m->x, m->y, m->z, m->w, (const int32_t*)duv,
@@ -1539,11 +1571,11 @@ int wass_mesh_finish_frame_async(wass_ctx* c, wass_mesh* m, double percentile, c
     if (c->scratch.cap < need && (rc = ensure(c, c->scratch, need))) return rc;
     hipStream_t s = c->ts();
     hipLaunchKernelGGL(k_frame_rt, dim3(1), dim3(64), 0, s, ds, (const unsigned long long*)kept1);
-    unsigned long long init[NSLOT * 6];
-    for (int i = 0; i < NSLOT; ++i) for (int k = 0; k < 6; ++k) init[i * 6 + k] = k < 3 ? ~0ull : 0ull;
-    if ((rc = ensure(c, c->limits, sizeof init))) return rc;
+    unsigned char* stage = nullptr;
+    if ((rc = host_stage(c, &stage))) return rc;
+    if ((rc = ensure(c, c->limits, NSLOT * 6 * 8))) return rc;
     unsigned long long* lim = (unsigned long long*)c->limits.p;            // [NSLOT][6] keys
-    WASS_HIP(c, hipMemcpyAsync(lim, init, sizeof init, hipMemcpyHostToDevice, s));
+    WASS_HIP(c, hipMemcpyAsync(lim, stage + 4096, NSLOT * 6 * 8, hipMemcpyHostToDevice, s));
     unsigned int* total = (unsigned int*)c->scratch.p;
     unsigned int* bcnt = (unsigned int*)((char*)c->scratch.p + 64);
     unsigned char* img = (unsigned char*)c->xyzc.p;
@@ -1561,6 +1593,7 @@ int wass_mesh_finish_frame_async(wass_ctx* c, wass_mesh* m, double percentile, c
     WASS_HIP(c, hipMemcpyAsync(dst, img, 148 + n * 6, hipMemcpyDeviceToHost, c->copy));
     WASS_HIP(c, hipEventRecord(c->ev_copy, c->copy));
     c->frame_pending = true;
+    c->frame_sgm_call = c->nsgm;              // the SGM call that fed this frame is the last one enqueued (0: none)
     return WASS_OK;
 }
 
@@ -1578,6 +1611,16 @@ int wass_ctx_frame_result(wass_ctx* c, wass_frame_result* out)
     if (h.ransac_found) { out->kept_after_ransac_crop = h.kept1; out->kept_final = h.kept2; out->refine_inliers = (uint64_t)(h.ninl + 0.5); }
     out->n_points = h.npts;
     out->xyzc_bytes = 148 + (uint64_t)h.npts * 6;
+    if (c->frame_sgm_call > 0 && c->nsgm - c->frame_sgm_call < 2) {
+        // status word of the frame's SGM call: copied to pinned memory in stream order long before the download this
+        // function has just waited for; the slot is reused two calls later
+        const uint32_t fl = c->h_flags[4 * (int)((c->frame_sgm_call - 1) & 1)];
+        out->sgm_cost_overflow = (int)(fl & 1);
+        out->sgm_timeout = (int)((fl >> 1) & 1);
+        if (fl & 2) c->halo_dirty = true;
+    } else {
+        out->sgm_cost_overflow = out->sgm_timeout = -1;      // unknown: no SGM call of this context fed the frame
+    }
     if (h.sel_fail == 2) return set_err(c, WASS_ERR_DEVICE, "radix select lost its rank (internal error)");
     return WASS_OK;
 }

@@ -83,13 +83,27 @@ class Context:
     def sgm_disparity_dev(self, d_right, d_left, params: SgmParams, d_out=None):
         """torch uint8 CUDA tensors in, torch int16 CUDA tensor out (asynchronous on self.stream)."""
         import torch
+        for name, t in (("d_right", d_right), ("d_left", d_left)):
+            if t.dtype != torch.uint8 or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1:
+                raise ValueError(f"{name}: expected a 2-D uint8 CUDA tensor with unit inner stride")
+            if t.device.index != self.device_id:
+                raise ValueError(f"{name} lives on {t.device}, the context on cuda:{self.device_id}")
+        if d_left.shape != d_right.shape or d_left.stride(0) != d_right.stride(0):
+            raise ValueError("d_right and d_left must have the same shape and pitch")
         h, w = d_right.shape
         if d_out is None:
             d_out = torch.empty((h, w), dtype=torch.int16, device=d_right.device)
+        elif d_out.dtype != torch.int16 or not d_out.is_contiguous() or tuple(d_out.shape) != (h, w):
+            raise ValueError("d_out: expected a contiguous int16 tensor of the image size")
         rc = self._lib.wass_sgm_disparity_dev(self._h, d_right.data_ptr(), d_left.data_ptr(), w, h,
                                               d_right.stride(0), C.byref(params), d_out.data_ptr())
         self._check(rc)
         return d_out
+
+    def wait_for_stream(self, stream_handle: int):
+        """Order everything enqueued on this context from now on after the work already enqueued on another HIP
+        stream (e.g. torch.cuda.current_stream().cuda_stream, which produced the input tensors)."""
+        self._check(self._lib.wass_ctx_wait_for_stream(self._h, C.c_void_p(stream_handle)))
 
     def sgm_timings(self, previous: bool = False) -> SgmTimings:
         """Stage times of the last SGM call (previous=True: of the call before it, which a pipelined driver can
