@@ -271,3 +271,12 @@ def test_synth_is_deterministic():
     a = synth.make_pair(64, 48, 16, 3); b = synth.make_pair(64, 48, 16, 3); c = synth.make_pair(64, 48, 16, 4)
     assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[0] != c[0]).any()
     assert a[0].min() >= 1 and a[0].max() <= 254
+
+
+def test_torch_generator_equals_numpy_generator():
+    """bench.py prepares its 64 full-size frames with the torch form of the generator (GPU, milliseconds): same images."""
+    for (w, h, D, fi) in ((201, 77, 32, 9), (320, 240, 64, 100003)):
+        r, l = synth.make_pair(w, h, D, fi)
+        rt, lt = synth.make_pair_torch(w, h, D, fi)
+        np.testing.assert_array_equal(rt.numpy(), r)
+        np.testing.assert_array_equal(lt.numpy(), l)

@@ -91,6 +91,47 @@ def make_pair(w: int, h: int, num_disp: int, frame_idx: int = 0, noise: bool = T
     return np.ascontiguousarray(right), np.ascontiguousarray(left)
 
 
+def _i64(c: int) -> int:
+    """64-bit constant as the int64 with the same bit pattern."""
+    c &= _M64
+    return c - (1 << 64) if c >= (1 << 63) else c
+
+
+def make_pair_torch(w: int, h: int, num_disp: int, frame_idx: int = 0, device="cpu"):
+    """make_pair() evaluated with torch (float64 sines, the 64-bit hash in wrapping int64 arithmetic) on `device`:
+    the same images (up to the last bit of a sine that falls exactly on a rounding boundary, which has not been
+    observed), in milliseconds on a GPU instead of seconds -- bench.py uses it to prepare 64 distinct full-size frames.
+    Returns (right, left) uint8 tensors on `device`."""
+    import torch
+    A, f, g, phi = texture_params(frame_idx)
+    x = torch.arange(w, dtype=torch.float64, device=device)[None, :]
+    y = torch.arange(h, dtype=torch.float64, device=device)[:, None]
+    d0, s = 0.15 * num_disp, 0.6 * num_disp
+    disp = d0 + s * (y / h) + 0.4 * torch.sin(2 * np.pi * x / 97.0) + 0.2 * torch.sin(2 * np.pi * y / 61.0)
+
+    def tex(u, v):
+        out = torch.full((h, w), 128.0, dtype=torch.float64, device=device)
+        for k in range(len(A)):
+            out += float(A[k]) * torch.sin(2 * np.pi * (float(f[k]) * u + float(g[k]) * v) + float(phi[k]))
+        return out
+
+    def noise(cam):
+        seed = (SEED_BASE + frame_idx) & _M64
+        yy = torch.arange(h, dtype=torch.int64, device=device)[:, None]
+        xx = torch.arange(w, dtype=torch.int64, device=device)[None, :]
+        z = _i64(seed) + _i64(0x9E3779B97F4A7C15) * (yy * 65536 + xx + 1) + _i64(0xD1B54A32D192ED03 * (cam + 1))
+        for sh, mul in ((30, 0xBF58476D1CE4E5B9), (27, 0x94D049BB133111EB)):
+            z = (z ^ ((z >> sh) & ((1 << (64 - sh)) - 1))) * _i64(mul)        # logical shift, wrapping multiply
+        z = z ^ ((z >> 31) & ((1 << 33) - 1))
+        # unsigned remainder of the bit pattern: U = z + 2^64 for z < 0, and 2^64 = 2 (mod 7)
+        return torch.remainder(torch.remainder(z, 7) + 2 * (z < 0).to(torch.int64), 7) - 3
+
+    left = tex(x, y) + noise(0)
+    right = tex(x - disp, y) + noise(1)
+    to_u8 = lambda t: torch.clamp(torch.round(t), 1, 254).to(torch.uint8).contiguous()
+    return to_u8(right), to_u8(left)
+
+
 def rig_geometry(w: int, h: int):
     """Ideal rig of SURVEY.md 8(d): K0=K1, R=I, T=(1,0,0), identity rectification."""
     f = 0.9 * w
