@@ -233,10 +233,9 @@ def main():
     NBUF = 3                                             # a frame's inputs must stay untouched until two more were submitted
     dbuf = [tuple(torch.empty((h, w), dtype=torch.uint8, device=dev) for _ in range(3))
             for _ in range(nf if args.resident_inputs else NBUF)]
-    # The upload rides on the context's own SGM stream, in front of the frame's first kernel: the runtime multiplexes
-    # all streams of a process onto four hardware queues, and a separate upload stream ended up sharing one with the
-    # context's tail stream, which serialised frame i's tail with frame i+1's SGM stage (-9 % pairs/s, measured)
-    h2d = torch.cuda.ExternalStream(ctx.stream, device=dev)
+    # The upload rides on the context's own SGM stream, in front of the frame's first kernel (wass_upload_async): the
+    # runtime multiplexes all streams of a process onto four hardware queues, and a separate upload stream ended up
+    # sharing one with the context's tail stream, which serialised frame i's tail with frame i+1's SGM stage (-9 % pairs/s)
     if args.resident_inputs:
         for k in range(nf):
             dbuf[k][0].copy_(host[k][0]); dbuf[k][1].copy_(host[k][1])
@@ -257,22 +256,15 @@ def main():
 
     def step(i):
         k = i % nf
-        if args.resident_inputs:
-            dr, dl, dm = dbuf[k]
-            cur = torch.cuda.current_stream(dev)
+        dr, dl, dm = dbuf[k] if args.resident_inputs else dbuf[i % NBUF]
+        if not args.resident_inputs:
+            ctx.upload_async(dr, host[k][0])
+            ctx.upload_async(dl, host[k][1])
+            ctx.burned_area_mask_dev(dr, dm)                # DISCARD_BURNED_AREAS mask of the right image (wass_stereo.cpp:1072)
+        if args.stage == "sgm":
+            ctx.sgm_disparity_dev(dr, dl, params, sgm_out)
         else:
-            dr, dl, dm = dbuf[i % NBUF]
-            cur = h2d
-        with torch.cuda.stream(cur):
-            if not args.resident_inputs:
-                dr.copy_(host[k][0], non_blocking=True)
-                dl.copy_(host[k][1], non_blocking=True)
-                torch.le(dr, 254, out=dm.view(torch.bool))      # DISCARD_BURNED_AREAS mask of the right image (wass_stereo.cpp:1072)
-            if args.stage == "sgm":
-                ctx.wait_for_stream(cur.cuda_stream)
-                ctx.sgm_disparity_dev(dr, dl, params, sgm_out)
-            else:
-                keep(pipe.submit(dr, dl, d_right_image=dr, d_right_mask=dm))      # orders itself after `cur`
+            keep(pipe.submit(dr, dl, d_right_image=dr, d_right_mask=dm))
 
     def barrier():
         if pipe is not None:

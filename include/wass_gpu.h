@@ -61,6 +61,14 @@ int wass_ctx_set_tail_overlap(wass_ctx* ctx, int on);
 int wass_ctx_set_debug(wass_ctx* ctx, int on);
 const char* wass_version(void);
 
+/* Stream-ordered upload on the context's SGM stream: h_src (pinned host memory for a truly asynchronous copy; it must
+ * stay valid until the copy has executed) -> d_dst.  Lets a sequence driver put a frame's images in front of its first
+ * kernel without a stream of its own (the runtime multiplexes all streams of a process onto four hardware queues). */
+int wass_upload_async(wass_ctx* ctx, void* d_dst, const void* h_src, size_t nbytes);
+/* DISCARD_BURNED_AREAS (wass_stereo.cpp:1072,1086): d_mask[i] = d_img[i] <= 254, on the context's SGM stream; feeds the
+ * left_mask / right_mask arguments of wass_triangulate_dev.  Both pointers 4-byte aligned. */
+int wass_burned_area_mask_dev(wass_ctx* ctx, const uint8_t* d_img, size_t n, uint8_t* d_mask);
+
 /* ------------------------------------------------------------------------
  * cv::StereoSGBM parameters as sgbm_dense_stereo sets them
  * (wass_stereo/wass_stereo.cpp:742-759,772-782).

@@ -15,7 +15,7 @@ import sys
 from collections import defaultdict
 
 out, config, ndirs = sys.argv[1], sys.argv[2], int(sys.argv[3])
-AGG = ("k_ckpt", "k_pair", "k_sweep")
+AGG = ("k_ckpt", "k_pair", "k_sweep", "k_edge_sweep", "k_tile")
 
 
 def per_kernel(sub, ctr):
@@ -37,9 +37,9 @@ for k in sorted(set(fetch) | set(write)):
         continue
     n = fetch[k][0]
     rows[k] = {"launches": n, "read_bytes_per_launch": 2 * fetch[k][1] / n * 1024, "write_bytes_per_launch": write[k][1] / max(write[k][0], 1) * 1024}
-# frames = launches of the last (WTA) kernel
-last = [k for k in rows if (", 2>" in k or ", 2," in k)]
-frames = rows[last[0]]["launches"] if last else 1
+# frames = launches of the horizontal cost sum (one per SGM call)
+hs = [k for k in fetch if k.startswith("k_hsum_q")]
+frames = fetch[hs[0]][0] if hs else 1
 for k, v in rows.items():
     tot_r += v["read_bytes_per_launch"] * v["launches"] / frames
     tot_w += v["write_bytes_per_launch"] * v["launches"] / frames

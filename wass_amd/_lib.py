@@ -124,6 +124,8 @@ SYMBOLS = {
     "wass_planes_mean_accumulate": (None, [C.POINTER(C.c_double), _i, C.POINTER(C.c_double)]),
     "wass_planes_mean_finish": (None, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
     "wass_ctx_wait_for_stream": (_i, [_vp, _vp]),
+    "wass_upload_async": (_i, [_vp, _vp, _vp, _sz]),
+    "wass_burned_area_mask_dev": (_i, [_vp, _vp, _sz, _vp]),
     "wass_coll_unique_id": (_i, [_vp]),
     "wass_coll_init": (_i, [_vp, _i, _i, _vp]),
     "wass_coll_allreduce_sum_f64": (_i, [_vp, C.POINTER(C.c_double), _i]),

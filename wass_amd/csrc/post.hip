@@ -26,6 +26,21 @@ __global__ void __launch_bounds__(256) k_convert(const int16_t* __restrict__ d16
     out[i] = r;
 }
 
+// DISCARD_BURNED_AREAS (wass_stereo.cpp:1072, 1086): mask = 0 where the undistorted image is saturated (value > 254)
+__global__ void __launch_bounds__(256) k_burned_mask(const uint8_t* __restrict__ img, size_t n, uint8_t* __restrict__ mask)
+{
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 4 <= n) {
+        const uint32_t v = *(const uint32_t*)(img + i);
+        uint32_t m = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m |= (uint32_t)(((v >> (8 * k)) & 0xFF) <= 254) << (8 * k);
+        *(uint32_t*)(mask + i) = m;
+    } else {
+        for (size_t k = i; k < n; ++k) mask[k] = img[k] <= 254;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_dilate_zero(const float* __restrict__ src, float* __restrict__ out, int w, int h)
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
@@ -158,5 +173,23 @@ extern "C" int wass_disparity_postprocess(wass_ctx* c, const int16_t* disp16, in
     if (rc) return rc;
     WASS_HIP(c, hipMemcpyAsync(out, c->fC.p, n * 4, hipMemcpyDeviceToHost, c->ts()));
     WASS_HIP(c, hipStreamSynchronize(c->ts()));
+    return WASS_OK;
+}
+
+extern "C" int wass_burned_area_mask_dev(wass_ctx* c, const uint8_t* d_img, size_t n, uint8_t* d_mask)
+{
+    if (!c || !d_img || !d_mask) return wass::set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    if (((uintptr_t)d_img | (uintptr_t)d_mask) & 3) return wass::set_err(c, WASS_ERR_INVALID_ARG, "image and mask must be 4-byte aligned");
+    WASS_HIP(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(wass::k_burned_mask, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, c->stream, d_img, n, d_mask);
+    WASS_HIP(c, hipGetLastError());
+    return WASS_OK;
+}
+
+extern "C" int wass_upload_async(wass_ctx* c, void* d_dst, const void* h_src, size_t nbytes)
+{
+    if (!c || !d_dst || !h_src) return wass::set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    WASS_HIP(c, hipSetDevice(c->device));
+    WASS_HIP(c, hipMemcpyAsync(d_dst, h_src, nbytes, hipMemcpyHostToDevice, c->stream));
     return WASS_OK;
 }

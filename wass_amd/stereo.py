@@ -105,6 +105,17 @@ class Context:
         stream (e.g. torch.cuda.current_stream().cuda_stream, which produced the input tensors)."""
         self._check(self._lib.wass_ctx_wait_for_stream(self._h, C.c_void_p(stream_handle)))
 
+    def upload_async(self, d_dst, h_src):
+        """Pinned host tensor -> device tensor on the context's SGM stream (wass_upload_async)."""
+        n = h_src.numel() * h_src.element_size()
+        if d_dst.numel() * d_dst.element_size() != n or not d_dst.is_contiguous() or not h_src.is_contiguous():
+            raise ValueError("upload_async: contiguous tensors of equal size expected")
+        self._check(self._lib.wass_upload_async(self._h, d_dst.data_ptr(), h_src.data_ptr(), n))
+
+    def burned_area_mask_dev(self, d_img, d_mask):
+        """d_mask = d_img <= 254 on the context's SGM stream (DISCARD_BURNED_AREAS, wass_stereo.cpp:1072)."""
+        self._check(self._lib.wass_burned_area_mask_dev(self._h, d_img.data_ptr(), d_img.numel(), d_mask.data_ptr()))
+
     def sgm_timings(self, previous: bool = False) -> SgmTimings:
         """Stage times of the last SGM call (previous=True: of the call before it, which a pipelined driver can
         read without waiting for the frame it has just enqueued)."""
