@@ -285,3 +285,59 @@ def test_ransac_failure_writes_nan_plane_and_continues(cli, tmp_path):
     _write_png(os.path.join(wd, "undistorted", "00000001.png"), flat)
     r = run(cli, cfg, wd)
     assert r.returncode == 255 and "Too few points triangulated" in r.stdout
+
+
+def _read_png(path):
+    b = open(path, "rb").read()
+    assert b[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, hdr = 8, b"", None
+    while pos < len(b):
+        n, t = struct.unpack(">I", b[pos:pos + 4])[0], b[pos + 4:pos + 8]
+        d = b[pos + 8:pos + 8 + n]
+        assert zlib.crc32(t + d) & 0xFFFFFFFF == struct.unpack(">I", b[pos + 8 + n:pos + 12 + n])[0]
+        if t == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", d)
+        elif t == b"IDAT":
+            idat += d
+        pos += 12 + n
+    w, h, depth, ctype = hdr[:4]
+    ch = {0: 1, 2: 3}[ctype]
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, w * ch + 1)
+    assert depth == 8 and (raw[:, 0] == 0).all()
+    return raw[:, 1:].reshape(h, w, ch).squeeze()
+
+
+@pytest.mark.gpu
+def test_debug_pictures_of_the_reference_are_written(cli, tmp_path, oracle):
+    """stereo / stereo_input / disparity_stereo_ouput (sic) / disparity_final_scaled /
+    disparity_coverage / graph_components, same stems as the reference (PNG instead of JPEG), same pixel arithmetic."""
+    w, h, D = 320, 240, 64
+    wd, cfg, right, left, rig = make_workdir(str(tmp_path), w, h, D)
+    r = run(cli, cfg, wd)
+    assert r.returncode == 0, r.stdout
+    st = _read_png(os.path.join(wd, "stereo.png"))
+    assert st.shape == (h, 2 * w, 3) and (st[0, :, 0] == 255).all() and (st[20, :, 1] == 0).all()       # a red line every 20 rows
+    np.testing.assert_array_equal(st[7, 10:w - 10, 1], left[7, 10:w - 10])                               # left | right, grey
+    np.testing.assert_array_equal(st[7, w + 10:2 * w - 10, 2], right[7, 10:w - 10])
+    si = _read_png(os.path.join(wd, "stereo_input.png"))
+    assert si.shape == (2 * h, w + D) and (si[:, :D] == 0).all()
+    np.testing.assert_array_equal(si[:h, D:], left); np.testing.assert_array_equal(si[h:, D:], right)
+    # disparity pictures: (v - min) / (max - min) * 255 of the oracle's maps (render.hpp:101-136)
+    p = oracle.wass_params(D)
+    d16, _ = oracle.dense_disparity16(right, left, p)
+    final = oracle.disparity_postprocess(d16, 1, D)
+    fs = _read_png(os.path.join(wd, "disparity_final_scaled.png"))
+    mn, mx = np.float32(min(final.min(), w + 1)), np.float32(final.max())
+    np.testing.assert_array_equal(fs, ((final - mn) / (mx - mn) * np.float32(255.0)).astype(np.uint8))
+    raw = _read_png(os.path.join(wd, "disparity_stereo_ouput.png"))
+    assert raw.shape == (h, w) and ((raw > 0) >= (fs > 0)).mean() > 0.99          # clean-up only ever removes pixels (up to hole filling)
+    cov = _read_png(os.path.join(wd, "disparity_coverage.png"))
+    assert cov.shape == (h // 2, w // 2, 3) and (cov[h // 4, w // 4] == [right[h // 2:h // 2 + 2, w // 2:w // 2 + 2].astype(int).sum() + 2 >> 2, 100,
+                                                                         right[h // 2:h // 2 + 2, w // 2:w // 2 + 2].astype(int).sum() + 2 >> 2]).all()
+    gc = _read_png(os.path.join(wd, "graph_components.png"))
+    assert gc.shape == (h // 2, w // 2, 3) and (gc[..., 1] == 255).mean() > 0.5 and (gc[..., 0] == 0).all()
+    # WASS_DEBUG_IMAGES=0 switches them off
+    wd2, cfg2, *_ = make_workdir(str(tmp_path / "b"), w, h, D)
+    r2 = subprocess.run([cli, cfg2, wd2], capture_output=True, text=True, env=dict(os.environ, WASS_DEBUG_IMAGES="0"))
+    assert r2.returncode == 0 and not os.path.exists(os.path.join(wd2, "stereo.png"))
+    assert open(os.path.join(wd2, "mesh_cam.xyzC"), "rb").read() == open(os.path.join(wd, "mesh_cam.xyzC"), "rb").read()

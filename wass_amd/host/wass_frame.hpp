@@ -7,7 +7,7 @@
 // reference.  There is NO CPU implementation of the hot path here: without a GPU (or
 // without libwassgpu.so) the program fails with exit code -1.
 //
-// Divergences from the reference, all listed in DESIGN.md: DENSE_SCALE must be 1; no JPEG debug renders;
+// Divergences from the reference, all listed in DESIGN.md: the debug pictures are PNG, not JPEG (render.hpp);
 // --measure (interactive GUI) is rejected.
 #pragma once
 
@@ -21,6 +21,7 @@
 #include "config.hpp"
 #include "hostio.hpp"
 #include "rectify.hpp"
+#include "render.hpp"
 
 using namespace wasshost;
 
@@ -246,8 +247,9 @@ struct FrameSummary {
 // created on `device` at the point where the reference would first need the GPU and handed back to the caller, who
 // destroys it.  mode: nullptr, "--rectify-only" or "--measure".  Returns the process exit code of wass_stereo (0 / -1).
 inline int wass_run_frame(const char* config_path, const std::string& workdir, const char* mode, int device, wass_ctx** ctxp,
-                          FrameSummary* summary)
+                          FrameSummary* summary, bool debug_images = true)
 {
+    if (const char* e = getenv("WASS_DEBUG_IMAGES")) debug_images = atoi(e) != 0;
     Env env;
     env.workdir = workdir;
     Config cfg;
@@ -292,6 +294,19 @@ inline int wass_run_frame(const char* config_path, const std::string& workdir, c
         env.timer << "Rectification";
         std::cout << "[P|20|100]" << std::endl;
         save_cams();
+        if (debug_images) {                                          // stereo.jpg (:1910-1925)
+            const int W0 = env.left.w, H0 = env.left.h;
+            ImageRGB l = gray_to_rgb(paste(env.left_crop, env.roi_l.x, env.roi_l.y, W0, H0)), r = gray_to_rgb(paste(env.right_crop, env.roi_r.x, env.roi_r.y, W0, H0));
+            rectangle_red(l, env.roi_l.x, env.roi_l.y, env.roi_l.width, env.roi_l.height);
+            rectangle_red(r, env.roi_r.x, env.roi_r.y, env.roi_r.width, env.roi_r.height);
+            ImageRGB st(2 * W0, H0);
+            for (int y = 0; y < H0; ++y) {
+                memcpy(&st.px[(size_t)y * st.w * 3], &l.px[(size_t)y * W0 * 3], (size_t)W0 * 3);
+                memcpy(&st.px[((size_t)y * st.w + W0) * 3], &r.px[(size_t)y * W0 * 3], (size_t)W0 * 3);
+                if (y % 20 == 0) for (int x = 0; x < st.w; ++x) st.set(y, x, 255, 0, 0);
+            }
+            write_png_rgb(path_join(env.workdir, "stereo.png"), st);
+        }
         WLOG_SCOPE("wass_stereo");
         if (mode && std::string("--rectify-only") == mode) { WLOGI << "All done."; return 0; }
         if (mode && std::string("--measure") == mode) { WLOGE << "--measure needs the interactive GUI, which this build does not have"; return -1; }
@@ -328,6 +343,32 @@ inline int wass_run_frame(const char* config_path, const std::string& workdir, c
         if (ero > 0) WLOGI << "applying erode filter (" << ero << " steps)"; else WLOGI << "erode filter skipped.";
         gpu_check(ctx, wass_disparity_postprocess(ctx, disp16.data(), cw, ch, &sp, dil, ero, cfg.get_int("MEDIAN_FILTER_WSIZE"), dispf.data()),
                   "wass_disparity_postprocess");
+        if (debug_images) {
+            const int D = sp.num_disp, offp = sp.disp_offset > 0 ? sp.disp_offset : 0, comp = sp.disp_offset > 0 ? 0 : -sp.disp_offset;
+            const int Wp = cw + D + offp;
+            Image in2(Wp, 2 * ch);                                   // stereo_input.jpg (:820-833): padded left above padded right
+            for (int y = 0; y < ch; ++y) {
+                memcpy(&in2.px[(size_t)y * Wp + (D + offp - comp)], &env.left_crop.px[(size_t)y * cw], cw);
+                memcpy(&in2.px[(size_t)(ch + y) * Wp + D], &env.right_crop.px[(size_t)y * cw], cw);
+            }
+            write_png_gray(path_join(env.workdir, "stereo_input.png"), in2);
+            std::vector<float> conv((size_t)cw * ch);                // clean_and_convert_disparity (:714-733) of the raw map
+            const double scl = 1.0 / sp.dense_scale;
+            for (size_t i = 0; i < conv.size(); ++i) {
+                float dval = ((float)disp16[i]) / 16.0f;
+                conv[i] = (dval <= (float)sp.min_disp || dval > (float)sp.num_disp) ? 0.0f : (float)((double)(dval + (float)sp.disp_offset) * scl);
+            }
+            write_png_gray(path_join(env.workdir, "disparity_stereo_ouput.png"), render_disparity_float(conv.data(), cw, ch));
+            write_png_gray(path_join(env.workdir, "disparity_final_scaled.png"), render_disparity_float(dispf.data(), cw, ch));
+            const int W0 = env.right.w, H0 = env.right.h;           // disparity_coverage.jpg (:1002-1017)
+            ImageRGB cov = gray_to_rgb(paste(env.right_crop, env.roi_r.x, env.roi_r.y, W0, H0));
+            for (int y = 0; y < ch; ++y)
+                for (int x = 0; x < cw; ++x)
+                    if (dispf[(size_t)y * cw + x] > 1.0f && env.roi_r.y + y < H0 && env.roi_r.x + x < W0)
+                        cov.px[((size_t)(env.roi_r.y + y) * W0 + env.roi_r.x + x) * 3 + 1] = 100;
+            rectangle_red(cov, env.roi_r.x, env.roi_r.y, env.roi_r.width, env.roi_r.height);
+            write_png_rgb(path_join(env.workdir, "disparity_coverage.png"), half_size(cov));
+        }
         WLOGI << "dense stereo completed successfully";
         env.timer << "Dense Stereo";
         std::cout << "[P|40|100]" << std::endl;
@@ -387,7 +428,18 @@ inline int wass_run_frame(const char* config_path, const std::string& workdir, c
         double pct = 0; uint64_t ngaps = 0, csize = 0;
         gpu_check(ctx, wass_mesh_zgap_percentile(ctx, mesh, cfg.get_double("ZGAP_PERCENTILE"), &pct, &ngaps), "wass_mesh_zgap_percentile");
         env.timer << "Z-gap stats";
+        std::vector<uint8_t> valid_before;
+        if (debug_images) { valid_before.resize((size_t)roi_r[2] * roi_r[3]); gpu_check(ctx, wass_mesh_download(ctx, mesh, valid_before.data(), nullptr, nullptr), "wass_mesh_download"); }
         gpu_check(ctx, wass_mesh_keep_biggest_component(ctx, mesh, pct, &csize), "wass_mesh_keep_biggest_component");
+        if (debug_images) {                                          // graph_components.jpg (PovMesh.cpp:222-250, 982-984)
+            std::vector<uint8_t> valid_after(valid_before.size());
+            gpu_check(ctx, wass_mesh_download(ctx, mesh, valid_after.data(), nullptr, nullptr), "wass_mesh_download");
+            ImageRGB gc(roi_r[2], roi_r[3]);
+            for (size_t i = 0; i < valid_after.size(); ++i)
+                if (valid_after[i]) { gc.px[3 * i + 1] = 255; }                     // biggest component: palette.back() = (0,255,0)
+                else if (valid_before[i]) { gc.px[3 * i + 2] = 255; }              // every other component: palette[0] = BGR (255,0,0)
+            write_png_rgb(path_join(env.workdir, "graph_components.png"), half_size(gc));
+        }
         WLOG_SCOPE("cluster");
         WLOGI << "biggest component size: " << csize << " (px)";
         env.timer << "Outlier removal";

@@ -70,7 +70,7 @@ bool read_plane_txt(const std::string& wd, FrameSummary& fs)
 }
 
 int worker(int rank, int world, int device, bool distinct_gpus, const unsigned char* uid, const char* cfg,
-           const std::vector<std::string>& wds, bool verbose, bool skip_existing, int fd)
+           const std::vector<std::string>& wds, bool verbose, bool skip_existing, bool debug_images, int fd)
 {
     if (!verbose) {                       // per-frame logs still go to <workdir>/wass_stereo_log.txt
         const int nul = open("/dev/null", O_WRONLY);
@@ -87,7 +87,7 @@ int worker(int rank, int world, int device, bool distinct_gpus, const unsigned c
             read_plane_txt(wds[i], fs))
             r.rc = 0;
         else
-            r.rc = exists(wds[i]) ? wass_run_frame(cfg, wds[i], nullptr, device, &ctx, &fs) : -1;
+            r.rc = exists(wds[i]) ? wass_run_frame(cfg, wds[i], nullptr, device, &ctx, &fs, debug_images) : -1;
         r.seconds = now() - t0;
         r.have_plane = r.rc == 0 && fs.have_plane;
         r.n_points = fs.n_points;
@@ -117,7 +117,7 @@ int worker(int rank, int world, int device, bool distinct_gpus, const unsigned c
 int main(int argc, char* argv[])
 {
     if (argc < 3) {
-        std::cout << "Usage:\n  wass_stereo_batch <config_file> <workdir>... [--gpus G] [--procs-per-gpu P] [--out <dir>] [--verbose] [--skip-existing]\n"
+        std::cout << "Usage:\n  wass_stereo_batch <config_file> <workdir>... [--gpus G] [--procs-per-gpu P] [--out <dir>] [--verbose] [--skip-existing] [--debug-images]\n"
                      "  wass_stereo_batch <config_file> --sequence <output_dir> [--gpus G] ...\n";
         return argc == 1 ? 0 : -1;
     }
@@ -125,7 +125,7 @@ int main(int argc, char* argv[])
     std::vector<std::string> wds;
     std::string outdir;
     int gpus = 1, ppg = 1;
-    bool verbose = false, skip_existing = false;
+    bool verbose = false, skip_existing = false, debug_images = false;
     for (int i = 2; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "--gpus" && i + 1 < argc) gpus = atoi(argv[++i]);
@@ -133,6 +133,7 @@ int main(int argc, char* argv[])
         else if (a == "--out" && i + 1 < argc) outdir = argv[++i];
         else if (a == "--verbose") verbose = true;
         else if (a == "--skip-existing") skip_existing = true;
+        else if (a == "--debug-images") debug_images = true;       // the reference's per-frame debug pictures (render.hpp); off here
         else if (a == "--sequence" && i + 1 < argc) {
             const std::string root = argv[++i];
             if (outdir.empty()) outdir = root;
@@ -172,7 +173,7 @@ int main(int argc, char* argv[])
         if (pid == 0) {
             close(pfd[0]);
             for (int q = 0; q < r; ++q) close(fds[q]);
-            _exit(worker(r, world, r / ppg, distinct, uid, cfg, wds, verbose, skip_existing, pfd[1]));
+            _exit(worker(r, world, r / ppg, distinct, uid, cfg, wds, verbose, skip_existing, debug_images, pfd[1]));
         }
         close(pfd[1]);
         pids[r] = pid; fds[r] = pfd[0];
