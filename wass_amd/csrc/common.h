@@ -198,6 +198,7 @@ struct CkptLayout {
     int K = 8;                       // steps per checkpoint segment
     int nfam = 0;
     int dx[4] = {}, dy[4] = {}, smode[4] = {}, nch[4] = {}, mseg[4] = {};
+    bool split[4] = {};              // family split in the middle (half_chain_geometry): nch counts sub-chains
     size_t off[5] = {};              // byte offsets into c->ckpt
     bool cols_from_cost = false;     // family 0 is the column family and its checkpoints come from k_vsum_col
     bool path2_from_cost = false;    // 5-path mode: k_vsum_col has already written S = L_2 (path 2 has no partner)

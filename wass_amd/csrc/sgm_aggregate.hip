@@ -115,23 +115,27 @@ __global__ void __launch_bounds__(256) k_sweep(const uint32_t* __restrict__ C, u
 // Phase 1 of a chain-family pair: the forward path over every chain, keeping only the (normalised)
 // state at the end of each K-step segment -- 1/K of a volume.  Reads C once, touches nothing else, so
 // the checkpoint sweeps of all families can run concurrently with any other kernel.
+// endstate != nullptr: the family is split in the middle (half_chain_geometry): c counts sub-chains, the sweep runs to the
+// end of its half and leaves its final state in endstate[c] for the pair kernel of the other half.
 template <int NP, int K>
 __global__ void __launch_bounds__(256) k_ckpt(const uint32_t* __restrict__ C, uint32_t* __restrict__ ckpt,
                                               int width1, int h, int dx, int dy, int P1, int P2, int nchains,
-                                              int maxseg)
+                                              int maxseg, uint32_t* __restrict__ endstate)
 {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
     if (c >= nchains) return;
     int x0, y0, n;
-    chain_geometry(c, dx, dy, width1, h, x0, y0, n);
+    if (endstate) half_chain_geometry(c, dx, dy, width1, h, x0, y0, n);
+    else chain_geometry(c, dx, dy, width1, h, x0, y0, n);
     const long long vec = 64 * NP;
     const long long step = ((long long)dy * width1 + dx) * vec;
     const uint32_t* cp0 = C + ((long long)y0 * width1 + x0) * vec + lane * NP;
     uint32_t* ck = ckpt + ((long long)c * maxseg) * vec + lane * NP;
     const us2 P1v = pk_splat(P1);
     const int F = n / K, r = n - F * K;            // F full segments, then a tail of r steps
-    const int ncp = F - (r > 0 ? 0 : 1);           // checkpoints needed: end of segments 0 .. ncp-1
+    // checkpoints needed: end of segments 0 .. ncp-1 (a split family also needs the state at the very end)
+    const int ncp = endstate ? F : F - (r > 0 ? 0 : 1);
     {
         PathState<NP> st;
         st.reset();
@@ -140,6 +144,7 @@ __global__ void __launch_bounds__(256) k_ckpt(const uint32_t* __restrict__ C, ui
         if (ncp > 0) load_seg<NP, K, false>(cp, step, K, cb);
         for (int s = 0; s < ncp; ++s) {
             if (s + 1 < ncp) load_seg<NP, K, false>(cp + K * step, step, K, cn);
+            else if (endstate && r > 0) load_seg<NP, K, true>(cp + K * step, step, r, cn);
 #pragma unroll
             for (int u = 0; u < K; ++u) {
                 us2 L[NP];
@@ -148,6 +153,16 @@ __global__ void __launch_bounds__(256) k_ckpt(const uint32_t* __restrict__ C, ui
             st.store_normalised(ck + (long long)s * vec);
             copy_seg<NP, K>(cb, cn);
             cp += K * step;
+        }
+        if (endstate) {
+            if (ncp == 0 && r > 0) load_seg<NP, K, true>(cp, step, r, cb);
+#pragma unroll
+            for (int u = 0; u < K; ++u)
+                if (u < r) {
+                    us2 L[NP];
+                    sgm_step<NP>(st, cb[u], L, P1v, P2);
+                }
+            st.store_normalised(endstate + (long long)c * vec + lane * NP);
         }
     }
 
@@ -161,13 +176,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
                                               uint32_t* __restrict__ ckpt, int width1, int h, int dx, int dy,
                                               int P1, int P2, int nchains, int maxseg, int D, int minD, int uniq,
                                               int keepS, int16_t* __restrict__ sel_d16,
-                                              uint32_t* __restrict__ sel_key)
+                                              uint32_t* __restrict__ sel_key, const uint32_t* __restrict__ endstate)
 {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
     if (c >= nchains) return;
     int x0, y0, n;
-    chain_geometry(c, dx, dy, width1, h, x0, y0, n);
+    if (endstate) half_chain_geometry(c, dx, dy, width1, h, x0, y0, n);    // split family: c counts sub-chains (k_ckpt)
+    else chain_geometry(c, dx, dy, width1, h, x0, y0, n);
     const long long vec = 64 * NP;
     const long long step = ((long long)dy * width1 + dx) * vec;
     const long long pixstep = (long long)dy * width1 + dx;
@@ -199,6 +215,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
     // ---- phase 2: the chain in reverse ------------------------------------------------------------
     PathState<NP> bw;
     bw.reset();
+    if (endstate) {                                // the backward path arrives from the other half of the chain
+        us2 nv[NP];
+        ld_stream_vec<NP>(endstate + (long long)(c ^ 1) * vec + lane * NP, nv);
+        bw.load_normalised(nv);
+    }
     if (r > 0) {                                   // tail segment F (guarded, not pipelined)
         const uint32_t* cp = cp0 + (long long)F * K * step;
         uint32_t* sp = sp0 + (long long)F * K * step;
@@ -301,19 +322,24 @@ CkptLayout ckpt_layout(const SgmDims& d)
 {
     CkptLayout L;
     L.K = ckpt_k(d.NP);
+    const char* agg = getenv("WASS_AGG");
+    const bool legacy = agg && (!strcmp(agg, "trio") || !strcmp(agg, "concurrent") || !strcmp(agg, "rowsfirst"));
+    const char* sp = getenv("WASS_SPLIT_ROWS");
+    const bool split_rows = !legacy && (!sp || atoi(sp) != 0);
     auto add = [&](int dx, int dy, int smode) {
         const int f = L.nfam++;
         L.dx[f] = dx; L.dy[f] = dy; L.smode[f] = smode;
         L.nch[f] = dy == 0 ? d.h : (dx == 0 ? d.width1 : d.width1 + d.h - 1);
-        const int maxlen = dy == 0 ? d.width1 : (dx == 0 ? d.h : (d.width1 < d.h ? d.width1 : d.h));
+        int maxlen = dy == 0 ? d.width1 : (dx == 0 ? d.h : (d.width1 < d.h ? d.width1 : d.h));
+        // rows: 2 058 chains are two waves per SIMD -- split them in the middle (half_chain_geometry) for twice the waves
+        L.split[f] = split_rows && dy == 0;
+        if (L.split[f]) { L.nch[f] *= 2; maxlen = maxlen - maxlen / 2; }
         L.mseg[f] = (maxlen + L.K - 1) / L.K;
-        const size_t b = (size_t)L.nch[f] * L.mseg[f] * (64 * d.NP) * sizeof(uint32_t);
+        const size_t b = (size_t)L.nch[f] * (L.mseg[f] + (L.split[f] ? 1 : 0)) * (64 * d.NP) * sizeof(uint32_t);   // + the end states
         L.off[f + 1] = L.off[f] + ((b + 255) & ~(size_t)255);
     };
     // The kernel that carries the winner-take-all goes last and should have the most chains (the WTA adds ~60
     // instructions per pixel): the anti-diagonals (width1 + h - 1 chains).
-    const char* agg = getenv("WASS_AGG");
-    const bool legacy = agg && (!strcmp(agg, "trio") || !strcmp(agg, "concurrent") || !strcmp(agg, "rowsfirst"));
     if (d.ndirs == 8 && !legacy) {
         L.cols_from_cost = true;
         add(0, 1, 0);                // columns:        paths 2 + 6   (S written)
@@ -368,14 +394,14 @@ static int launch_aggregate_trio(wass_ctx* c, const SgmDims& d, int* n_launches)
         if ((rc = ensure(c, c->ckpt, cb))) return rc;
         uint32_t* ck = (uint32_t*)c->ckpt.p;
         hipLaunchKernelGGL((k_ckpt<NP, K>), dim3((nch + 3) / 4), dim3(256), 0, c->side2, C, ck, d.width1, d.h, -1, 1, d.P1, d.P2,
-                           nch, mseg);
+                           nch, mseg, (uint32_t*)nullptr);
         ++nl;
         WASS_HIP(c, hipEventRecord(c->ev_ckpt[1], c->side2));
         WASS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_ckpt[0], 0));
         WASS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_ckpt[1], 0));
         hipLaunchKernelGGL((k_pair<NP, K, 3>), dim3((nch + 3) / 4), dim3(256), 0, c->stream, C, S, (const uint32_t*)S2, ck,
                            d.width1, d.h, -1, 1, d.P1, d.P2, nch, mseg, d.D, d.minD, d.uniq, c->debug ? 1 : 0,
-                           (int16_t*)c->sel_d16.p, (uint32_t*)c->sel_key.p);
+                           (int16_t*)c->sel_d16.p, (uint32_t*)c->sel_key.p, (const uint32_t*)nullptr);
         ++nl;
     } else {
         if ((rc = launch_trio(c, d, S2, haloB, -1, +1, false, c->side))) return rc;              // paths 4, 3 -> S2
@@ -433,8 +459,9 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
         const int nch = lay.nch[f], mseg = lay.mseg[f];
         static const bool two = getenv("WASS_SIDE_STREAMS") && atoi(getenv("WASS_SIDE_STREAMS")) == 2;
         hipStream_t ss = (two && (f & 1)) ? c->side2 : c->side;
-        hipLaunchKernelGGL((k_ckpt<NP, K>), dim3((nch + 3) / 4), dim3(256), 0, ss, C,
-                           (uint32_t*)((char*)c->ckpt.p + off[f]), d.width1, d.h, dx, dy, d.P1, d.P2, nch, mseg);
+        uint32_t* ckf = (uint32_t*)((char*)c->ckpt.p + off[f]);
+        hipLaunchKernelGGL((k_ckpt<NP, K>), dim3((nch + 3) / 4), dim3(256), 0, ss, C, ckf, d.width1, d.h, dx, dy, d.P1, d.P2, nch, mseg,
+                           lay.split[f] ? ckf + (size_t)nch * mseg * (64 * NP) : (uint32_t*)nullptr);
         WASS_HIP(c, hipEventRecord(c->ev_ckpt[f], ss));
         ++nl;
     }
@@ -461,7 +488,8 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
         const dim3 grid((nch + 3) / 4), block(256);
 #define WASS_PAIR(SMODE, STREAM, SOUT)                                                                       \
         hipLaunchKernelGGL((k_pair<NP, K, SMODE>), grid, block, 0, STREAM, C, SOUT, S2, ck, d.width1, d.h, dx, dy, \
-                           d.P1, d.P2, nch, mseg, d.D, d.minD, d.uniq, c->debug ? 1 : 0, sd, sk)
+                           d.P1, d.P2, nch, mseg, d.D, d.minD, d.uniq, c->debug ? 1 : 0, sd, sk,                \
+                           lay.split[f] ? (const uint32_t*)(ck + (size_t)nch * mseg * (64 * NP)) : (const uint32_t*)nullptr)
         if (conc && f == 1) {                       // columns -> S2 on the second side stream, concurrent with the rows
             WASS_HIP(c, hipStreamWaitEvent(c->side2, c->ev_ckpt[f], 0));
             WASS_PAIR(0, c->side2, (uint32_t*)c->S2.p);

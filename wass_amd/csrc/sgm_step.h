@@ -209,6 +209,19 @@ __device__ __forceinline__ void chain_geometry(int c, int dx, int dy, int width1
     }
 }
 
+// Meet-in-the-middle split of a chain family (rows / columns have only ~2 chains per SIMD): sub-chain c2 = 2c + half is
+// the first n/2 pixels of chain c walked in the family's direction (half 0), or the remaining ones walked from the far end
+// in the opposite direction (half 1).  Both start at an image border with the all-zero state, so their checkpoint sweeps
+// are independent; the state each one ends with is exactly the state the OTHER half's backward sweep starts from, so
+// the two pair kernels are independent too: twice the waves for the same bytes.
+__device__ __forceinline__ void half_chain_geometry(int c2, int& dx, int& dy, int width1, int h, int& x0, int& y0, int& n)
+{
+    chain_geometry(c2 >> 1, dx, dy, width1, h, x0, y0, n);
+    const int mid = n / 2;
+    if (c2 & 1) { x0 += (n - 1) * dx; y0 += (n - 1) * dy; dx = -dx; dy = -dy; n -= mid; }
+    else n = mid;
+}
+
 // K consecutive vectors of a chain -> registers; GUARD: only the first len exist
 template <int NP, int K, bool GUARD>
 __device__ __forceinline__ void load_seg(const uint32_t* __restrict__ p, long long step, int len, us2 (&dst)[K][NP])
