@@ -31,7 +31,7 @@ extern "C" {
 typedef enum {
     WASS_OK = 0,
     WASS_ERR_INVALID_ARG = -1,
-    WASS_ERR_UNSUPPORTED = -2,   /* e.g. speckle filter on, DENSE_SCALE != 1   */
+    WASS_ERR_UNSUPPORTED = -2,   /* e.g. MAX_DISPARITY > 1024, WINSIZE > 17     */
     WASS_ERR_NO_MEMORY = -3,
     WASS_ERR_DEVICE = -4,        /* HIP runtime error, no GPU                  */
     WASS_ERR_COST_OVERFLOW = -5, /* int16 cost precondition violated (A.7)     */
@@ -83,11 +83,11 @@ typedef struct {
     int uniq_ratio;       /* DENSE_UNIQUENESS_RATIO                          */
     int disp12_max_diff;  /* DENSE_DISP12MAXDIFF                             */
     int prefilter_cap;    /* DENSE_PREFILTER_CAP                             */
-    int speckle_win;      /* DENSE_SPECKLE_WINDOW_SIZE (must be <= 0)        */
+    int speckle_win;      /* DENSE_SPECKLE_WINDOW_SIZE (> 0: cv::filterSpeckles) */
     int speckle_range;    /* DENSE_SPECKLE_RANGE                             */
     int ndirs;            /* 5 or 8                                          */
     int disp_offset;      /* DISPARITY_OFFSET (:747,801-812)                 */
-    double dense_scale;   /* DENSE_SCALE (:745); only 1.0 is supported       */
+    double dense_scale;   /* DENSE_SCALE (:745)                              */
 } wass_sgm_params;
 
 /* Replaces wass_stereo.cpp:820-839: zero-pad both rectified crops, run
@@ -96,6 +96,9 @@ typedef struct {
  * disp16_out: w x h int16 (4 fractional bits), in the right image's frame.
  * Returns WASS_ERR_COST_OVERFLOW (result still written) if a block cost
  * exceeded the int16 range the reference's scalar and SIMD builds agree on. */
+/* DENSE_SCALE != 1 (:788-796): both crops are first resized with cv::resize INTER_CUBIC -- by (scale, 1) when the scale is
+ * above 1, by (scale, scale) below -- and disp16_out has the size of the RESIZED crops: */
+int wass_dense_input_size(int w, int h, double dense_scale, int* ws, int* hs);
 int wass_sgm_disparity(wass_ctx* ctx, const uint8_t* right, const uint8_t* left,
                        int w, int h, size_t pitch, const wass_sgm_params* p,
                        int16_t* disp16_out);
@@ -131,8 +134,8 @@ int wass_sgm_debug_fetch(wass_ctx* ctx, int16_t* C_out, int16_t* S_out, int16_t*
 
 
 /* ------------------------------------------------------------------------
- * Disparity clean-up, rows a7-a9.  Replaces wass_stereo.cpp:853-945 at
- * DENSE_SCALE == 1: clean_and_convert_disparity (:714-733), DISP_DILATE_STEPS
+ * Disparity clean-up, rows a7-a9.  Replaces wass_stereo.cpp:853-945 (this form:
+ * DENSE_SCALE == 1, see _ex below): clean_and_convert_disparity (:714-733), DISP_DILATE_STEPS
  * x matrix_dilate_zero (:617-662, including its column-shift quirk),
  * DISP_EROSION_STEPS x matrix_erode_zero (:665-711), the same-size
  * NN/cubic resize + extra erosion mask (:903-928) and the optional
@@ -145,6 +148,19 @@ int wass_disparity_postprocess(wass_ctx* ctx, const int16_t* disp16, int w, int 
 int wass_disparity_postprocess_dev(wass_ctx* ctx, const int16_t* d_disp16, int w, int h,
                                    const wass_sgm_params* p, int dilate_steps, int erode_steps,
                                    int median_wsize, float* d_disp_f32_out);
+/* The same with every option of wass_stereo.cpp:853-986: disp16 is ws x hs (wass_dense_input_size), the result is
+ * out_w x out_h = roi_comb_right.size(): the converted map is multiplied by 1/DENSE_SCALE (:853), resized with
+ * cv::resize INTER_NEAREST and INTER_CUBIC (:903-904), masked by the eroded nearest copy (:908-928), median-filtered,
+ * and -- cc_threshold = DENSE_DISPARITY_BIGGEST_COMPONENT_THRESHOLD > 0 -- zeroed where the squared 3x3 Sobel gradient
+ * exceeds the threshold and outside the largest 8-connected component of what is left (:947-986). */
+int wass_disparity_postprocess_ex(wass_ctx* ctx, const int16_t* disp16, int ws, int hs, const wass_sgm_params* p,
+                                  int dilate_steps, int erode_steps, int median_wsize, int cc_threshold,
+                                  int out_w, int out_h, float* disp_f32_out);
+int wass_disparity_postprocess_ex_dev(wass_ctx* ctx, const int16_t* d_disp16, int ws, int hs, const wass_sgm_params* p,
+                                      int dilate_steps, int erode_steps, int median_wsize, int cc_threshold,
+                                      int out_w, int out_h, float* d_disp_f32_out);
+/* :947-986 alone, in place on a device map (test hook / building block) */
+int wass_biggest_component_by_gradient_dev(wass_ctx* ctx, float* d_disp, int w, int h, int threshold);
 
 /* ------------------------------------------------------------------------
  * Triangulation, rows a10-a13.  Replaces triangulate(StereoMatchEnv&)

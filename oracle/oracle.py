@@ -145,6 +145,52 @@ def disparity_postprocess(d16, mindisp, num_disp, disp_offset=0, dilate_steps=1,
     return out
 
 
+def resize_dsize(sw, sh, fx, fy):
+    dw, dh = C.c_int(), C.c_int()
+    lib().orc_resize_dsize(sw, sh, C.c_double(fx), C.c_double(fy), C.byref(dw), C.byref(dh))
+    return dw.value, dh.value
+
+
+def resize_cubic_u8(img, fx, fy):
+    """cv::resize(img, dst, Size(), fx, fy, INTER_CUBIC) for CV_8UC1."""
+    img = np.ascontiguousarray(img, np.uint8)
+    sh, sw = img.shape
+    dw, dh = resize_dsize(sw, sh, fx, fy)
+    out = np.empty((dh, dw), np.uint8)
+    lib().orc_resize_cubic_u8(_p(img, C.c_uint8), sw, sh, _p(out, C.c_uint8), dw, dh, C.c_double(1.0 / fx), C.c_double(1.0 / fy))
+    return out
+
+
+def dense_inputs(right, left, dense_scale):
+    """wass_stereo.cpp:788-796 (identity at scale 1: the reference's defect there is not reproduced)."""
+    if dense_scale == 1.0:
+        return right, left
+    fx, fy = (dense_scale, 1.0) if dense_scale > 1.0 else (dense_scale, dense_scale)
+    return resize_cubic_u8(right, fx, fy), resize_cubic_u8(left, fx, fy)
+
+
+def disparity_postprocess_ex(d16, mindisp, num_disp, out_w, out_h, disp_offset=0, dense_scale=1.0, dilate_steps=1, erode_steps=2,
+                             cc_threshold=0):
+    d16 = np.ascontiguousarray(d16, np.int16)
+    out = np.empty((out_h, out_w), np.float32)
+    lib().orc_disparity_postprocess_ex(_p(d16, C.c_int16), d16.shape[1], d16.shape[0], mindisp, num_disp, disp_offset,
+                                       C.c_double(dense_scale), dilate_steps, erode_steps, cc_threshold, out_w, out_h, _p(out, C.c_float))
+    return out
+
+
+def biggest_component_by_gradient(disp, threshold):
+    out = np.ascontiguousarray(disp, np.float32).copy()
+    lib().orc_biggest_component_by_gradient.restype = C.c_size_t
+    area = lib().orc_biggest_component_by_gradient(_p(out, C.c_float), out.shape[1], out.shape[0], threshold)
+    return out, int(area)
+
+
+def filter_speckles(img, new_val, max_size, max_diff):
+    out = np.ascontiguousarray(img, np.int16).copy()
+    lib().orc_filter_speckles(_p(out, C.c_int16), out.shape[1], out.shape[0], new_val, max_size, max_diff)
+    return out
+
+
 def make_geom(g: dict, use_custom=False, disparity_compensation=0.0, dense_scale=1.0) -> Geom:
     G = Geom()
     for k in ("K_left", "K_right", "R", "T", "R1", "R2", "P1", "P2", "HLi", "HRi"):

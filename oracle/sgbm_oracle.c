@@ -145,7 +145,6 @@ int orc_sgbm_compute(const uint8_t* img1, const uint8_t* img2, int w, int h,
     if (stats) { stats->max_C = stats->max_L = stats->overflow = 0; }
     if (w <= 0 || h <= 0 || D <= 0 || (D % 16) != 0 || minD < 0 || (p->mode != 5 && p->mode != 8))
         return -1;
-    if (p->speckle_window > 0) return -2;     /* filterSpeckles not restated (off in WASS) */
 
     raw = raw_out ? raw_out : (int16_t*)malloc((size_t)w * h * sizeof(int16_t));
     if (!raw) return -3;
@@ -390,6 +389,8 @@ int orc_sgbm_compute(const uint8_t* img1, const uint8_t* img2, int w, int h,
 
     /* A.6 */
     orc_median3_i16(raw, disp16, w, h);
+    /* StereoSGBMImpl::compute: filterSpeckles(disp, (minDisparity - 1) * 16, speckleWindowSize, 16 * speckleRange) */
+    if (p->speckle_window > 0) orc_filter_speckles(disp16, w, h, INVALID_SCALED, p->speckle_window, 16 * p->speckle_range);
     if (!raw_out) free(raw);
     if (stats) {
         stats->max_C = maxC; stats->max_L = maxL;

@@ -77,6 +77,18 @@ void orc_disparity_postprocess(const int16_t* disp16, int w, int h, int mindisp,
                                int num_disp, int disp_offset, int dilate_steps,
                                int erode_steps, float* out);
 
+/* ---- optional parts of sgbm_dense_stereo, row a9 (a9_oracle.c; PARITY UNPINNED, OpenCV restated) ---- */
+void orc_resize_dsize(int sw, int sh, double fx, double fy, int* dw, int* dh);          /* cv::resize(.., Size(), fx, fy) */
+/* scale = source step per destination pixel (1/fx, or source size / destination size when dsize was given) */
+void orc_resize_cubic_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, double scale_x, double scale_y);
+void orc_resize_cubic_f32(const float* src, int sw, int sh, float* dst, int dw, int dh, double scale_x, double scale_y);
+void orc_resize_nn_f32(const float* src, int sw, int sh, float* dst, int dw, int dh, double scale_x, double scale_y);
+size_t orc_biggest_component_by_gradient(float* disp, int w, int h, int threshold);     /* wass_stereo.cpp:947-986 */
+void orc_filter_speckles(int16_t* img, int w, int h, int newVal, int maxSpeckleSize, int maxDiff);
+void orc_disparity_postprocess_ex(const int16_t* disp16, int ws, int hs, int mindisp, int num_disp, int disp_offset,
+                                  double dense_scale, int dilate_steps, int erode_steps, int cc_threshold, int ow, int oh,
+                                  float* out);
+
 /* ---- geometry for unrectify (wass_stereo.cpp:299-324) + triangulate ---- */
 typedef struct {
     double K_left[9], K_right[9];   /* intrinsics (row major)              */

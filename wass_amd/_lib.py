@@ -124,6 +124,10 @@ SYMBOLS = {
     "wass_planes_mean_accumulate": (None, [C.POINTER(C.c_double), _i, C.POINTER(C.c_double)]),
     "wass_planes_mean_finish": (None, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
     "wass_ctx_wait_for_stream": (_i, [_vp, _vp]),
+    "wass_dense_input_size": (_i, [_i, _i, C.c_double, C.POINTER(_i), C.POINTER(_i)]),
+    "wass_disparity_postprocess_ex": (_i, [_vp, _vp, _i, _i, C.POINTER(SgmParams), _i, _i, _i, _i, _i, _i, _vp]),
+    "wass_disparity_postprocess_ex_dev": (_i, [_vp, _vp, _i, _i, C.POINTER(SgmParams), _i, _i, _i, _i, _i, _i, _vp]),
+    "wass_biggest_component_by_gradient_dev": (_i, [_vp, _vp, _i, _i, _i]),
     "wass_upload_async": (_i, [_vp, _vp, _vp, _sz]),
     "wass_burned_area_mask_dev": (_i, [_vp, _vp, _sz, _vp]),
     "wass_coll_unique_id": (_i, [_vp]),

@@ -47,9 +47,8 @@ static int make_dims(wass_ctx* c, int w, int h, const wass_sgm_params* p, SgmDim
     if (p->num_disp > 1024) return set_err(c, WASS_ERR_UNSUPPORTED, "MAX_DISPARITY %d > 1024", p->num_disp);
     if (p->min_disp < 0) return set_err(c, WASS_ERR_UNSUPPORTED, "negative MIN_DISPARITY is not supported");
     if (p->ndirs != 5 && p->ndirs != 8) return set_err(c, WASS_ERR_INVALID_ARG, "ndirs must be 5 or 8");
-    if (p->speckle_win > 0)
-        return set_err(c, WASS_ERR_UNSUPPORTED, "DENSE_SPECKLE_WINDOW_SIZE > 0 (filterSpeckles) is not supported");
-    if (p->dense_scale != 1.0) return set_err(c, WASS_ERR_UNSUPPORTED, "DENSE_SCALE != 1.0 is not supported");
+    d.speckle_win = p->speckle_win > 0 ? p->speckle_win : 0;
+    d.speckle_range = p->speckle_range;
     const int win = p->win > 0 ? p->win : 5;
     if (win > 17) return set_err(c, WASS_ERR_UNSUPPORTED, "WINSIZE %d > 17 is not supported", win);
     d.w = w; d.h = h; d.D = p->num_disp;
@@ -126,7 +125,7 @@ void wass_ctx_destroy(wass_ctx* c)
     coll_release(c);
     mesh_pool_purge(c);
     for (Buf* b : { &c->img1, &c->img2, &c->bt1, &c->bt2, &c->hsum, &c->C, &c->S, &c->S2, &c->halo, &c->ckpt, &c->edges, &c->sel_d16, &c->sel_key, &c->raw,
-                    &c->flags, &c->tmp_in0, &c->tmp_in1, &c->tmp_out, &c->tmp_mask, &c->fA, &c->fB, &c->fC, &c->scratch, &c->counters, &c->dstate, &c->rect_tab, &c->rect_mx, &c->rect_my, &c->xyzc, &c->limits })
+                    &c->flags, &c->tmp_in0, &c->tmp_in1, &c->tmp_out, &c->tmp_mask, &c->fA, &c->fB, &c->fC, &c->fD, &c->fE, &c->uf, &c->rs_r, &c->rs_l, &c->raw2, &c->scratch, &c->counters, &c->dstate, &c->rect_tab, &c->rect_mx, &c->rect_my, &c->xyzc, &c->limits })
         release(*b);
     for (auto& set : c->evs) for (auto& e : set) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_ckpt) if (e) (void)hipEventDestroy(e);
@@ -192,10 +191,25 @@ int wass_sgm_disparity_dev(wass_ctx* c, const uint8_t* d_right, const uint8_t* d
 {
     if (!c || !d_right || !d_left || !d_out) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
     if (pitch < (size_t)w) return set_err(c, WASS_ERR_INVALID_ARG, "pitch %zu < width %d", pitch, w);
-    SgmDims d;
-    int rc = make_dims(c, w, h, p, d);
-    if (rc) return rc;
+    if (!p || !(p->dense_scale > 0)) return set_err(c, WASS_ERR_INVALID_ARG, "DENSE_SCALE must be positive");
     WASS_HIP(c, hipSetDevice(c->device));
+    int rc;
+    if (p->dense_scale != 1.0) {
+        // wass_stereo.cpp:788-796: both crops resized with cv::resize INTER_CUBIC (x only when the scale is > 1) before the
+        // padding; the disparity map comes out at that size (wass_dense_input_size)
+        int ws = 0, hs = 0;
+        if (wass_dense_input_size(w, h, p->dense_scale, &ws, &hs) != WASS_OK) return set_err(c, WASS_ERR_INVALID_ARG, "DENSE_SCALE %g leaves no image", p->dense_scale);
+        if ((rc = ensure(c, c->rs_r, (size_t)ws * hs)) || (rc = ensure(c, c->rs_l, (size_t)ws * hs))) return rc;
+        const double fx = p->dense_scale, fy = p->dense_scale > 1.0 ? 1.0 : p->dense_scale;
+        if ((rc = resize_inputs_dev(c, d_right, w, h, pitch, (uint8_t*)c->rs_r.p, ws, hs, fx, fy, c->stream)) ||
+            (rc = resize_inputs_dev(c, d_left, w, h, pitch, (uint8_t*)c->rs_l.p, ws, hs, fx, fy, c->stream)))
+            return rc;
+        d_right = (const uint8_t*)c->rs_r.p; d_left = (const uint8_t*)c->rs_l.p;
+        w = ws; h = hs; pitch = (size_t)ws;
+    }
+    SgmDims d;
+    rc = make_dims(c, w, h, p, d);
+    if (rc) return rc;
 
     const size_t npad = (size_t)d.Wp * d.h;
     const size_t vol = d.cells() * sizeof(uint16_t);
@@ -232,7 +246,15 @@ int wass_sgm_disparity_dev(wass_ctx* c, const uint8_t* d_right, const uint8_t* d
     // with tail overlap the previous frame's clean-up may still be reading the caller's disparity buffer if the
     // caller does not alternate two of them; its first kernel is the only reader
     if (c->tail_overlap) WASS_HIP(c, hipStreamWaitEvent(s, c->ev_post, 0));
-    if ((rc = launch_median_crop(c, d, d_out))) return rc;
+    if (d.speckle_win > 0) {
+        // StereoSGBMImpl::compute: medianBlur, then filterSpeckles(disp, (minD - 1) * 16, window, 16 * range) on the whole padded
+        // map (regions may reach into the columns that wass_stereo crops away), then the crop of :839
+        if ((rc = ensure(c, c->raw2, npad * 2))) return rc;
+        if ((rc = launch_median_full(c, d, (int16_t*)c->raw2.p))) return rc;
+        if ((rc = speckle_filter_dev(c, (int16_t*)c->raw2.p, d.Wp, d.h, (d.minD - 1) * 16, d.speckle_win, 16 * d.speckle_range, s))) return rc;
+        WASS_HIP(c, hipMemcpy2DAsync(d_out, (size_t)d.w * 2, (const int16_t*)c->raw2.p + d.D, (size_t)d.Wp * 2, (size_t)d.w * 2, d.h,
+                                     hipMemcpyDeviceToDevice, s));
+    } else if ((rc = launch_median_crop(c, d, d_out))) return rc;
     WASS_HIP(c, hipEventRecord(c->ev[5], s));
     // status word for wass_sgm_last_timings / the host entry point, in stream order (a blocking hipMemcpy on the
     // null stream would queue behind whatever else the process has in flight)
@@ -292,15 +314,18 @@ int wass_sgm_disparity(wass_ctx* c, const uint8_t* right, const uint8_t* left, i
     if (w <= 0 || h <= 0 || pitch < (size_t)w) return set_err(c, WASS_ERR_INVALID_ARG, "bad image geometry");
     WASS_HIP(c, hipSetDevice(c->device));
     const size_t n = (size_t)w * h;
-    int rc;
-    if ((rc = ensure(c, c->tmp_in0, n)) || (rc = ensure(c, c->tmp_in1, n)) || (rc = ensure(c, c->tmp_out, n * 2)))
+    int rc, ws = w, hs = h;
+    if (p && p->dense_scale != 1.0 && wass_dense_input_size(w, h, p->dense_scale, &ws, &hs) != WASS_OK)
+        return set_err(c, WASS_ERR_INVALID_ARG, "DENSE_SCALE %g leaves no image", p->dense_scale);
+    const size_t no = (size_t)ws * hs;                                   // the map has the size of the RESIZED inputs
+    if ((rc = ensure(c, c->tmp_in0, n)) || (rc = ensure(c, c->tmp_in1, n)) || (rc = ensure(c, c->tmp_out, no * 2)))
         return rc;
     WASS_HIP(c, hipMemcpy2DAsync(c->tmp_in0.p, w, right, pitch, w, h, hipMemcpyHostToDevice, c->stream));
     WASS_HIP(c, hipMemcpy2DAsync(c->tmp_in1.p, w, left, pitch, w, h, hipMemcpyHostToDevice, c->stream));
     rc = wass_sgm_disparity_dev(c, (const uint8_t*)c->tmp_in0.p, (const uint8_t*)c->tmp_in1.p, w, h, w, p,
                                 (int16_t*)c->tmp_out.p);
     if (rc) return rc;
-    WASS_HIP(c, hipMemcpyAsync(disp16_out, c->tmp_out.p, n * 2, hipMemcpyDeviceToHost, c->stream));
+    WASS_HIP(c, hipMemcpyAsync(disp16_out, c->tmp_out.p, no * 2, hipMemcpyDeviceToHost, c->stream));
     WASS_HIP(c, hipStreamSynchronize(c->stream));
     const uint32_t fl = c->h_flags[4 * (int)((c->nsgm - 1) & 1)];
     if (fl & 2) {

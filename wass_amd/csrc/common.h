@@ -89,6 +89,7 @@ struct SgmDims {
     int ftzero;
     int ndirs;
     int off_pos, comp;   // max(off,0), max(-off,0)
+    int speckle_win = 0, speckle_range = 0;   // cv::filterSpeckles inside compute() when speckle_win > 0
     size_t cells() const { return (size_t)h * width1 * Dp; }
 };
 
@@ -123,6 +124,10 @@ struct wass_ctx {
     wass::Buf tmp_in0, tmp_in1, tmp_out;   // staging for the host-pointer entry points
     wass::Buf tmp_mask;
     wass::Buf fA, fB, fC;          // float32 maps of the disparity clean-up
+    wass::Buf fD, fE;              // DENSE_SCALE != 1: nearest / cubic copies at the output size (post.hip)
+    wass::Buf uf;                  // union-find parent / size arrays of the optional component filters (post_opt.hip)
+    wass::Buf rs_r, rs_l;          // DENSE_SCALE != 1: resized SGBM inputs
+    wass::Buf raw2;                // speckle filter: median-filtered padded disparity
     wass::Buf counters;            // striped atomics of the mesh stages
     wass::Buf dstate;              // device-resident scalar record + radix histogram (mesh.hip DevState)
     wass::Buf scratch;             // mesh stages: gaps / labels / partial sums / packed output
@@ -219,6 +224,12 @@ bool tile_schedule_enabled();        // WASS_AGG=tile
 int launch_aggregate_tile(wass_ctx* c, const SgmDims& d, int* n_launches);
 
 void coll_release(wass_ctx* c);               // coll.hip
+// post_opt.hip: optional parts of sgbm_dense_stereo (row a9)
+int speckle_filter_dev(wass_ctx* c, int16_t* img, int w, int h, int newVal, int maxSize, int maxDiff, hipStream_t s);
+int biggest_component_dev(wass_ctx* c, float* disp, int w, int h, int threshold, uint8_t* flag, hipStream_t s);
+int resize_inputs_dev(wass_ctx* c, const uint8_t* src, int w, int h, size_t pitch, uint8_t* dst, int ws, int hs, double fx, double fy,
+                      hipStream_t s);
+int resize_f32_dev(wass_ctx* c, const float* src, int sw, int sh, float* dst, int dw, int dh, bool cubic, hipStream_t s);
 void mesh_pool_purge(const void* owner);      // mesh.hip: parked mesh allocations of a context that is going away
 
 // stage launchers (each enqueues on c->stream)
@@ -227,6 +238,7 @@ int launch_cost_volume(wass_ctx* c, const SgmDims& d);
 int launch_aggregate(wass_ctx* c, const SgmDims& d, int* n_launches);
 int launch_select(wass_ctx* c, const SgmDims& d);
 int launch_median_crop(wass_ctx* c, const SgmDims& d, int16_t* d_out);
+int launch_median_full(wass_ctx* c, const SgmDims& d, int16_t* d_padded_out);   // the whole padded map (speckle filter path)
 // pipelined column-strip sweeps (sgm_trio.hip)
 size_t trio_halo_bytes(const SgmDims& d);
 int launch_trio(wass_ctx* c, const SgmDims& d, uint32_t* Sout, unsigned long long* halo, int xdir, int ydir, bool has_v,

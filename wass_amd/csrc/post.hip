@@ -120,60 +120,91 @@ __global__ void __launch_bounds__(256) k_median_f32(const float* __restrict__ sr
 
 using namespace wass;
 
-extern "C" int wass_disparity_postprocess_dev(wass_ctx* c, const int16_t* d_disp16, int w, int h,
-                                              const wass_sgm_params* p, int dilate_steps, int erode_steps,
-                                              int median_wsize, float* d_out)
+extern "C" int wass_disparity_postprocess_ex_dev(wass_ctx* c, const int16_t* d_disp16, int ws, int hs, const wass_sgm_params* p,
+                                                 int dilate_steps, int erode_steps, int median_wsize, int cc_threshold, int ow,
+                                                 int oh, float* d_out)
 {
-    if (!c || !d_disp16 || !p || !d_out || w <= 0 || h <= 0) return set_err(c, WASS_ERR_INVALID_ARG, "bad argument");
+    if (!c || !d_disp16 || !p || !d_out || ws <= 0 || hs <= 0 || ow <= 0 || oh <= 0) return set_err(c, WASS_ERR_INVALID_ARG, "bad argument");
     if (c->tail_overlap && c->have_last) WASS_HIP(c, hipStreamWaitEvent(c->tail, c->ev[6], 0));   // the SGM call that produced d_disp16
-    if (p->dense_scale != 1.0) return set_err(c, WASS_ERR_UNSUPPORTED, "DENSE_SCALE != 1.0 is not supported");
+    if (!(p->dense_scale > 0)) return set_err(c, WASS_ERR_INVALID_ARG, "DENSE_SCALE must be positive");
     if (median_wsize >= 3 && median_wsize != 3 && median_wsize != 5)
         return set_err(c, WASS_ERR_UNSUPPORTED, "MEDIAN_FILTER_WSIZE must be 0, 3 or 5 for float maps (cv::medianBlur)");
     WASS_HIP(c, hipSetDevice(c->device));
-    const size_t n = (size_t)w * h;
+    const size_t n = (size_t)ws * hs, no = (size_t)ow * oh;
+    const bool same = ow == ws && oh == hs;                      // cv::resize to the same size is a copy
     int rc;
-    if ((rc = ensure(c, c->fA, n * 4)) || (rc = ensure(c, c->fB, n * 4))) return rc;
+    if ((rc = ensure(c, c->fA, (n > no ? n : no) * 4)) || (rc = ensure(c, c->fB, (n > no ? n : no) * 4))) return rc;
+    if (!same && ((rc = ensure(c, c->fD, no * 4)) || (rc = ensure(c, c->fE, no * 4)))) return rc;
     float* a = (float*)c->fA.p;
     float* b = (float*)c->fB.p;
     hipStream_t s = c->ts();
-    const dim3 grid2((w + 255) / 256, h), blk(256);
+    const dim3 grid2((ws + 255) / 256, hs), gout((ow + 255) / 256, oh), blk(256);
     const int off = p->disp_offset > 0 ? p->disp_offset : 0;    // :803-808
     hipLaunchKernelGGL(k_convert, dim3((unsigned)((n + 255) / 256)), blk, 0, s, d_disp16, n, p->min_disp, p->num_disp,
                        off, 1.0 / p->dense_scale, a);
     // d_disp16 has been consumed: the next SGM call may overwrite it (it waits for this before its last kernel)
     if (c->tail_overlap) WASS_HIP(c, hipEventRecord(c->ev_post, s));
     for (int k = 1; k <= dilate_steps; ++k) {
-        hipLaunchKernelGGL(k_dilate_zero, grid2, blk, 0, s, (const float*)a, b, w, h);
+        hipLaunchKernelGGL(k_dilate_zero, grid2, blk, 0, s, (const float*)a, b, ws, hs);
         float* t = a; a = b; b = t;
     }
     for (int k = 1; k <= erode_steps; ++k) {
-        hipLaunchKernelGGL(k_erode_zero<false>, grid2, blk, 0, s, (const float*)a, (const float*)nullptr, b, w, h);
+        hipLaunchKernelGGL(k_erode_zero<false>, grid2, blk, 0, s, (const float*)a, (const float*)nullptr, b, ws, hs);
         float* t = a; a = b; b = t;
     }
-    // :903-928  out = cubic copy (== a) where erode(NN copy == a) != 0
+    // :903-928  nearest and bicubic copies at roi_comb_right.size(); out = cubic copy where erode(nearest copy) != 0
+    const float* nn = a;
+    const float* cub = a;
+    if (!same) {
+        if ((rc = resize_f32_dev(c, a, ws, hs, (float*)c->fD.p, ow, oh, false, s)) || (rc = resize_f32_dev(c, a, ws, hs, (float*)c->fE.p, ow, oh, true, s)))
+            return rc;
+        nn = (const float*)c->fD.p; cub = (const float*)c->fE.p;
+    }
     float* masked = median_wsize >= 3 ? b : d_out;
-    hipLaunchKernelGGL(k_erode_zero<true>, grid2, blk, 0, s, (const float*)a, (const float*)a, masked, w, h);
-    if (median_wsize == 3) hipLaunchKernelGGL(k_median_f32<3>, grid2, blk, 0, s, (const float*)masked, d_out, w, h);
-    else if (median_wsize == 5) hipLaunchKernelGGL(k_median_f32<5>, grid2, blk, 0, s, (const float*)masked, d_out, w, h);
+    hipLaunchKernelGGL(k_erode_zero<true>, gout, blk, 0, s, nn, cub, masked, ow, oh);
+    if (median_wsize == 3) hipLaunchKernelGGL(k_median_f32<3>, gout, blk, 0, s, (const float*)masked, d_out, ow, oh);
+    else if (median_wsize == 5) hipLaunchKernelGGL(k_median_f32<5>, gout, blk, 0, s, (const float*)masked, d_out, ow, oh);
     WASS_HIP(c, hipGetLastError());
+    if (cc_threshold > 0) {                                      // :947-986
+        if ((rc = ensure(c, c->tmp_mask, no))) return rc;
+        if ((rc = biggest_component_dev(c, d_out, ow, oh, cc_threshold, (uint8_t*)c->tmp_mask.p, s))) return rc;
+    }
+    return WASS_OK;
+}
+
+extern "C" int wass_disparity_postprocess_dev(wass_ctx* c, const int16_t* d_disp16, int w, int h,
+                                              const wass_sgm_params* p, int dilate_steps, int erode_steps,
+                                              int median_wsize, float* d_out)
+{
+    if (p && p->dense_scale != 1.0)
+        return set_err(c, WASS_ERR_INVALID_ARG, "DENSE_SCALE != 1: the map and the output differ in size, use wass_disparity_postprocess_ex");
+    return wass_disparity_postprocess_ex_dev(c, d_disp16, w, h, p, dilate_steps, erode_steps, median_wsize, 0, w, h, d_out);
+}
+
+extern "C" int wass_disparity_postprocess_ex(wass_ctx* c, const int16_t* disp16, int ws, int hs, const wass_sgm_params* p,
+                                             int dilate_steps, int erode_steps, int median_wsize, int cc_threshold, int ow, int oh,
+                                             float* out)
+{
+    if (!c || !disp16 || !out || ws <= 0 || hs <= 0 || ow <= 0 || oh <= 0) return set_err(c, WASS_ERR_INVALID_ARG, "bad argument");
+    WASS_HIP(c, hipSetDevice(c->device));
+    const size_t n = (size_t)ws * hs, no = (size_t)ow * oh;
+    int rc;
+    if ((rc = ensure(c, c->tmp_out, n * 2)) || (rc = ensure(c, c->fC, no * 4))) return rc;
+    WASS_HIP(c, hipMemcpyAsync(c->tmp_out.p, disp16, n * 2, hipMemcpyHostToDevice, c->ts()));
+    rc = wass_disparity_postprocess_ex_dev(c, (const int16_t*)c->tmp_out.p, ws, hs, p, dilate_steps, erode_steps, median_wsize,
+                                           cc_threshold, ow, oh, (float*)c->fC.p);
+    if (rc) return rc;
+    WASS_HIP(c, hipMemcpyAsync(out, c->fC.p, no * 4, hipMemcpyDeviceToHost, c->ts()));
+    WASS_HIP(c, hipStreamSynchronize(c->ts()));
     return WASS_OK;
 }
 
 extern "C" int wass_disparity_postprocess(wass_ctx* c, const int16_t* disp16, int w, int h, const wass_sgm_params* p,
                                           int dilate_steps, int erode_steps, int median_wsize, float* out)
 {
-    if (!c || !disp16 || !out || w <= 0 || h <= 0) return set_err(c, WASS_ERR_INVALID_ARG, "bad argument");
-    WASS_HIP(c, hipSetDevice(c->device));
-    const size_t n = (size_t)w * h;
-    int rc;
-    if ((rc = ensure(c, c->tmp_out, n * 2)) || (rc = ensure(c, c->fC, n * 4))) return rc;
-    WASS_HIP(c, hipMemcpyAsync(c->tmp_out.p, disp16, n * 2, hipMemcpyHostToDevice, c->ts()));
-    rc = wass_disparity_postprocess_dev(c, (const int16_t*)c->tmp_out.p, w, h, p, dilate_steps, erode_steps, median_wsize,
-                                        (float*)c->fC.p);
-    if (rc) return rc;
-    WASS_HIP(c, hipMemcpyAsync(out, c->fC.p, n * 4, hipMemcpyDeviceToHost, c->ts()));
-    WASS_HIP(c, hipStreamSynchronize(c->ts()));
-    return WASS_OK;
+    if (p && p->dense_scale != 1.0)
+        return set_err(c, WASS_ERR_INVALID_ARG, "DENSE_SCALE != 1: the map and the output differ in size, use wass_disparity_postprocess_ex");
+    return wass_disparity_postprocess_ex(c, disp16, w, h, p, dilate_steps, erode_steps, median_wsize, 0, w, h, out);
 }
 
 extern "C" int wass_burned_area_mask_dev(wass_ctx* c, const uint8_t* d_img, size_t n, uint8_t* d_mask)

@@ -105,4 +105,12 @@ int launch_median_crop(wass_ctx* c, const SgmDims& d, int16_t* d_out)
     return WASS_OK;
 }
 
+int launch_median_full(wass_ctx* c, const SgmDims& d, int16_t* d_padded_out)
+{
+    dim3 grid((d.Wp + 255) / 256, d.h);
+    hipLaunchKernelGGL(k_median_crop, grid, dim3(256), 0, c->stream, (const int16_t*)c->raw.p, d.Wp, d.h, 0, d.Wp, d_padded_out);
+    WASS_HIP(c, hipGetLastError());
+    return WASS_OK;
+}
+
 }  // namespace wass

@@ -327,12 +327,14 @@ inline int wass_run_frame(const char* config_path, const std::string& workdir, c
         sp.ndirs = cfg.get_int("DENSE_PATHS");
         sp.disp_offset = cfg.get_int("DISPARITY_OFFSET");
         sp.dense_scale = cfg.get_double("DENSE_SCALE");
-        if (cfg.get_int("DENSE_DISPARITY_BIGGEST_COMPONENT_THRESHOLD") > 0)
-            throw std::runtime_error("DENSE_DISPARITY_BIGGEST_COMPONENT_THRESHOLD > 0 is not supported");
+        const int cc_threshold = cfg.get_int("DENSE_DISPARITY_BIGGEST_COMPONENT_THRESHOLD");
         WLOGI << "Disparity offset: " << sp.disp_offset << " px";
         env.disparity_compensation = sp.disp_offset > 0 ? 0 : -sp.disp_offset;
         const int cw = env.right_crop.w, ch = env.right_crop.h;
-        std::vector<int16_t> disp16((size_t)cw * ch);
+        int ws = cw, hs = ch;                                        // DENSE_SCALE != 1: SGBM runs on resized crops (:788-796)
+        if (wass_dense_input_size(cw, ch, sp.dense_scale, &ws, &hs) != WASS_OK) throw std::runtime_error("invalid DENSE_SCALE");
+        WLOGI << "Dense-stereo input resize: [" << cw << " x " << ch << "] -> [" << ws << " x " << hs << "]";
+        std::vector<int16_t> disp16((size_t)ws * hs);
         WLOGI << "computing dense disparity map... (may take a while)";
         const int rc = wass_sgm_disparity(ctx, env.right_crop.px.data(), env.left_crop.px.data(), cw, ch, (size_t)cw, &sp, disp16.data());
         gpu_check(ctx, rc, "wass_sgm_disparity", true);
@@ -341,8 +343,13 @@ inline int wass_run_frame(const char* config_path, const std::string& workdir, c
         const int dil = cfg.get_int("DISP_DILATE_STEPS"), ero = cfg.get_int("DISP_EROSION_STEPS");
         if (dil > 0) WLOGI << "applying dilate filter (" << dil << " steps)"; else WLOGI << "dilate filter skipped.";
         if (ero > 0) WLOGI << "applying erode filter (" << ero << " steps)"; else WLOGI << "erode filter skipped.";
-        gpu_check(ctx, wass_disparity_postprocess(ctx, disp16.data(), cw, ch, &sp, dil, ero, cfg.get_int("MEDIAN_FILTER_WSIZE"), dispf.data()),
-                  "wass_disparity_postprocess");
+        if (cfg.get_int("MEDIAN_FILTER_WSIZE") >= 3) WLOGI << "applying median filter (window size " << cfg.get_int("MEDIAN_FILTER_WSIZE") << " px.)";
+        if (cc_threshold > 0) {
+            WLOGI << "extracting the biggest connected component from the disparity map";
+            WLOGI << "assuming a sq gradient magnitude of " << cc_threshold;
+        }
+        gpu_check(ctx, wass_disparity_postprocess_ex(ctx, disp16.data(), ws, hs, &sp, dil, ero, cfg.get_int("MEDIAN_FILTER_WSIZE"), cc_threshold,
+                                                     cw, ch, dispf.data()), "wass_disparity_postprocess");
         if (debug_images) {
             const int D = sp.num_disp, offp = sp.disp_offset > 0 ? sp.disp_offset : 0, comp = sp.disp_offset > 0 ? 0 : -sp.disp_offset;
             const int Wp = cw + D + offp;
@@ -351,14 +358,14 @@ inline int wass_run_frame(const char* config_path, const std::string& workdir, c
                 memcpy(&in2.px[(size_t)y * Wp + (D + offp - comp)], &env.left_crop.px[(size_t)y * cw], cw);
                 memcpy(&in2.px[(size_t)(ch + y) * Wp + D], &env.right_crop.px[(size_t)y * cw], cw);
             }
-            write_png_gray(path_join(env.workdir, "stereo_input.png"), in2);
-            std::vector<float> conv((size_t)cw * ch);                // clean_and_convert_disparity (:714-733) of the raw map
+            if (sp.dense_scale == 1.0) write_png_gray(path_join(env.workdir, "stereo_input.png"), in2);   // (the resized inputs stay on the GPU)
+            std::vector<float> conv((size_t)ws * hs);                // clean_and_convert_disparity (:714-733) of the raw map
             const double scl = 1.0 / sp.dense_scale;
             for (size_t i = 0; i < conv.size(); ++i) {
                 float dval = ((float)disp16[i]) / 16.0f;
                 conv[i] = (dval <= (float)sp.min_disp || dval > (float)sp.num_disp) ? 0.0f : (float)((double)(dval + (float)sp.disp_offset) * scl);
             }
-            write_png_gray(path_join(env.workdir, "disparity_stereo_ouput.png"), render_disparity_float(conv.data(), cw, ch));
+            write_png_gray(path_join(env.workdir, "disparity_stereo_ouput.png"), render_disparity_float(conv.data(), ws, hs));
             write_png_gray(path_join(env.workdir, "disparity_final_scaled.png"), render_disparity_float(dispf.data(), cw, ch));
             const int W0 = env.right.w, H0 = env.right.h;           // disparity_coverage.jpg (:1002-1017)
             ImageRGB cov = gray_to_rgb(paste(env.right_crop, env.roi_r.x, env.roi_r.y, W0, H0));

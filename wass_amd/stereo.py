@@ -16,6 +16,14 @@ from ._lib import (Geom, PlaneResult, RefineParams, SgmParams, SgmTimings, TriPa
                    default_sgm_params)
 
 
+def dense_input_size(w: int, h: int, dense_scale: float):
+    """Size of the SGBM inputs / of the raw disparity map for a DENSE_SCALE (wass_stereo.cpp:788-796)."""
+    ws, hs = C.c_int(), C.c_int()
+    if _lib.load().wass_dense_input_size(w, h, C.c_double(dense_scale), C.byref(ws), C.byref(hs)) != 0:
+        raise ValueError("bad DENSE_SCALE")
+    return ws.value, hs.value
+
+
 class Context:
     """One GPU, one stream, its scratch HBM (wass_ctx)."""
 
@@ -74,7 +82,8 @@ class Context:
         if right.shape != left.shape or right.ndim != 2:
             raise ValueError("right/left must be 2-D u8 arrays of equal shape")
         h, w = right.shape
-        out = np.empty((h, w), np.int16)
+        ws, hs = dense_input_size(w, h, params.dense_scale)      # DENSE_SCALE != 1: the map has the size of the resized crops
+        out = np.empty((hs, ws), np.int16)
         rc = self._lib.wass_sgm_disparity(self._h, right.ctypes.data, left.ctypes.data, w, h, w,
                                           C.byref(params), out.ctypes.data)
         self._check(rc, allow=(_lib.WASS_ERR_COST_OVERFLOW,) if allow_overflow else ())
@@ -145,6 +154,16 @@ class Context:
         out = np.empty((h, w), np.float32)
         self._check(self._lib.wass_disparity_postprocess(self._h, disp16.ctypes.data, w, h, C.byref(params),
                                                          dilate_steps, erode_steps, median_wsize, out.ctypes.data))
+        return out
+
+    def disparity_postprocess_ex(self, disp16: np.ndarray, params: SgmParams, out_w: int, out_h: int, dilate_steps: int = 1,
+                                 erode_steps: int = 2, median_wsize: int = 0, cc_threshold: int = 0) -> np.ndarray:
+        """wass_stereo.cpp:853-986 with every option (DENSE_SCALE, biggest component by gradient)."""
+        disp16 = np.ascontiguousarray(disp16, np.int16)
+        hs, ws = disp16.shape
+        out = np.empty((out_h, out_w), np.float32)
+        self._check(self._lib.wass_disparity_postprocess_ex(self._h, disp16.ctypes.data, ws, hs, C.byref(params), dilate_steps,
+                                                            erode_steps, median_wsize, cc_threshold, out_w, out_h, out.ctypes.data))
         return out
 
     def disparity_postprocess_dev(self, d_disp16, params: SgmParams, dilate_steps: int = 1, erode_steps: int = 2,
