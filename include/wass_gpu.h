@@ -303,6 +303,21 @@ int wass_mesh_encode_xyzc_async(wass_ctx* ctx, wass_mesh* m, const double plane[
                                 size_t* nbytes);
 void wass_free(void* p);
 
+/* ---- row f3: the first step of the gridding stage from the device-resident mesh ----------------------------------
+ * gridding/wassgridsurface/wassgridsurface.py:316-365 (_grid_task, "IDW"): align the cloud on the sequence's mean sea
+ * plane (R, T = wass_RT_from_plane(mean plane), z negated: wass_utils.py:38-61), scale by the baseline in metres, bin the
+ * points on the width x height grid over [xmin,xmax] x [ymin,ymax] (:322-326) and fill the gaps with
+ * IDWInterpolator(KSIZE=5, exp=2.4, reps=1) (IDWInterpolator.py:23-58).  grid_out: height x width float32, NaN outside
+ * the closed point mask; mask_out (may be NULL) that mask.  A cell takes the mean of its points (deterministic) where the
+ * reference takes the median of ten random sub-samples (randomised): see grid.hip. */
+typedef struct {
+    double R[9], T[3];              /* gridsetup["Rpl"], ["Tpl"]                        */
+    double baseline;                /* gridsetup["CAM_BASELINE"] (metres)               */
+    double xmin, xmax, ymin, ymax;  /* grid extent in metres                            */
+    int    width, height;           /* XX.shape[1], XX.shape[0]                         */
+} wass_grid_setup;
+int wass_mesh_grid_idw(wass_ctx* ctx, const wass_mesh* m, const wass_grid_setup* gs, float* grid_out, uint8_t* mask_out);
+
 /* Coll-1: NaN-aware mean of per-frame planes (np.nanmean of planes.txt,
  * gridding/wassgridsurface/wassgridsurface.py:672-678).  Reduces
  * [sum a, sum b, sum c, sum d, n_valid] into acc5 (caller all-reduces acc5

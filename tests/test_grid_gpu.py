@@ -1,0 +1,52 @@
+"""Row f3: surface gridding straight from the device-resident mesh (grid.hip) against oracle/grid_oracle.py."""
+import numpy as np
+import pytest
+
+import wass_amd
+from wass_amd import default_sgm_params, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_grid_matches_oracle_on_a_random_cloud(gpu_ctx):
+    from oracle import grid_oracle as G
+    rng = np.random.default_rng(4)
+    w, h = 160, 120
+    plane = np.array([0.02, 0.81, 0.586, -11.0]); plane[:3] /= np.linalg.norm(plane[:3])
+    # points near the plane: x, y spread, z solved from the plane + a wave
+    X = rng.uniform(-6, 6, (h, w)); Y = rng.uniform(-3, 3, (h, w))
+    Z = (-plane[3] - plane[0] * X - plane[1] * Y) / plane[2] + 0.05 * np.sin(X * 2.0)
+    valid = (rng.random((h, w)) < 0.7).astype(np.uint8)
+    p3d = np.stack([X, Y, Z], axis=-1)
+    mesh = gpu_ctx.mesh_upload(valid, p3d)
+    args = dict(baseline=2.5, xmin=-12.0, xmax=12.0, ymin=-30.0, ymax=-5.0, width=96, height=80)
+    grid, mask = mesh.grid_idw(plane, **args)
+    pts = p3d[valid.astype(bool)].T.copy()
+    ref, rmask = G.grid_idw(pts, plane, **args)
+    np.testing.assert_array_equal(mask, rmask)
+    assert 0.05 < mask.mean() < 1.0 and np.isnan(grid[mask == 0]).all()
+    np.testing.assert_allclose(grid[mask == 1], ref[rmask == 1], rtol=0, atol=2e-6)      # float32 output of an fp64 computation
+    # the same cloud in a different point order gives the same grid, bit for bit (fixed-point accumulation)
+    perm = rng.permutation(w * h)
+    mesh2 = gpu_ctx.mesh_upload(valid.ravel()[perm].reshape(h, w), p3d.reshape(-1, 3)[perm].reshape(h, w, 3))
+    grid2, _ = mesh2.grid_idw(plane, **args)
+    np.testing.assert_array_equal(grid, grid2)
+
+
+def test_grid_of_the_synthetic_sea_plane_is_flat(gpu_ctx):
+    """Whole path: SGM -> clean-up -> triangulation -> plane fit -> grid.  Aligned on its own plane the synthetic surface
+    (an exact plane plus a +-0.6 px disparity ripple) is flat to a few centimetres at a 2.5 m baseline."""
+    w, h, D = 640, 480, 64
+    right, left = synth.make_pair(w, h, D, frame_idx=3)
+    p = default_sgm_params(D, ndirs=5)
+    roi = (0, 0, w, h)
+    f = gpu_ctx.disparity_postprocess(gpu_ctx.sgm_disparity(right, left, p), p)
+    mesh, n = gpu_ctx.triangulate(f, w, h, roi, roi, wass_amd.make_geom(synth.rig_geometry(w, h)), right, None, (right <= 254).astype(np.uint8))
+    mesh.remove_outliers(99.0)
+    res = mesh.fit_plane(wass_amd.ransac_sample(w, h, 400, 12345), 1.0, 1.5)
+    assert res.found
+    plane = np.array(res.plane[:])
+    grid, mask = mesh.grid_idw(plane, 2.5, -20.0, 20.0, -80.0, -20.0, 200, 300)
+    assert mask.mean() > 0.2
+    z = grid[mask == 1]
+    assert abs(np.nanmean(z)) < 0.05 and np.nanstd(z) < 0.5

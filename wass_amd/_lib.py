@@ -44,6 +44,12 @@ class FrameResult(C.Structure):
                 ("sgm_cost_overflow", C.c_int), ("sgm_timeout", C.c_int)]
 
 
+class GridSetup(C.Structure):
+    """wass_grid_setup"""
+    _fields_ = [("R", C.c_double * 9), ("T", C.c_double * 3), ("baseline", C.c_double), ("xmin", C.c_double), ("xmax", C.c_double),
+                ("ymin", C.c_double), ("ymax", C.c_double), ("width", C.c_int), ("height", C.c_int)]
+
+
 class Geom(C.Structure):
     """wass_geom"""
     _fields_ = [("K_left", C.c_double * 9), ("K_right", C.c_double * 9), ("R", C.c_double * 9), ("T", C.c_double * 3),
@@ -121,6 +127,7 @@ SYMBOLS = {
     "wass_mesh_finish_frame_async": (_i, [_vp, _vp, C.c_double, _vp, _i, C.c_double, C.POINTER(RefineParams), C.c_double, _vp, _sz]),
     "wass_ctx_frame_result": (_i, [_vp, C.POINTER(FrameResult)]),
     "wass_free": (None, [_vp]),
+    "wass_mesh_grid_idw": (_i, [_vp, _vp, C.POINTER(GridSetup), _vp, _vp]),
     "wass_planes_mean_accumulate": (None, [C.POINTER(C.c_double), _i, C.POINTER(C.c_double)]),
     "wass_planes_mean_finish": (None, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
     "wass_ctx_wait_for_stream": (_i, [_vp, _vp]),

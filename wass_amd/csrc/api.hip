@@ -125,7 +125,7 @@ void wass_ctx_destroy(wass_ctx* c)
     coll_release(c);
     mesh_pool_purge(c);
     for (Buf* b : { &c->img1, &c->img2, &c->bt1, &c->bt2, &c->hsum, &c->C, &c->S, &c->S2, &c->halo, &c->ckpt, &c->edges, &c->sel_d16, &c->sel_key, &c->raw,
-                    &c->flags, &c->tmp_in0, &c->tmp_in1, &c->tmp_out, &c->tmp_mask, &c->fA, &c->fB, &c->fC, &c->fD, &c->fE, &c->uf, &c->rs_r, &c->rs_l, &c->raw2, &c->scratch, &c->counters, &c->dstate, &c->rect_tab, &c->rect_mx, &c->rect_my, &c->xyzc, &c->limits })
+                    &c->flags, &c->tmp_in0, &c->tmp_in1, &c->tmp_out, &c->tmp_mask, &c->fA, &c->fB, &c->fC, &c->fD, &c->fE, &c->uf, &c->rs_r, &c->rs_l, &c->raw2, &c->grid, &c->scratch, &c->counters, &c->dstate, &c->rect_tab, &c->rect_mx, &c->rect_my, &c->xyzc, &c->limits })
         release(*b);
     for (auto& set : c->evs) for (auto& e : set) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_ckpt) if (e) (void)hipEventDestroy(e);

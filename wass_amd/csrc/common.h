@@ -128,6 +128,7 @@ struct wass_ctx {
     wass::Buf uf;                  // union-find parent / size arrays of the optional component filters (post_opt.hip)
     wass::Buf rs_r, rs_l;          // DENSE_SCALE != 1: resized SGBM inputs
     wass::Buf raw2;                // speckle filter: median-filtered padded disparity
+    wass::Buf grid;                // wass_mesh_grid_idw: accumulators and maps of the surface grid (grid.hip)
     wass::Buf counters;            // striped atomics of the mesh stages
     wass::Buf dstate;              // device-resident scalar record + radix histogram (mesh.hip DevState)
     wass::Buf scratch;             // mesh stages: gaps / labels / partial sums / packed output
@@ -168,6 +169,20 @@ struct wass_ctx {
     bool debug = false;            // keep the finished S volume for wass_sgm_debug_fetch
     wass_sgm_timings timings = {};
     bool timings_valid = false;
+};
+
+// organised point cloud in HBM (PovMesh, wass_stereo/PovMesh.h:33-51, as structure of arrays)
+struct wass_mesh {
+    int w = 0, h = 0;
+    uint8_t* valid = nullptr;
+    double* x = nullptr;
+    double* y = nullptr;
+    double* z = nullptr;
+    uint8_t* gray = nullptr;
+    size_t bytes = 0;
+    int device = 0;
+    const void* owner = nullptr;   // the context whose stream orders every use of this allocation
+    size_t n() const { return (size_t)w * h; }
 };
 
 namespace wass {

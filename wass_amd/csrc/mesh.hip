@@ -15,19 +15,6 @@
 #include <new>
 #include <vector>
 
-struct wass_mesh {
-    int w = 0, h = 0;
-    uint8_t* valid = nullptr;
-    double* x = nullptr;
-    double* y = nullptr;
-    double* z = nullptr;
-    uint8_t* gray = nullptr;
-    size_t bytes = 0;
-    int device = 0;
-    const void* owner = nullptr;   // the context whose stream orders every use of this allocation
-    size_t n() const { return (size_t)w * h; }
-};
-
 namespace wass {
 
 struct GeomDev {
