@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""What wasscli would see: wall time per frame of the drop-in executables at config B (process start -> exit).
+
+    python scripts/cli_throughput.py [--frames 8] [--config B]
+
+Builds N synthetic workdirs (PNG + XML inputs as wass_prepare / wass_autocalibrate leave them), then times
+  1. wass_stereo <cfg> <wd>              one process per frame, like wasscli (cli/wasscli/wasscli.py:326-346)
+  2. wass_stereo_batch <cfg> --sequence   one worker process with a persistent context
+"""
+import argparse
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--frames", type=int, default=8)
+ap.add_argument("--config", default="B")
+args = ap.parse_args()
+import numpy as np  # noqa: E402
+from test_cli import _write_png, _write_xml  # noqa: E402
+from wass_amd import build, synth  # noqa: E402
+import bench  # noqa: E402
+
+w, h, D = bench.CONFIGS[args.config]
+cli = build.build_host()
+tmp = tempfile.mkdtemp(prefix="wass_cli_")
+seq = os.path.join(tmp, "output")
+rig = synth.rig_geometry(w, h)
+cfg = os.path.join(tmp, "stereo_config.txt")
+open(cfg, "w").write(f"MAX_DISPARITY={D}\nRANDOM_SEED=12345\nUSE_CUSTOM_STEREORECTIFY=true\nRECTIFY_ANGLE=1e-6\nDISABLE_RECTIFY_ROI=true\n")
+for i in range(args.frames):
+    wd = os.path.join(seq, "%06d_wd" % i)
+    os.makedirs(os.path.join(wd, "undistorted"))
+    right, left = [t.numpy() for t in synth.make_pair_torch(w, h, D, frame_idx=i)]
+    _write_png(os.path.join(wd, "undistorted", "00000000.png"), left)
+    _write_png(os.path.join(wd, "undistorted", "00000001.png"), right)
+    _write_xml(os.path.join(wd, "intrinsics_00000000.xml"), "intr", rig["K_left"])
+    _write_xml(os.path.join(wd, "intrinsics_00000001.xml"), "intr", rig["K_right"])
+    _write_xml(os.path.join(wd, "ext_R.xml"), "R", rig["R"])
+    _write_xml(os.path.join(wd, "ext_T.xml"), "T", np.array(rig["T"]).reshape(3, 1) * 2.5)
+
+
+def timed(cmd, env=None):
+    t0 = time.perf_counter()
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    return time.perf_counter() - t0, r
+
+
+for dbg in ("1", "0"):
+    env = dict(os.environ, WASS_DEBUG_IMAGES=dbg)
+    ts = []
+    for i in range(min(3, args.frames)):
+        t, r = timed([cli, cfg, os.path.join(seq, "%06d_wd" % i)], env)
+        assert r.returncode == 0, r.stdout[-2000:]
+        ts.append(t)
+    print(f"wass_stereo, one process per frame, debug pictures {'on' if dbg == '1' else 'off'}: {min(ts):.2f} s/frame (best of {len(ts)})")
+    if dbg == "0":
+        print("  time table of the last run:\n" + "\n".join(l for l in r.stdout.splitlines() if "|" in l and "P|" not in l))
+for procs in (1, 2, 4):
+    t, r = timed([build.BATCH, cfg, "--sequence", seq, "--procs-per-gpu", str(procs)])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    print(f"wass_stereo_batch, {procs} worker process(es) on one GPU, {args.frames} frames: {t:.2f} s total = {t / args.frames:.3f} s/frame = "
+          f"{args.frames / t:.2f} frames/s")
+log = open(os.path.join(seq, "%06d_wd" % (args.frames - 1), "wass_stereo_log.txt")).read()
+print("  time table of the last frame of the batch (persistent context):\n" + "\n".join(l for l in log.splitlines() if "|" in l and "P|" not in l))

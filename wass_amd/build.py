@@ -69,7 +69,7 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
         src = os.path.join(HOST_DIR, name)
         if force or _newer(src, exe, deps):
             cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", "-Wno-unused-function", src, "-o", exe,
-                   "-L" + _HERE, "-lwassgpu", "-lz", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath-link," + "/opt/rocm/lib"]
+                   "-L" + _HERE, "-lwassgpu", "-lz", "-pthread", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath-link," + "/opt/rocm/lib"]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
