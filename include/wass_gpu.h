@@ -229,6 +229,10 @@ int wass_mesh_keep_biggest_component(wass_ctx* ctx, wass_mesh* m, double zgap, u
  * drawn by the caller with rand() as in :680-691 (wass_ransac_sample does that).
  * Returns WASS_OK with *found = 0 when best < width*height/10 (:773). */
 int wass_ransac_sample(int width, int height, int rounds, int32_t* uv_triplets);
+/* The same draw from a PRIVATE generator that restates glibc's srand(seed) + rand(): what the reference gets for
+ * RANDOM_SEED = seed (wass_stereo.cpp:1864-1872; RANSAC is its only rand() consumer), independent of whoever else in
+ * the process calls rand() -- threads of the HIP runtime do. */
+int wass_ransac_sample_seeded(uint32_t seed, int width, int height, int rounds, int32_t* uv_triplets);
 int wass_mesh_ransac_plane(wass_ctx* ctx, wass_mesh* m, const int32_t* uv_triplets, int rounds,
                            double thr, double plane_out[4], uint64_t* best_inliers, int* found);
 /* crop_plane (:780-815) */
@@ -369,6 +373,13 @@ int wass_undistort(wass_ctx* ctx, const uint8_t* src, int w, int h, size_t src_s
                    const double* dist, int n_dist, uint8_t* dst);
 int wass_undistort_dev(wass_ctx* ctx, const uint8_t* d_src, int w, int h, size_t src_stride, const double K[9],
                        const double* dist, int n_dist, uint8_t* d_dst);
+/* Row f2: cv::CLAHE::apply(src, dst) of wass_prepare (wass_prepare.cpp:257-262; createCLAHE(clip_limit, Size(tiles_x,
+ * tiles_y)) at :446-449), CV_8UC1: clipped per-tile histograms, bilinear blend of the four neighbouring look-up tables.
+ * dst is w x h, tightly packed. */
+int wass_clahe(wass_ctx* ctx, const uint8_t* src, int w, int h, size_t src_stride, double clip_limit, int tiles_x, int tiles_y,
+               uint8_t* dst);
+int wass_clahe_dev(wass_ctx* ctx, const uint8_t* d_src, int w, int h, size_t src_stride, double clip_limit, int tiles_x, int tiles_y,
+                   uint8_t* d_dst);
 /* cv::warpPerspective(src, dst, H, Size(dw,dh)) with the default INTER_LINEAR / BORDER_CONSTANT 0
  * (wass_stereo.cpp:515-516); H maps source to destination pixels (it is inverted internally). */
 int wass_warp_perspective(wass_ctx* ctx, const uint8_t* src, int sw, int sh, size_t src_stride, const double H[9],

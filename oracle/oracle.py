@@ -145,6 +145,15 @@ def disparity_postprocess(d16, mindisp, num_disp, disp_offset=0, dilate_steps=1,
     return out
 
 
+def clahe(img, clip_limit, tiles):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.empty_like(img)
+    rc = lib().orc_clahe(_p(img, C.c_uint8), img.shape[1], img.shape[0], C.c_size_t(img.shape[1]), C.c_double(clip_limit), tiles, tiles,
+                         _p(out, C.c_uint8))
+    assert rc == 0
+    return out
+
+
 def resize_dsize(sw, sh, fx, fy):
     dw, dh = C.c_int(), C.c_int()
     lib().orc_resize_dsize(sw, sh, C.c_double(fx), C.c_double(fy), C.byref(dw), C.byref(dh))

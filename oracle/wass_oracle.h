@@ -77,6 +77,9 @@ void orc_disparity_postprocess(const int16_t* disp16, int w, int h, int mindisp,
                                int num_disp, int disp_offset, int dilate_steps,
                                int erode_steps, float* out);
 
+/* cv::CLAHE::apply, CV_8UC1 (clahe_oracle.c; wass_prepare.cpp:257-262; PARITY UNPINNED) */
+int orc_clahe(const uint8_t* src, int w, int h, size_t stride, double clip_limit, int tiles_x, int tiles_y, uint8_t* dst);
+
 /* ---- optional parts of sgbm_dense_stereo, row a9 (a9_oracle.c; PARITY UNPINNED, OpenCV restated) ---- */
 void orc_resize_dsize(int sw, int sh, double fx, double fy, int* dw, int* dh);          /* cv::resize(.., Size(), fx, fy) */
 /* scale = source step per destination pixel (1/fx, or source size / destination size when dsize was given) */

@@ -85,3 +85,14 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "wass_oracle" not in txt, f
+
+
+def test_seeded_ransac_sampler_is_glibc_srand_rand(built, oracle):
+    """wass_ransac_sample_seeded restates glibc's srand(seed) + rand() with private state (the HIP runtime's threads draw
+    from libc rand(), which made RANDOM_SEED runs differ from each other): compared with the real libc here, where no
+    GPU runtime is loaded (oracle.ransac_sample = libc srand + rand in the same loop, PovMesh.cpp:680-691)."""
+    import numpy as np
+    import wass_amd
+    for seed in (0, 1, 7, 12345, 2 ** 31 - 1, 2 ** 32 - 1, 987654321):
+        for w, h, rounds in ((210, 140, 400), (2456, 2058, 400), (11, 9, 8)):
+            np.testing.assert_array_equal(wass_amd.ransac_sample(w, h, rounds, seed), oracle.ransac_sample(w, h, rounds, seed))

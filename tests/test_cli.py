@@ -250,6 +250,19 @@ def _check_outputs(r, wd, oracle, f, roi_l, roi_r, geom, right, left, min_fill):
 
 
 @pytest.mark.gpu
+def test_fixed_random_seed_runs_are_reproducible(cli, tmp_path):
+    """RANDOM_SEED != -1 (wass_stereo.cpp:1864-1872): two runs over the same workdir write identical files."""
+    import shutil
+    wd, cfg, *_ = make_workdir(str(tmp_path), 160, 120, 16)
+    wd2 = os.path.join(str(tmp_path), "again_wd")
+    shutil.copytree(wd, wd2)
+    for d in (wd, wd2):
+        assert run(cli, cfg, d).returncode == 0
+    for name in ("mesh_cam.xyzC", "plane.txt", "plane_refinement_inliers.xyz", "P0cam.txt", "disparity_final_scaled.png"):
+        assert open(os.path.join(wd, name), "rb").read() == open(os.path.join(wd2, name), "rb").read(), name
+
+
+@pytest.mark.gpu
 def test_config_a_with_opencv_rectification(cli, tmp_path, oracle):
     """USE_CUSTOM_STEREORECTIFY=false (the reference's default): cv::stereoRectify alpha=1 + initUndistortRectifyMap +
     bicubic remap (wass_stereo.cpp:530-610), then the same chain on the cropped ROIs."""

@@ -1,0 +1,244 @@
+"""Row f2: wass_prepare -- CLAHE (oracle known answers on CPU, HIP parity on the GPU) and the drop-in executable
+(reference: src/wass_prepare/wass_prepare.cpp:36-39,257-275,303-540)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from test_cli import _read_png_gray, _write_png, _write_xml
+
+
+@pytest.fixture(scope="module")
+def prepare():
+    from wass_amd import build
+    build.build_host()
+    return build.PREPARE
+
+
+def run(exe, *args, cwd=None):
+    return subprocess.run([exe, *args], capture_output=True, text=True, cwd=cwd)
+
+
+# ------------------------------------------------------------------ CPU: the oracle's CLAHE against hand-computed answers
+def test_clahe_flat_histogram_is_plain_equalisation(oracle):
+    """One tile holding every grey level equally often and no clipping: LUT[v] = round((v + 1) * 255 / 256)."""
+    img = np.arange(256, dtype=np.uint8).reshape(16, 16)
+    got = oracle.clahe(img, 0.0, 1)
+    v = img.astype(np.float32)
+    np.testing.assert_array_equal(got, np.rint((v + 1) * (np.float32(255) / np.float32(256))).astype(np.uint8))
+
+
+def test_clahe_constant_image_clip_and_redistribution(oracle):
+    """A constant 32 x 32 tile (area 1024), clip limit 2: clip = int(2 * 1024 / 256) = 8; the 1016 clipped counts give
+    3 to every bin plus one more to bins 0, 1, ..., 247 (remainder 248, step 1).  The bin of the constant v = 100 ends
+    at 8 + 3 + 1 = 12; cumulative(100) = 100 * 4 + 12 = 412 -> LUT = rint(412 * 255 / 1024) = 103."""
+    img = np.full((32, 32), 100, np.uint8)
+    got = oracle.clahe(img, 2.0, 1)
+    assert (got == 103).all()
+    # remainder with a step > 1: area 1024, clip limit 3.5 -> clip 14, clipped 1010 = 3 * 256 + 242 ... step 1 again;
+    # a 40 x 40 tile (area 1600), clip limit 1 -> clip 6, clipped 1594 = 6 * 256 + 58 -> step 4: bins 0, 4, ..., 228 get one more.
+    img = np.full((40, 40), 100, np.uint8)
+    got = oracle.clahe(img, 1.0, 1)
+    cum = 100 * 6 + 26 + (6 + 6 + 1)        # bins 0..99: 6 each + 25 extras (0, 4, ..., 96); bin 100: clip 6 + 6 + 1 extra (100 % 4 == 0)
+    assert (got == int(np.rint(np.float32(cum) * (np.float32(255) / np.float32(1600))))).all()
+
+
+def test_clahe_blend_and_padding_properties(oracle):
+    rng = np.random.default_rng(5)
+    # one tile -> every pixel uses the same table: the map is monotone in the input grey level
+    img = rng.integers(0, 256, (48, 64), dtype=np.uint8)
+    out = oracle.clahe(img, 4.0, 1)
+    order = np.argsort(img.ravel(), kind="stable")
+    assert (np.diff(out.ravel()[order].astype(int)) >= 0).all()
+    # a grid that does not divide the image: the result keeps the input size and equals the result for the
+    # REFLECT_101-extended image cropped back (tile size of the extended image = that of the padded one)
+    img = rng.integers(0, 256, (50, 70), dtype=np.uint8)
+    out = oracle.clahe(img, 2.0, 8)
+    assert out.shape == img.shape
+    pad = np.pad(img, ((0, 8 - 50 % 8), (0, 8 - 70 % 8)), mode="reflect")
+    np.testing.assert_array_equal(oracle.clahe(pad, 2.0, 8)[:50, :70], out)
+    # horizontally mirrored input -> mirrored output is NOT guaranteed (tile coordinates are asymmetric), but a
+    # constant image stays constant whatever the grid
+    flat = np.full((50, 70), 17, np.uint8)
+    assert len(np.unique(oracle.clahe(flat, 2.0, 5))) == 1
+
+
+# ------------------------------------------------------------------ CPU: executable boundary
+def test_prepare_no_arguments_prints_options_and_exits_zero(prepare):
+    r = run(prepare)
+    assert r.returncode == 0
+    for opt in ("--workdir", "--calibdir", "--c0", "--c1", "--demosaic", "--hdr", "--dolp-aolp", "--save-channels", "--save-stokes",
+                "--continue-if-existing", "--genconfig"):
+        assert opt in r.stdout
+
+
+def test_prepare_genconfig(prepare, tmp_path):
+    r = run(prepare, "--genconfig", cwd=str(tmp_path))
+    assert r.returncode == 0
+    text = open(tmp_path / "prepare_config.txt").read()
+    assert text.startswith("# CAM0 CLAHE cliplimit parameter\n# \n#CAM0_CLAHE_CLIPLIMIT=2.0\n\n")
+    assert [l[1:].split("=")[0] for l in text.splitlines() if l.startswith("#CAM")] == [
+        "CAM0_CLAHE_CLIPLIMIT", "CAM0_CLAHE_TILEGRIDSIZE", "CAM1_CLAHE_CLIPLIMIT", "CAM1_CLAHE_TILEGRIDSIZE"]
+
+
+def test_prepare_argument_errors(prepare, tmp_path):
+    calib = tmp_path / "calib"; calib.mkdir()
+    wd = str(tmp_path / "wd")
+    cases = [
+        (["--bogus"], "unrecognised option"),
+        (["--calibdir", str(calib), "--c0", "a.png", "--c1", "b.png"], "workdir option not specified"),
+        (["--workdir", wd, "--c0", "a.png", "--c1", "b.png"], "calibdir option not specified"),
+        (["--workdir", wd, "--calibdir", str(calib), "--c0", "a.png"], "c0 and c1 options must be both specified"),
+        (["--workdir", wd, "--calibdir", str(tmp_path / "nope"), "--c0", "a.png", "--c1", "b.png"], "Invalid calibration directory"),
+        (["--workdir", str(calib), "--calibdir", str(calib), "--c0", "a.png", "--c1", "b.png"], "already exists."),
+        (["--workdir", wd, "--calibdir", str(calib), "--c0", "a.png", "--c1", "b.png", "--demosaic"], "polarimetric"),
+    ]
+    for args, msg in cases:
+        r = run(prepare, *args)
+        assert r.returncode == 255 and msg in r.stdout, (args, r.stdout)
+    assert not os.path.exists(wd)
+    # missing intrinsics: the workdir is created (as in the reference) and the program stops with -1
+    r = run(prepare, "--workdir", wd, "--calibdir", str(calib), "--c0", "a.png", "--c1", "b.png")
+    assert r.returncode == 255 and "[P|10|100]" in r.stdout and "Unable to load" in r.stdout and os.path.isdir(wd)
+    # an ill-typed configuration value is an error before anything is created
+    (calib / "prepare_config.txt").write_text("CAM0_CLAHE_TILEGRIDSIZE=many\n")
+    r = run(prepare, "--workdir", str(tmp_path / "wd2"), "--calibdir", str(calib), "--c0", "a.png", "--c1", "b.png")
+    assert r.returncode == 255 and "invalid value" in r.stdout and not os.path.exists(tmp_path / "wd2")
+
+
+def _calibdir(tmp_path, w, h, clahe_cfg=None, distortion=True):
+    calib = tmp_path / "calib"; calib.mkdir()
+    K0 = np.array([[0.9 * w, 0, w / 2 - 3.5], [0, 0.9 * w, h / 2 + 2.25], [0, 0, 1]])
+    K1 = np.array([[0.92 * w, 0, w / 2 + 1.5], [0, 0.92 * w, h / 2 - 4.0], [0, 0, 1]])
+    d0 = np.array([-0.21, 0.08, 1e-3, -5e-4, 0.01])
+    d1 = np.array([-0.18, 0.05, -7e-4, 3e-4, 0.0])
+    _write_xml(calib / "intrinsics_00.xml", "intr", K0)
+    _write_xml(calib / "intrinsics_01.xml", "intr", K1)
+    if distortion:
+        _write_xml(calib / "distortion_00.xml", "dist", d0.reshape(5, 1))
+        _write_xml(calib / "distortion_01.xml", "dist", d1.reshape(1, 5))      # row or column vector, as calibration tools write either
+    R = np.eye(3); T = np.array([[2.5], [0.01], [-0.02]])
+    _write_xml(calib / "ext_R.xml", "R", R)
+    _write_xml(calib / "ext_T.xml", "T", T)
+    if clahe_cfg is not None:
+        (calib / "prepare_config.txt").write_text(clahe_cfg)
+    return calib, K0, K1, (d0 if distortion else np.zeros(5)), (d1 if distortion else np.zeros(5)), R, T
+
+
+def _images(tmp_path, w, h, seed=3):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    out = []
+    for k in range(2):
+        img = 90 + 50 * np.sin(xx / (7.0 + k)) * np.cos(yy / (5.0 + 2 * k)) + rng.normal(0, 9, (h, w))
+        img = np.clip(img, 0, 255).astype(np.uint8)
+        _write_png(tmp_path / f"cam{k}.png", img)
+        out.append(img)
+    return out
+
+
+def test_prepare_without_gpu_is_a_loud_failure(prepare, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    calib, *_ = _calibdir(tmp_path, 96, 64)
+    _images(tmp_path, 96, 64)
+    wd = tmp_path / "wd"
+    r = run(prepare, "--workdir", str(wd), "--calibdir", str(calib), "--c0", str(tmp_path / "cam0.png"), "--c1", str(tmp_path / "cam1.png"))
+    assert r.returncode == 255 and "unable to open the GPU" in r.stdout
+    assert not os.path.exists(wd / "undistorted" / "00000000.png")
+
+
+# ------------------------------------------------------------------ GPU: HIP CLAHE vs the oracle, bit-exact
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,tiles,clip", [(64, 48, 1, 2.0), (64, 48, 4, 2.0), (70, 50, 8, 2.0), (333, 257, 16, 40.0), (100, 60, 150, 2.0),
+                                            (612, 512, 8, 0.0), (2456, 2058, 150, 2.0), (2456, 2058, 8, 3.0), (31, 17, 3, 0.7)])
+def test_clahe_matches_oracle(gpu_ctx, oracle, w, h, tiles, clip):
+    rng = np.random.default_rng(w * 7 + tiles)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.clip(100 + 60 * np.sin(xx / 23.0) * np.cos(yy / 17.0) + rng.normal(0, 12, (h, w)), 0, 255).astype(np.uint8)
+    if tiles == 16:
+        img[:h // 2] = 255                     # saturated half: heavy clipping, large redistribution
+    np.testing.assert_array_equal(gpu_ctx.clahe(img, clip, tiles), oracle.clahe(img, clip, tiles))
+
+
+@pytest.mark.gpu
+def test_clahe_rejects_bad_arguments(gpu_ctx):
+    img = np.zeros((8, 8), np.uint8)
+    with pytest.raises(Exception):
+        gpu_ctx.clahe(img, 2.0, 0)
+
+
+# ------------------------------------------------------------------ GPU: the executable end to end
+@pytest.mark.gpu
+@pytest.mark.parametrize("clahe_cfg", [None, "CAM0_CLAHE_TILEGRIDSIZE=6\nCAM0_CLAHE_CLIPLIMIT=3.0\nCAM1_CLAHE_TILEGRIDSIZE=150\n"])
+def test_prepare_writes_the_workdir_wass_stereo_reads(prepare, tmp_path, oracle, clahe_cfg):
+    w, h = 200, 150
+    calib, K0, K1, d0, d1, R, T = _calibdir(tmp_path, w, h, clahe_cfg)
+    img0, img1 = _images(tmp_path, w, h)
+    wd = tmp_path / "out" / "000000_wd"
+    r = run(prepare, "--workdir", str(wd), "--calibdir", str(calib), "--c0", str(tmp_path / "cam0.png"), "--c1=" + str(tmp_path / "cam1.png"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    marks = [l for l in r.stdout.splitlines() if l.startswith("[P|")]
+    assert marks == ["[P|10|100]", "[P|20|100]", "[P|50|100]", "[P|70|100]", "[P|100|100]"]
+    assert "All done, exiting" in r.stdout and f"Output image size: {w}x{h}" in r.stdout
+    if clahe_cfg is None:
+        assert "Unable to load" in r.stdout and "prepare_config.txt" in r.stdout      # logged, not fatal (wass_prepare.cpp:398-401)
+        e0, e1 = img0, img1
+    else:
+        assert "Settings loaded" in r.stdout
+        e0, e1 = oracle.clahe(img0, 3.0, 6), oracle.clahe(img1, 2.0, 150)
+    np.testing.assert_array_equal(_read_png_gray(wd / "undistorted" / "00000000.png"), oracle.undistort(e0, K0, d0))
+    np.testing.assert_array_equal(_read_png_gray(wd / "undistorted" / "00000001.png"), oracle.undistort(e1, K1, d1))
+    # the calibration files wass_stereo loads (wass_stereo.cpp:93-124), read back with the same kind of reader
+    import re
+
+    def xml(path, node):
+        s = open(path).read()
+        m = re.search(rf"<{node} type_id=\"opencv-matrix\">\s*<rows>(\d+)</rows>\s*<cols>(\d+)</cols>\s*<dt>d</dt>\s*<data>(.*?)</data>", s, re.S)
+        return np.array(m.group(3).split(), float).reshape(int(m.group(1)), int(m.group(2)))
+    np.testing.assert_array_equal(xml(wd / "intrinsics_00000000.xml", "intr"), K0)
+    np.testing.assert_array_equal(xml(wd / "intrinsics_00000001.xml", "intr"), K1)
+    np.testing.assert_array_equal(xml(wd / "ext_R.xml", "R"), R)
+    np.testing.assert_array_equal(xml(wd / "ext_T.xml", "T"), T)
+    # running again: refused without --continue-if-existing, accepted with it
+    args = ["--workdir", str(wd), "--calibdir", str(calib), "--c0", str(tmp_path / "cam0.png"), "--c1", str(tmp_path / "cam1.png")]
+    assert run(prepare, *args).returncode == 255
+    assert run(prepare, *args, "--continue-if-existing").returncode == 0
+
+
+@pytest.mark.gpu
+def test_prepare_without_distortion_files_copies_the_images(prepare, tmp_path):
+    """distortion_0X.xml missing -> zeros(5,1) (wass_prepare.cpp:428-440): cv::undistort with K' = K is the identity."""
+    w, h = 96, 64
+    calib, *_ = _calibdir(tmp_path, w, h, distortion=False)
+    img0, img1 = _images(tmp_path, w, h)
+    wd = tmp_path / "wd"
+    r = run(prepare, "--workdir", str(wd), "--calibdir", str(calib), "--c0", str(tmp_path / "cam0.png"), "--c1", str(tmp_path / "cam1.png"))
+    assert r.returncode == 0 and r.stdout.count("not found. Assuming no distortion.") == 2
+    np.testing.assert_array_equal(_read_png_gray(wd / "undistorted" / "00000000.png"), img0)
+    np.testing.assert_array_equal(_read_png_gray(wd / "undistorted" / "00000001.png"), img1)
+
+
+@pytest.mark.gpu
+def test_prepare_then_stereo(prepare, tmp_path):
+    """wass_prepare's workdir is accepted by wass_stereo as is (file names, XML node layout, PNG encoding)."""
+    from wass_amd import build, synth
+    from test_cli import make_workdir
+    w, h, D = 160, 120, 16
+    wd0, cfg, right, left, rig = make_workdir(str(tmp_path), w, h, D)
+    calib = tmp_path / "calib"; calib.mkdir()
+    _write_xml(calib / "intrinsics_00.xml", "intr", rig["K_left"])
+    _write_xml(calib / "intrinsics_01.xml", "intr", rig["K_right"])
+    _write_xml(calib / "ext_R.xml", "R", rig["R"])
+    _write_xml(calib / "ext_T.xml", "T", np.array(rig["T"]).reshape(3, 1) * 2.5)
+    _write_png(tmp_path / "l.png", left); _write_png(tmp_path / "r.png", right)
+    wd = tmp_path / "prepared_wd"
+    r = run(prepare, "--workdir", str(wd), "--calibdir", str(calib), "--c0", str(tmp_path / "l.png"), "--c1", str(tmp_path / "r.png"))
+    assert r.returncode == 0, r.stdout
+    a = subprocess.run([build.CLI, cfg, str(wd)], capture_output=True, text=True)
+    b = subprocess.run([build.CLI, cfg, wd0], capture_output=True, text=True)
+    assert a.returncode == 0 and b.returncode == 0, a.stdout[-2000:]
+    for name in ("mesh_cam.xyzC", "plane.txt", "P0cam.txt", "P1cam.txt"):
+        assert open(wd / name, "rb").read() == open(os.path.join(wd0, name), "rb").read(), name

@@ -112,6 +112,7 @@ SYMBOLS = {
     "wass_mesh_zgap_percentile": (_i, [_vp, _vp, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "wass_mesh_keep_biggest_component": (_i, [_vp, _vp, C.c_double, C.POINTER(C.c_uint64)]),
     "wass_ransac_sample": (_i, [_i, _i, _i, _vp]),
+    "wass_ransac_sample_seeded": (_i, [C.c_uint32, _i, _i, _i, _vp]),
     "wass_mesh_ransac_plane": (_i, [_vp, _vp, _vp, _i, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
                                     C.POINTER(_i)]),
     "wass_mesh_crop_plane": (_i, [_vp, _vp, C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_uint64)]),
@@ -137,6 +138,8 @@ SYMBOLS = {
     "wass_biggest_component_by_gradient_dev": (_i, [_vp, _vp, _i, _i, _i]),
     "wass_upload_async": (_i, [_vp, _vp, _vp, _sz]),
     "wass_burned_area_mask_dev": (_i, [_vp, _vp, _sz, _vp]),
+    "wass_clahe": (_i, [_vp, _vp, _i, _i, _sz, C.c_double, _i, _i, _vp]),
+    "wass_clahe_dev": (_i, [_vp, _vp, _i, _i, _sz, C.c_double, _i, _i, _vp]),
     "wass_coll_unique_id": (_i, [_vp]),
     "wass_coll_init": (_i, [_vp, _i, _i, _vp]),
     "wass_coll_allreduce_sum_f64": (_i, [_vp, C.POINTER(C.c_double), _i]),

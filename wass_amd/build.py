@@ -58,14 +58,15 @@ HOST_DIR = os.path.join(_HERE, "host")
 BIN_DIR = os.path.join(_HERE, "bin")
 CLI = os.path.join(BIN_DIR, "wass_stereo")
 BATCH = os.path.join(BIN_DIR, "wass_stereo_batch")
+PREPARE = os.path.join(BIN_DIR, "wass_prepare")
 
 
 def build_host(force: bool = False, verbose: bool = False) -> str:
-    """The drop-in wass_stereo executable: plain C++17 (g++) above the C ABI, linked against libwassgpu.so."""
+    """The drop-in wass_stereo / wass_prepare executables and the batch driver: plain C++17 (g++) above the C ABI, linked against libwassgpu.so."""
     build(force=False)
     os.makedirs(BIN_DIR, exist_ok=True)
     deps = sorted(glob.glob(os.path.join(HOST_DIR, "*.hpp"))) + [os.path.join(_HERE, "..", "include", "wass_gpu.h"), SO]
-    for name, exe in (("wass_stereo.cpp", CLI), ("wass_stereo_batch.cpp", BATCH)):
+    for name, exe in (("wass_stereo.cpp", CLI), ("wass_stereo_batch.cpp", BATCH), ("wass_prepare.cpp", PREPARE)):
         src = os.path.join(HOST_DIR, name)
         if force or _newer(src, exe, deps):
             cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", "-Wno-unused-function", src, "-o", exe,

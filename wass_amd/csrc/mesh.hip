@@ -1322,9 +1322,12 @@ int wass_mesh_remove_outliers(wass_ctx* c, wass_mesh* m, double percentile, doub
     return WASS_OK;
 }
 
-// PovMesh.cpp:680-691 with libc rand(); the caller has srand()'ed (wass_stereo.cpp:1864-1872).
+}  // extern "C"
+
+// PovMesh.cpp:680-691: three (u, v) grid positions per round, re-drawn while any two are closer than 1 % of the height.
 // GCC evaluates the arguments of cv::Vec2i(rand()%iW, rand()%iH) right to left: v is drawn first.
-int wass_ransac_sample(int width, int height, int rounds, int32_t* uv)
+template <typename Rand>
+static int ransac_sample_with(Rand&& next, int width, int height, int rounds, int32_t* uv)
 {
     if (width <= 0 || height <= 0 || rounds < 0 || !uv) return WASS_ERR_INVALID_ARG;
     const double mindist = height * 0.01;
@@ -1332,7 +1335,7 @@ int wass_ransac_sample(int width, int height, int rounds, int32_t* uv)
     long guard = 0;
     while (r < rounds) {
         int p[6];
-        for (int k = 0; k < 3; k++) { const int v = rand() % height; const int u = rand() % width; p[2 * k] = u; p[2 * k + 1] = v; }
+        for (int k = 0; k < 3; k++) { const int v = next() % height; const int u = next() % width; p[2 * k] = u; p[2 * k + 1] = v; }
         const double d12 = sqrt((double)(p[0] - p[2]) * (p[0] - p[2]) + (double)(p[1] - p[3]) * (p[1] - p[3]));
         const double d23 = sqrt((double)(p[2] - p[4]) * (p[2] - p[4]) + (double)(p[3] - p[5]) * (p[3] - p[5]));
         const double d13 = sqrt((double)(p[0] - p[4]) * (p[0] - p[4]) + (double)(p[1] - p[5]) * (p[1] - p[5]));
@@ -1344,6 +1347,59 @@ int wass_ransac_sample(int width, int height, int rounds, int32_t* uv)
         r++;
     }
     return WASS_OK;
+}
+
+// glibc's srand(seed) + rand() restated (the TYPE_3 additive feedback generator of stdlib/random_r.c: 31 words seeded
+// by the Lehmer recurrence 16807 x mod 2^31 - 1, taps 31 and 3, the first 310 outputs discarded, result = word >> 1),
+// with PRIVATE state: the sequence the reference sees when RANSAC is the only consumer of rand() after srand(seed),
+// which is the case in wass_stereo (PovMesh.cpp:680-682 holds its only rand() calls).
+namespace {
+struct GlibcRand {
+    uint32_t r[34];
+    int i = 0;
+    explicit GlibcRand(uint32_t seed)
+    {
+        int32_t w[34];
+        w[0] = seed == 0 ? 1 : (int32_t)seed;
+        for (int k = 1; k < 31; ++k) {
+            // 16807 * w mod (2^31 - 1) by Schrage's split, exactly as glibc does it (the first word may be negative)
+            const long hi = w[k - 1] / 127773, lo = w[k - 1] % 127773;
+            long word = 16807 * lo - 2836 * hi;
+            if (word < 0) word += 2147483647;
+            w[k] = (int32_t)word;
+        }
+        for (int k = 0; k < 31; ++k) r[k] = (uint32_t)w[k];
+        for (int k = 31; k < 34; ++k) r[k] = r[k - 31];
+        // ring of 34 words: word n = word n-31 + word n-3; glibc discards 310 outputs after seeding
+        i = 0;
+        for (int k = 0; k < 310; ++k) (void)next_word();
+    }
+    uint32_t next_word()
+    {
+        // position i holds word n-34; n-31 is i+3, n-3 is i+31
+        const uint32_t v = r[(i + 3) % 34] + r[(i + 31) % 34];
+        r[i] = v;
+        i = (i + 1) % 34;
+        return v;
+    }
+    int operator()() { return (int)(next_word() >> 1); }
+};
+}  // namespace
+
+extern "C" {
+
+// libc rand(); the caller has srand()'ed (wass_stereo.cpp:1864-1872).  rand() has process-wide state: any other consumer
+// between srand() and this call (measured: threads of the HIP runtime draw from it) changes the sequence -- a host that
+// wants the reference's run-to-run reproducibility for a fixed RANDOM_SEED uses wass_ransac_sample_seeded.
+int wass_ransac_sample(int width, int height, int rounds, int32_t* uv)
+{
+    return ransac_sample_with([]() { return rand(); }, width, height, rounds, uv);
+}
+
+int wass_ransac_sample_seeded(uint32_t seed, int width, int height, int rounds, int32_t* uv)
+{
+    GlibcRand g(seed);
+    return ransac_sample_with(g, width, height, rounds, uv);
 }
 
 int wass_mesh_ransac_plane(wass_ctx* c, wass_mesh* m, const int32_t* uv, int rounds, double thr, double plane_out[4],

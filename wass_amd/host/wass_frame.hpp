@@ -268,8 +268,10 @@ inline int wass_run_frame(const char* config_path, const std::string& workdir, c
         try { cfg.load(ifs); } catch (const std::runtime_error& er) { WLOGE << er.what(); return -1; }
         if (save_configuration(cfg, path_join(env.workdir, "stereo_config.txt")) != 0) WLOGE << "Unable to save stereo configuration file";
     }
-    if (cfg.get_int("RANDOM_SEED") == -1) srand((unsigned int)time(0));
-    else { srand(cfg.get_int("RANDOM_SEED")); WLOGI << "random seed set to: " << cfg.get_int("RANDOM_SEED"); }
+    // :1864-1872.  The reference srand()s here and RANSAC (PovMesh.cpp:680-682) is its only rand() consumer; this process also
+    // hosts the HIP runtime, whose threads draw from libc rand(), so the seed goes to the library's private generator instead.
+    unsigned int ransac_seed = (unsigned int)time(0);
+    if (cfg.get_int("RANDOM_SEED") != -1) { ransac_seed = (unsigned int)cfg.get_int("RANDOM_SEED"); WLOGI << "random seed set to: " << cfg.get_int("RANDOM_SEED"); }
 
     wass_ctx* ctx = *ctxp;
     wass_mesh* mesh = nullptr;
@@ -470,7 +472,7 @@ inline int wass_run_frame(const char* config_path, const std::string& workdir, c
         WLOGI << "estimating best fitting plane...";
         const int rounds = cfg.get_int("PLANE_RANSAC_ROUNDS");
         std::vector<int32_t> uv((size_t)std::max(rounds, 1) * 6);
-        if (rounds <= 0 || wass_ransac_sample(mw, mh, rounds, uv.data()) != WASS_OK) throw std::runtime_error("invalid PLANE_RANSAC_ROUNDS / mesh size");
+        if (rounds <= 0 || wass_ransac_sample_seeded(ransac_seed, mw, mh, rounds, uv.data()) != WASS_OK) throw std::runtime_error("invalid PLANE_RANSAC_ROUNDS / mesh size");
         double plane[4] = { 0, 0, 0, 0 };
         uint64_t best = 0; int found = 0;
         gpu_check(ctx, wass_mesh_ransac_plane(ctx, mesh, uv.data(), rounds, cfg.get_double("PLANE_RANSAC_THRESHOLD"), plane, &best, &found), "wass_mesh_ransac_plane");

@@ -218,6 +218,14 @@ class Context:
                                              out.ctypes.data))
         return out
 
+    def clahe(self, src: np.ndarray, clip_limit: float, tiles: int) -> np.ndarray:
+        """cv::createCLAHE(clip_limit, Size(tiles, tiles))->apply(src, dst) of wass_prepare (wass_prepare.cpp:257-262,446-449)."""
+        src = np.ascontiguousarray(src, np.uint8)
+        out = np.empty_like(src)
+        self._check(self._lib.wass_clahe(self._h, src.ctypes.data, src.shape[1], src.shape[0], src.shape[1], float(clip_limit), int(tiles),
+                                         int(tiles), out.ctypes.data))
+        return out
+
     def warp_perspective(self, src: np.ndarray, H, dw: int, dh: int, roi=None) -> np.ndarray:
         """cv::warpPerspective(src, dst, H, Size(dw, dh)) (INTER_LINEAR, zero border)."""
         src = np.ascontiguousarray(src, np.uint8)
@@ -290,18 +298,14 @@ def make_geom(g: dict, use_custom=False, disparity_compensation=0.0, dense_scale
     return G
 
 
-_rand_lock = __import__("threading").Lock()          # libc rand() has process-wide state
-
-
 def ransac_sample(width: int, height: int, rounds: int, seed: int) -> np.ndarray:
-    """srand(seed) + the reference's sampling loop (PovMesh.cpp:680-691)."""
+    """srand(seed) + the reference's sampling loop (PovMesh.cpp:680-691), drawn from the library's private restatement of
+    glibc's generator (libc rand() itself is shared with every thread of the process, the HIP runtime's included)."""
     lib = _lib.load()
     uv = np.empty((rounds, 6), np.int32)
-    with _rand_lock:
-        C.CDLL(None).srand(C.c_uint(seed))
-        rc = lib.wass_ransac_sample(width, height, rounds, uv.ctypes.data)
+    rc = lib.wass_ransac_sample_seeded(int(seed) & 0xFFFFFFFF, width, height, rounds, uv.ctypes.data)
     if rc != 0:
-        raise WassError(rc, "wass_ransac_sample failed")
+        raise WassError(rc, "wass_ransac_sample_seeded failed")
     return uv
 
 
