@@ -1,74 +1,62 @@
-// micro-benchmark: does the 256 MiB Infinity Cache serve re-reads of a band of the cost volume faster than HBM?
-// Access pattern of the chain kernels: one wave per column, 512-byte vectors, stride = one image row (W vectors).
-// For a band of R rows (R * W * 512 B) the same band is (a) read repeatedly, (b) written by one kernel and read by
-// the next, (c) read-modify-written repeatedly.
+// mall.hip -- how fast is a read-modify-write stream (the S volume's access pattern) when its working set fits the
+// 256 MiB Infinity Cache?  Repeated passes over a buffer of X MiB: rw (16 B load + 16 B store per lane) and read-only.
+//   hipcc --offload-arch=gfx950 -O3 scripts/micro/mall.hip -o /tmp/mall && /tmp/mall
 #include <hip/hip_runtime.h>
-#include <stdio.h>
-#include <stdint.h>
-#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 
-template <int MODE>   // 0 read, 1 write, 2 read-modify-write
-__global__ void __launch_bounds__(256) k_band(uint2* __restrict__ A, long long W, long long R, unsigned* sink)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__global__ void __launch_bounds__(256) k_rw(u32x4* __restrict__ p, size_t n)
 {
-    const int lane = threadIdx.x & 63;
-    const long long c = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= W) return;
-    uint2* a = A + c * 64 + lane;
-    unsigned acc = 0;
-    for (long long k0 = 0; k0 + 8 <= R; k0 += 8) {
-        uint2 v[8];
-        if (MODE != 1) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = a[(k0 + u) * W * 64];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (MODE == 0) acc += v[u].x;
-            else if (MODE == 1) a[(k0 + u) * W * 64] = make_uint2((unsigned)k0, lane);
-            else { uint2 o = v[u]; o.x += 1; a[(k0 + u) * W * 64] = o; }
-        }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        u32x4 v = NT ? __builtin_nontemporal_load(p + i) : p[i];
+        v += 1u;
+        if (NT) __builtin_nontemporal_store(v, p + i); else p[i] = v;
     }
-    if (MODE == 0 && acc == 0xdeadbeef) *sink = acc;
+}
+template <bool NT>
+__global__ void __launch_bounds__(256) k_ro(const u32x4* __restrict__ p, size_t n, u32x4* __restrict__ sink)
+{
+    u32x4 acc = { 0, 0, 0, 0 };
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += NT ? __builtin_nontemporal_load(p + i) : p[i];
+    if (acc.x == 0x12345678u) sink[0] = acc;
 }
 
 int main()
 {
-    const long long W = 2455;
-    const size_t total = (size_t)W * 2058 * 512;
-    void* A; unsigned* sink;
-    CK(hipMalloc(&A, total)); CK(hipMalloc(&sink, 4)); CK(hipMemset(A, 1, total));
+    const size_t maxb = (size_t)4 << 30;
+    u32x4* buf; u32x4* sink;
+    hipMalloc(&buf, maxb); hipMalloc(&sink, 64);
+    hipMemset(buf, 0, maxb);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const dim3 grid((unsigned)((W + 3) / 4)), block(256);
-    printf("band rows | MiB   | re-read GB/s | write->read GB/s (read leg) | rmw GB/s (r+w bytes)\n");
-    for (long long R : { 16LL, 32LL, 64LL, 96LL, 128LL, 160LL, 192LL, 256LL, 384LL, 512LL, 1024LL, 2056LL }) {
-        const double mib = (double)R * W * 512 / (1 << 20), gb = (double)R * W * 512 / 1e9;
-        const int reps = 20;
-        float ms;
-        // (a) repeated reads
-        hipLaunchKernelGGL(k_band<0>, grid, block, 0, 0, (uint2*)A, W, R, sink);
-        hipEventRecord(e0);
-        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_band<0>, grid, block, 0, 0, (uint2*)A, W, R, sink);
-        hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
-        const double rr = gb / (ms / reps * 1e-3);
-        // (b) write then read: time the pair, subtract a write-only run
-        float mw, mwr;
-        hipEventRecord(e0);
-        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_band<1>, grid, block, 0, 0, (uint2*)A, W, R, sink);
-        hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&mw, e0, e1);
-        hipEventRecord(e0);
-        for (int r = 0; r < reps; ++r) {
-            hipLaunchKernelGGL(k_band<1>, grid, block, 0, 0, (uint2*)A, W, R, sink);
-            hipLaunchKernelGGL(k_band<0>, grid, block, 0, 0, (uint2*)A, W, R, sink);
+    const size_t sizes_mb[] = { 8, 16, 32, 64, 96, 128, 160, 192, 256, 384, 512, 1024, 4096 };
+    printf("%8s %12s %12s %12s %12s   (TB/s; rw counts read + write bytes)\n", "MiB", "rw", "rw_nt", "ro", "ro_nt");
+    for (size_t mb : sizes_mb) {
+        const size_t bytes = mb << 20, n = bytes / 16;
+        const int iters = (int)((((size_t)16 << 30) / bytes) < 4 ? 4 : (((size_t)16 << 30) / bytes));
+        const int grid = 256 * 8;
+        float t[4];
+        for (int mode = 0; mode < 4; ++mode) {
+            auto launch = [&]() {
+                switch (mode) {
+                    case 0: hipLaunchKernelGGL(k_rw<false>, dim3(grid), dim3(256), 0, 0, buf, n); break;
+                    case 1: hipLaunchKernelGGL(k_rw<true>, dim3(grid), dim3(256), 0, 0, buf, n); break;
+                    case 2: hipLaunchKernelGGL(k_ro<false>, dim3(grid), dim3(256), 0, 0, buf, n, sink); break;
+                    default: hipLaunchKernelGGL(k_ro<true>, dim3(grid), dim3(256), 0, 0, buf, n, sink); break;
+                }
+            };
+            for (int w = 0; w < 3; ++w) launch();
+            hipEventRecord(e0, 0);
+            for (int it = 0; it < iters; ++it) launch();
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+            hipEventElapsedTime(&t[mode], e0, e1);
+            t[mode] = (float)((double)bytes * iters * (mode < 2 ? 2 : 1) / (t[mode] * 1e-3) / 1e12);
         }
-        hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&mwr, e0, e1);
-        const double wr = gb / ((mwr - mw) / reps * 1e-3), wo = gb / (mw / reps * 1e-3);
-        // (c) repeated read-modify-write
-        hipEventRecord(e0);
-        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_band<2>, grid, block, 0, 0, (uint2*)A, W, R, sink);
-        hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
-        const double rmw = 2 * gb / (ms / reps * 1e-3);
-        printf("%9lld | %5.0f | %12.0f | %10.0f (write-only %5.0f) | %8.0f   [%.1f us per read launch]\n", R, mib, rr, wr, wo, rmw,
-               gb / rr * 1e6);
+        printf("%8zu %12.2f %12.2f %12.2f %12.2f\n", mb, t[0], t[1], t[2], t[3]);
     }
     return 0;
 }

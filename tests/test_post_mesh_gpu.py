@@ -35,6 +35,19 @@ def test_postprocess_parity(gpu_ctx, oracle, w, h, D, dil, ero, off):
     np.testing.assert_array_equal(got, ref)
 
 
+def test_postprocess_one_kernel_per_step_path(gpu_ctx, oracle, monkeypatch):
+    """WASS_CLEAN_CHAIN=0 selects the one-kernel-per-step path (what DENSE_SCALE != 1 always uses) instead of the fused tile kernel."""
+    rng = np.random.default_rng(11)
+    d16 = (rng.integers(20, 400, (75, 210))).astype(np.int16)
+    d16[rng.random(d16.shape) < 0.1] = 0
+    p = default_sgm_params(32)
+    fused = gpu_ctx.disparity_postprocess(d16, p, 1, 2, 3)
+    monkeypatch.setenv("WASS_CLEAN_CHAIN", "0")
+    steps = gpu_ctx.disparity_postprocess(d16, p, 1, 2, 3)
+    np.testing.assert_array_equal(fused, steps)
+    np.testing.assert_array_equal(gpu_ctx.disparity_postprocess(d16, p, 2, 1, 0), oracle.disparity_postprocess(d16, 1, 32, 0, 2, 1))
+
+
 def test_postprocess_stage_by_stage(gpu_ctx, oracle):
     """dilate only / erode only, against the oracle's single filters (the mask step adds one erosion)."""
     rng = np.random.default_rng(5)

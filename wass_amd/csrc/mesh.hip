@@ -469,62 +469,105 @@ __global__ void k_ransac_planes(const uint8_t* __restrict__ valid, const double*
     cand[r] = pc;
 }
 
-// every candidate plane scored in ONE pass over the points: each thread keeps PTS points in registers
-// and walks the plane list held in LDS; a ballot turns 64 comparisons into one counter update.
+// Every candidate plane scored in ONE pass over the points: each thread keeps PTS points in registers and walks the
+// plane list held in LDS; a ballot turns 64 comparisons into one counter update.
+//
+// The reference's test is fabs(((a*x + b*y) + c*z) + d) < thr in fp64 (PovMesh.cpp:717-742), six dependent fp64
+// operations per point and plane.  Here the decision is taken in PACKED FP32 (v_pk_fma_f32, two points per
+// instruction) against two thresholds thr -+ margin, where margin bounds the worst-case difference between the fp32
+// value and the fp64 one: inputs rounded to fp32 (2^-24 each) and three fused roundings give
+// |t32 - t64| <= 5 * 2^-24 * (|a x| + |b y| + |c z| + |d|); the kernel uses 8 * 2^-24 * ((|a| + |b| + |c|) * M + |d| + thr) with
+// M = the largest |coordinate| among the thread's own points (all three factors rounded up).  A point between the two
+// thresholds is "ambiguous"; if a wave meets one for some plane it recounts that plane over its points with the
+// reference's fp64 expression, so the counts are EXACTLY the reference's (tests compare them at full size).
+// Invalid points are replaced by the origin and the block subtracts (their number) x [origin is an inlier] at the end,
+// which removes the validity mask from the inner loop.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <int PTS>
 __global__ void __launch_bounds__(256) k_ransac_score(const uint8_t* __restrict__ valid, const double* __restrict__ X,
                                                       const double* __restrict__ Y, const double* __restrict__ Z, size_t n,
                                                       const PlaneCand* __restrict__ cand, int rounds, double thr,
                                                       unsigned long long* __restrict__ counts)
 {
+    static_assert(PTS % 2 == 0, "points are processed in packed pairs");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* pl = (double*)smem;                                   // [rounds][4]
-    unsigned int* lc = (unsigned int*)(pl + (size_t)rounds * 4);  // [rounds]
+    float4* plf = (float4*)smem;                                  // [rounds] a, b, c, d in fp32
+    float2* plm = (float2*)(plf + rounds);                        // [rounds] (|a|+|b|+|c|) rounded up, 2^-21 (|d| + thr) rounded up
+    unsigned int* lc = (unsigned int*)(plm + rounds);             // [rounds]
+    __shared__ unsigned int s_ninv;
+    const float up = 1.0f + 0x1p-20f, G = 0x1p-21f;
     for (int r = threadIdx.x; r < rounds; r += 256) {
-        pl[r * 4] = cand[r].n[0]; pl[r * 4 + 1] = cand[r].n[1]; pl[r * 4 + 2] = cand[r].n[2]; pl[r * 4 + 3] = cand[r].d;
+        const double a = cand[r].n[0], b = cand[r].n[1], c = cand[r].n[2], d = cand[r].d;
+        plf[r] = make_float4((float)a, (float)b, (float)c, (float)d);
+        plm[r] = make_float2((float)(fabs(a) + fabs(b) + fabs(c)) * up, (float)(fabs(d) + fabs(thr)) * up * G);
         lc[r] = 0;
     }
+    if (threadIdx.x == 0) s_ninv = 0;
     __syncthreads();
-    double px[PTS], py[PTS], pz[PTS];
-    unsigned long long vmask[PTS];                                // lanes of this wave whose point k exists and is valid
+    f32x2 px[PTS / 2], py[PTS / 2], pz[PTS / 2];
     const size_t base = (size_t)blockIdx.x * 256 * PTS + threadIdx.x;
-    bool any = false;
+    unsigned int ninv = 0;
+    double m = 0.0;
 #pragma unroll
     for (int k = 0; k < PTS; ++k) {
         const size_t i = base + (size_t)k * 256;
         const bool pv = i < n && valid[i];
-        px[k] = pv ? X[i] : 0.0; py[k] = pv ? Y[i] : 0.0; pz[k] = pv ? Z[i] : 0.0;
-        vmask[k] = __builtin_amdgcn_ballot_w64(pv);
-        any |= pv;
+        const double x = pv ? X[i] : 0.0, y = pv ? Y[i] : 0.0, z = pv ? Z[i] : 0.0;
+        ninv += pv ? 0u : 1u;
+        m = fmax(m, fmax(fabs(x), fmax(fabs(y), fabs(z))));
+        px[k / 2][k % 2] = (float)x; py[k / 2][k % 2] = (float)y; pz[k / 2][k % 2] = (float)z;
     }
-    if (__syncthreads_or(any)) {
-        // Branch-free inner loop: invalid points are computed and masked out of the ballot; the next plane is
-        // fetched from LDS while the current one is scored; lane (r & 63) collects the count of round r and the
-        // wave adds 64 rounds to the block totals with one LDS atomic instruction.
-        const int lane = threadIdx.x & 63;
-        unsigned int mine = 0;
-        double a = pl[0], b = pl[1], c = pl[2], d = pl[3];
-        for (int r = 0; r < rounds; ++r) {
-            const int rn = r + 1 < rounds ? r + 1 : r;
-            const double an = pl[rn * 4], bn = pl[rn * 4 + 1], cn = pl[rn * 4 + 2], dn = pl[rn * 4 + 3];
-            unsigned int cnt = 0;
+    const float Mg = (float)m * up * G;                            // 2^-21 M, rounded up
+    const float thr_f = (float)thr;
+    const int lane = threadIdx.x & 63;
+    unsigned int mine = 0;
+    for (int r = 0; r < rounds; ++r) {
+        const float4 p = plf[r];
+        const float2 pm = plm[r];
+        const float margin = __builtin_fmaf(pm.x, Mg, pm.y);
+        const float lo = thr_f - margin, hi = thr_f + margin;
+        const f32x2 a2 = { p.x, p.x }, b2 = { p.y, p.y }, c2 = { p.z, p.z }, d2 = { p.w, p.w };
+        unsigned int cnt = 0, cnt_maybe = 0;
 #pragma unroll
+        for (int k = 0; k < PTS / 2; ++k) {
+            const f32x2 t = __builtin_elementwise_fma(a2, px[k], __builtin_elementwise_fma(b2, py[k], __builtin_elementwise_fma(c2, pz[k], d2)));
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float at = __builtin_fabsf(t[e]);
+                const unsigned long long in = __builtin_amdgcn_ballot_w64(at < lo);
+                const unsigned long long maybe = __builtin_amdgcn_ballot_w64(!(at >= hi));     // also true for NaN
+                cnt += (unsigned)__popcll(in);
+                cnt_maybe += (unsigned)__popcll(maybe);            // in is a subset of maybe: equal counts <=> no point in between
+            }
+        }
+        if (cnt != cnt_maybe) {                                                 // wave-uniform and rare: this plane again, the reference's way
+            const double a = cand[r].n[0], b = cand[r].n[1], c = cand[r].n[2], d = cand[r].d;
+            cnt = 0;
             for (int k = 0; k < PTS; ++k) {
-                const bool in = fabs((a * px[k] + b * py[k] + c * pz[k]) + d) < thr;
-                cnt += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(in) & vmask[k]);
+                const size_t i = base + (size_t)k * 256;
+                const bool pv = i < n && valid[i];
+                const double x = pv ? X[i] : 0.0, y = pv ? Y[i] : 0.0, z = pv ? Z[i] : 0.0;
+                cnt += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(fabs((a * x + b * y + c * z) + d) < thr));
             }
-            mine += lane == (r & 63) ? cnt : 0u;
-            if ((r & 63) == 63 || r == rounds - 1) {              // wave-uniform
-                const int rr = (r & ~63) + lane;
-                if (rr <= r && mine) atomicAdd(&lc[rr], mine);
-                mine = 0;
-            }
-            a = an; b = bn; c = cn; d = dn;
+        }
+        mine += lane == (r & 63) ? cnt : 0u;
+        if ((r & 63) == 63 || r == rounds - 1) {                  // wave-uniform: lane l holds the count of round (r & ~63) + l
+            const int rr = (r & ~63) + lane;
+            if (rr <= r && mine) atomicAdd(&lc[rr], mine);
+            mine = 0;
         }
     }
+    if (ninv) atomicAdd(&s_ninv, ninv);
     __syncthreads();
-    for (int r = threadIdx.x; r < rounds; r += 256)
-        if (lc[r]) atomicAdd(&counts[r], (unsigned long long)lc[r]);
+    const unsigned int binv = s_ninv;
+    for (int r = threadIdx.x; r < rounds; r += 256) {
+        // the stand-ins of the invalid points sit at the origin: same expression, x = y = z = 0
+        const double a = cand[r].n[0], b = cand[r].n[1], c = cand[r].n[2], d = cand[r].d;
+        const bool origin_in = fabs((a * 0.0 + b * 0.0 + c * 0.0) + d) < thr;
+        const unsigned int v = lc[r] - (origin_in ? binv : 0u);
+        if (v) atomicAdd(&counts[r], (unsigned long long)v);
+    }
 }
 
 // ------------------------------------------------------------------ crop_plane (PovMesh.cpp:780-815)
@@ -1422,7 +1465,7 @@ int wass_mesh_ransac_plane(wass_ctx* c, wass_mesh* m, const int32_t* uv, int rou
     hipLaunchKernelGGL(k_ransac_planes, dim3((rounds + 63) / 64), dim3(64), 0, c->ts(), m->valid, m->x, m->y, m->z, m->w,
                        (const int32_t*)duv, rounds, cand);
     constexpr int PTS = 8;
-    const size_t lds = (size_t)rounds * (32 + 4);
+    const size_t lds = (size_t)rounds * (16 + 8 + 4);
     if (lds > 64 * 1024) return set_err(c, WASS_ERR_UNSUPPORTED, "PLANE_RANSAC_ROUNDS %d too large (max 1800)", rounds);
     hipLaunchKernelGGL(k_ransac_score<PTS>, dim3((unsigned)((n + 256 * PTS - 1) / (256 * PTS))), dim3(256), lds, c->ts(),
                        m->valid, m->x, m->y, m->z, n, (const PlaneCand*)cand, rounds, thr, counts);
@@ -1522,7 +1565,7 @@ static int enqueue_fit_plane(wass_ctx* c, wass_mesh* m, const int32_t* uv, int r
     unsigned long long* kept1 = (unsigned long long*)c->counters.p;            // [NSLOT]
     unsigned long long* kept2 = kept1 + NSLOT;
     constexpr int PTS = 8;
-    const size_t lds = (size_t)rounds * (32 + 4);
+    const size_t lds = (size_t)rounds * (16 + 8 + 4);
     if (lds > 64 * 1024) return set_err(c, WASS_ERR_UNSUPPORTED, "PLANE_RANSAC_ROUNDS %d too large (max 1800)", rounds);
     hipStream_t s = c->ts();
     {   // the caller's sample array may be pageable and short-lived: go through the pinned stage (the previous frame's

@@ -116,6 +116,123 @@ __global__ void __launch_bounds__(256) k_median_f32(const float* __restrict__ sr
     out[(size_t)y * w + x] = v[N / 2];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The whole same-size clean-up chain in one launch: clean_and_convert -> dilate x nd -> erode x ne -> mask by one more
+// erosion -> optional median, tile by tile in LDS (the separate kernels above move the 20 MB float map through HBM once
+// per step).  Every step evaluates the SAME per-pixel expressions as the one-step kernels at global coordinates, so the
+// results are bit-identical; a tile carries a halo wide enough that the cells an output pixel depends on are all computed
+// inside the tile: one row / column per erosion and per median ring, one row and two columns to the right per dilation
+// (its stencil is centred on column k+1).  Cells whose stencil would leave the tile keep their value -- that garbage
+// moves inwards by exactly the halo consumed per step and never reaches the output area.
+// ---------------------------------------------------------------------------------------------------------------------
+struct ChainDims { int w, h, nd, ne, med, hl, hr, hv, tw, th; };
+
+constexpr int CHAIN_TX = 64, CHAIN_TY = 32;
+
+template <int KS>
+__device__ __forceinline__ float median_at(const float* __restrict__ buf, int tw, int lx0, int ly0, int x, int y, int w, int h)
+{
+    constexpr int R = KS / 2, N = KS * KS;
+    float v[N];
+#pragma unroll
+    for (int a = -R; a <= R; ++a)
+#pragma unroll
+        for (int b = -R; b <= R; ++b) {
+            const int yy = min(max(y + a, 0), h - 1), xx = min(max(x + b, 0), w - 1);
+            v[(a + R) * KS + (b + R)] = buf[(yy - ly0) * tw + (xx - lx0)];
+        }
+#pragma unroll
+    for (int i = 0; i <= N / 2; ++i)
+#pragma unroll
+        for (int j = i + 1; j < N; ++j) {
+            const float lo = fminf(v[i], v[j]), hi = fmaxf(v[i], v[j]);
+            v[i] = lo; v[j] = hi;
+        }
+    return v[N / 2];
+}
+
+__global__ void __launch_bounds__(256) k_clean_chain(const int16_t* __restrict__ d16, ChainDims cd, int mindisp, int numdisp, int disp_offset,
+                                                     double scale, float* __restrict__ out)
+{
+    extern __shared__ float chain_lds[];
+    const int tw = cd.tw, th = cd.th, cells = tw * th, w = cd.w, h = cd.h;
+    float* A = chain_lds;
+    float* B = chain_lds + cells;
+    const int gx0 = blockIdx.x * CHAIN_TX - cd.hl, gy0 = blockIdx.y * CHAIN_TY - cd.hv;      // global coordinates of tile cell (0, 0)
+    // ---- clean_and_convert (k_convert)
+    for (int t = threadIdx.x; t < cells; t += 256) {
+        const int ly = t / tw, lx = t - ly * tw, y = gy0 + ly, x = gx0 + lx;
+        float r = 0.0f;
+        if (x >= 0 && x < w && y >= 0 && y < h) {
+            float dval = ((float)d16[(size_t)y * w + x]) / 16.0f;
+            if (!(dval <= (float)mindisp || dval > (float)numdisp)) {
+                dval += (float)disp_offset;
+                r = (float)((double)dval * scale);
+            }
+        }
+        A[t] = r;
+    }
+    __syncthreads();
+    // ---- dilations (k_dilate_zero)
+    for (int s = 0; s < cd.nd; ++s) {
+        for (int t = threadIdx.x; t < cells; t += 256) {
+            const int ly = t / tw, lx = t - ly * tw, i = gy0 + ly, k = gx0 + lx;
+            float v = A[t];
+            if (i >= 1 && i < h - 1 && k >= 0 && k <= w - 3 && v == 0.0f && ly >= 1 && ly < th - 1 && lx + 2 < tw) {
+                const float* tp = A + t - tw + 1;
+                const float* bp = A + t + tw + 1;
+                const float* cp = A + t + 1;
+                float avg = 0.0f; int n = 0;
+                if (tp[-1] > 0) { avg += tp[-1]; ++n; }
+                if (tp[1] > 0) { avg += tp[1]; ++n; }
+                if (tp[0] > 0) { avg += tp[0]; ++n; }
+                if (bp[-1] > 0) { avg += bp[-1]; ++n; }
+                if (bp[1] > 0) { avg += bp[1]; ++n; }
+                if (bp[0] > 0) { avg += bp[0]; ++n; }
+                if (cp[-1] > 0) { avg += cp[-1]; ++n; }
+                if (cp[1] > 0) { avg += cp[1]; ++n; }
+                if (n > 1) v = avg / (float)n;
+            }
+            B[t] = v;
+        }
+        __syncthreads();
+        float* tmp = A; A = B; B = tmp;
+    }
+    // ---- erosions (k_erode_zero<false>), the last one as the mask of the map before it (k_erode_zero<true> with nn == cub)
+    for (int s = 0; s <= cd.ne; ++s) {
+        const bool mask = s == cd.ne;
+        for (int t = threadIdx.x; t < cells; t += 256) {
+            const int ly = t / tw, lx = t - ly * tw, i = gy0 + ly, j = gx0 + lx;
+            const float c0 = A[t];
+            float v = c0;
+            if (i >= 0 && i < h && j >= 0 && j < w) {
+                if (i == 0 || i == h - 1) v = 0.0f;
+                else if (j == 0 || (j == w - 1 && w >= 2)) v = 0.0f;
+                else if (j < w - 1 && ly >= 1 && ly < th - 1 && lx >= 1 && lx < tw - 1) {
+                    const float* tp = A + t - tw;
+                    const float* bp = A + t + tw;
+                    const bool z = (tp[0] == 0) | (tp[-1] == 0) | (tp[1] == 0) | (bp[0] == 0) | (bp[-1] == 0) | (bp[1] == 0) | (A[t - 1] == 0) |
+                                   (A[t + 1] == 0);
+                    if (z) v = 0.0f;
+                }
+            }
+            B[t] = mask ? (v == 0.0f ? 0.0f : c0) : v;
+        }
+        __syncthreads();
+        float* tmp = A; A = B; B = tmp;
+    }
+    // ---- output area (+ median)
+    for (int t = threadIdx.x; t < CHAIN_TX * CHAIN_TY; t += 256) {
+        const int oy = t / CHAIN_TX, ox = t - oy * CHAIN_TX, y = blockIdx.y * CHAIN_TY + oy, x = blockIdx.x * CHAIN_TX + ox;
+        if (x >= w || y >= h) continue;
+        float v;
+        if (cd.med == 3) v = median_at<3>(A, tw, gx0, gy0, x, y, w, h);
+        else if (cd.med == 5) v = median_at<5>(A, tw, gx0, gy0, x, y, w, h);
+        else v = A[(oy + cd.hv) * tw + ox + cd.hl];
+        out[(size_t)y * w + x] = v;
+    }
+}
+
 }  // namespace wass
 
 using namespace wass;
@@ -140,6 +257,26 @@ extern "C" int wass_disparity_postprocess_ex_dev(wass_ctx* c, const int16_t* d_d
     hipStream_t s = c->ts();
     const dim3 grid2((ws + 255) / 256, hs), gout((ow + 255) / 256, oh), blk(256);
     const int off = p->disp_offset > 0 ? p->disp_offset : 0;    // :803-808
+    {
+        const int rm = median_wsize >= 3 ? median_wsize / 2 : 0;
+        ChainDims cd;
+        cd.w = ws; cd.h = hs; cd.nd = dilate_steps > 0 ? dilate_steps : 0; cd.ne = erode_steps > 0 ? erode_steps : 0; cd.med = median_wsize >= 3 ? median_wsize : 0;
+        cd.hl = cd.ne + 1 + rm; cd.hr = 2 * cd.nd + cd.ne + 1 + rm; cd.hv = cd.nd + cd.ne + 1 + rm;
+        cd.tw = CHAIN_TX + cd.hl + cd.hr; cd.th = CHAIN_TY + 2 * cd.hv;
+        const size_t lds = (size_t)cd.tw * cd.th * 2 * sizeof(float);
+        const char* env = getenv("WASS_CLEAN_CHAIN");
+        if (same && lds <= 64 * 1024 && !(env && atoi(env) == 0)) {
+            hipLaunchKernelGGL(k_clean_chain, dim3((ws + CHAIN_TX - 1) / CHAIN_TX, (hs + CHAIN_TY - 1) / CHAIN_TY), blk, lds, s, d_disp16, cd,
+                               p->min_disp, p->num_disp, off, 1.0 / p->dense_scale, d_out);
+            if (c->tail_overlap) WASS_HIP(c, hipEventRecord(c->ev_post, s));
+            WASS_HIP(c, hipGetLastError());
+            if (cc_threshold > 0) {                              // :947-986
+                if ((rc = ensure(c, c->tmp_mask, no))) return rc;
+                if ((rc = biggest_component_dev(c, d_out, ow, oh, cc_threshold, (uint8_t*)c->tmp_mask.p, s))) return rc;
+            }
+            return WASS_OK;
+        }
+    }
     hipLaunchKernelGGL(k_convert, dim3((unsigned)((n + 255) / 256)), blk, 0, s, d_disp16, n, p->min_disp, p->num_disp,
                        off, 1.0 / p->dense_scale, a);
     // d_disp16 has been consumed: the next SGM call may overwrite it (it waits for this before its last kernel)
