@@ -252,11 +252,13 @@ __device__ __forceinline__ bool vlink(const uint8_t* valid, const double* Z, int
 }
 __global__ void __launch_bounds__(256) k_ccl_init(const uint8_t* __restrict__ valid, const double* __restrict__ Z, int w, int n,
                                                   const double* __restrict__ zgap_p, int* __restrict__ parent,
-                                                  unsigned int* __restrict__ size, unsigned int* __restrict__ mincm)
+                                                  unsigned int* __restrict__ size, unsigned int* __restrict__ mincm,
+                                                  unsigned long long* __restrict__ best)
 {
     const double zgap = *zgap_p;
     __shared__ int wmax[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) *best = 0;                                       // k_ccl_best (three launches later) takes the maximum into it
     const bool v = i < n && valid[i];
     // start of my horizontal run inside this block = last "break" at or before me
     int s = (threadIdx.x == 0 || !v || !hlink(valid, Z, w, i, zgap)) ? i : -1;
@@ -295,27 +297,34 @@ __global__ void __launch_bounds__(256) k_ccl_flatten(int n, int* parent)
 }
 // component sizes and smallest column-major index: one update per run of equal roots inside a wave, and the
 // dominant root of a block is pre-aggregated in LDS
+constexpr int CCL_COUNT_CHUNKS = 8;
 __global__ void __launch_bounds__(1024) k_ccl_count(int n, int w, int h, const int* __restrict__ parent,
                                                     unsigned int* __restrict__ size, unsigned int* __restrict__ mincm)
 {
     __shared__ int r0s;
     __shared__ unsigned int agg, aggmin;
-    const int i = blockIdx.x * 1024 + threadIdx.x;
-    const int r = i < n ? parent[i] : -1;
-    if (threadIdx.x == 0) { r0s = r; agg = 0; aggmin = 0xFFFFFFFFu; }
+    // a block walks CCL_COUNT_CHUNKS consecutive chunks of 1024 pixels: the root of its first pixel (almost always the
+    // one big component) is totalled in LDS and reaches its global counter once per block -- updates of one address
+    // serialise, and 5 000 blocks updating the same root were most of this kernel's time
+    const int first = blockIdx.x * (1024 * CCL_COUNT_CHUNKS);
+    if (threadIdx.x == 0) { r0s = first < n ? parent[first] : -1; agg = 0; aggmin = 0xFFFFFFFFu; }
     __syncthreads();
     const int r0 = r0s;
     const int lane = threadIdx.x & 63;
-    const int prev = __shfl_up(r, 1);
-    // a run also ends at a row boundary so that its head has the smallest column index of the run
-    const bool head = r >= 0 && (lane == 0 || prev != r || (i % w) == 0);
-    const unsigned long long heads = __ballot(head || r < 0);
-    if (head) {
-        const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
-        const int len = above ? (__ffsll((long long)above)) : (64 - lane);
-        const unsigned int cm = (unsigned)((i % w) * h + (i / w));
-        if (r == r0) { atomicAdd(&agg, (unsigned)len); atomicMin(&aggmin, cm); }      // LDS
-        else { atomicAdd(&size[r], (unsigned)len); atomicMin(&mincm[r], cm); }
+    for (int ch = 0; ch < CCL_COUNT_CHUNKS; ++ch) {
+        const int i = first + ch * 1024 + threadIdx.x;
+        const int r = i < n ? parent[i] : -1;
+        const int prev = __shfl_up(r, 1);
+        // a run also ends at a row boundary so that its head has the smallest column index of the run
+        const bool head = r >= 0 && (lane == 0 || prev != r || (i % w) == 0);
+        const unsigned long long heads = __ballot(head || r < 0);
+        if (head) {
+            const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+            const int len = above ? (__ffsll((long long)above)) : (64 - lane);
+            const unsigned int cm = (unsigned)((i % w) * h + (i / w));
+            if (r == r0) { atomicAdd(&agg, (unsigned)len); atomicMin(&aggmin, cm); }      // LDS
+            else { atomicAdd(&size[r], (unsigned)len); atomicMin(&mincm[r], cm); }
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0 && agg) { atomicAdd(&size[r0], agg); atomicMin(&mincm[r0], aggmin); }
@@ -372,33 +381,43 @@ struct DevState {
 };
 
 // z gaps computed on the fly (no gap array): histogram of one 11-bit digit of the fp64 bit patterns that match the
-// prefix found so far
+// prefix found so far.  Blocks own a 256-column strip and walk rows (no index divisions); their totals go to one of
+// GAP_HIST_COPIES copies of the global histogram (same-address atomics serialise), which k_radix_pick adds up.
+constexpr int GAP_HIST_COPIES = 4;
+// 5 x 11 + 9 bits = 64.  (13-bit digits, five passes: measured SLOWER -- 42 + 23 us per pass against 26 + 11: the 32 KB
+// histogram per workgroup costs occupancy and the pick kernel scans four times the bins.)
+constexpr int GAP_BITS = 11, GAP_BINS = 1 << GAP_BITS, GAP_PASSES = 6;
 __global__ void __launch_bounds__(256) k_gap_hist(const uint8_t* __restrict__ valid, const double* __restrict__ Z, int w, int h,
                                                   int shift, unsigned int mask, const DevState* __restrict__ ds,
                                                   unsigned int* __restrict__ hist)
 {
-    __shared__ unsigned int lh[2048];
-    for (int i = threadIdx.x; i < 2048; i += 256) lh[i] = 0;
+    __shared__ unsigned int lh[GAP_BINS];
+    for (int i = threadIdx.x; i < GAP_BINS; i += 256) lh[i] = 0;
     __syncthreads();
     const int hi_shift = ds->sel_hi_shift;
     const unsigned long long prefix = ds->sel_prefix;
-    const size_t n = (size_t)w * h;
-    for (size_t c = (size_t)blockIdx.x * 256 + threadIdx.x; c < n; c += (size_t)gridDim.x * 256) {
-        const int i = (int)(c / w), j = (int)(c % w);
-        if (i < 1 || j < 1 || j >= w - 1 || !valid[c]) continue;
-        const double z = Z[c];
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= 1 && j < w - 1)
+        for (int i = 1 + blockIdx.y; i < h; i += gridDim.y) {
+            // all loads first and unconditionally (rows i-1 and i exist, columns j-1 .. j+1 too): independent requests in flight
+            const size_t c = (size_t)i * w + j, up = c - w;
+            const uint8_t vc = valid[c], v0 = valid[up - 1], v1 = valid[up], v2 = valid[up + 1];
+            const double z = Z[c], z0 = Z[up - 1], z1 = Z[up], z2 = Z[up + 1];
+            if (!vc) continue;
+            const double zn[3] = { z0, z1, z2 };
+            const uint8_t vn[3] = { v0, v1, v2 };
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const size_t nb = c - w - 1 + k;
-            if (!valid[nb]) continue;
-            const unsigned long long key = (unsigned long long)__double_as_longlong(fabs(z - Z[nb]));
-            if (hi_shift < 64 && (key >> hi_shift) != prefix) continue;
-            atomicAdd(&lh[(unsigned)(key >> shift) & mask], 1u);
+            for (int k = 0; k < 3; ++k) {
+                if (!vn[k]) continue;
+                const unsigned long long key = (unsigned long long)__double_as_longlong(fabs(z - zn[k]));
+                if (hi_shift < 64 && (key >> hi_shift) != prefix) continue;
+                atomicAdd(&lh[(unsigned)(key >> shift) & mask], 1u);
+            }
         }
-    }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2048; i += 256)
-        if (lh[i]) atomicAdd(&hist[i], lh[i]);
+    unsigned int* mine = hist + (size_t)((blockIdx.x + blockIdx.y) % GAP_HIST_COPIES) * GAP_BINS;
+    for (int i = threadIdx.x; i < GAP_BINS; i += 256)
+        if (lh[i]) atomicAdd(&mine[i], lh[i]);
 }
 // one workgroup: pick the bin that holds rank k, extend the prefix; pass 0 also derives k from the percentile
 __global__ void __launch_bounds__(256) k_radix_pick(unsigned int* __restrict__ hist, int pass, int shift, int nbits,
@@ -406,6 +425,12 @@ __global__ void __launch_bounds__(256) k_radix_pick(unsigned int* __restrict__ h
 {
     __shared__ unsigned long long tot[256];
     const int nb = 1 << nbits, per = (nb + 255) / 256;
+    for (int i = threadIdx.x; i < GAP_BINS; i += 256) {                                  // fold the copies into copy 0
+        unsigned int t = hist[i];
+        for (int cpy = 1; cpy < GAP_HIST_COPIES; ++cpy) t += hist[(size_t)cpy * GAP_BINS + i];
+        hist[i] = t;
+    }
+    __syncthreads();
     unsigned long long s = 0;
     for (int b = threadIdx.x * per; b < min(nb, (threadIdx.x + 1) * per); ++b) s += hist[b];
     tot[threadIdx.x] = s;
@@ -438,7 +463,7 @@ __global__ void __launch_bounds__(256) k_radix_pick(unsigned int* __restrict__ h
         if (ds->sel_fail == 1) ds->zgap = __longlong_as_double(0x7FF8000000000000ll);     // no gaps: NaN
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2048; i += 256) hist[i] = 0;                           // ready for the next pass
+    for (int i = threadIdx.x; i < GAP_BINS * GAP_HIST_COPIES; i += 256) hist[i] = 0;        // ready for the next pass
 }
 
 // ------------------------------------------------------------------ RANSAC (PovMesh.cpp:665-777)
@@ -446,10 +471,14 @@ struct PlaneCand { double n[3]; double d; int ok; int pad; };
 
 __global__ void k_ransac_planes(const uint8_t* __restrict__ valid, const double* __restrict__ X, const double* __restrict__ Y,
                                 const double* __restrict__ Z, int w, const int32_t* __restrict__ uv, int rounds,
-                                PlaneCand* __restrict__ cand)
+                                PlaneCand* __restrict__ cand, unsigned long long* __restrict__ counts,
+                                unsigned long long* __restrict__ zero, int nzero)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    // the score / crop kernels that follow accumulate into these: cleared here instead of by separate fill launches
+    for (int k = r; k < nzero; k += gridDim.x * blockDim.x) zero[k] = 0;
     if (r >= rounds) return;
+    counts[r] = 0;
     const int32_t* c = uv + (size_t)r * 6;
     const size_t i1 = (size_t)c[1] * w + c[0], i2 = (size_t)c[3] * w + c[2], i3 = (size_t)c[5] * w + c[4];
     PlaneCand pc;
@@ -679,6 +708,37 @@ __global__ void __launch_bounds__(256) k_refine_moments(const uint8_t* __restric
     }
     block_sum_store<5>(acc, partial);
 }
+// crop_plane by the RANSAC plane (k_crop_plane_dev) and pass 0 of the refinement in ONE pass over the points: the same
+// walk as k_refine_moments (grid, stride and therefore summation order), with the crop decision taken -- and written to
+// valid -- just before the point is offered to the moments.
+__global__ void __launch_bounds__(256) k_crop_moments_dev(uint8_t* __restrict__ valid, const double* __restrict__ X,
+                                                          const double* __restrict__ Y, const double* __restrict__ Z, int w, size_t n,
+                                                          const double* __restrict__ plane, const int* __restrict__ enable, double thr,
+                                                          unsigned long long* __restrict__ kept, RefineDev rp,
+                                                          double* __restrict__ partial)
+{
+    const bool crop = *enable != 0;
+    const double a = plane[0], b = plane[1], c = plane[2], d = plane[3];
+    unsigned int cnt = 0;
+    double acc[5] = { 0, 0, 0, 0, 0 };
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        if (!valid[i]) continue;
+        const double px = X[i], py = Y[i], pz = Z[i];
+        if (crop) {
+            if (fabs((a * px + b * py + c * pz) + d) < thr) ++cnt;
+            else { valid[i] = 0; continue; }
+        }
+        const int u = (int)(i % w), v = (int)(i / w);
+        if (u < rp.umin || u > rp.umax || v < rp.vmin || v > rp.vmax) continue;
+        const double dist = sqrt(px * px + py * py + pz * pz);
+        if (!(px > rp.xmin && px < rp.xmax && py > rp.ymin && py < rp.ymax && dist < rp.maxd)) continue;
+        const double wt = rp.weighted ? dist : 1.0;
+        acc[0] += 1.0; acc[1] += wt; acc[2] += px * wt; acc[3] += py * wt; acc[4] += pz * wt;
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(kept + slot_of_block(), (unsigned long long)cnt);
+    block_sum_store<5>(acc, partial);
+}
 // pass 1: weighted scatter matrix around the centroid (6 unique entries)
 __global__ void __launch_bounds__(256) k_refine_cov(const uint8_t* __restrict__ valid, const double* __restrict__ X,
                                                     const double* __restrict__ Y, const double* __restrict__ Z, int w, size_t n,
@@ -864,25 +924,27 @@ __global__ void __launch_bounds__(256) k_xyzc_limits(const uint8_t* __restrict__
 // exclusive scan of the per-block counts (single block; nblocks <= ~25k at full size)
 __global__ void __launch_bounds__(1024) k_scan_blocks(unsigned int* __restrict__ cnt, int nb, unsigned int* __restrict__ total)
 {
-    __shared__ unsigned int sh[1024];
-    unsigned int carry = 0;
-    for (int base = 0; base < nb; base += 1024) {
-        const int i = base + threadIdx.x;
-        const unsigned int v = i < nb ? cnt[i] : 0;
-        sh[threadIdx.x] = v;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            const unsigned int t = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0;
-            __syncthreads();
-            sh[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (i < nb) cnt[i] = carry + sh[threadIdx.x] - v;
-        const unsigned int tot = sh[1023];
-        __syncthreads();
-        carry += tot;
+    // exclusive scan of nb counts by one workgroup: each of the 16 waves owns a contiguous range and reads it 64 at a time
+    // (coalesced, independent loads); range totals meet in LDS, then every wave rewrites its range with a running carry
+    __shared__ unsigned int wtot[16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int per = ((nb + 15) / 16 + 63) & ~63, begin = min(nb, wv * per), end = min(nb, begin + per);
+    unsigned int sum = 0;
+    for (int i = begin + lane; i < end; i += 64) sum += cnt[i];
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+    if (lane == 0) wtot[wv] = sum;
+    __syncthreads();
+    unsigned int carry = 0, all = 0;
+    for (int k = 0; k < 16; ++k) { if (k < wv) carry += wtot[k]; all += wtot[k]; }
+    if (threadIdx.x == 0) *total = all;
+    for (int base = begin; base < end; base += 64) {
+        const int i = base + lane;
+        const unsigned int v = i < end ? cnt[i] : 0;
+        unsigned int incl = v;
+        for (int o = 1; o < 64; o <<= 1) { const unsigned int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        if (i < end) cnt[i] = carry + incl - v;
+        carry += __shfl(incl, 63);
     }
-    if (threadIdx.x == 0) *total = carry;
 }
 __device__ __forceinline__ void xyzc_pack_body(const uint8_t* __restrict__ valid, const double* __restrict__ X,
                                                const double* __restrict__ Y, const double* __restrict__ Z, size_t n,
@@ -1179,7 +1241,7 @@ __host__ __device__ inline void rt_from_plane(const double plane[4], double R[9]
 }
 
 // frame tail, step 1: the plane that main() would pass to save_as_xyz_compressed (wass_stereo.cpp:2108-2123)
-__global__ void k_frame_rt(DevState* __restrict__ ds, const unsigned long long* __restrict__ kept /* [2][NSLOT] */)
+__global__ void k_frame_rt(DevState* __restrict__ ds)
 {
     if (threadIdx.x || blockIdx.x) return;
     const bool have = ds->ransac_found && ds->refine_ok;
@@ -1190,30 +1252,88 @@ __global__ void k_frame_rt(DevState* __restrict__ ds, const unsigned long long* 
         for (int i = 0; i < 9; ++i) ds->rtR[i] = ds->rtRinv[i] = (i % 4 == 0) ? 1.0 : 0.0;
         for (int i = 0; i < 3; ++i) ds->rtT[i] = ds->rtTinv[i] = 0.0;
     }
-    unsigned long long k1 = 0, k2 = 0;
-    for (int i = 0; i < NSLOT; ++i) { k1 += kept[i]; k2 += kept[NSLOT + i]; }
-    ds->kept1 = k1; ds->kept2 = k2;
 }
-__global__ void __launch_bounds__(256) k_xyzc_limits_dev(const uint8_t* __restrict__ valid, const double* __restrict__ X,
-                                                         const double* __restrict__ Y, const double* __restrict__ Z, size_t n,
-                                                         const DevState* __restrict__ ds, unsigned long long* __restrict__ lim)
+// frame tail, step 2 -- three passes over the points in one: crop_plane by the refined plane (k_crop_plane_dev), the
+// limits of the transformed survivors (k_xyzc_limits_dev) and the per-block survivor counts of the compaction
+// (k_block_counts).  Block b owns points [256 b, 256 b + 256), as the pack kernel does.
+constexpr int CLC_CHUNKS = 16;
+__global__ void __launch_bounds__(256) k_crop_limits_counts_dev(uint8_t* __restrict__ valid, const double* __restrict__ X,
+                                                                const double* __restrict__ Y, const double* __restrict__ Z, size_t n,
+                                                                const DevState* __restrict__ ds, double thr,
+                                                                unsigned long long* __restrict__ kept, unsigned long long* __restrict__ lim,
+                                                                unsigned int* __restrict__ blockcnt, unsigned int nchunks)
 {
-    RTDev rt;
-    for (int i = 0; i < 9; ++i) rt.R[i] = ds->rtR[i];
-    for (int i = 0; i < 3; ++i) rt.T[i] = ds->rtT[i];
-    xyzc_limits_body(valid, X, Y, Z, n, rt, lim);
+    const bool crop = ds->refine_ok != 0;
+    const double a = ds->plane[0], b = ds->plane[1], c = ds->plane[2], d = ds->plane[3];
+    double R[9], T[3];
+    for (int k = 0; k < 9; ++k) R[k] = ds->rtR[k];
+    for (int k = 0; k < 3; ++k) T[k] = ds->rtT[k];
+    unsigned long long mn[3] = { ~0ull, ~0ull, ~0ull }, mx[3] = { 0, 0, 0 };
+    unsigned int nkept = 0;
+    // a workgroup walks CLC_CHUNKS chunks of 256 points (chunk = compaction block of the pack kernel) and meets the global
+    // counters once at the end: one update per wave and chunk was half a million same-line atomics
+    for (int ch = 0; ch < CLC_CHUNKS; ++ch) {
+        const unsigned int chunk = blockIdx.x * CLC_CHUNKS + ch;
+        if (chunk >= nchunks) break;
+        const size_t i = (size_t)chunk * 256 + threadIdx.x;
+        bool v = i < n && valid[i];
+        if (v) {
+            const double p[3] = { X[i], Y[i], Z[i] };
+            if (crop && !(fabs((a * p[0] + b * p[1] + c * p[2]) + d) < thr)) { valid[i] = 0; v = false; }
+            if (v) {
+                double t[3];
+                mulv(R, p, t);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const unsigned long long key = dkey(t[k] + T[k]);
+                    mn[k] = key < mn[k] ? key : mn[k];
+                    mx[k] = key > mx[k] ? key : mx[k];
+                }
+                ++nkept;
+            }
+        }
+        const int cnt = __syncthreads_count(v);
+        if (threadIdx.x == 0) blockcnt[chunk] = (unsigned)cnt;
+    }
+    for (int o = 32; o > 0; o >>= 1) nkept += __shfl_down(nkept, o);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long lo = __shfl_down(mn[k], o), hi = __shfl_down(mx[k], o);
+            mn[k] = lo < mn[k] ? lo : mn[k];
+            mx[k] = hi > mx[k] ? hi : mx[k];
+        }
+    if ((threadIdx.x & 63) == 0 && nkept) {
+        if (crop) atomicAdd(kept + slot_of_block(), (unsigned long long)nkept);
+        unsigned long long* l = lim + (size_t)slot_of_block() * 6;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { atomicMin(&l[k], mn[k]); atomicMax(&l[3 + k], mx[k]); }
+    }
 }
 // frame tail: limits -> scale factors, and the 148-byte header of the file image (PovMesh.cpp:417-436)
 __global__ void k_frame_header(DevState* __restrict__ ds, const unsigned long long* __restrict__ lim, const unsigned int* __restrict__ total,
-                               unsigned char* __restrict__ img)
+                               const unsigned long long* __restrict__ kept /* [2][NSLOT] */, unsigned char* __restrict__ img)
 {
-    if (threadIdx.x || blockIdx.x) return;
+    if (blockIdx.x) return;
+    {
+        unsigned long long k1 = 0, k2 = 0;
+        for (int i = threadIdx.x; i < NSLOT; i += 64) { k1 += kept[i]; k2 += kept[NSLOT + i]; }
+        for (int o = 32; o > 0; o >>= 1) { k1 += __shfl_down(k1, o); k2 += __shfl_down(k2, o); }
+        if (threadIdx.x == 0) { ds->kept1 = k1; ds->kept2 = k2; }
+    }
     unsigned long long hl[6] = { ~0ull, ~0ull, ~0ull, 0, 0, 0 };
-    for (int i = 0; i < NSLOT; ++i)
+    for (int i = threadIdx.x; i < NSLOT; i += 64)
         for (int k = 0; k < 3; ++k) {
             if (lim[i * 6 + k] < hl[k]) hl[k] = lim[i * 6 + k];
             if (lim[i * 6 + 3 + k] > hl[3 + k]) hl[3 + k] = lim[i * 6 + 3 + k];
         }
+    for (int o = 32; o > 0; o >>= 1)
+        for (int k = 0; k < 3; ++k) {
+            const unsigned long long a = __shfl_down(hl[k], o), b = __shfl_down(hl[3 + k], o);
+            if (a < hl[k]) hl[k] = a;
+            if (b > hl[3 + k]) hl[3 + k] = b;
+        }
+    if (threadIdx.x) return;
     const unsigned int npts = *total;
     double mx[3];
     for (int k = 0; k < 3; ++k) {
@@ -1245,9 +1365,10 @@ __global__ void __launch_bounds__(256) k_xyzc_pack_dev(const uint8_t* __restrict
     xyzc_pack_body(valid, X, Y, Z, n, rt, ds->mn[0], ds->mn[1], ds->mn[2], ds->sc[0], ds->sc[1], ds->sc[2], blockoff, out);
 }
 
+constexpr size_t DSTATE_HIST_OFF = (sizeof(DevState) + 255) & ~(size_t)255;
 static int dstate(wass_ctx* c, DevState** ds)
 {
-    int rc = ensure(c, c->dstate, sizeof(DevState) + 2048 * 4);
+    int rc = ensure(c, c->dstate, DSTATE_HIST_OFF + (size_t)GAP_HIST_COPIES * GAP_BINS * 4);
     if (rc) return rc;
     *ds = (DevState*)c->dstate.p;
     return WASS_OK;
@@ -1265,11 +1386,10 @@ static int enqueue_ccl(wass_ctx* c, wass_mesh* m, DevState* ds)
     unsigned int* mincm = size + n;
     unsigned long long* best = &ds->ccl_best;
     const dim3 blk(256), g1(nblk(n));
-    WASS_HIP(c, hipMemsetAsync(best, 0, 8, c->ts()));
-    hipLaunchKernelGGL(k_ccl_init, g1, blk, 0, c->ts(), m->valid, m->z, m->w, (int)n, (const double*)&ds->zgap, parent, size, mincm);
+    hipLaunchKernelGGL(k_ccl_init, g1, blk, 0, c->ts(), m->valid, m->z, m->w, (int)n, (const double*)&ds->zgap, parent, size, mincm, best);
     hipLaunchKernelGGL(k_ccl_merge, g1, blk, 0, c->ts(), m->valid, m->z, m->w, (int)n, (const double*)&ds->zgap, parent);
     hipLaunchKernelGGL(k_ccl_flatten, g1, blk, 0, c->ts(), (int)n, parent);
-    hipLaunchKernelGGL(k_ccl_count, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, c->ts(), (int)n, m->w, m->h,
+    hipLaunchKernelGGL(k_ccl_count, dim3((unsigned)((n + 1024 * CCL_COUNT_CHUNKS - 1) / (1024 * CCL_COUNT_CHUNKS))), dim3(1024), 0, c->ts(), (int)n, m->w, m->h,
                        (const int*)parent, size, mincm);
     hipLaunchKernelGGL(k_ccl_best, g1, blk, 0, c->ts(), (int)n, (const int*)parent, (const unsigned int*)size,
                        (const unsigned int*)mincm, best);
@@ -1331,15 +1451,16 @@ static int enqueue_remove_outliers(wass_ctx* c, wass_mesh* m, double percentile,
     DevState* ds = nullptr;
     int rc = dstate(c, &ds);
     if (rc) return rc;
-    unsigned int* hist = (unsigned int*)(ds + 1);
+    unsigned int* hist = (unsigned int*)((char*)ds + DSTATE_HIST_OFF);      // 256-byte aligned: one fill kernel, not three
     unsigned char* stage = nullptr;
     if ((rc = host_stage(c, &stage))) return rc;
     WASS_HIP(c, hipStreamWaitEvent(c->ts(), c->ev_copy, 0));            // the copy stream may still be reading the last frame's record
     WASS_HIP(c, hipMemcpyAsync(ds, stage, sizeof(DevState), hipMemcpyHostToDevice, c->ts()));
-    WASS_HIP(c, hipMemsetAsync(hist, 0, 2048 * 4, c->ts()));
-    for (int pass = 0; pass < 6; ++pass) {
-        const int shift = pass < 5 ? 64 - 11 * (pass + 1) : 0, nbits = pass < 5 ? 11 : 9;
-        hipLaunchKernelGGL(k_gap_hist, dim3(2048), dim3(256), 0, c->ts(), m->valid, m->z, m->w, m->h, shift, (1u << nbits) - 1u,
+    WASS_HIP(c, hipMemsetAsync(hist, 0, (size_t)GAP_HIST_COPIES * GAP_BINS * 4, c->ts()));
+    for (int pass = 0; pass < GAP_PASSES; ++pass) {
+        const int shift = pass < GAP_PASSES - 1 ? 64 - GAP_BITS * (pass + 1) : 0;       // 53, 42, 31, 20, 9, 0 (last digit: 9 bits)
+        const int nbits = pass < GAP_PASSES - 1 ? GAP_BITS : 64 - GAP_BITS * (GAP_PASSES - 1);
+        hipLaunchKernelGGL(k_gap_hist, dim3((m->w + 255) / 256, 256), dim3(256), 0, c->ts(), m->valid, m->z, m->w, m->h, shift, (1u << nbits) - 1u,
                            (const DevState*)ds, hist);
         hipLaunchKernelGGL(k_radix_pick, dim3(1), dim3(256), 0, c->ts(), hist, pass, shift, nbits, percentile, ds);
     }
@@ -1461,9 +1582,8 @@ int wass_mesh_ransac_plane(wass_ctx* c, wass_mesh* m, const int32_t* uv, int rou
     unsigned long long* counts = (unsigned long long*)(cand + rounds);
     int32_t* duv = (int32_t*)(counts + rounds);
     WASS_HIP(c, hipMemcpyAsync(duv, uv, (size_t)rounds * 24, hipMemcpyHostToDevice, c->ts()));
-    WASS_HIP(c, hipMemsetAsync(counts, 0, (size_t)rounds * 8, c->ts()));
     hipLaunchKernelGGL(k_ransac_planes, dim3((rounds + 63) / 64), dim3(64), 0, c->ts(), m->valid, m->x, m->y, m->z, m->w,
-                       (const int32_t*)duv, rounds, cand);
+                       (const int32_t*)duv, rounds, cand, counts, (unsigned long long*)nullptr, 0);
     constexpr int PTS = 8;
     const size_t lds = (size_t)rounds * (16 + 8 + 4);
     if (lds > 64 * 1024) return set_err(c, WASS_ERR_UNSUPPORTED, "PLANE_RANSAC_ROUNDS %d too large (max 1800)", rounds);
@@ -1543,7 +1663,7 @@ int wass_mesh_refine_plane(wass_ctx* c, wass_mesh* m, const wass_refine_params* 
 // wass_stereo.cpp:2062-2107 as one call: ransac_find_plane -> crop_plane(ransac_thr) -> refine_plane ->
 // crop_plane(max_distance); candidate choice, centroid and the 3x3 eigen-solve run on the device, one read-back.
 static int enqueue_fit_plane(wass_ctx* c, wass_mesh* m, const int32_t* uv, int rounds, double ransac_thr, const wass_refine_params* rp,
-                             double max_distance, DevState** dsp, unsigned long long** keptp)
+                             double max_distance, DevState** dsp, unsigned long long** keptp, bool final_crop = true)
 {
     if (!c || !m || !uv || !rp || rounds <= 0) return set_err(c, WASS_ERR_INVALID_ARG, "bad argument");
     for (int r = 0; r < rounds * 3; ++r)
@@ -1578,15 +1698,11 @@ static int enqueue_fit_plane(wass_ctx* c, wass_mesh* m, const int32_t* uv, int r
         WASS_HIP(c, hipEventRecord(c->ev_stage, s));
         c->stage_uv_busy = true;
     }
-    WASS_HIP(c, hipMemsetAsync(counts, 0, (size_t)rounds * 8, s));
-    WASS_HIP(c, hipMemsetAsync(kept1, 0, (size_t)2 * NSLOT * 8, s));
     hipLaunchKernelGGL(k_ransac_planes, dim3((rounds + 63) / 64), dim3(64), 0, s, m->valid, m->x, m->y, m->z, m->w, (const int32_t*)duv,
-                       rounds, cand);
+                       rounds, cand, counts, kept1, 2 * NSLOT);
     hipLaunchKernelGGL(k_ransac_score<PTS>, dim3((unsigned)((n + 256 * PTS - 1) / (256 * PTS))), dim3(256), lds, s, m->valid, m->x,
                        m->y, m->z, n, (const PlaneCand*)cand, rounds, ransac_thr, counts);
     hipLaunchKernelGGL(k_ransac_pick, dim3(1), dim3(64), 0, s, (const PlaneCand*)cand, (const unsigned long long*)counts, rounds, n, ds);
-    hipLaunchKernelGGL(k_crop_plane_dev, dim3(2048), dim3(256), 0, s, m->valid, m->x, m->y, m->z, n, (const double*)ds->ransac_plane,
-                       (const int*)&ds->ransac_found, ransac_thr, kept1);
     RefineDev rd;
     rd.xmin = rp->xmin; rd.xmax = rp->xmax; rd.ymin = rp->ymin; rd.ymax = rp->ymax; rd.maxd = rp->max_distance;
     rd.weighted = rp->weight_by_distance;
@@ -1594,12 +1710,14 @@ static int enqueue_fit_plane(wass_ctx* c, wass_mesh* m, const int32_t* uv, int r
     rd.umax = rp->central_third_only ? m->w * 3 / 4 : m->w - 1;
     rd.vmin = rp->central_third_only ? m->h / 4 : 0;
     rd.vmax = rp->central_third_only ? m->h * 2 / 3 : m->h - 1;
-    hipLaunchKernelGGL(k_refine_moments, dim3(NB), dim3(256), 0, s, m->valid, m->x, m->y, m->z, m->w, n, rd, part);
+    hipLaunchKernelGGL(k_crop_moments_dev, dim3(NB), dim3(256), 0, s, m->valid, m->x, m->y, m->z, m->w, n, (const double*)ds->ransac_plane,
+                       (const int*)&ds->ransac_found, ransac_thr, kept1, rd, part);
     hipLaunchKernelGGL(k_refine_centroid, dim3(1), dim3(64), 0, s, (const double*)part, NB, (const int*)&ds->ransac_found, ds);
     hipLaunchKernelGGL(k_refine_cov_dev, dim3(NB), dim3(256), 0, s, m->valid, m->x, m->y, m->z, m->w, n, rd, (const DevState*)ds, part);
     hipLaunchKernelGGL(k_refine_finish, dim3(1), dim3(64), 0, s, (const double*)part, NB, ds);
-    hipLaunchKernelGGL(k_crop_plane_dev, dim3(2048), dim3(256), 0, s, m->valid, m->x, m->y, m->z, n, (const double*)ds->plane,
-                       (const int*)&ds->refine_ok, max_distance, kept2);
+    if (final_crop)                                              // the frame tail folds this pass into its limits / counts pass
+        hipLaunchKernelGGL(k_crop_plane_dev, dim3(2048), dim3(256), 0, s, m->valid, m->x, m->y, m->z, n, (const double*)ds->plane,
+                           (const int*)&ds->refine_ok, max_distance, kept2);
     WASS_HIP(c, hipGetLastError());
     *dsp = ds;
     *keptp = kept1;
@@ -1649,14 +1767,14 @@ int wass_mesh_finish_frame_async(wass_ctx* c, wass_mesh* m, double percentile, c
     unsigned long long* kept1 = nullptr;
     int rc;
     if ((rc = enqueue_remove_outliers(c, m, percentile, &ds))) return rc;
-    if ((rc = enqueue_fit_plane(c, m, uv, rounds, ransac_thr, rp, max_distance, &ds, &kept1))) return rc;
+    if ((rc = enqueue_fit_plane(c, m, uv, rounds, ransac_thr, rp, max_distance, &ds, &kept1, false))) return rc;
     const unsigned nb = nblk(n);
     if ((rc = ensure(c, c->xyzc, 148 + n * 6 + 16))) return rc;
     // block counts live behind the candidate area of the scratch buffer, which enqueue_fit_plane sized; grow if needed
     const size_t need = 64 + (size_t)nb * 4 + 16;
     if (c->scratch.cap < need && (rc = ensure(c, c->scratch, need))) return rc;
     hipStream_t s = c->ts();
-    hipLaunchKernelGGL(k_frame_rt, dim3(1), dim3(64), 0, s, ds, (const unsigned long long*)kept1);
+    hipLaunchKernelGGL(k_frame_rt, dim3(1), dim3(64), 0, s, ds);
     unsigned char* stage = nullptr;
     if ((rc = host_stage(c, &stage))) return rc;
     if ((rc = ensure(c, c->limits, NSLOT * 6 * 8))) return rc;
@@ -1666,10 +1784,11 @@ int wass_mesh_finish_frame_async(wass_ctx* c, wass_mesh* m, double percentile, c
     unsigned int* bcnt = (unsigned int*)((char*)c->scratch.p + 64);
     unsigned char* img = (unsigned char*)c->xyzc.p;
     WASS_HIP(c, hipStreamWaitEvent(s, c->ev_copy, 0));                    // a previous download still reading the image
-    hipLaunchKernelGGL(k_xyzc_limits_dev, dim3(1024), dim3(256), 0, s, m->valid, m->x, m->y, m->z, n, (const DevState*)ds, lim);
-    hipLaunchKernelGGL(k_block_counts, dim3(nb), dim3(256), 0, s, m->valid, n, bcnt);
+    hipLaunchKernelGGL(k_crop_limits_counts_dev, dim3((nb + CLC_CHUNKS - 1) / CLC_CHUNKS), dim3(256), 0, s, m->valid, m->x, m->y, m->z, n,
+                       (const DevState*)ds, max_distance, kept1 + NSLOT, lim, bcnt, nb);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, bcnt, (int)nb, total);
-    hipLaunchKernelGGL(k_frame_header, dim3(1), dim3(64), 0, s, ds, (const unsigned long long*)lim, (const unsigned int*)total, img);
+    hipLaunchKernelGGL(k_frame_header, dim3(1), dim3(64), 0, s, ds, (const unsigned long long*)lim, (const unsigned int*)total,
+                       (const unsigned long long*)kept1, img);
     hipLaunchKernelGGL(k_xyzc_pack_dev, dim3(nb), dim3(256), 0, s, m->valid, m->x, m->y, m->z, n, (const DevState*)ds,
                        (const unsigned int*)bcnt, (uint16_t*)(img + 148));
     WASS_HIP(c, hipGetLastError());
