@@ -233,9 +233,9 @@ def main():
     NBUF = 3                                             # a frame's inputs must stay untouched until two more were submitted
     dbuf = [tuple(torch.empty((h, w), dtype=torch.uint8, device=dev) for _ in range(3))
             for _ in range(nf if args.resident_inputs else NBUF)]
-    # The upload rides on the context's own SGM stream, in front of the frame's first kernel (wass_upload_async): the
-    # runtime multiplexes all streams of a process onto four hardware queues, and a separate upload stream ended up
-    # sharing one with the context's tail stream, which serialised frame i's tail with frame i+1's SGM stage (-9 % pairs/s)
+    # The uploads go through wass_upload_async (the context's copy stream + an event the SGM stream waits for): the
+    # runtime multiplexes all streams of a process onto four hardware queues, and a separate upload stream of torch's
+    # ended up sharing one with the context's tail stream, which serialised frame i's tail with frame i+1's SGM stage
     if args.resident_inputs:
         for k in range(nf):
             dbuf[k][0].copy_(host[k][0]); dbuf[k][1].copy_(host[k][1])
@@ -254,13 +254,22 @@ def main():
         if o is not None:
             planes.append(o.plane); npts_hist.append(o.n_points); nbytes_hist.append(len(o.xyzc)); overflows.append(o.cost_overflow)
 
+    def upload(i):
+        k = i % nf
+        dr, dl, dm = dbuf[i % NBUF]
+        ctx.upload_async(dr, host[k][0])
+        ctx.upload_async(dl, host[k][1])
+
     def step(i):
+        # One upload per step, of the NEXT frame (what a sequence driver does after decoding frame i+1 while frame i is
+        # on the GPU): the transfer runs on the copy stream underneath frame i; buffer (i+1) % 3 was last used by frame i-2.
         k = i % nf
         dr, dl, dm = dbuf[k] if args.resident_inputs else dbuf[i % NBUF]
         if not args.resident_inputs:
-            ctx.upload_async(dr, host[k][0])
-            ctx.upload_async(dl, host[k][1])
+            if i == 0:
+                upload(0)
             ctx.burned_area_mask_dev(dr, dm)                # DISCARD_BURNED_AREAS mask of the right image (wass_stereo.cpp:1072)
+            upload(i + 1)
         if args.stage == "sgm":
             ctx.sgm_disparity_dev(dr, dl, params, sgm_out)
         else:

@@ -61,9 +61,12 @@ int wass_ctx_set_tail_overlap(wass_ctx* ctx, int on);
 int wass_ctx_set_debug(wass_ctx* ctx, int on);
 const char* wass_version(void);
 
-/* Stream-ordered upload on the context's SGM stream: h_src (pinned host memory for a truly asynchronous copy; it must
- * stay valid until the copy has executed) -> d_dst.  Lets a sequence driver put a frame's images in front of its first
- * kernel without a stream of its own (the runtime multiplexes all streams of a process onto four hardware queues). */
+/* Asynchronous upload h_src -> d_dst on the context's copy stream (h_src: pinned host memory, valid until the copy has
+ * executed).  The calls of this library that READ device inputs (wass_sgm_disparity_dev, wass_burned_area_mask_dev) wait
+ * for the pending uploads that cover their input pointers, and everything later in a frame is ordered after the SGM
+ * call; nothing else waits.  A driver that uploads frame i+1 just before it submits frame i (three input sets: the
+ * buffer was last used by frame i-2) gets the transfer underneath frame i's kernels.  A kernel of the caller's own that
+ * reads d_dst must be ordered by the caller (wass_ctx_synchronize, or pass the buffer through one of the calls above). */
 int wass_upload_async(wass_ctx* ctx, void* d_dst, const void* h_src, size_t nbytes);
 /* DISCARD_BURNED_AREAS (wass_stereo.cpp:1072,1086): d_mask[i] = d_img[i] <= 254, on the context's SGM stream; feeds the
  * left_mask / right_mask arguments of wass_triangulate_dev.  Both pointers 4-byte aligned. */

@@ -129,6 +129,40 @@ def test_device_pointer_entry(gpu_ctx, oracle):
     assert t.total_ms > 0 and t.aggregate_launches >= 1 and t.cost_overflow == 0
 
 
+def test_uploads_are_ordered_before_the_calls_that_read_them(gpu_ctx):
+    """wass_upload_async copies on the context's copy stream; wass_burned_area_mask_dev and wass_sgm_disparity_dev wait for
+    the uploads that cover their inputs.  Several frames are uploaded back to back into a ring of buffers (as bench.py does,
+    one frame ahead) and every result must equal the one computed from inputs that were resident all along."""
+    import torch
+    w, h, D = 320, 200, 32
+    p = default_sgm_params(D, ndirs=8)
+    frames = [synth.make_pair(w, h, D, frame_idx=40 + k) for k in range(5)]
+    for r, _ in frames:
+        r[5:9, 7:30] = 255                                        # burned pixels for the mask
+    want = [gpu_ctx.sgm_disparity(r, l, p) for r, l in frames]
+    pinned = [(torch.from_numpy(r).pin_memory(), torch.from_numpy(l).pin_memory()) for r, l in frames]
+    ring = [tuple(torch.zeros((h, w), dtype=torch.uint8, device="cuda") for _ in range(3)) for _ in range(3)]
+    outs = [torch.empty((h, w), dtype=torch.int16, device="cuda") for _ in frames]
+    torch.cuda.synchronize()
+
+    def upload(k):
+        gpu_ctx.upload_async(ring[k % 3][0], pinned[k][0])
+        gpu_ctx.upload_async(ring[k % 3][1], pinned[k][1])
+    upload(0)
+    for k in range(len(frames)):
+        dr, dl, dm = ring[k % 3]
+        gpu_ctx.burned_area_mask_dev(dr, dm)
+        if k + 1 < len(frames):
+            upload(k + 1)
+        gpu_ctx.sgm_disparity_dev(dr, dl, p, outs[k])
+        if k == 2:
+            gpu_ctx.synchronize()
+            np.testing.assert_array_equal(dm.cpu().numpy(), (frames[k][0] <= 254).astype(np.uint8))
+    gpu_ctx.synchronize()
+    for k in range(len(frames)):
+        np.testing.assert_array_equal(outs[k].cpu().numpy(), want[k])
+
+
 def test_overflow_is_reported(gpu_ctx):
     """Costs beyond the int16 precondition (A.7) are flagged, not silently wrong."""
     import wass_amd

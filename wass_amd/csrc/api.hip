@@ -143,6 +143,7 @@ void wass_ctx_destroy(wass_ctx* c)
     if (c->ev_producer) (void)hipEventDestroy(c->ev_producer);
     if (c->ev_pack) (void)hipEventDestroy(c->ev_pack);
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
+    for (auto& u : c->uploads) if (u.ev) (void)hipEventDestroy(u.ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -194,6 +195,7 @@ int wass_sgm_disparity_dev(wass_ctx* c, const uint8_t* d_right, const uint8_t* d
     if (!p || !(p->dense_scale > 0)) return set_err(c, WASS_ERR_INVALID_ARG, "DENSE_SCALE must be positive");
     WASS_HIP(c, hipSetDevice(c->device));
     int rc;
+    if ((rc = wait_uploads(c, d_right, c->stream)) || (rc = wait_uploads(c, d_left, c->stream))) return rc;
     if (p->dense_scale != 1.0) {
         // wass_stereo.cpp:788-796: both crops resized with cv::resize INTER_CUBIC (x only when the scale is > 1) before the
         // padding; the disparity map comes out at that size (wass_dense_input_size)

@@ -150,6 +150,10 @@ struct wass_ctx {
     bool tail_overlap = false;
     hipStream_t ts() const { return tail_overlap ? tail : stream; }
     hipEvent_t ev_pack = nullptr, ev_copy = nullptr;
+    // wass_upload_async: uploads in flight on the copy stream, by destination; consumers wait for the matching event
+    struct UploadSlot { const char* dst = nullptr; size_t n = 0; hipEvent_t ev = nullptr; bool pending = false; };
+    UploadSlot uploads[8];
+    int upload_next = 0;
     wass::Buf rect_tab;            // fixed-point interpolation tables of the rectification resamplers (rectify.hip)
     bool rect_tab_ready = false;
     wass::Buf rect_mx, rect_my;    // staging for host-pointer map uploads
@@ -253,6 +257,7 @@ int launch_cost_volume(wass_ctx* c, const SgmDims& d);
 int launch_aggregate(wass_ctx* c, const SgmDims& d, int* n_launches);
 int launch_select(wass_ctx* c, const SgmDims& d);
 int launch_median_crop(wass_ctx* c, const SgmDims& d, int16_t* d_out);
+int wait_uploads(wass_ctx* c, const void* p, hipStream_t s);   // order s after the pending uploads that cover p
 int launch_median_full(wass_ctx* c, const SgmDims& d, int16_t* d_padded_out);   // the whole padded map (speckle filter path)
 // pipelined column-strip sweeps (sgm_trio.hip)
 size_t trio_halo_bytes(const SgmDims& d);

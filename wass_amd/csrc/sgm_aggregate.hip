@@ -326,13 +326,19 @@ CkptLayout ckpt_layout(const SgmDims& d)
     const bool legacy = agg && (!strcmp(agg, "trio") || !strcmp(agg, "concurrent") || !strcmp(agg, "rowsfirst"));
     const char* sp = getenv("WASS_SPLIT_ROWS");
     const bool split_rows = !legacy && (!sp || atoi(sp) != 0);
+    const char* sdg = getenv("WASS_SPLIT_DIAG");
+    const bool split_diag = !legacy && (!sdg || atoi(sdg) != 0);
+    const char* sc = getenv("WASS_SPLIT_COLS");
+    const bool split_cols = !legacy && d.ndirs == 8 && (!sc || atoi(sc) != 0);      // only the family that k_vsum_col produces
     auto add = [&](int dx, int dy, int smode) {
         const int f = L.nfam++;
         L.dx[f] = dx; L.dy[f] = dy; L.smode[f] = smode;
         L.nch[f] = dy == 0 ? d.h : (dx == 0 ? d.width1 : d.width1 + d.h - 1);
         int maxlen = dy == 0 ? d.width1 : (dx == 0 ? d.h : (d.width1 < d.h ? d.width1 : d.h));
-        // rows: 2 058 chains are two waves per SIMD -- split them in the middle (half_chain_geometry) for twice the waves
-        L.split[f] = split_rows && dy == 0;
+        // rows: 2 058 chains are two waves per SIMD -- split them in the middle (half_chain_geometry) for twice the waves.
+        // Measured at config B, same box, three runs each: columns split 1.40 -> 1.11 ms (k_vsum_col), diagonals split
+        // 7.90 -> 7.60 ms (aggregation): twice the waves, and the longest chain of a diagonal family halves.
+        L.split[f] = (split_rows && dy == 0) || (split_cols && dx == 0) || (split_diag && dx != 0 && dy != 0);
         if (L.split[f]) { L.nch[f] *= 2; maxlen = maxlen - maxlen / 2; }
         L.mseg[f] = (maxlen + L.K - 1) / L.K;
         const size_t b = (size_t)L.nch[f] * (L.mseg[f] + (L.split[f] ? 1 : 0)) * (64 * d.NP) * sizeof(uint32_t);   // + the end states

@@ -307,23 +307,36 @@ __global__ void __launch_bounds__(256) k_vsum(const uint32_t* __restrict__ hsum,
 // ---------------------------------------------------------------------------
 // ET > 0 (tile-fused schedule, sgm_tile.hip): instead of the checkpoints the wave stores the state with which path 2
 // enters every tile row (tile edge ET), i.e. it is that path's k_edge_sweep.
-template <int NP, int K, bool PATH2, int ET>
+// SPLIT (8-path pair schedule): the column family is cut in the middle like the row family (half_chain_geometry): wave
+// 2x walks rows 0 .. h/2-1 downwards with path 2, wave 2x+1 walks rows h-1 .. h/2 UPWARDS with path 6 -- the vertical
+// window sum does not care about the direction.  Both start from the all-zero state at an image border; each leaves its
+// final state in endstate[], where the pair kernel of the other half picks it up.  Twice the waves (2 456 columns are
+// only 2.4 waves per SIMD) for this kernel and for the family's pair kernel.
+template <int NP, int K, bool PATH2, int ET, bool SPLIT>
 __global__ void __launch_bounds__(256) k_vsum_col(const uint32_t* __restrict__ hsum, int width1, int h, int D, int SH2,
                                                   int P1, int P2, uint32_t* __restrict__ C, uint32_t* __restrict__ ckpt,
-                                                  int maxseg, uint32_t* __restrict__ S, uint32_t* __restrict__ flags)
+                                                  int maxseg, uint32_t* __restrict__ S, uint32_t* __restrict__ flags,
+                                                  uint32_t* __restrict__ endstate)
 {
+    static_assert(!SPLIT || (!PATH2 && ET == 0), "only the pair schedule's column family is split");
     extern __shared__ __attribute__((aligned(16))) uint32_t ringbuf[];   // [4 waves][WIN][NP][64]
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int x = blockIdx.x * 4 + wv;
+    const int c2 = blockIdx.x * 4 + wv;
+    const int x = SPLIT ? c2 >> 1 : c2;
     if (x >= width1) return;
+    const bool up = SPLIT && (c2 & 1);
+    const int n = SPLIT ? (up ? h - h / 2 : h / 2) : h;              // rows of this walk
+    const int ystart = up ? h - 1 : 0, dir = up ? -1 : 1;
+    // image row of logical row t of the walk, clamped like the window of the reference (replicated border rows)
+    auto yrow = [&](int t) { const int y = ystart + dir * t; return y < 0 ? 0 : (y > h - 1 ? h - 1 : y); };
     const int WIN = 2 * SH2 + 1;
     uint32_t* ring = ringbuf + (size_t)wv * WIN * NP * 64 + lane;
     const size_t vec = 64 * NP, rowstride = (size_t)width1 * vec;
     const uint32_t* hp = hsum + (size_t)x * vec + lane * NP;
     uint32_t* cp = C + (size_t)x * vec + lane * NP;
     uint32_t* ck = ET > 0 ? ckpt + (size_t)x * vec + lane * NP       // row-edge array of path 2: [tile row][x]
-                          : ckpt + (size_t)x * maxseg * vec + lane * NP;
+                          : ckpt + (size_t)c2 * maxseg * vec + lane * NP;
     uint32_t* sp = S + (size_t)x * vec + lane * NP;
     // the state after row y enters the next tile row at y + 1
     auto edge = [&](const PathState<NP>& s_, int y) {
@@ -338,9 +351,8 @@ __global__ void __launch_bounds__(256) k_vsum_col(const uint32_t* __restrict__ h
     us2 acc[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) acc[j] = pk_splat(0);
-    for (int k = 0; k < WIN; ++k) {                                   // ring slot k holds row clamp(k - SH2)
-        int yy = k - SH2;
-        yy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
+    for (int k = 0; k < WIN; ++k) {                                   // ring slot k holds logical row k - SH2
+        const int yy = yrow(k - SH2);
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             const uint32_t v = hp[(size_t)yy * rowstride + j];
@@ -349,21 +361,20 @@ __global__ void __launch_bounds__(256) k_vsum_col(const uint32_t* __restrict__ h
         }
     }
     bool over = false;
-    int slot = 0;                                                     // slot of row clamp(y - SH2): the one leaving next
+    int slot = 0;                                                     // slot of logical row t - SH2: the one leaving next
     PathState<NP> st;
     st.reset();
-    const int F = h / K, r = h - F * K;
-    const int ncp = F - (r > 0 ? 0 : 1);                              // checkpoints k_pair reads: end of segments 0..ncp-1
+    const int F = n / K, r = n - F * K;
+    // checkpoints k_pair reads: end of segments 0..ncp-1 (a split family keeps all of them, like k_ckpt)
+    const int ncp = SPLIT ? F : F - (r > 0 ? 0 : 1);
 
-    // rows entering the window while rows yb .. yb+K-1 are finished: min(y + SH2 + 1, h - 1)
-    auto fetch = [&](int yb, us2 (&dst)[K][NP]) {
+    // rows entering the window while logical rows tb .. tb+K-1 are finished: logical t + SH2 + 1
+    auto fetch = [&](int tb, us2 (&dst)[K][NP]) {
 #pragma unroll
-        for (int u = 0; u < K; ++u) {
-            const int ya = min(yb + u + SH2 + 1, h - 1);
-            ld_stream_vec<NP>(hp + (size_t)ya * rowstride, dst[u]);
-        }
+        for (int u = 0; u < K; ++u) ld_stream_vec<NP>(hp + (size_t)yrow(tb + u + SH2 + 1) * rowstride, dst[u]);
     };
-    auto row = [&](int y, const us2 (&in)[NP]) {
+    auto row = [&](int t, const us2 (&in)[NP]) {
+        const int y = ystart + dir * t;
         us2 cv[NP], L[NP];
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
@@ -392,7 +403,7 @@ __global__ void __launch_bounds__(256) k_vsum_col(const uint32_t* __restrict__ h
     // K rows at a time with the three dependent pieces decoupled: (a) the K vectors leaving the window are read from
     // the LDS ring back to back, (b) the K cost vectors are finished and stored, (c) the path recurrence runs over
     // them.  Needs K distinct ring slots, i.e. K <= WIN; narrower windows take the row-by-row form.
-    auto group = [&](int y0, const us2 (&in)[K][NP]) {
+    auto group = [&](int t0, const us2 (&in)[K][NP]) {
         us2 old[K][NP], cv[K][NP];
 #pragma unroll
         for (int u = 0; u < K; ++u) {
@@ -415,7 +426,7 @@ __global__ void __launch_bounds__(256) k_vsum_col(const uint32_t* __restrict__ h
                 acc[j] = acc[j] + in[u][j] - old[u][j];
                 ring[(sl * NP + j) * 64] = as_u32(in[u][j]);
             }
-            st_stream_vec<NP>(cp + (size_t)(y0 + u) * rowstride, cv[u]);
+            st_stream_vec<NP>(cp + (size_t)(ystart + dir * (t0 + u)) * rowstride, cv[u]);
         }
         slot += K;
         slot = slot >= WIN ? slot - WIN : slot;
@@ -423,12 +434,12 @@ __global__ void __launch_bounds__(256) k_vsum_col(const uint32_t* __restrict__ h
         for (int u = 0; u < K; ++u) {
             us2 L[NP];
             sgm_step<NP>(st, cv[u], L, P1v, P2);
-            edge(st, y0 + u);
+            edge(st, ystart + dir * (t0 + u));
             if (PATH2) {
                 us2 s2[NP];
 #pragma unroll
                 for (int j = 0; j < NP; ++j) s2[j] = pk_min(L[j], cap);
-                st_stream_vec<NP>(sp + (size_t)(y0 + u) * rowstride, s2);
+                st_stream_vec<NP>(sp + (size_t)(ystart + dir * (t0 + u)) * rowstride, s2);
             }
         }
     };
@@ -437,7 +448,7 @@ __global__ void __launch_bounds__(256) k_vsum_col(const uint32_t* __restrict__ h
     fetch(0, nb);
     const bool batched = K <= WIN;
     for (int s = 0; s < F; ++s) {
-        if ((s + 1) * K < h) fetch((s + 1) * K, nn);
+        if ((s + 1) * K < n) fetch((s + 1) * K, nn);
         if (batched) {
             group(s * K, nb);
         } else {
@@ -450,6 +461,7 @@ __global__ void __launch_bounds__(256) k_vsum_col(const uint32_t* __restrict__ h
 #pragma unroll
     for (int u = 0; u < K; ++u)
         if (u < r) row(F * K + u, nb[u]);
+    if (SPLIT) st.store_normalised(endstate + (size_t)c2 * vec + lane * NP);
     if (__any(over) && lane == 0) atomicOr(flags, 1u);
 }
 
@@ -482,10 +494,11 @@ static int launch_cost_np(wass_ctx* c, const SgmDims& d)
         const EdgeLayout el = edge_layout(d);
         int rc = ensure(c, c->edges, el.total);
         if (rc) return rc;
-        WASS_HIP(c, hipFuncSetAttribute((const void*)k_vsum_col<NP, K, false, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-        hipLaunchKernelGGL((k_vsum_col<NP, K, false, T>), dim3((d.width1 + 3) / 4), dim3(256), lds2, c->stream, (const uint32_t*)c->hsum.p,
+        WASS_HIP(c, hipFuncSetAttribute((const void*)k_vsum_col<NP, K, false, T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        hipLaunchKernelGGL((k_vsum_col<NP, K, false, T, false>), dim3((d.width1 + 3) / 4), dim3(256), lds2, c->stream, (const uint32_t*)c->hsum.p,
                            d.width1, d.h, d.D, d.SW2, d.P1, d.P2, (uint32_t*)c->C.p,
-                           (uint32_t*)((char*)c->edges.p + el.off_row[FAM_COLS][0]), 0, (uint32_t*)nullptr, (uint32_t*)c->flags.p);
+                           (uint32_t*)((char*)c->edges.p + el.off_row[FAM_COLS][0]), 0, (uint32_t*)nullptr, (uint32_t*)c->flags.p,
+                           (uint32_t*)nullptr);
         WASS_HIP(c, hipGetLastError());
         return WASS_OK;
     }
@@ -495,15 +508,22 @@ static int launch_cost_np(wass_ctx* c, const SgmDims& d)
         int rc = ensure(c, c->ckpt, lay.off[lay.nfam]);
         if (rc) return rc;
         const dim3 grid((d.width1 + 3) / 4), block(256);
-        if (lay.cols_from_cost) {
-            WASS_HIP(c, hipFuncSetAttribute((const void*)k_vsum_col<NP, K, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-            hipLaunchKernelGGL((k_vsum_col<NP, K, false, 0>), grid, block, lds2, c->stream, (const uint32_t*)c->hsum.p, d.width1, d.h, d.D,
+        if (lay.cols_from_cost && lay.split[0]) {
+            uint32_t* ckf = (uint32_t*)((char*)c->ckpt.p + lay.off[0]);
+            WASS_HIP(c, hipFuncSetAttribute((const void*)k_vsum_col<NP, K, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            hipLaunchKernelGGL((k_vsum_col<NP, K, false, 0, true>), dim3((2 * d.width1 + 3) / 4), block, lds2, c->stream, (const uint32_t*)c->hsum.p,
+                               d.width1, d.h, d.D, d.SW2, d.P1, d.P2, (uint32_t*)c->C.p, ckf, lay.mseg[0], (uint32_t*)c->S.p,
+                               (uint32_t*)c->flags.p, ckf + (size_t)lay.nch[0] * lay.mseg[0] * (64 * NP));
+        } else if (lay.cols_from_cost) {
+            WASS_HIP(c, hipFuncSetAttribute((const void*)k_vsum_col<NP, K, false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            hipLaunchKernelGGL((k_vsum_col<NP, K, false, 0, false>), grid, block, lds2, c->stream, (const uint32_t*)c->hsum.p, d.width1, d.h, d.D,
                                d.SW2, d.P1, d.P2, (uint32_t*)c->C.p, (uint32_t*)((char*)c->ckpt.p + lay.off[0]), lay.mseg[0],
-                               (uint32_t*)c->S.p, (uint32_t*)c->flags.p);
+                               (uint32_t*)c->S.p, (uint32_t*)c->flags.p, (uint32_t*)nullptr);
         } else {
-            WASS_HIP(c, hipFuncSetAttribute((const void*)k_vsum_col<NP, K, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-            hipLaunchKernelGGL((k_vsum_col<NP, K, true, 0>), grid, block, lds2, c->stream, (const uint32_t*)c->hsum.p, d.width1, d.h, d.D,
-                               d.SW2, d.P1, d.P2, (uint32_t*)c->C.p, (uint32_t*)c->ckpt.p, 0, (uint32_t*)c->S.p, (uint32_t*)c->flags.p);
+            WASS_HIP(c, hipFuncSetAttribute((const void*)k_vsum_col<NP, K, true, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            hipLaunchKernelGGL((k_vsum_col<NP, K, true, 0, false>), grid, block, lds2, c->stream, (const uint32_t*)c->hsum.p, d.width1, d.h, d.D,
+                               d.SW2, d.P1, d.P2, (uint32_t*)c->C.p, (uint32_t*)c->ckpt.p, 0, (uint32_t*)c->S.p, (uint32_t*)c->flags.p,
+                               (uint32_t*)nullptr);
         }
         WASS_HIP(c, hipGetLastError());
         return WASS_OK;
