@@ -209,6 +209,22 @@ def test_biggest_component_tie_break_and_empty(gpu_ctx, oracle):
     assert e.keep_biggest_component(1.0) == 0 and not e.download()[0].any()
 
 
+def test_mesh_may_outlive_its_context():
+    """A mesh destroyed after its context (garbage-collection order) frees its allocation instead of parking it for an owner
+    that no longer exists; a new context then works normally."""
+    import gc
+    c2 = wass_amd.Context(0)
+    m = c2.mesh_upload(np.ones((6, 7), np.uint8), np.zeros((6, 7, 3)))
+    c2.close()
+    del m
+    gc.collect()
+    c3 = wass_amd.Context(0)
+    m3 = c3.mesh_upload(np.ones((6, 7), np.uint8), np.ones((6, 7, 3)))
+    assert m3.download()[0].all()
+    del m3
+    c3.close()
+
+
 def test_ransac_sampler_matches_oracle(oracle):
     a = wass_amd.ransac_sample(210, 140, 400, 12345)
     b = oracle.ransac_sample(210, 140, 400, 12345)

@@ -112,6 +112,7 @@ int wass_ctx_create(int device_id, wass_ctx** out)
     if (ensure(c, c->flags, 64) != WASS_OK) { wass_ctx_destroy(c); return WASS_ERR_NO_MEMORY; }
     if (hipHostMalloc((void**)&c->h_flags, 64, hipHostMallocDefault) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_NO_MEMORY; }
     c->h_flags[0] = c->h_flags[4] = 0;
+    mesh_pool_ctx_alive(c, true);
     *out = c;
     return WASS_OK;
 }
@@ -123,6 +124,7 @@ void wass_ctx_destroy(wass_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->tail) (void)hipStreamSynchronize(c->tail);
     coll_release(c);
+    mesh_pool_ctx_alive(c, false);
     mesh_pool_purge(c);
     for (Buf* b : { &c->img1, &c->img2, &c->bt1, &c->bt2, &c->hsum, &c->C, &c->S, &c->S2, &c->halo, &c->ckpt, &c->edges, &c->sel_d16, &c->sel_key, &c->raw,
                     &c->flags, &c->tmp_in0, &c->tmp_in1, &c->tmp_out, &c->tmp_mask, &c->fA, &c->fB, &c->fC, &c->fD, &c->fE, &c->uf, &c->rs_r, &c->rs_l, &c->raw2, &c->grid, &c->scratch, &c->counters, &c->dstate, &c->rect_tab, &c->rect_mx, &c->rect_my, &c->xyzc, &c->limits })

@@ -249,6 +249,7 @@ int biggest_component_dev(wass_ctx* c, float* disp, int w, int h, int threshold,
 int resize_inputs_dev(wass_ctx* c, const uint8_t* src, int w, int h, size_t pitch, uint8_t* dst, int ws, int hs, double fx, double fy,
                       hipStream_t s);
 int resize_f32_dev(wass_ctx* c, const float* src, int sw, int sh, float* dst, int dw, int dh, bool cubic, hipStream_t s);
+void mesh_pool_ctx_alive(const void* ctx, bool alive);   // mesh.hip: only live contexts get allocations parked for them
 void mesh_pool_purge(const void* owner);      // mesh.hip: parked mesh allocations of a context that is going away
 
 // stage launchers (each enqueues on c->stream)

@@ -1000,6 +1000,15 @@ __global__ void __launch_bounds__(256) k_deinterleave(const double* __restrict__
 struct PoolEntry { void* p; size_t bytes; int device; const void* owner; };
 static PoolEntry g_pool[8];
 static std::mutex g_pool_mu;
+// contexts that exist: a mesh may be destroyed AFTER its context (a garbage collector picks the order), and an
+// allocation parked under a dead owner would never be purged -- or be handed to a new context at the same address
+static const void* g_live[64];
+void mesh_pool_ctx_alive(const void* ctx, bool alive)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (auto& e : g_live)
+        if (alive ? e == nullptr : e == ctx) { e = alive ? ctx : nullptr; return; }
+}
 static void* pool_take(size_t bytes, int device, const void* owner)
 {
     std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -1010,6 +1019,9 @@ static void* pool_take(size_t bytes, int device, const void* owner)
 static bool pool_give(void* p, size_t bytes, int device, const void* owner)
 {
     std::lock_guard<std::mutex> lk(g_pool_mu);
+    bool live = false;
+    for (const void* e : g_live) live = live || e == owner;
+    if (!live) return false;                                     // the caller frees the allocation
     for (auto& e : g_pool)
         if (!e.p) { e.p = p; e.bytes = bytes; e.device = device; e.owner = owner; return true; }
     return false;

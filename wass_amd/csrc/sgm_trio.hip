@@ -16,8 +16,12 @@
 // fence, no s_waitcnt on the producer -- then writes the 0xFF pattern back so the buffer is ready for the next
 // frame.  Loads for row t+1 are issued during row t, so a consumer that lags (the steady state) never waits.
 // Every spin is bounded; on time-out the wave raises flags[0] bit 1 and leaves (the host then re-initialises
-// the buffer and reports an error) -- no hang.  All waves of a launch are resident at once (one 64-thread
-// workgroup per strip; <= 1228 strips even at 4K), so a producer can always run.
+// the buffer and reports an error) -- no hang.  Forward progress is NOT guaranteed by residency: a launch has up to
+// 1228 one-wave workgroups and the kernel runs about one wave per SIMD (1024 slots, fewer when other streams hold
+// some), so it relies on workgroups being dispatched in ascending order -- a producer strip is then always resident or
+// finished before its consumer spins.  That order is what the hardware does but no API promises it; if it ever failed,
+// consumers would run into the spin bound and the frame would be reported as failed (never a wrong result, never a
+// hang).  This schedule is an opt-in experiment (WASS_AGG=trio), not the production path.
 //
 // Compared with the chain kernels (sgm_aggregate.hip) this needs no checkpoint sweep and no forward
 // recomputation: per cell, C is read once and S written once for three paths.
