@@ -21,6 +21,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=8)
 ap.add_argument("--config", default="B")
+ap.add_argument("--procs", default="1,2,4", help="worker processes per GPU to try with wass_stereo_batch")
+ap.add_argument("--skip-single", action="store_true", help="skip the one-process-per-frame runs")
 args = ap.parse_args()
 import numpy as np  # noqa: E402
 from test_cli import _write_png, _write_xml  # noqa: E402
@@ -52,7 +54,7 @@ def timed(cmd, env=None):
     return time.perf_counter() - t0, r
 
 
-for dbg in ("1", "0"):
+for dbg in (() if args.skip_single else ("1", "0")):
     env = dict(os.environ, WASS_DEBUG_IMAGES=dbg)
     ts = []
     for i in range(min(3, args.frames)):
@@ -62,7 +64,7 @@ for dbg in ("1", "0"):
     print(f"wass_stereo, one process per frame, debug pictures {'on' if dbg == '1' else 'off'}: {min(ts):.2f} s/frame (best of {len(ts)})")
     if dbg == "0":
         print("  time table of the last run:\n" + "\n".join(l for l in r.stdout.splitlines() if "|" in l and "P|" not in l))
-for procs in (1, 2, 4):
+for procs in [int(x) for x in args.procs.split(",")]:
     t, r = timed([build.BATCH, cfg, "--sequence", seq, "--procs-per-gpu", str(procs)])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     print(f"wass_stereo_batch, {procs} worker process(es) on one GPU, {args.frames} frames: {t:.2f} s total = {t / args.frames:.3f} s/frame = "
