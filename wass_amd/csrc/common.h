@@ -151,7 +151,7 @@ struct wass_ctx {
     hipStream_t ts() const { return tail_overlap ? tail : stream; }
     hipEvent_t ev_pack = nullptr, ev_copy = nullptr;
     // wass_upload_async: uploads in flight on the copy stream, by destination; consumers wait for the matching event
-    struct UploadSlot { const char* dst = nullptr; size_t n = 0; hipEvent_t ev = nullptr; bool pending = false; };
+    struct UploadSlot { const char* dst = nullptr; size_t n = 0; hipEvent_t ev = nullptr; bool pending = false, consumed = false; };
     UploadSlot uploads[8];
     int upload_next = 0;
     wass::Buf rect_tab;            // fixed-point interpolation tables of the rectification resamplers (rectify.hip)

@@ -364,8 +364,8 @@ int wait_uploads(wass_ctx* c, const void* p, hipStream_t s)
 {
     for (auto& u : c->uploads)
         if (u.pending && (const char*)p >= u.dst && (const char*)p < u.dst + u.n) {
-            WASS_HIP(c, hipStreamWaitEvent(s, u.ev, 0));
-            u.pending = false;
+            WASS_HIP(c, hipStreamWaitEvent(s, u.ev, 0));       // stays pending: another stream may read the same buffer
+            u.consumed = true;
         }
     return WASS_OK;
 }
@@ -378,9 +378,9 @@ extern "C" int wass_upload_async(wass_ctx* c, void* d_dst, const void* h_src, si
     auto& u = c->uploads[c->upload_next];
     c->upload_next = (c->upload_next + 1) % 8;
     if (!u.ev) WASS_HIP(c, hipEventCreateWithFlags(&u.ev, hipEventDisableTiming));
-    if (u.pending) WASS_HIP(c, hipStreamWaitEvent(c->stream, u.ev, 0));     // never consumed: order it conservatively
+    if (u.pending && !u.consumed) WASS_HIP(c, hipStreamWaitEvent(c->stream, u.ev, 0));     // never consumed: order it conservatively
     WASS_HIP(c, hipMemcpyAsync(d_dst, h_src, nbytes, hipMemcpyHostToDevice, c->copy));
     WASS_HIP(c, hipEventRecord(u.ev, c->copy));
-    u.dst = (const char*)d_dst; u.n = nbytes; u.pending = true;
+    u.dst = (const char*)d_dst; u.n = nbytes; u.pending = true; u.consumed = false;
     return WASS_OK;
 }
