@@ -249,6 +249,11 @@ typedef struct {
 /* refine_plane (:581-660): weighted PCA plane through the inliers */
 int wass_mesh_refine_plane(wass_ctx* ctx, wass_mesh* m, const wass_refine_params* rp,
                            double plane_out[4], uint64_t* n_inliers);
+/* plane_refinement_inliers.xyz (wass_stereo.cpp:2077-2085): the points main() writes after refine_plane -- every
+ * `every`-th (10) refinement inlier of PovMesh.cpp:590-606 in raster order -- selected on the device.  *xyz_out: malloc'ed
+ * n_out x 3 doubles (release with wass_free); NULL when there is none. */
+int wass_mesh_refinement_inliers(wass_ctx* ctx, wass_mesh* m, const wass_refine_params* rp, int every, double** xyz_out,
+                                 uint64_t* n_out);
 /* Fused forms of the calls above for throughput: same results, but every intermediate decision (radix-select
  * digits, winning component, best RANSAC candidate, centroid, 3x3 eigenvector) is taken on the device and the
  * host reads back once.

@@ -246,7 +246,12 @@ def _check_outputs(r, wd, oracle, f, roi_l, roi_r, geom, right, left, min_fill):
     # mesh.ply header (PovMesh.cpp:473-483)
     head = open(os.path.join(wd, "mesh.ply"), "rb").read(200).decode("latin1")
     assert head.startswith(f"ply\nformat binary_little_endian 1.0\nelement vertex {npts}\nproperty float x\n")
-    assert os.path.exists(os.path.join(wd, "plane_refinement_inliers.xyz"))
+    # plane_refinement_inliers.xyz: "x y z" per line in the stream's default (%g) format (wass_stereo.cpp:2077-2085)
+    lines = open(os.path.join(wd, "plane_refinement_inliers.xyz")).read().splitlines()
+    assert len(lines) > 100
+    for ln in lines[:50] + lines[-50:]:
+        toks = ln.split(" ")
+        assert len(toks) == 3 and all("%g" % float(t) == t for t in toks), ln
 
 
 @pytest.mark.gpu

@@ -209,6 +209,31 @@ def test_biggest_component_tie_break_and_empty(gpu_ctx, oracle):
     assert e.keep_biggest_component(1.0) == 0 and not e.download()[0].any()
 
 
+@pytest.mark.parametrize("central", [False, True])
+def test_refinement_inliers_are_selected_on_the_device(gpu_ctx, central):
+    """wass_mesh_refinement_inliers == every 10th point that passes refine_plane's tests (PovMesh.cpp:590-606), counted in
+    raster order over the (optionally central-third) window -- what wass_stereo.cpp:2077-2085 writes to
+    plane_refinement_inliers.xyz."""
+    rng = np.random.default_rng(3)
+    h, w = 123, 517                                               # several 256-point blocks per row, ragged last block
+    p3d = rng.normal(0, 30, (h, w, 3))
+    p3d[..., 2] += 60
+    valid = (rng.random((h, w)) < 0.8).astype(np.uint8)
+    m = gpu_ctx.mesh_upload(valid, p3d)
+    kw = dict(xmin=-40.0, xmax=35.0, ymin=-50.0, ymax=45.0, max_distance=75.0)
+    got = m.refinement_inliers(every=10, central_third_only=central, **kw)
+    u0, u1, v0, v1 = (w // 4, w * 3 // 4, h // 4, h * 2 // 3) if central else (0, w - 1, 0, h - 1)
+    uu, vv = np.meshgrid(np.arange(w), np.arange(h))
+    x, y, z = p3d[..., 0], p3d[..., 1], p3d[..., 2]
+    ok = (valid != 0) & (uu >= u0) & (uu <= u1) & (vv >= v0) & (vv <= v1) & (x > kw["xmin"]) & (x < kw["xmax"]) & \
+         (y > kw["ymin"]) & (y < kw["ymax"]) & (np.sqrt(x * x + y * y + z * z) < kw["max_distance"])
+    want = p3d[ok][::10]                                          # boolean indexing walks the grid in raster order
+    np.testing.assert_array_equal(got, want)
+    assert m.refinement_inliers(every=1, central_third_only=central, **kw).shape[0] == ok.sum()
+    empty = gpu_ctx.mesh_upload(np.zeros((5, 6), np.uint8), np.zeros((5, 6, 3)))
+    assert empty.refinement_inliers().shape == (0, 3)
+
+
 def test_mesh_may_outlive_its_context():
     """A mesh destroyed after its context (garbage-collection order) frees its allocation instead of parking it for an owner
     that no longer exists; a new context then works normally."""

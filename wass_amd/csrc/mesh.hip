@@ -757,6 +757,42 @@ __global__ void __launch_bounds__(256) k_refine_cov(const uint8_t* __restrict__ 
     block_sum_store<6>(acc, partial);
 }
 
+// plane_refinement_inliers.xyz (wass_stereo.cpp:2077-2085 writes every 10th refinement inlier, in raster order): the
+// selection runs on the device so that the host fetches ~150 000 points instead of the whole 126 MB mesh.
+// pass 1: refinement inliers per block of 256 points; pass 2 (after the scan): inlier number k of the raster order is
+// kept when k % every == 0, at position k / every.
+__global__ void __launch_bounds__(256) k_inlier_counts(const uint8_t* __restrict__ valid, const double* __restrict__ X,
+                                                       const double* __restrict__ Y, const double* __restrict__ Z, int w, size_t n,
+                                                       RefineDev rp, unsigned int* __restrict__ blockcnt)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    double px, py, pz, wt;
+    const bool in = i < n && refine_inlier(rp, valid, X, Y, Z, w, i, px, py, pz, wt);
+    const int c = __syncthreads_count(in);
+    if (threadIdx.x == 0) blockcnt[blockIdx.x] = (unsigned)c;
+}
+__global__ void __launch_bounds__(256) k_inlier_pack(const uint8_t* __restrict__ valid, const double* __restrict__ X,
+                                                     const double* __restrict__ Y, const double* __restrict__ Z, int w, size_t n,
+                                                     RefineDev rp, const unsigned int* __restrict__ blockoff, unsigned int every,
+                                                     double* __restrict__ out)
+{
+    __shared__ unsigned int wsum[4];
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    double px = 0, py = 0, pz = 0, wt;
+    const bool in = i < n && refine_inlier(rp, valid, X, Y, Z, w, i, px, py, pz, wt);
+    const unsigned long long bal = __ballot(in);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) wsum[wv] = (unsigned)__popcll(bal);
+    __syncthreads();
+    unsigned int k = blockoff[blockIdx.x];
+    for (int q = 0; q < wv; ++q) k += wsum[q];
+    k += (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+    if (in && k % every == 0) {
+        double* o = out + (size_t)(k / every) * 3;
+        o[0] = px; o[1] = py; o[2] = pz;
+    }
+}
+
 // smallest-eigenvalue eigenvector of a symmetric 3x3 (cyclic Jacobi); stands in for row 2 of cv::SVD's vt
 __host__ __device__ static void smallest_eigvec3(const double Ain[9], double vout[3])
 {
@@ -1669,6 +1705,46 @@ int wass_mesh_refine_plane(wass_ctx* c, wass_mesh* m, const wass_refine_params* 
     if (nrm[2] < 0) { nrm[0] *= -1.0; nrm[1] *= -1.0; nrm[2] *= -1.0; }   // :646-649
     plane_out[0] = nrm[0]; plane_out[1] = nrm[1]; plane_out[2] = nrm[2];
     plane_out[3] = -(nrm[0] * cx + nrm[1] * cy + nrm[2] * cz);
+    return WASS_OK;
+}
+
+int wass_mesh_refinement_inliers(wass_ctx* c, wass_mesh* m, const wass_refine_params* rp, int every, double** xyz_out, uint64_t* n_out)
+{
+    if (!c || !m || !rp || !xyz_out || !n_out || every <= 0) return set_err(c, WASS_ERR_INVALID_ARG, "bad argument");
+    WASS_HIP(c, hipSetDevice(c->device));
+    *xyz_out = nullptr; *n_out = 0;
+    RefineDev rd;
+    rd.xmin = rp->xmin; rd.xmax = rp->xmax; rd.ymin = rp->ymin; rd.ymax = rp->ymax; rd.maxd = rp->max_distance;
+    rd.weighted = rp->weight_by_distance;
+    rd.umin = rp->central_third_only ? m->w / 4 : 0;
+    rd.umax = rp->central_third_only ? m->w * 3 / 4 : m->w - 1;
+    rd.vmin = rp->central_third_only ? m->h / 4 : 0;
+    rd.vmax = rp->central_third_only ? m->h * 2 / 3 : m->h - 1;
+    const size_t n = m->n();
+    const unsigned nb = nblk(n);
+    const size_t cap = (n + (size_t)every - 1) / (size_t)every;                 // at most every point is an inlier
+    const size_t off_cnt = 64, off_out = (off_cnt + (size_t)nb * 4 + 255) & ~(size_t)255;
+    int rc = ensure(c, c->scratch, off_out + cap * 24);
+    if (rc) return rc;
+    unsigned int* total = (unsigned int*)c->scratch.p;
+    unsigned int* bcnt = (unsigned int*)((char*)c->scratch.p + off_cnt);
+    double* dout = (double*)((char*)c->scratch.p + off_out);
+    hipStream_t s = c->ts();
+    hipLaunchKernelGGL(k_inlier_counts, dim3(nb), dim3(256), 0, s, m->valid, m->x, m->y, m->z, m->w, n, rd, bcnt);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, bcnt, (int)nb, total);
+    hipLaunchKernelGGL(k_inlier_pack, dim3(nb), dim3(256), 0, s, m->valid, m->x, m->y, m->z, m->w, n, rd, (const unsigned int*)bcnt,
+                       (unsigned)every, dout);
+    unsigned int ht = 0;
+    WASS_HIP(c, hipMemcpyAsync(&ht, total, 4, hipMemcpyDeviceToHost, s));
+    WASS_HIP(c, hipStreamSynchronize(s));
+    const size_t keep = ((size_t)ht + (size_t)every - 1) / (size_t)every;
+    if (keep == 0) return WASS_OK;
+    double* host = (double*)malloc(keep * 24);
+    if (!host) return set_err(c, WASS_ERR_NO_MEMORY, "out of host memory");
+    hipError_t e = hipMemcpyAsync(host, dout, keep * 24, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { free(host); return set_err(c, WASS_ERR_DEVICE, "download: %s", hipGetErrorString(e)); }
+    *xyz_out = host; *n_out = keep;
     return WASS_OK;
 }
 

@@ -449,6 +449,19 @@ class Mesh:
         self.ctx._check(self.ctx._lib.wass_mesh_refine_plane(self.ctx._h, self._h, C.byref(rp), plane, C.byref(n)))
         return np.array(plane[:]), int(n.value)
 
+    def refinement_inliers(self, every=10, xmin=-9999., xmax=9999., ymin=-9999., ymax=9999., max_distance=70.0,
+                           central_third_only=False) -> np.ndarray:
+        """The points of plane_refinement_inliers.xyz (wass_stereo.cpp:2077-2085): every `every`-th refinement inlier in raster
+        order, selected on the device; (n, 3) float64."""
+        rp = RefineParams(xmin, xmax, ymin, ymax, max_distance, 1, int(central_third_only))
+        ptr = C.POINTER(C.c_double)(); n = C.c_uint64()
+        self.ctx._check(self.ctx._lib.wass_mesh_refinement_inliers(self.ctx._h, self._h, C.byref(rp), int(every), C.byref(ptr), C.byref(n)))
+        if not n.value:
+            return np.zeros((0, 3))
+        out = np.ctypeslib.as_array(ptr, shape=(n.value, 3)).copy()
+        self.ctx._lib.wass_free(ptr)
+        return out
+
     def encode_xyzc_to(self, plane, dst_ptr: int, capacity: int) -> int:
         """mesh_cam.xyzC bytes into a caller-owned host buffer (e.g. a pinned torch tensor); returns the size."""
         nb = C.c_size_t()
