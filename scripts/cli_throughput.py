@@ -22,6 +22,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=8)
 ap.add_argument("--config", default="B")
 ap.add_argument("--procs", default="1,2,4", help="worker processes per GPU to try with wass_stereo_batch")
+ap.add_argument("--replicate", type=int, default=1, help="extra copies of every workdir (inputs symlinked) so that a long sequence is cheap to set up")
 ap.add_argument("--skip-single", action="store_true", help="skip the one-process-per-frame runs")
 args = ap.parse_args()
 import numpy as np  # noqa: E402
@@ -63,6 +64,17 @@ for i in range(args.frames):
     _write_xml(os.path.join(wd, "ext_T.xml"), "T", np.array(rig["T"]).reshape(3, 1) * 2.5)
 
 
+nframes = args.frames
+for r in range(1, args.replicate):
+    for i in range(args.frames):
+        src = os.path.join(seq, "%06d_wd" % i)
+        dst = os.path.join(seq, "%06d_wd" % nframes)
+        os.makedirs(os.path.join(dst, "undistorted"))
+        for f in ("undistorted/00000000.png", "undistorted/00000001.png", "intrinsics_00000000.xml", "intrinsics_00000001.xml", "ext_R.xml", "ext_T.xml"):
+            os.symlink(os.path.join(src, f), os.path.join(dst, f))
+        nframes += 1
+
+
 def timed(cmd, env=None):
     t0 = time.perf_counter()
     r = subprocess.run(cmd, capture_output=True, text=True, env=env)
@@ -82,7 +94,7 @@ for dbg in (() if args.skip_single else ("1", "0")):
 for procs in [int(x) for x in args.procs.split(",")]:
     t, r = timed([build.BATCH, cfg, "--sequence", seq, "--procs-per-gpu", str(procs)])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    print(f"wass_stereo_batch, {procs} worker process(es) on one GPU, {args.frames} frames: {t:.2f} s total = {t / args.frames:.3f} s/frame = "
-          f"{args.frames / t:.2f} frames/s")
-log = open(os.path.join(seq, "%06d_wd" % (args.frames - 1), "wass_stereo_log.txt")).read()
+    print(f"wass_stereo_batch, {procs} worker process(es) on one GPU, {nframes} frames: {t:.2f} s total = {t / nframes:.3f} s/frame = "
+          f"{nframes / t:.2f} frames/s")
+log = open(os.path.join(seq, "%06d_wd" % (nframes - 1), "wass_stereo_log.txt")).read()
 print("  time table of the last frame of the batch (persistent context):\n" + "\n".join(l for l in log.splitlines() if "|" in l and "P|" not in l))
