@@ -211,6 +211,19 @@ int wass_triangulate_dev(wass_ctx* ctx, const float* d_disp_roi, int W, int H,
                          const uint8_t* d_right_img, int img_w, int img_h,
                          const uint8_t* d_left_mask, const uint8_t* d_right_mask,
                          const wass_tri_params* tp, wass_mesh** out, uint64_t* n_pts);
+/* Why triangulate kept or rejected each pixel of the grid: what the reference paints into its debug pictures
+ * undistorted/R0.jpg (low nibble) and R1.jpg (high nibble), wass_stereo.cpp:1111-1119,1216-1338.  codes_out: width x
+ * height bytes (host). */
+enum {
+    WASS_CODE_NONE = 0,            /* not processed (no disparity): black */
+    WASS_CODE_GREY = 1,            /* triangulated: the rectified image's grey value */
+    WASS_CODE_OUTSIDE_IMAGE = 2,   /* teal   (255,255,0) BGR */
+    WASS_CODE_OUTSIDE_BBOX = 3,    /* yellow (0,255,255): outside the bounding box or masked out */
+    WASS_CODE_ANGLE = 4,           /* green  (0,255,0): rays too parallel */
+    WASS_CODE_TOO_CLOSE = 5,       /* blue   (255,0,0) */
+    WASS_CODE_TOO_DISTANT = 6      /* red    (0,0,255) */
+};
+int wass_mesh_reject_codes(wass_ctx* ctx, const wass_mesh* m, uint8_t* codes_out);
 void wass_mesh_destroy(wass_mesh* m);
 int wass_mesh_size(const wass_mesh* m, int* width, int* height);
 /* copy the cloud to host (test hook, PLY / xyzbin writers): valid[w*h],

@@ -352,6 +352,13 @@ def test_debug_pictures_of_the_reference_are_written(cli, tmp_path, oracle):
     cov = _read_png(os.path.join(wd, "disparity_coverage.png"))
     assert cov.shape == (h // 2, w // 2, 3) and (cov[h // 4, w // 4] == [right[h // 2:h // 2 + 2, w // 2:w // 2 + 2].astype(int).sum() + 2 >> 2, 100,
                                                                          right[h // 2:h // 2 + 2, w // 2:w // 2 + 2].astype(int).sum() + 2 >> 2]).all()
+    # undistorted/R0, R1 (wass_stereo.cpp:1381-1382): grey of the rectified right / matched left pixel where a point was made
+    R0 = _read_png(os.path.join(wd, "undistorted", "R0.png")); R1 = _read_png(os.path.join(wd, "undistorted", "R1.png"))
+    assert R0.shape == (h, w, 3) and R1.shape == (h, w, 3)
+    grey0 = (R0[..., 0] == R0[..., 1]) & (R0[..., 1] == R0[..., 2]) & (R0.sum(-1) > 0)
+    assert grey0.mean() > 0.5 and (R0[grey0][:, 0] == right[grey0]).mean() > 0.99     # identity rectification: R0's grey IS the right image
+    grey1 = (R1[..., 0] == R1[..., 1]) & (R1[..., 1] == R1[..., 2]) & (R1.sum(-1) > 0)
+    assert grey1.mean() > 0.5
     gc = _read_png(os.path.join(wd, "graph_components.png"))
     assert gc.shape == (h // 2, w // 2, 3) and (gc[..., 1] == 255).mean() > 0.5 and (gc[..., 0] == 0).all()
     # WASS_DEBUG_IMAGES=0 switches them off

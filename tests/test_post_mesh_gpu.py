@@ -127,6 +127,15 @@ def test_triangulate_parity(gpu_ctx, oracle, use_custom):
     np.testing.assert_allclose(p3d[both], p_ref[both], rtol=1e-12, atol=1e-12)   # fp64, same op order
     np.testing.assert_array_equal(gray[both], g_ref[both])
     assert (p3d[valid == 0] == 0).all()
+    # what the reference paints into undistorted/R0.jpg / R1.jpg (wass_stereo.cpp:1216-1338): grey exactly where a point was
+    # made, black where there was no disparity, yellow in R0 only where only the LEFT mask rejected the pixel
+    c0, c1 = mesh.reject_codes()
+    GREY, NONE, BBOX = 1, 0, 3
+    np.testing.assert_array_equal((c0 == GREY) & (c1 == GREY), valid == 1)
+    assert ((c0 == NONE) == (c1 == NONE)).all() and (c0[droi <= 1.0] == NONE).all() and (c0 == NONE).sum() < 0.5 * c0.size
+    left_only = (c0 == BBOX) & (c1 == GREY)
+    assert 0.01 * c0.size < left_only.sum() < 0.12 * c0.size          # the left mask drops 5 % of the pixels at random
+    assert set(np.unique(c0)) <= {0, 1, 2, 3, 4, 5, 6} and set(np.unique(c1)) <= {0, 1, 2, 3, 4, 5, 6}
 
 
 def test_triangulate_depth_matches_ground_truth(gpu_ctx):

@@ -183,6 +183,7 @@ struct wass_mesh {
     double* y = nullptr;
     double* z = nullptr;
     uint8_t* gray = nullptr;
+    uint8_t* codes = nullptr;      // why triangulate kept or rejected a pixel (R0 / R1 debug pictures), WASS_CODE_*
     size_t bytes = 0;
     int device = 0;
     const void* owner = nullptr;   // the context whose stream orders every use of this allocation

@@ -109,7 +109,8 @@ __global__ void __launch_bounds__(256) k_triangulate(const float* __restrict__ d
                                                      double by0, double bx1, double by1, double cam_distance,
                                                      uint8_t* __restrict__ valid, double* __restrict__ X,
                                                      double* __restrict__ Y, double* __restrict__ Z,
-                                                     uint8_t* __restrict__ gray, unsigned long long* __restrict__ count)
+                                                     uint8_t* __restrict__ gray, uint8_t* __restrict__ codes,
+                                                     unsigned long long* __restrict__ count)
 {
     unsigned int found = 0;
     const size_t npx = (size_t)mw * mh;
@@ -118,6 +119,9 @@ __global__ void __launch_bounds__(256) k_triangulate(const float* __restrict__ d
     bool ok = false;
     double P[3] = { 0, 0, 0 };
     uint8_t gv = 0;
+    // what the reference paints into dbg_R0 (low nibble) / dbg_R1 (high nibble) for this pixel (:1216-1338); later
+    // assignments overwrite earlier ones exactly as there
+    unsigned int c0 = WASS_CODE_NONE, c1 = WASS_CODE_NONE;
     const float dv = disp[idx];
     const int xr = rrx + u, yr = rry + v;
     if (dv > 1.0f) {                                                  // min_disp = 1 (:1100,1177)
@@ -128,15 +132,19 @@ __global__ void __launch_bounds__(256) k_triangulate(const float* __restrict__ d
             unrectify(g, (double)xl, (double)yl, true, pi);
             unrectify(g, (double)xr, (double)yr, false, qi);
             bool skip = false;
+            c0 = c1 = WASS_CODE_GREY;
             if (pi[0] < 1 || pi[0] >= img_w - 1 || pi[1] < 1 || pi[1] >= img_h - 1 ||
-                qi[0] < 1 || qi[0] >= img_w - 1 || qi[1] < 1 || qi[1] >= img_h - 1)
+                qi[0] < 1 || qi[0] >= img_w - 1 || qi[1] < 1 || qi[1] >= img_h - 1) {
                 skip = true;                                          // :1223
+                c0 = c1 = WASS_CODE_OUTSIDE_IMAGE;
+            }
             const double p[2] = { (pi[0] - g.Kl[2]) / g.Kl[0], (pi[1] - g.Kl[5]) / g.Kl[4] };
             const double q[2] = { (qi[0] - g.Kr[2]) / g.Kr[0], (qi[1] - g.Kr[5]) / g.Kr[4] };
-            if (pi[0] <= bx0 || pi[1] <= by0 || pi[0] >= bx1 || pi[1] >= by1) skip = true;   // :1236
-            if (!skip) {                                              // :1244,1250 (short-circuited: no OOB reads)
-                if (lmask && lmask[(size_t)(int)pi[1] * img_w + (int)pi[0]] == 0) skip = true;
-                if (rmask && rmask[(size_t)(int)qi[1] * img_w + (int)qi[0]] == 0) skip = true;
+            const bool inside = !skip;
+            if (pi[0] <= bx0 || pi[1] <= by0 || pi[0] >= bx1 || pi[1] >= by1) { skip = true; c0 = c1 = WASS_CODE_OUTSIDE_BBOX; }   // :1236
+            if (inside) {                                             // :1244,1250 (only where the reference's reads are in bounds)
+                if (lmask && lmask[(size_t)(int)pi[1] * img_w + (int)pi[0]] == 0) { skip = true; c0 = WASS_CODE_OUTSIDE_BBOX; }
+                if (rmask && rmask[(size_t)(int)qi[1] * img_w + (int)qi[0]] == 0) { skip = true; c1 = WASS_CODE_OUTSIDE_BBOX; }
             }
             if (min_angle > 0) {                                      // :1258-1269
                 double d1[3] = { p[0], p[1], 1.0 }, qq[3] = { q[0], q[1], 1.0 }, d2[3];
@@ -147,13 +155,15 @@ __global__ void __launch_bounds__(256) k_triangulate(const float* __restrict__ d
                 d1[0] /= n1; d1[1] /= n1; d1[2] /= n1;
                 d2[0] /= n2; d2[1] /= n2; d2[2] /= n2;
                 const double ang = fabs(acos(d1[0] * d2[0] + d1[1] * d2[1] + d1[2] * d2[2]) * 57.29577951);
-                if (ang < min_angle) skip = true;
+                if (ang < min_angle) { skip = true; c0 = c1 = WASS_CODE_ANGLE; }
             }
             if (!skip) {
                 triangulate_point(p, q, g.R, g.T, P);                 // :1286
                 const double dist = sqrt(P[0] * P[0] + P[1] * P[1] + P[2] * P[2]);
-                if (!(dist < cam_distance / 10.0 || P[2] < 1.0) && !(dist > cam_distance * 200.0 || P[2] > 1E30)) {
-                    ok = true;                                        // :1329-1340
+                if (dist < cam_distance / 10.0 || P[2] < 1.0) c0 = c1 = WASS_CODE_TOO_CLOSE;             // :1329
+                else if (dist > cam_distance * 200.0 || P[2] > 1E30) c0 = c1 = WASS_CODE_TOO_DISTANT;   // :1335
+                else {
+                    ok = true;
                     gv = right_img[(size_t)(int)qi[1] * img_w + (int)qi[0]];   // :1342
                 }
             }
@@ -162,6 +172,7 @@ __global__ void __launch_bounds__(256) k_triangulate(const float* __restrict__ d
     valid[idx] = ok ? 1 : 0;
     X[idx] = ok ? P[0] : 0.0; Y[idx] = ok ? P[1] : 0.0; Z[idx] = ok ? P[2] : 0.0;
     gray[idx] = gv;
+    codes[idx] = (uint8_t)(c0 | (c1 << 4));
     found += ok ? 1u : 0u;
     }
     for (int o = 32; o > 0; o >>= 1) found += __shfl_down(found, o);
@@ -1076,14 +1087,15 @@ static int mesh_alloc(wass_ctx* c, int w, int h, wass_mesh** out)
     if (!m) return set_err(c, WASS_ERR_NO_MEMORY, "out of host memory");
     m->w = w; m->h = h;
     const size_t n = m->n();
-    // one allocation: x | y | z | valid | gray
-    const size_t bytes = n * 8 * 3 + ((n + 255) & ~(size_t)255) * 2;
+    // one allocation: x | y | z | valid | gray | codes
+    const size_t bytes = n * 8 * 3 + ((n + 255) & ~(size_t)255) * 3;
     m->bytes = bytes; m->device = c->device; m->owner = c;
     void* base = pool_take(bytes, c->device, c);
     if (!base && hipMalloc(&base, bytes) != hipSuccess) { delete m; return set_err(c, WASS_ERR_NO_MEMORY, "hipMalloc(%zu) failed", bytes); }
     m->x = (double*)base; m->y = m->x + n; m->z = m->y + n;
     m->valid = (uint8_t*)(m->z + n);
     m->gray = m->valid + ((n + 255) & ~(size_t)255);
+    m->codes = m->gray + ((n + 255) & ~(size_t)255);
     *out = m;
     return WASS_OK;
 }
@@ -1123,6 +1135,15 @@ void wass_mesh_destroy(wass_mesh* m)
     delete m;
 }
 
+int wass_mesh_reject_codes(wass_ctx* c, const wass_mesh* m, uint8_t* codes_out)
+{
+    if (!c || !m || !codes_out) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    WASS_HIP(c, hipSetDevice(c->device));
+    WASS_HIP(c, hipMemcpyAsync(codes_out, m->codes, m->n(), hipMemcpyDeviceToHost, c->ts()));
+    WASS_HIP(c, hipStreamSynchronize(c->ts()));
+    return WASS_OK;
+}
+
 int wass_mesh_size(const wass_mesh* m, int* width, int* height)
 {
     if (!m) return WASS_ERR_INVALID_ARG;
@@ -1159,7 +1180,7 @@ int wass_triangulate_dev(wass_ctx* c, const float* d_disp, int W, int H, const i
     dim3 grid(4096);
     hipLaunchKernelGGL(k_triangulate, grid, dim3(256), 0, c->ts(), d_disp, W, H, roi_l[0], roi_r[0], roi_r[1], m->w, m->h,
                        gd, d_right_img, img_w, img_h, d_lmask, d_rmask, tp->min_angle_deg, tp->bbox[0], tp->bbox[1],
-                       tp->bbox[2], tp->bbox[3], tp->cam_distance, m->valid, m->x, m->y, m->z, m->gray, cnt);
+                       tp->bbox[2], tp->bbox[3], tp->cam_distance, m->valid, m->x, m->y, m->z, m->gray, m->codes, cnt);
     unsigned long long hc = 0;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { wass_mesh_destroy(m); return set_err(c, WASS_ERR_DEVICE, "triangulate: %s", hipGetErrorString(e)); }
@@ -1221,6 +1242,7 @@ int wass_mesh_upload(wass_ctx* c, int width, int height, const uint8_t* valid, c
     hipError_t e = hipMemcpyAsync(m->valid, valid, n, hipMemcpyHostToDevice, c->ts());
     if (e == hipSuccess) e = gray ? hipMemcpyAsync(m->gray, gray, n, hipMemcpyHostToDevice, c->ts())
                                   : hipMemsetAsync(m->gray, 0, n, c->ts());
+    if (e == hipSuccess) e = hipMemsetAsync(m->codes, 0, n, c->ts());          // an uploaded mesh has no triangulation history
     if (e == hipSuccess) e = hipMemcpyAsync(c->scratch.p, p3d, n * 24, hipMemcpyHostToDevice, c->ts());
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_deinterleave, dim3(nblk(n)), dim3(256), 0, c->ts(), (const double*)c->scratch.p, n, m->x, m->y, m->z);

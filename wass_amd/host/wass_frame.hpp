@@ -433,6 +433,32 @@ inline int wass_run_frame(const char* config_path, const std::string& workdir, c
                   "wass_triangulate");
         WLOGI << "... 100%";
         WLOGI << n_pts << " valid points found";
+        if (debug_images) {                                          // undistorted/R0.jpg, R1.jpg (:1111-1119, 1216-1338, 1381-1382)
+            // per processed pixel of the right ROI: the rectified grey value, overpainted with the colour of the test that
+            // rejected it (the codes come from the triangulation kernel); R1's grey is the LEFT rectified image at the match
+            const int gw = roi_r[2], gh = roi_r[3], W0 = env.left.w, H0 = env.left.h;
+            std::vector<uint8_t> codes((size_t)gw * gh);
+            gpu_check(ctx, wass_mesh_reject_codes(ctx, mesh, codes.data()), "wass_mesh_reject_codes");
+            ImageRGB R0(W0, H0), R1(W0, H0);
+            static const uint8_t rgb[7][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 255, 255 }, { 255, 255, 0 }, { 0, 255, 0 }, { 0, 0, 255 }, { 255, 0, 0 } };
+            const float comp = (float)(g.disparity_compensation / g.dense_scale);
+            for (int v = 0; v < gh; ++v)
+                for (int u = 0; u < gw; ++u) {
+                    const uint8_t cd = codes[(size_t)v * gw + u];
+                    const int c0 = cd & 15, c1 = cd >> 4, xr = roi_r[0] + u, yr = roi_r[1] + v;
+                    if (xr < 0 || xr >= W0 || yr < 0 || yr >= H0) continue;
+                    if (c0 == WASS_CODE_GREY) { const uint8_t gv = env.right_crop.at(v, u); R0.set(yr, xr, gv, gv, gv); }
+                    else if (c0 != WASS_CODE_NONE) R0.set(yr, xr, rgb[c0][0], rgb[c0][1], rgb[c0][2]);
+                    if (c1 == WASS_CODE_GREY) {
+                        const float xl = (float)((float)(u + roi_l[0]) - dispf[(size_t)v * gw + u] + comp);
+                        const int lx = (int)std::floor(xl + 0.5f) - roi_l[0], ly = yr - roi_l[1];
+                        const uint8_t gv = (lx >= 0 && lx < env.left_crop.w && ly >= 0 && ly < env.left_crop.h) ? env.left_crop.at(ly, lx) : 0;
+                        R1.set(yr, xr, gv, gv, gv);
+                    } else if (c1 != WASS_CODE_NONE) R1.set(yr, xr, rgb[c1][0], rgb[c1][1], rgb[c1][2]);
+                }
+            write_png_rgb(path_join(path_join(env.workdir, "undistorted"), "R0.png"), R0);
+            write_png_rgb(path_join(path_join(env.workdir, "undistorted"), "R1.png"), R1);
+        }
         if (summary) summary->n_points = n_pts;
         env.timer << "Triangulation";
         std::cout << "[P|60|100]" << std::endl;

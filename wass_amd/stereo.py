@@ -449,6 +449,12 @@ class Mesh:
         self.ctx._check(self.ctx._lib.wass_mesh_refine_plane(self.ctx._h, self._h, C.byref(rp), plane, C.byref(n)))
         return np.array(plane[:]), int(n.value)
 
+    def reject_codes(self):
+        """(R0 codes, R1 codes) per grid pixel: why triangulate kept or rejected it (WASS_CODE_*; wass_stereo.cpp:1216-1338)."""
+        out = np.empty((self.height, self.width), np.uint8)
+        self.ctx._check(self.ctx._lib.wass_mesh_reject_codes(self.ctx._h, self._h, out.ctypes.data))
+        return out & 15, out >> 4
+
     def refinement_inliers(self, every=10, xmin=-9999., xmax=9999., ymin=-9999., ymax=9999., max_distance=70.0,
                            central_third_only=False) -> np.ndarray:
         """The points of plane_refinement_inliers.xyz (wass_stereo.cpp:2077-2085): every `every`-th refinement inlier in raster
