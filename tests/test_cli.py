@@ -263,7 +263,7 @@ def test_fixed_random_seed_runs_are_reproducible(cli, tmp_path):
     shutil.copytree(wd, wd2)
     for d in (wd, wd2):
         assert run(cli, cfg, d).returncode == 0
-    for name in ("mesh_cam.xyzC", "plane.txt", "plane_refinement_inliers.xyz", "P0cam.txt", "disparity_final_scaled.png"):
+    for name in ("mesh_cam.xyzC", "plane.txt", "plane_refinement_inliers.xyz", "P0cam.txt", "disparity_final_scaled.jpg"):
         assert open(os.path.join(wd, name), "rb").read() == open(os.path.join(wd2, name), "rb").read(), name
 
 
@@ -331,7 +331,8 @@ def test_debug_pictures_of_the_reference_are_written(cli, tmp_path, oracle):
     disparity_coverage / graph_components, same stems as the reference (PNG instead of JPEG), same pixel arithmetic."""
     w, h, D = 320, 240, 64
     wd, cfg, right, left, rig = make_workdir(str(tmp_path), w, h, D)
-    r = run(cli, cfg, wd)
+    # WASS_DEBUG_FORMAT=png: the same pictures, lossless, so that the pixel arithmetic can be checked exactly
+    r = subprocess.run([cli, cfg, wd], capture_output=True, text=True, env=dict(os.environ, WASS_DEBUG_FORMAT="png"))
     assert r.returncode == 0, r.stdout
     st = _read_png(os.path.join(wd, "stereo.png"))
     assert st.shape == (h, 2 * w, 3) and (st[0, :, 0] == 255).all() and (st[20, :, 1] == 0).all()       # a red line every 20 rows
@@ -361,8 +362,20 @@ def test_debug_pictures_of_the_reference_are_written(cli, tmp_path, oracle):
     assert grey1.mean() > 0.5
     gc = _read_png(os.path.join(wd, "graph_components.png"))
     assert gc.shape == (h // 2, w // 2, 3) and (gc[..., 1] == 255).mean() > 0.5 and (gc[..., 0] == 0).all()
+    # default: the reference's file names (.jpg, cv::imwrite), decodable by an independent decoder, the same pictures
+    wd3, cfg3, *_ = make_workdir(str(tmp_path / "c"), w, h, D)
+    r3 = run(cli, cfg3, wd3)
+    assert r3.returncode == 0, r3.stdout
+    Image = pytest.importorskip("PIL.Image")
+    for name in ("stereo", "stereo_input", "disparity_stereo_ouput", "disparity_final_scaled", "disparity_coverage", "graph_components",
+                 os.path.join("undistorted", "R0"), os.path.join("undistorted", "R1")):
+        assert not os.path.exists(os.path.join(wd3, name + ".png"))
+        jpg = np.asarray(Image.open(os.path.join(wd3, name + ".jpg"))).astype(int)
+        png = _read_png(os.path.join(wd, name + ".png")).astype(int)
+        assert jpg.shape == png.shape, name
+        assert np.abs(jpg - png).mean() < 4.0, (name, np.abs(jpg - png).mean())
     # WASS_DEBUG_IMAGES=0 switches them off
     wd2, cfg2, *_ = make_workdir(str(tmp_path / "b"), w, h, D)
     r2 = subprocess.run([cli, cfg2, wd2], capture_output=True, text=True, env=dict(os.environ, WASS_DEBUG_IMAGES="0"))
-    assert r2.returncode == 0 and not os.path.exists(os.path.join(wd2, "stereo.png"))
+    assert r2.returncode == 0 and not os.path.exists(os.path.join(wd2, "stereo.png")) and not os.path.exists(os.path.join(wd2, "stereo.jpg"))
     assert open(os.path.join(wd2, "mesh_cam.xyzC"), "rb").read() == open(os.path.join(wd, "mesh_cam.xyzC"), "rb").read()

@@ -5,12 +5,17 @@
 //   disparity_final_scaled.jpg     :1001                       render_disparity_float of the final map
 //   disparity_coverage.jpg         :1002-1017                  right image, green = 100 where disparity > 1, ROI, half size
 //   graph_components.jpg           PovMesh.cpp:222-250,982-984 biggest component green, the rest in palette colours, half size
-// Same stems, same pixel arithmetic (render.hpp:101-136 for the disparity pictures), but written as PNG: there is no
-// JPEG encoder without OpenCV, and nothing downstream reads these files ("debug outputs").
-// undistorted/R0.jpg / R1.jpg (per-pixel rejection codes of triangulate(), :1111-1382) are not produced.
+//   undistorted/R0.jpg, R1.jpg     :1111-1119,1216-1382        grey where a point was triangulated, else the colour of the rejecting test
+// Same names, same pixel arithmetic (render.hpp:101-136 for the disparity pictures), written by the baseline JPEG encoder of
+// jpeg.hpp (quality 95 like cv::imwrite's default; the BYTES differ from libjpeg's, the pictures do not).
+// WASS_DEBUG_FORMAT=png writes lossless <stem>.png instead (the tests check the pixel arithmetic on those).
 #pragma once
 
+#include <cstdlib>
+#include <cstring>
+
 #include "hostio.hpp"
+#include "jpeg.hpp"
 
 namespace wasshost {
 
@@ -51,6 +56,17 @@ inline bool write_png_raw(const std::string& filename, int w, int h, int channel
     return !ofs.fail();
 }
 inline bool write_png_rgb(const std::string& f, const ImageRGB& im) { return write_png_raw(f, im.w, im.h, 3, im.px.data()); }
+
+// debug pictures: <stem>.jpg like the reference, or <stem>.png with WASS_DEBUG_FORMAT=png
+inline bool debug_png() { const char* e = getenv("WASS_DEBUG_FORMAT"); return e && !strcmp(e, "png"); }
+inline bool write_debug_gray(const std::string& stem, const Image& im)
+{
+    return debug_png() ? write_png_gray(stem + ".png", im) : write_jpeg_raw(stem + ".jpg", im.w, im.h, 1, im.px.data());
+}
+inline bool write_debug_rgb(const std::string& stem, const ImageRGB& im)
+{
+    return debug_png() ? write_png_rgb(stem + ".png", im) : write_jpeg_raw(stem + ".jpg", im.w, im.h, 3, im.px.data());
+}
 
 // render.hpp:101-136: (v - min) / (max - min) * 255 with min starting at cols + 1 and max at 0
 inline Image render_disparity_float(const float* disp, int w, int h)

@@ -313,7 +313,7 @@ inline int wass_run_frame(const char* config_path, const std::string& workdir, c
                 memcpy(&st.px[((size_t)y * st.w + W0) * 3], &r.px[(size_t)y * W0 * 3], (size_t)W0 * 3);
                 if (y % 20 == 0) for (int x = 0; x < st.w; ++x) st.set(y, x, 255, 0, 0);
             }
-            write_png_rgb(path_join(env.workdir, "stereo.png"), st);
+            write_debug_rgb(path_join(env.workdir, "stereo"), st);
         }
         WLOG_SCOPE("wass_stereo");
         if (mode && std::string("--rectify-only") == mode) { WLOGI << "All done."; return 0; }
@@ -366,15 +366,15 @@ inline int wass_run_frame(const char* config_path, const std::string& workdir, c
                 memcpy(&in2.px[(size_t)y * Wp + (D + offp - comp)], &env.left_crop.px[(size_t)y * cw], cw);
                 memcpy(&in2.px[(size_t)(ch + y) * Wp + D], &env.right_crop.px[(size_t)y * cw], cw);
             }
-            if (sp.dense_scale == 1.0) write_png_gray(path_join(env.workdir, "stereo_input.png"), in2);   // (the resized inputs stay on the GPU)
+            if (sp.dense_scale == 1.0) write_debug_gray(path_join(env.workdir, "stereo_input"), in2);   // (the resized inputs stay on the GPU)
             std::vector<float> conv((size_t)ws * hs);                // clean_and_convert_disparity (:714-733) of the raw map
             const double scl = 1.0 / sp.dense_scale;
             for (size_t i = 0; i < conv.size(); ++i) {
                 float dval = ((float)disp16[i]) / 16.0f;
                 conv[i] = (dval <= (float)sp.min_disp || dval > (float)sp.num_disp) ? 0.0f : (float)((double)(dval + (float)sp.disp_offset) * scl);
             }
-            write_png_gray(path_join(env.workdir, "disparity_stereo_ouput.png"), render_disparity_float(conv.data(), ws, hs));
-            write_png_gray(path_join(env.workdir, "disparity_final_scaled.png"), render_disparity_float(dispf.data(), cw, ch));
+            write_debug_gray(path_join(env.workdir, "disparity_stereo_ouput"), render_disparity_float(conv.data(), ws, hs));
+            write_debug_gray(path_join(env.workdir, "disparity_final_scaled"), render_disparity_float(dispf.data(), cw, ch));
             const int W0 = env.right.w, H0 = env.right.h;           // disparity_coverage.jpg (:1002-1017)
             ImageRGB cov = gray_to_rgb(paste(env.right_crop, env.roi_r.x, env.roi_r.y, W0, H0));
             for (int y = 0; y < ch; ++y)
@@ -382,7 +382,7 @@ inline int wass_run_frame(const char* config_path, const std::string& workdir, c
                     if (dispf[(size_t)y * cw + x] > 1.0f && env.roi_r.y + y < H0 && env.roi_r.x + x < W0)
                         cov.px[((size_t)(env.roi_r.y + y) * W0 + env.roi_r.x + x) * 3 + 1] = 100;
             rectangle_red(cov, env.roi_r.x, env.roi_r.y, env.roi_r.width, env.roi_r.height);
-            write_png_rgb(path_join(env.workdir, "disparity_coverage.png"), half_size(cov));
+            write_debug_rgb(path_join(env.workdir, "disparity_coverage"), half_size(cov));
         }
         WLOGI << "dense stereo completed successfully";
         env.timer << "Dense Stereo";
@@ -456,8 +456,8 @@ inline int wass_run_frame(const char* config_path, const std::string& workdir, c
                         R1.set(yr, xr, gv, gv, gv);
                     } else if (c1 != WASS_CODE_NONE) R1.set(yr, xr, rgb[c1][0], rgb[c1][1], rgb[c1][2]);
                 }
-            write_png_rgb(path_join(path_join(env.workdir, "undistorted"), "R0.png"), R0);
-            write_png_rgb(path_join(path_join(env.workdir, "undistorted"), "R1.png"), R1);
+            write_debug_rgb(path_join(path_join(env.workdir, "undistorted"), "R0"), R0);
+            write_debug_rgb(path_join(path_join(env.workdir, "undistorted"), "R1"), R1);
         }
         if (summary) summary->n_points = n_pts;
         env.timer << "Triangulation";
@@ -479,7 +479,7 @@ inline int wass_run_frame(const char* config_path, const std::string& workdir, c
             for (size_t i = 0; i < valid_after.size(); ++i)
                 if (valid_after[i]) { gc.px[3 * i + 1] = 255; }                     // biggest component: palette.back() = (0,255,0)
                 else if (valid_before[i]) { gc.px[3 * i + 2] = 255; }              // every other component: palette[0] = BGR (255,0,0)
-            write_png_rgb(path_join(env.workdir, "graph_components.png"), half_size(gc));
+            write_debug_rgb(path_join(env.workdir, "graph_components"), half_size(gc));
         }
         WLOG_SCOPE("cluster");
         WLOGI << "biggest component size: " << csize << " (px)";
