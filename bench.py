@@ -137,6 +137,22 @@ def cpu_baseline(config: str, max_procs: int = 32):
     }
 
 
+def repeat_check(planes, npts, warmup, nf):
+    """The timed region cycles through nf distinct frames: every revisit of a frame must give the SAME plane and point count,
+    bit for bit (the pipeline overlaps uploads, the SGM stage and the tail of neighbouring frames on four streams; a missing
+    ordering between them would show up here as a frame that changes with its neighbours)."""
+    seen, revisits, bad = {}, 0, 0
+    for i, (pl, n) in enumerate(zip(planes, npts)):
+        k = (warmup + i) % nf
+        key = (tuple(np.asarray(pl, np.float64).view(np.uint64).tolist()), int(n))
+        if k in seen:
+            revisits += 1
+            bad += seen[k] != key
+        else:
+            seen[k] = key
+    return {"frames_revisited": revisits, "mismatches": int(bad)}
+
+
 def measured_traffic(config: str, ndirs: int):
     """Per-frame HBM bytes of the aggregation kernels from the committed rocprofv3 PMC summary of this command
     (profiles/*traffic_<config>_<ndirs>path.json, produced by scripts/profile.sh + scripts/traffic_json.py): the newest."""
@@ -379,6 +395,7 @@ def main():
             "points_per_frame": int(np.mean(npts_hist)) if npts_hist else None,
             "xyzc_bytes_per_frame": int(np.mean(nbytes_hist)) if nbytes_hist else None,
             "cost_overflow": int(overflow),
+            "repeat_check": repeat_check(planes, npts_hist, args.warmup, nf),
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.config)
