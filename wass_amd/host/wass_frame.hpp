@@ -17,6 +17,7 @@
 
 #include <cstdlib>
 #include <ctime>
+#include <memory>
 #include <thread>
 
 #include "../../include/wass_gpu.h"
@@ -76,7 +77,39 @@ void swapLeftRight(Env& e)                                                      
     computeP(e);
 }
 
-bool load_data(Env& env, const Config& cfg)                                               // :337-445
+// A host thread that is always joined (on every return path and by exceptions).
+struct BgTask {
+    std::thread t;
+    template <typename F> void run(F&& f) { wait(); t = std::thread(std::forward<F>(f)); }
+    void wait() { if (t.joinable()) t.join(); }
+    ~BgTask() { wait(); }
+};
+// File writes that may finish while the NEXT frame is being processed (sequence driver); one job in flight.
+struct AsyncWriter {
+    BgTask task;
+    bool failed = false;
+    template <typename F> void submit(F&& f) { task.run([this, f]() { if (!f()) failed = true; }); }
+    void wait() { task.wait(); }
+};
+
+// The two input pictures of a workdir, decoded ahead of time: a sequence driver inflates the next frame's PNGs on a host
+// thread while the current frame is on the GPU (zlib is the whole "Data load" time, ~50 ms at 2456 x 2058).
+struct Preload {
+    std::string workdir;
+    Image left, right;
+    std::string error;             // non-empty: what read_png_gray threw (reported by load_data as if it had read the files itself)
+};
+inline void preload_images(const std::string& workdir, Preload& p)
+{
+    p.workdir = workdir; p.error.clear();
+    std::string err1;
+    std::thread t1([&]() { try { p.right = read_png_gray(path_join(workdir, "undistorted/00000001.png")); } catch (const std::exception& e) { err1 = e.what(); } });
+    try { p.left = read_png_gray(path_join(workdir, "undistorted/00000000.png")); } catch (const std::exception& e) { p.error = e.what(); }
+    t1.join();
+    if (p.error.empty()) p.error = err1;
+}
+
+bool load_data(Env& env, const Config& cfg, Preload* pre = nullptr, BgTask* bg = nullptr)    // :337-445
 {
     WLOG_SCOPE("load_data");
     env.R = load_matrix_xml(path_join(env.workdir, "ext_R.xml"));
@@ -94,20 +127,15 @@ bool load_data(Env& env, const Config& cfg)                                     
     if (env.K0.rows != 3 || env.K0.cols != 3 || env.K1.rows != 3 || env.K1.cols != 3) { WLOGE << "invalid intrinsics"; return false; }
     env.K_left = env.K0; env.K_right = env.K1;
     computeP(env);
-    try {
-        // the two PNGs are inflated side by side (zlib is the whole "Data load" time: 2 x 35 ms at 2456 x 2058)
-        std::exception_ptr err1;
-        std::thread t1([&]() { try { env.right = read_png_gray(path_join(env.workdir, "undistorted/00000001.png")); } catch (...) { err1 = std::current_exception(); } });
-        try { env.left = read_png_gray(path_join(env.workdir, "undistorted/00000000.png")); } catch (...) { t1.join(); throw; }
-        t1.join();
-        if (err1) std::rethrow_exception(err1);
+    {
+        Preload local;
+        if (!pre || pre->workdir != env.workdir) { preload_images(env.workdir, local); pre = &local; }   // the two PNGs are inflated side by side
+        if (!pre->error.empty()) { WLOGE << "unable to load input images: " << pre->error; return false; }
+        env.left = std::move(pre->left); env.right = std::move(pre->right);
         env.left_index = 0;
         WLOGI << "image 0 loaded, Size: " << env.left.w << "x" << env.left.h;
         env.right_index = 1;
         WLOGI << "image 1 loaded, Size: " << env.right.w << "x" << env.right.h;
-    } catch (const std::exception& e) {
-        WLOGE << "unable to load input images: " << e.what();
-        return false;
     }
     if (env.left.w != env.right.w || env.left.h != env.right.h) { WLOGE << "left and right images differ in size"; return false; }
     const double sis = cfg.get_double("SAVE_INPUT_SCALE");
@@ -118,8 +146,15 @@ bool load_data(Env& env, const Config& cfg)                                     
         WLOGI << "  scaled size: " << nw << "x" << nh;
         WLOGI << "        scale: " << scale;
         if (nw > 0 && nh > 0) {
-            write_png_gray(path_join(env.workdir, "00000000_s.png"), resize_cubic(env.left, (int)nw, (int)nh));
-            write_png_gray(path_join(env.workdir, "00000001_s.png"), resize_cubic(env.right, (int)nw, (int)nh));
+            // resize + deflate of the two previews (~20 ms) on a host thread while the frame goes to the GPU.  The task owns
+            // copies of the pictures: rectify() may swap env.left / env.right (swapLeftRight) while it runs.
+            auto l = std::make_shared<Image>(env.left), r = std::make_shared<Image>(env.right);
+            const std::string wd = env.workdir;
+            auto work = [l, r, wd, nw, nh]() {
+                write_png_gray(path_join(wd, "00000000_s.png"), resize_cubic(*l, (int)nw, (int)nh));
+                write_png_gray(path_join(wd, "00000001_s.png"), resize_cubic(*r, (int)nw, (int)nh));
+            };
+            if (bg) bg->run(work); else work();
         }
         Mat k0 = scaled(env.K_left, scale), k1 = scaled(env.K_right, scale);
         k0(2, 2) = 1; k1(2, 2) = 1;
@@ -253,7 +288,7 @@ struct FrameSummary {
 // created on `device` at the point where the reference would first need the GPU and handed back to the caller, who
 // destroys it.  mode: nullptr, "--rectify-only" or "--measure".  Returns the process exit code of wass_stereo (0 / -1).
 inline int wass_run_frame(const char* config_path, const std::string& workdir, const char* mode, int device, wass_ctx** ctxp,
-                          FrameSummary* summary, bool debug_images = true)
+                          FrameSummary* summary, bool debug_images = true, Preload* preloaded = nullptr, AsyncWriter* writer = nullptr)
 {
     if (const char* e = getenv("WASS_DEBUG_IMAGES")) debug_images = atoi(e) != 0;
     Env env;
@@ -277,11 +312,12 @@ inline int wass_run_frame(const char* config_path, const std::string& workdir, c
     wass_ctx* ctx = *ctxp;
     wass_mesh* mesh = nullptr;
     int ret = 0;
+    BgTask previews;                                             // declared before the try block: joined after env's last use
     try {
         WLOGI << "Reconstructing " << env.workdir;
         env.timer.start();
         env.cam_distance = 1.0;
-        if (!load_data(env, cfg)) return -1;
+        if (!load_data(env, cfg, preloaded, &previews)) return -1;
         env.timer << "Data load";
         std::cout << "[P|10|100]" << std::endl;
         auto save_cams = [&]() {
@@ -584,10 +620,16 @@ inline int wass_run_frame(const char* config_path, const std::string& workdir, c
             WLOGI << "saving mesh as compressed xyz file...";
             void* bytes = nullptr; size_t nb = 0;
             gpu_check(ctx, wass_mesh_encode_xyzc(ctx, mesh, have_plane ? plane : nullptr, &bytes, &nb), "wass_mesh_encode_xyzc");
-            std::ofstream ofs(path_join(env.workdir, "mesh_cam.xyzC").c_str(), std::ios::binary);
-            const bool ok = !ofs.fail() && ofs.write((const char*)bytes, (std::streamsize)nb).good();
-            wass_free(bytes);
-            if (!ok) { WLOGE << "unable to save mesh data"; throw GpuError("write failed"); }
+            const std::string xyzc_path = path_join(env.workdir, "mesh_cam.xyzC");
+            auto write_xyzc = [xyzc_path, bytes, nb]() {
+                std::ofstream ofs(xyzc_path.c_str(), std::ios::binary);
+                const bool ok = !ofs.fail() && ofs.write((const char*)bytes, (std::streamsize)nb).good();
+                wass_free(bytes);
+                if (!ok) fprintf(stderr, "wass_stereo [error] unable to save %s\n", xyzc_path.c_str());
+                return ok;
+            };
+            if (writer) writer->submit(write_xyzc);              // sequence driver: the 28 MB write overlaps the next frame
+            else if (!write_xyzc()) { WLOGE << "unable to save mesh data"; throw GpuError("write failed"); }
             WLOGI << "total data size: " << ((double)nb / 1E6) << " MB";
             WLOG_SCOPE("wass_stereo");
         } else {

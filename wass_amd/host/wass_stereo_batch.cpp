@@ -78,16 +78,28 @@ int worker(int rank, int world, int device, bool distinct_gpus, const unsigned c
     }
     wass_ctx* ctx = nullptr;
     double acc[5] = { 0, 0, 0, 0, 0 };
-    for (size_t i = (size_t)rank; i < wds.size(); i += (size_t)world) {
+    // the next frame's PNGs are inflated on a host thread while this frame is being processed
+    Preload pre[2];
+    AsyncWriter writer;                                          // a frame's mesh_cam.xyzC is written while the next frame runs
+    std::thread loader;
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{ loader };     // also on the early returns
+    auto done = [&](size_t k) { return skip_existing && (exists(path_join(wds[k], "mesh_cam.xyzC")) || exists(path_join(wds[k], "mesh_cam.xyzbin"))); };
+    auto start_load = [&](size_t k, int slot) {
+        if (k < wds.size() && exists(wds[k]) && !done(k)) loader = std::thread([&, k, slot]() { preload_images(wds[k], pre[slot]); });
+    };
+    start_load((size_t)rank, 0);
+    int slot = 0;
+    for (size_t i = (size_t)rank; i < wds.size(); i += (size_t)world, slot ^= 1) {
         Record r = {};
         r.index = (int)i;
         const double t0 = now();
         FrameSummary fs;
-        if (skip_existing && (exists(path_join(wds[i], "mesh_cam.xyzC")) || exists(path_join(wds[i], "mesh_cam.xyzbin"))) &&
-            read_plane_txt(wds[i], fs))
+        if (loader.joinable()) loader.join();                     // this frame's pictures (slot) are in memory now
+        start_load(i + (size_t)world, slot ^ 1);
+        if (done(i) && read_plane_txt(wds[i], fs))
             r.rc = 0;
         else
-            r.rc = exists(wds[i]) ? wass_run_frame(cfg, wds[i], nullptr, device, &ctx, &fs, debug_images) : -1;
+            r.rc = exists(wds[i]) ? wass_run_frame(cfg, wds[i], nullptr, device, &ctx, &fs, debug_images, &pre[slot], &writer) : -1;
         r.seconds = now() - t0;
         r.have_plane = r.rc == 0 && fs.have_plane;
         r.n_points = fs.n_points;
@@ -95,6 +107,9 @@ int worker(int rank, int world, int device, bool distinct_gpus, const unsigned c
         if (r.rc == 0) wass_planes_mean_accumulate(r.plane, 1, acc);     // NaN planes are skipped (nanmean)
         if (!write_all(fd, &r, sizeof r)) return 2;
     }
+    if (loader.joinable()) loader.join();
+    writer.wait();
+    if (writer.failed) return 4;
     Tail t = {};
     t.magic = 0x57415353;
     if (world > 1 && distinct_gpus) {
