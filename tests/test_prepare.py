@@ -222,6 +222,22 @@ def test_prepare_without_distortion_files_copies_the_images(prepare, tmp_path):
 
 
 @pytest.mark.gpu
+def test_prepare_reads_tiff_inputs(prepare, tmp_path):
+    """wasscli hands wass_prepare whatever the cameras wrote: tif / tiff / png (wasscli.py:47); TIFF goes through host/tiff.hpp."""
+    Image = pytest.importorskip("PIL.Image")
+    w, h = 96, 64
+    calib, *_ = _calibdir(tmp_path, w, h, distortion=False)
+    img0, img1 = _images(tmp_path, w, h)
+    Image.fromarray(img0).save(tmp_path / "cam0.tif", compression="tiff_lzw")
+    Image.fromarray(img1).save(tmp_path / "cam1.tiff")
+    wd = tmp_path / "wd"
+    r = run(prepare, "--workdir", str(wd), "--calibdir", str(calib), "--c0", str(tmp_path / "cam0.tif"), "--c1", str(tmp_path / "cam1.tiff"))
+    assert r.returncode == 0, r.stdout
+    np.testing.assert_array_equal(_read_png_gray(wd / "undistorted" / "00000000.png"), img0)
+    np.testing.assert_array_equal(_read_png_gray(wd / "undistorted" / "00000001.png"), img1)
+
+
+@pytest.mark.gpu
 def test_prepare_then_stereo(prepare, tmp_path):
     """wass_prepare's workdir is accepted by wass_stereo as is (file names, XML node layout, PNG encoding)."""
     from wass_amd import build, synth

@@ -1,0 +1,89 @@
+"""The TIFF reader of wass_prepare's inputs (wass_amd/host/tiff.hpp; wasscli lists tif / tiff among the supported formats,
+cli/wasscli/wasscli.py:47): files written by Pillow / libtiff in the variants cameras and converters produce must decode to
+the grey picture cv::imread(IMREAD_GRAYSCALE) would give."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+Image = pytest.importorskip("PIL.Image")
+
+
+@pytest.fixture(scope="module")
+def tool():
+    src = os.path.join(HERE, "native", "tiff_check.cpp")
+    deps = [src] + [os.path.join(HERE, "..", "wass_amd", "host", f) for f in ("tiff.hpp", "hostio.hpp")]
+    out_dir = os.path.join(HERE, "native", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    exe = os.path.join(out_dir, "tiff_check")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wno-unused-function", src, "-o", exe, "-lz"])
+    return exe
+
+
+def _decode(tool, path, tmp_path):
+    out = tmp_path / "out.raw"
+    r = subprocess.run([tool, str(path), str(out)], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr.strip())
+    blob = out.read_bytes()
+    nl = blob.index(b"\n")
+    w, h = map(int, blob[:nl].split())
+    return np.frombuffer(blob[nl + 1:], np.uint8).reshape(h, w)
+
+
+def _grey(w, h, seed):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = 120 + 80 * np.sin(xx / 9.0) * np.cos(yy / 13.0) + rng.normal(0, 6, (h, w))
+    img[h // 3:h // 3 + 10, : w // 2] = 200                               # long runs: PackBits / LZW repeats
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("compression", [None, "tiff_lzw", "tiff_adobe_deflate", "packbits"])
+@pytest.mark.parametrize("w,h", [(64, 48), (333, 257), (1200, 901)])
+def test_grey_tiff_variants(tool, tmp_path, compression, w, h):
+    img = _grey(w, h, w)
+    path = tmp_path / "g.tif"
+    Image.fromarray(img).save(path, compression=compression) if compression else Image.fromarray(img).save(path)
+    np.testing.assert_array_equal(_decode(tool, path, tmp_path), img)
+
+
+def test_lzw_with_noise_fills_the_code_table(tool, tmp_path):
+    """Incompressible data drives the LZW table through every code width and several ClearCodes."""
+    img = np.random.default_rng(0).integers(0, 256, (400, 600), dtype=np.uint8)
+    path = tmp_path / "n.tif"
+    Image.fromarray(img).save(path, compression="tiff_lzw")
+    np.testing.assert_array_equal(_decode(tool, path, tmp_path), img)
+
+
+def test_rgb_and_16_bit(tool, tmp_path):
+    rgb = np.stack([_grey(120, 90, 1), _grey(120, 90, 2), _grey(120, 90, 3)], -1)
+    path = tmp_path / "c.tif"
+    Image.fromarray(rgb).save(path, compression="tiff_lzw")
+    want = (rgb[..., 0].astype(int) * 4899 + rgb[..., 1].astype(int) * 9617 + rgb[..., 2].astype(int) * 1868 + 8192) >> 14   # BT.601, as for PNG
+    np.testing.assert_array_equal(_decode(tool, path, tmp_path), want.astype(np.uint8))
+    g16 = (_grey(100, 70, 5).astype(np.uint16) << 8) | 0x5A
+    path16 = tmp_path / "d.tif"
+    Image.fromarray(g16).save(path16)
+    np.testing.assert_array_equal(_decode(tool, path16, tmp_path), (g16 >> 8).astype(np.uint8))
+
+
+def test_png_still_goes_through_the_same_entry_point(tool, tmp_path):
+    img = _grey(77, 55, 9)
+    path = tmp_path / "p.png"
+    Image.fromarray(img).save(path)
+    np.testing.assert_array_equal(_decode(tool, path, tmp_path), img)
+
+
+def test_unsupported_files_are_refused_with_a_message(tool, tmp_path):
+    jpg = tmp_path / "x.jpg"
+    Image.fromarray(_grey(32, 32, 1)).save(jpg)
+    with pytest.raises(RuntimeError, match="JPEG input is not supported"):
+        _decode(tool, jpg, tmp_path)
+    bad = tmp_path / "t.tif"
+    bad.write_bytes(b"II*\x00\x08\x00\x00\x00\x00\x00")
+    with pytest.raises(RuntimeError):
+        _decode(tool, bad, tmp_path)

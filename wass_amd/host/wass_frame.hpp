@@ -23,6 +23,7 @@
 #include "../../include/wass_gpu.h"
 #include "config.hpp"
 #include "hostio.hpp"
+#include "tiff.hpp"
 #include "rectify.hpp"
 #include "render.hpp"
 
@@ -434,7 +435,7 @@ inline int wass_run_frame(const char* config_path, const std::string& workdir, c
                 const std::string fn = path_join(env.workdir, name);
                 WLOGI << "Loading " << fn << " as " << which << " camera mask";
                 try {
-                    const Image aux = read_png_gray(fn);
+                    const Image aux = read_image_gray(fn);              // PNG or TIFF
                     if (aux.w == iw && aux.h == ih) for (size_t i = 0; i < m.size(); ++i) m[i] = aux.px[i] > 0 ? 1 : 0;   // threshold(0.5)
                     else WLOGE << "not found or invalid image.";
                 } catch (const std::exception&) { WLOGE << "not found or invalid image."; }
