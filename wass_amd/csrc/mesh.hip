@@ -113,9 +113,11 @@ __global__ void __launch_bounds__(256) k_triangulate(const float* __restrict__ d
                                                      unsigned long long* __restrict__ count)
 {
     unsigned int found = 0;
-    const size_t npx = (size_t)mw * mh;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < npx; idx += (size_t)gridDim.x * 256) {
-    const int u = (int)(idx % mw), v = (int)(idx / mw);
+    // a workgroup owns a 256-column strip and walks rows: no 64-bit division per pixel
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u < mw)
+    for (int v = blockIdx.y; v < mh; v += gridDim.y) {
+    const size_t idx = (size_t)v * mw + u;
     bool ok = false;
     double P[3] = { 0, 0, 0 };
     uint8_t gv = 0;
@@ -1177,7 +1179,7 @@ int wass_triangulate_dev(wass_ctx* c, const float* d_disp, int W, int H, const i
     gd.comp_over_scale = g->disparity_compensation / g->dense_scale;
     unsigned long long* cnt = nullptr;
     if ((rc = counters_reset(c, &cnt))) { wass_mesh_destroy(m); return rc; }
-    dim3 grid(4096);
+    dim3 grid((m->w + 255) / 256, std::min(m->h, 512));
     hipLaunchKernelGGL(k_triangulate, grid, dim3(256), 0, c->ts(), d_disp, W, H, roi_l[0], roi_r[0], roi_r[1], m->w, m->h,
                        gd, d_right_img, img_w, img_h, d_lmask, d_rmask, tp->min_angle_deg, tp->bbox[0], tp->bbox[1],
                        tp->bbox[2], tp->bbox[3], tp->cam_distance, m->valid, m->x, m->y, m->z, m->gray, m->codes, cnt);
