@@ -698,7 +698,8 @@ __device__ __forceinline__ void block_sum_store(double (&v)[NV], double* __restr
 __device__ __forceinline__ bool refine_inlier(const RefineDev& rp, const uint8_t* valid, const double* X, const double* Y,
                                               const double* Z, int w, size_t i, double& px, double& py, double& pz, double& wt)
 {
-    const int u = (int)(i % w), v = (int)(i / w);
+    const unsigned int ii = (unsigned int)i;                     // a mesh has fewer than 2^31 points: 32-bit division
+    const int u = (int)(ii % (unsigned int)w), v = (int)(ii / (unsigned int)w);
     if (u < rp.umin || u > rp.umax || v < rp.vmin || v > rp.vmax || !valid[i]) return false;
     px = X[i]; py = Y[i]; pz = Z[i];
     const double dist = sqrt(px * px + py * py + pz * pz);
@@ -741,7 +742,8 @@ __global__ void __launch_bounds__(256) k_crop_moments_dev(uint8_t* __restrict__ 
             if (fabs((a * px + b * py + c * pz) + d) < thr) ++cnt;
             else { valid[i] = 0; continue; }
         }
-        const int u = (int)(i % w), v = (int)(i / w);
+        const unsigned int ii = (unsigned int)i;
+        const int u = (int)(ii % (unsigned int)w), v = (int)(ii / (unsigned int)w);
         if (u < rp.umin || u > rp.umax || v < rp.vmin || v > rp.vmax) continue;
         const double dist = sqrt(px * px + py * py + pz * pz);
         if (!(px > rp.xmin && px < rp.xmax && py > rp.ymin && py < rp.ymax && dist < rp.maxd)) continue;
@@ -1089,6 +1091,7 @@ static int mesh_alloc(wass_ctx* c, int w, int h, wass_mesh** out)
     if (!m) return set_err(c, WASS_ERR_NO_MEMORY, "out of host memory");
     m->w = w; m->h = h;
     const size_t n = m->n();
+    if (n > 0x7FFFFFFFull) { delete m; return set_err(c, WASS_ERR_UNSUPPORTED, "mesh too large (%d x %d)", w, h); }   // kernels index points with 32 bits
     // one allocation: x | y | z | valid | gray | codes
     const size_t bytes = n * 8 * 3 + ((n + 255) & ~(size_t)255) * 3;
     m->bytes = bytes; m->device = c->device; m->owner = c;
