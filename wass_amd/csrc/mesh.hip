@@ -511,105 +511,129 @@ __global__ void k_ransac_planes(const uint8_t* __restrict__ valid, const double*
     cand[r] = pc;
 }
 
-// Every candidate plane scored in ONE pass over the points: each thread keeps PTS points in registers and walks the
-// plane list held in LDS; a ballot turns 64 comparisons into one counter update.
+// Every candidate plane scored in ONE pass over the points.  A wave owns a PATCH of the grid, 64 columns x PTS rows (lane =
+// column, so every row is one coalesced load), keeps its points in registers and walks the plane list held in LDS.
 //
-// The reference's test is fabs(((a*x + b*y) + c*z) + d) < thr in fp64 (PovMesh.cpp:717-742), six dependent fp64
-// operations per point and plane.  Here the decision is taken in PACKED FP32 (v_pk_fma_f32, two points per
-// instruction) against two thresholds thr -+ margin, where margin bounds the worst-case difference between the fp32
-// value and the fp64 one: inputs rounded to fp32 (2^-24 each) and three fused roundings give
-// |t32 - t64| <= 5 * 2^-24 * (|a x| + |b y| + |c z| + |d|); the kernel uses 8 * 2^-24 * ((|a| + |b| + |c|) * M + |d| + thr) with
-// M = the largest |coordinate| among the thread's own points (all three factors rounded up).  A point between the two
-// thresholds is "ambiguous"; if a wave meets one for some plane it recounts that plane over its points with the
-// reference's fp64 expression, so the counts are EXACTLY the reference's (tests compare them at full size).
-// Invalid points are replaced by the origin and the block subtracts (their number) x [origin is an inlier] at the end,
-// which removes the validity mask from the inner loop.
+// The reference's test is fabs(((a*x + b*y) + c*z) + d) < thr in fp64 for every point and plane (PovMesh.cpp:717-742).  Two
+// shortcuts, both exact:
+//  1. PATCH BOUNDS.  A patch is a compact piece of a smooth surface.  With its bounding box (centre c, half extents e) every
+//     point p of the patch has |n.p + d - (n.c + d)| <= |a| ex + |b| ey + |c| ez =: r.  If |n.c + d| + r < thr the whole patch
+//     lies inside the band: the plane gets the patch's valid-point count and no point is looked at; if |n.c + d| - r >= thr
+//     none does.  Both sides carry a margin (2^-40 of the magnitudes involved) that covers the rounding of the bound itself
+//     and of the reference's own fp64 evaluation.  For a bad candidate the band crosses the image as a strip and almost every
+//     patch is outside it; for a good one almost every patch is inside.
+//  2. For the patches that straddle a band edge the decision per point is taken in PACKED FP32 (v_pk_fma_f32, two points per
+//     instruction) against thr -+ margin, margin = 2^-21 ((|a|+|b|+|c|) M + |d| + thr) with M = the largest |coordinate| of the
+//     thread's points, which bounds the fp32-fp64 difference (inputs rounded to fp32, three fused roundings:
+//     <= 5 * 2^-24 * (|a x| + |b y| + |c z| + |d|)); a wave that meets a point between the two thresholds recounts that plane
+//     with the reference's fp64 expression.
+// The counts are therefore EXACTLY the reference's (tests compare 400 planes x 4.8 M points).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int PTS>
 __global__ void __launch_bounds__(256) k_ransac_score(const uint8_t* __restrict__ valid, const double* __restrict__ X,
-                                                      const double* __restrict__ Y, const double* __restrict__ Z, size_t n,
+                                                      const double* __restrict__ Y, const double* __restrict__ Z, int w, int h,
                                                       const PlaneCand* __restrict__ cand, int rounds, double thr,
                                                       unsigned long long* __restrict__ counts)
 {
     static_assert(PTS % 2 == 0, "points are processed in packed pairs");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float4* plf = (float4*)smem;                                  // [rounds] a, b, c, d in fp32
-    float2* plm = (float2*)(plf + rounds);                        // [rounds] (|a|+|b|+|c|) rounded up, 2^-21 (|d| + thr) rounded up
-    unsigned int* lc = (unsigned int*)(plm + rounds);             // [rounds]
-    __shared__ unsigned int s_ninv;
-    const float up = 1.0f + 0x1p-20f, G = 0x1p-21f;
+    double* pl = (double*)smem;                                   // [rounds][4]
+    unsigned int* lc = (unsigned int*)(pl + (size_t)rounds * 4);  // [rounds]
     for (int r = threadIdx.x; r < rounds; r += 256) {
-        const double a = cand[r].n[0], b = cand[r].n[1], c = cand[r].n[2], d = cand[r].d;
-        plf[r] = make_float4((float)a, (float)b, (float)c, (float)d);
-        plm[r] = make_float2((float)(fabs(a) + fabs(b) + fabs(c)) * up, (float)(fabs(d) + fabs(thr)) * up * G);
+        pl[r * 4] = cand[r].n[0]; pl[r * 4 + 1] = cand[r].n[1]; pl[r * 4 + 2] = cand[r].n[2]; pl[r * 4 + 3] = cand[r].d;
         lc[r] = 0;
     }
-    if (threadIdx.x == 0) s_ninv = 0;
     __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // patch of this wave: columns [64 (4 bx + wv), +64), rows [PTS by, +PTS)
+    const int col = (blockIdx.x * 4 + wv) * 64 + lane, row0 = blockIdx.y * PTS;
     f32x2 px[PTS / 2], py[PTS / 2], pz[PTS / 2];
-    const size_t base = (size_t)blockIdx.x * 256 * PTS + threadIdx.x;
-    unsigned int ninv = 0;
-    double m = 0.0;
+    unsigned long long vmask[PTS];
+    double mnx = 1e300, mny = 1e300, mnz = 1e300, mxx = -1e300, mxy = -1e300, mxz = -1e300, m = 0.0;
+    unsigned int nvalid = 0;
 #pragma unroll
     for (int k = 0; k < PTS; ++k) {
-        const size_t i = base + (size_t)k * 256;
-        const bool pv = i < n && valid[i];
+        const int row = row0 + k;
+        const bool pv = col < w && row < h && valid[(size_t)row * w + col];
+        const size_t i = (size_t)row * w + col;
         const double x = pv ? X[i] : 0.0, y = pv ? Y[i] : 0.0, z = pv ? Z[i] : 0.0;
-        ninv += pv ? 0u : 1u;
-        m = fmax(m, fmax(fabs(x), fmax(fabs(y), fabs(z))));
+        vmask[k] = __builtin_amdgcn_ballot_w64(pv);
+        nvalid += (unsigned)__popcll(vmask[k]);
+        if (pv) {
+            mnx = fmin(mnx, x); mxx = fmax(mxx, x); mny = fmin(mny, y); mxy = fmax(mxy, y); mnz = fmin(mnz, z); mxz = fmax(mxz, z);
+            m = fmax(m, fmax(fabs(x), fmax(fabs(y), fabs(z))));
+        }
         px[k / 2][k % 2] = (float)x; py[k / 2][k % 2] = (float)y; pz[k / 2][k % 2] = (float)z;
     }
-    const float Mg = (float)m * up * G;                            // 2^-21 M, rounded up
-    const float thr_f = (float)thr;
-    const int lane = threadIdx.x & 63;
-    unsigned int mine = 0;
-    for (int r = 0; r < rounds; ++r) {
-        const float4 p = plf[r];
-        const float2 pm = plm[r];
-        const float margin = __builtin_fmaf(pm.x, Mg, pm.y);
-        const float lo = thr_f - margin, hi = thr_f + margin;
-        const f32x2 a2 = { p.x, p.x }, b2 = { p.y, p.y }, c2 = { p.z, p.z }, d2 = { p.w, p.w };
-        unsigned int cnt = 0, cnt_maybe = 0;
-#pragma unroll
-        for (int k = 0; k < PTS / 2; ++k) {
-            const f32x2 t = __builtin_elementwise_fma(a2, px[k], __builtin_elementwise_fma(b2, py[k], __builtin_elementwise_fma(c2, pz[k], d2)));
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const float at = __builtin_fabsf(t[e]);
-                const unsigned long long in = __builtin_amdgcn_ballot_w64(at < lo);
-                const unsigned long long maybe = __builtin_amdgcn_ballot_w64(!(at >= hi));     // also true for NaN
-                cnt += (unsigned)__popcll(in);
-                cnt_maybe += (unsigned)__popcll(maybe);            // in is a subset of maybe: equal counts <=> no point in between
-            }
+    if (nvalid) {                                                 // wave-uniform
+        for (int o = 32; o > 0; o >>= 1) {
+            mnx = fmin(mnx, __shfl_xor(mnx, o)); mxx = fmax(mxx, __shfl_xor(mxx, o));
+            mny = fmin(mny, __shfl_xor(mny, o)); mxy = fmax(mxy, __shfl_xor(mxy, o));
+            mnz = fmin(mnz, __shfl_xor(mnz, o)); mxz = fmax(mxz, __shfl_xor(mxz, o));
         }
-        if (cnt != cnt_maybe) {                                                 // wave-uniform and rare: this plane again, the reference's way
-            const double a = cand[r].n[0], b = cand[r].n[1], c = cand[r].n[2], d = cand[r].d;
-            cnt = 0;
-            for (int k = 0; k < PTS; ++k) {
-                const size_t i = base + (size_t)k * 256;
-                const bool pv = i < n && valid[i];
-                const double x = pv ? X[i] : 0.0, y = pv ? Y[i] : 0.0, z = pv ? Z[i] : 0.0;
-                cnt += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(fabs((a * x + b * y + c * z) + d) < thr));
+        const double cx = 0.5 * (mnx + mxx), cy = 0.5 * (mny + mxy), cz = 0.5 * (mnz + mxz);
+        // half extents, widened so that c +- e really contains min and max after the roundings above
+        const double ex = (0.5 * (mxx - mnx)) * (1.0 + 0x1p-50) + 0x1p-1000, ey = (0.5 * (mxy - mny)) * (1.0 + 0x1p-50) + 0x1p-1000,
+                     ez = (0.5 * (mxz - mnz)) * (1.0 + 0x1p-50) + 0x1p-1000;
+        const float up = 1.0f + 0x1p-20f, G = 0x1p-21f;
+        const float Mg = (float)m * up * G, thr_f = (float)thr, thr_g = (float)fabs(thr) * up * G;
+        // 64 planes at a time: lane l takes the patch test for plane r0 + l (so the test costs the wave ~2 cycles per plane),
+        // the planes it cannot decide are then scored point by point, one after the other
+        for (int r0 = 0; r0 < rounds; r0 += 64) {
+            const int rl = r0 + lane;
+            const bool act = rl < rounds;
+            int dec = 2;
+            if (act) {
+                const double a = pl[rl * 4], b = pl[rl * 4 + 1], c = pl[rl * 4 + 2], d = pl[rl * 4 + 3];
+                const double tc = fabs(a * cx + b * cy + c * cz + d);
+                const double rad = fabs(a) * ex + fabs(b) * ey + fabs(c) * ez;
+                const double slack = 0x1p-40 * (fabs(a * cx) + fabs(b * cy) + fabs(c * cz) + fabs(d) + rad + fabs(thr));
+                dec = (tc + rad + slack < thr) ? 1 : ((tc - rad - slack >= thr) ? 2 : 0);
             }
-        }
-        mine += lane == (r & 63) ? cnt : 0u;
-        if ((r & 63) == 63 || r == rounds - 1) {                  // wave-uniform: lane l holds the count of round (r & ~63) + l
-            const int rr = (r & ~63) + lane;
-            if (rr <= r && mine) atomicAdd(&lc[rr], mine);
-            mine = 0;
+            unsigned int mine = dec == 1 ? nvalid : 0u;           // lane l holds the count of round r0 + l
+            unsigned long long und = __builtin_amdgcn_ballot_w64(dec == 0);
+            while (und) {                                         // wave-uniform
+                const int j = __builtin_ctzll(und);
+                und &= und - 1;
+                const int r = r0 + j;
+                const double a = pl[r * 4], b = pl[r * 4 + 1], c = pl[r * 4 + 2], d = pl[r * 4 + 3];
+                const float af = (float)a, bf = (float)b, cf = (float)c, df = (float)d;
+                const float nr = (float)(fabs(a) + fabs(b) + fabs(c)) * up;
+                const float margin = __builtin_fmaf(nr, Mg, (float)fabs(d) * up * G + thr_g);
+                const float lo = thr_f - margin, hi = thr_f + margin;
+                const f32x2 a2 = { af, af }, b2 = { bf, bf }, c2 = { cf, cf }, d2 = { df, df };
+                unsigned int cnt = 0, cnt_maybe = 0;
+#pragma unroll
+                for (int k = 0; k < PTS / 2; ++k) {
+                    const f32x2 t = __builtin_elementwise_fma(a2, px[k], __builtin_elementwise_fma(b2, py[k], __builtin_elementwise_fma(c2, pz[k], d2)));
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float at = __builtin_fabsf(t[e]);
+                        const unsigned long long in = __builtin_amdgcn_ballot_w64(at < lo) & vmask[2 * k + e];
+                        const unsigned long long maybe = __builtin_amdgcn_ballot_w64(!(at >= hi)) & vmask[2 * k + e];     // also true for NaN
+                        cnt += (unsigned)__popcll(in);
+                        cnt_maybe += (unsigned)__popcll(maybe);    // in is a subset of maybe: equal counts <=> no point in between
+                    }
+                }
+                if (cnt != cnt_maybe) {                           // wave-uniform and rare: this plane again, the reference's way
+                    cnt = 0;
+                    for (int k = 0; k < PTS; ++k) {
+                        const int row = row0 + k;
+                        const bool pv = col < w && row < h && valid[(size_t)row * w + col];
+                        const size_t i = (size_t)row * w + col;
+                        const double x = pv ? X[i] : 0.0, y = pv ? Y[i] : 0.0, z = pv ? Z[i] : 0.0;
+                        cnt += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(pv && fabs((a * x + b * y + c * z) + d) < thr));
+                    }
+                }
+                mine += lane == j ? cnt : 0u;
+            }
+            if (act && mine) atomicAdd(&lc[rl], mine);
         }
     }
-    if (ninv) atomicAdd(&s_ninv, ninv);
     __syncthreads();
-    const unsigned int binv = s_ninv;
-    for (int r = threadIdx.x; r < rounds; r += 256) {
-        // the stand-ins of the invalid points sit at the origin: same expression, x = y = z = 0
-        const double a = cand[r].n[0], b = cand[r].n[1], c = cand[r].n[2], d = cand[r].d;
-        const bool origin_in = fabs((a * 0.0 + b * 0.0 + c * 0.0) + d) < thr;
-        const unsigned int v = lc[r] - (origin_in ? binv : 0u);
-        if (v) atomicAdd(&counts[r], (unsigned long long)v);
-    }
+    for (int r = threadIdx.x; r < rounds; r += 256)
+        if (lc[r]) atomicAdd(&counts[r], (unsigned long long)lc[r]);
 }
 
 // ------------------------------------------------------------------ crop_plane (PovMesh.cpp:780-815)
@@ -1660,10 +1684,10 @@ int wass_mesh_ransac_plane(wass_ctx* c, wass_mesh* m, const int32_t* uv, int rou
     hipLaunchKernelGGL(k_ransac_planes, dim3((rounds + 63) / 64), dim3(64), 0, c->ts(), m->valid, m->x, m->y, m->z, m->w,
                        (const int32_t*)duv, rounds, cand, counts, (unsigned long long*)nullptr, 0);
     constexpr int PTS = 8;
-    const size_t lds = (size_t)rounds * (16 + 8 + 4);
+    const size_t lds = (size_t)rounds * (32 + 4);
     if (lds > 64 * 1024) return set_err(c, WASS_ERR_UNSUPPORTED, "PLANE_RANSAC_ROUNDS %d too large (max 1800)", rounds);
-    hipLaunchKernelGGL(k_ransac_score<PTS>, dim3((unsigned)((n + 256 * PTS - 1) / (256 * PTS))), dim3(256), lds, c->ts(),
-                       m->valid, m->x, m->y, m->z, n, (const PlaneCand*)cand, rounds, thr, counts);
+    hipLaunchKernelGGL(k_ransac_score<PTS>, dim3((m->w + 255) / 256, (m->h + PTS - 1) / PTS), dim3(256), lds, c->ts(),
+                       m->valid, m->x, m->y, m->z, m->w, m->h, (const PlaneCand*)cand, rounds, thr, counts);
     std::vector<PlaneCand> hc(rounds);
     std::vector<unsigned long long> hn(rounds);
     WASS_HIP(c, hipMemcpyAsync(hc.data(), cand, (size_t)rounds * sizeof(PlaneCand), hipMemcpyDeviceToHost, c->ts()));
@@ -1800,7 +1824,7 @@ static int enqueue_fit_plane(wass_ctx* c, wass_mesh* m, const int32_t* uv, int r
     unsigned long long* kept1 = (unsigned long long*)c->counters.p;            // [NSLOT]
     unsigned long long* kept2 = kept1 + NSLOT;
     constexpr int PTS = 8;
-    const size_t lds = (size_t)rounds * (16 + 8 + 4);
+    const size_t lds = (size_t)rounds * (32 + 4);
     if (lds > 64 * 1024) return set_err(c, WASS_ERR_UNSUPPORTED, "PLANE_RANSAC_ROUNDS %d too large (max 1800)", rounds);
     hipStream_t s = c->ts();
     {   // the caller's sample array may be pageable and short-lived: go through the pinned stage (the previous frame's
@@ -1815,8 +1839,8 @@ static int enqueue_fit_plane(wass_ctx* c, wass_mesh* m, const int32_t* uv, int r
     }
     hipLaunchKernelGGL(k_ransac_planes, dim3((rounds + 63) / 64), dim3(64), 0, s, m->valid, m->x, m->y, m->z, m->w, (const int32_t*)duv,
                        rounds, cand, counts, kept1, 2 * NSLOT);
-    hipLaunchKernelGGL(k_ransac_score<PTS>, dim3((unsigned)((n + 256 * PTS - 1) / (256 * PTS))), dim3(256), lds, s, m->valid, m->x,
-                       m->y, m->z, n, (const PlaneCand*)cand, rounds, ransac_thr, counts);
+    hipLaunchKernelGGL(k_ransac_score<PTS>, dim3((m->w + 255) / 256, (m->h + PTS - 1) / PTS), dim3(256), lds, s, m->valid, m->x,
+                       m->y, m->z, m->w, m->h, (const PlaneCand*)cand, rounds, ransac_thr, counts);
     hipLaunchKernelGGL(k_ransac_pick, dim3(1), dim3(64), 0, s, (const PlaneCand*)cand, (const unsigned long long*)counts, rounds, n, ds);
     RefineDev rd;
     rd.xmin = rp->xmin; rd.xmax = rp->xmax; rd.ymin = rp->ymin; rd.ymax = rp->ymax; rd.maxd = rp->max_distance;
