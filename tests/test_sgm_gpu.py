@@ -129,6 +129,30 @@ def test_device_pointer_entry(gpu_ctx, oracle):
     assert t.total_ms > 0 and t.aggregate_launches >= 1 and t.cost_overflow == 0
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_random_small_shapes_match_the_oracle(gpu_ctx, oracle, seed):
+    """Heights and widths down to a few pixels: chains of length 1-3, families split in the middle with an empty half, windows
+    wider than the image, rows fewer than a checkpoint segment -- final map and S volume against the oracle, both path modes."""
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(6):
+        h = int(rng.integers(1, 24)); w = int(rng.integers(3, 60)); D = int(rng.choice([16, 32, 48]))
+        win = int(rng.choice([1, 3, 5, 9, 13])); ndirs = int(rng.choice([5, 8])); mind = int(rng.integers(0, 3))
+        right = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        left = np.roll(right, int(rng.integers(1, 6)), axis=1) if rng.random() < 0.7 else rng.integers(0, 256, (h, w), dtype=np.uint8)
+        p = default_sgm_params(D, ndirs=ndirs, win=win, min_disp=mind, p2_mult=int(rng.choice([32, 8])))
+        p.uniq_ratio = int(rng.choice([0, 1, 10]))
+        try:
+            ref, st = oracle.dense_disparity16(right, left, _oracle_params(oracle, p))
+        except RuntimeError:                                      # image narrower than half the window: OpenCV reads past the row there
+            with pytest.raises(Exception):
+                gpu_ctx.sgm_disparity(right, left, p)
+            continue
+        if st.overflow:
+            continue                                              # outside the int16 precondition of A.7: OpenCV wraps, the GPU saturates
+        got = gpu_ctx.sgm_disparity(right, left, p)
+        np.testing.assert_array_equal(got, ref, err_msg=f"w={w} h={h} D={D} win={win} ndirs={ndirs} minD={mind}")
+
+
 def test_uploads_are_ordered_before_the_calls_that_read_them(gpu_ctx):
     """wass_upload_async copies on the context's copy stream; wass_burned_area_mask_dev and wass_sgm_disparity_dev wait for
     the uploads that cover their inputs.  Several frames are uploaded back to back into a ring of buffers (as bench.py does,
