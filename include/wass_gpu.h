@@ -164,6 +164,10 @@ int wass_disparity_postprocess_ex_dev(wass_ctx* ctx, const int16_t* d_disp16, in
                                       int out_w, int out_h, float* d_disp_f32_out);
 /* :947-986 alone, in place on a device map (test hook / building block) */
 int wass_biggest_component_by_gradient_dev(wass_ctx* ctx, float* d_disp, int w, int h, int threshold);
+/* the "large gradient" mask (non-zero where the squared Sobel magnitude exceeded the threshold, :951-957) of the last
+ * component extraction on this context (cc_threshold > 0 in wass_disparity_postprocess_ex or the call above), w x h bytes to
+ * the host: what the reference paints into disparity_large_gradient.jpg (:958-960) */
+int wass_large_gradient_mask(wass_ctx* ctx, int w, int h, uint8_t* mask_out);
 
 /* ------------------------------------------------------------------------
  * Triangulation, rows a10-a13.  Replaces triangulate(StereoMatchEnv&)

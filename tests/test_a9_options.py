@@ -126,9 +126,16 @@ def test_cli_accepts_the_three_options(tmp_path):
     cli = build.build_host()
     wd, cfg, *_ = make_workdir(str(tmp_path), 320, 240, 64, extra_cfg="DENSE_SCALE=0.5\nDENSE_DISPARITY_BIGGEST_COMPONENT_THRESHOLD=900\n"
                                                                         "DENSE_SPECKLE_WINDOW_SIZE=40\n")
-    r = subprocess.run([cli, cfg, wd], capture_output=True, text=True)
+    r = subprocess.run([cli, cfg, wd], capture_output=True, text=True, env=dict(os.environ, WASS_DEBUG_FORMAT="png"))
     assert r.returncode == 0, r.stdout
     assert "Dense-stereo input resize: [320 x 240] -> [160 x 120]" in r.stdout
+    # the option's two debug pictures (wass_stereo.cpp:958-960, 981-983): 255 on large gradients / outside the kept component
+    from test_cli import _read_png
+    lg = _read_png(os.path.join(wd, "disparity_large_gradient.png")); nb = _read_png(os.path.join(wd, "disparity_biggest_component.png"))
+    fs = _read_png(os.path.join(wd, "disparity_final_scaled.png"))
+    assert lg.shape == nb.shape == fs.shape and set(np.unique(lg)) <= {0, 255} and set(np.unique(nb)) <= {0, 255}
+    assert 0 < (lg == 255).mean() < 0.5 and 0.05 < (nb == 0).mean() < 0.99
+    assert (nb[lg == 255] == 255).all()                            # a large-gradient pixel is zeroed, so it is never in the component
     assert "extracting the biggest connected component" in r.stdout
     n = int.from_bytes(open(os.path.join(wd, "mesh_cam.xyzC"), "rb").read(4), "little")
     assert n > 20000

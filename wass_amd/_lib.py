@@ -116,6 +116,7 @@ SYMBOLS = {
     "wass_mesh_ransac_plane": (_i, [_vp, _vp, _vp, _i, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
                                     C.POINTER(_i)]),
     "wass_mesh_crop_plane": (_i, [_vp, _vp, C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_uint64)]),
+    "wass_large_gradient_mask": (_i, [_vp, _i, _i, _vp]),
     "wass_mesh_reject_codes": (_i, [_vp, _vp, _vp]),
     "wass_mesh_refine_plane": (_i, [_vp, _vp, C.POINTER(RefineParams), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "wass_mesh_refinement_inliers": (_i, [_vp, _vp, C.POINTER(RefineParams), _i, C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_uint64)]),

@@ -272,3 +272,15 @@ extern "C" int wass_biggest_component_by_gradient_dev(wass_ctx* c, float* d_disp
     if (rc) return rc;
     return biggest_component_dev(c, d_disp, w, h, threshold, (uint8_t*)c->tmp_mask.p, c->ts());
 }
+
+// disparity_large_gradient.jpg (wass_stereo.cpp:957-960): the mask the last component extraction of this context used
+extern "C" int wass_large_gradient_mask(wass_ctx* c, int w, int h, uint8_t* mask_out)
+{
+    if (!c || !mask_out || w <= 0 || h <= 0) return set_err(c, WASS_ERR_INVALID_ARG, "bad argument");
+    const size_t n = (size_t)w * h;
+    if (!c->tmp_mask.p || c->tmp_mask.cap < n) return set_err(c, WASS_ERR_INVALID_ARG, "no component extraction of that size has run on this context");
+    WASS_HIP(c, hipSetDevice(c->device));
+    WASS_HIP(c, hipMemcpyAsync(mask_out, c->tmp_mask.p, n, hipMemcpyDeviceToHost, c->ts()));
+    WASS_HIP(c, hipStreamSynchronize(c->ts()));
+    return WASS_OK;
+}

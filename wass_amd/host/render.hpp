@@ -6,6 +6,7 @@
 //   disparity_coverage.jpg         :1002-1017                  right image, green = 100 where disparity > 1, ROI, half size
 //   graph_components.jpg           PovMesh.cpp:222-250,982-984 biggest component green, the rest in palette colours, half size
 //   undistorted/R0.jpg, R1.jpg     :1111-1119,1216-1382        grey where a point was triangulated, else the colour of the rejecting test
+//   disparity_large_gradient.jpg, disparity_biggest_component.jpg  :958-960, 981-983   the two masks of the component option
 // Same names, same pixel arithmetic (render.hpp:101-136 for the disparity pictures), written by the baseline JPEG encoder of
 // jpeg.hpp (quality 95 like cv::imwrite's default; the BYTES differ from libjpeg's, the pictures do not).
 // WASS_DEBUG_FORMAT=png writes lossless <stem>.png instead (the tests check the pixel arithmetic on those).

@@ -395,6 +395,16 @@ inline int wass_run_frame(const char* config_path, const std::string& workdir, c
         }
         gpu_check(ctx, wass_disparity_postprocess_ex(ctx, disp16.data(), ws, hs, &sp, dil, ero, cfg.get_int("MEDIAN_FILTER_WSIZE"), cc_threshold,
                                                      cw, ch, dispf.data()), "wass_disparity_postprocess");
+        if (debug_images && cc_threshold > 0) {                      // :958-960, 981-983
+            Image lg(cw, ch), nb(cw, ch);
+            gpu_check(ctx, wass_large_gradient_mask(ctx, cw, ch, lg.px.data()), "wass_large_gradient_mask");
+            for (size_t i = 0; i < lg.px.size(); ++i) {
+                lg.px[i] = lg.px[i] ? 255 : 0;
+                nb.px[i] = dispf[i] == 0.0f ? 255 : 0;               // 255 outside the biggest component: the map is non-zero exactly on it
+            }
+            write_debug_gray(path_join(env.workdir, "disparity_large_gradient"), lg);
+            write_debug_gray(path_join(env.workdir, "disparity_biggest_component"), nb);
+        }
         if (debug_images) {
             const int D = sp.num_disp, offp = sp.disp_offset > 0 ? sp.disp_offset : 0, comp = sp.disp_offset > 0 ? 0 : -sp.disp_offset;
             const int Wp = cw + D + offp;
