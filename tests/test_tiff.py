@@ -1,4 +1,4 @@
-"""The TIFF reader of wass_prepare's inputs (wass_amd/host/tiff.hpp; wasscli lists tif / tiff among the supported formats,
+"""The TIFF and JPEG readers of wass_prepare's inputs (wass_amd/host/tiff.hpp; wasscli lists tif / tiff among the supported formats,
 cli/wasscli/wasscli.py:47): files written by Pillow / libtiff in the variants cameras and converters produce must decode to
 the grey picture cv::imread(IMREAD_GRAYSCALE) would give."""
 import os
@@ -14,7 +14,7 @@ Image = pytest.importorskip("PIL.Image")
 @pytest.fixture(scope="module")
 def tool():
     src = os.path.join(HERE, "native", "tiff_check.cpp")
-    deps = [src] + [os.path.join(HERE, "..", "wass_amd", "host", f) for f in ("tiff.hpp", "hostio.hpp")]
+    deps = [src] + [os.path.join(HERE, "..", "wass_amd", "host", f) for f in ("tiff.hpp", "hostio.hpp", "jpeg_read.hpp")]
     out_dir = os.path.join(HERE, "native", "_build")
     os.makedirs(out_dir, exist_ok=True)
     exe = os.path.join(out_dir, "tiff_check")
@@ -78,11 +78,47 @@ def test_png_still_goes_through_the_same_entry_point(tool, tmp_path):
     np.testing.assert_array_equal(_decode(tool, path, tmp_path), img)
 
 
+@pytest.mark.parametrize("mode,subsampling,w,h", [("L", None, 64, 48), ("L", None, 333, 257), ("RGB", 0, 100, 75), ("RGB", 1, 211, 97), ("RGB", 2, 640, 480),
+                                                      ("RGB", 2, 17, 9)])
+def test_baseline_jpeg_decodes_to_what_libjpeg_gives(tool, tmp_path, mode, subsampling, w, h):
+    """cv::imread(IMREAD_GRAYSCALE) lets libjpeg decode to grey = the luminance plane alone; Pillow's draft mode "L" asks libjpeg
+    for the same thing."""
+    g = _grey(w, h, w + h)
+    if mode == "L":
+        src = Image.fromarray(g)
+    else:
+        src = Image.fromarray(np.stack([g, np.roll(g, 5, 1), 255 - g], -1))
+    path = tmp_path / "x.jpg"
+    kw = {} if subsampling is None else {"subsampling": subsampling}
+    src.save(path, quality=92, **kw)
+    im = Image.open(path)
+    im.draft("L", (w, h))                                                   # libjpeg decodes straight to grey (JCS_GRAYSCALE), like cv::imread
+    want = np.asarray(im)
+    assert want.ndim == 2
+    got = _decode(tool, path, tmp_path)
+    assert got.shape == want.shape
+    d = np.abs(got.astype(int) - want.astype(int))
+    assert d.max() <= 2 and d.mean() < 0.3, (d.max(), d.mean())            # double-precision IDCT against libjpeg's integer IDCT
+
+
+def test_jpeg_restart_intervals_and_progressive(tool, tmp_path):
+    g = _grey(200, 120, 4)
+    path = tmp_path / "r.jpg"
+    try:
+        Image.fromarray(g).save(path, quality=90, restart_marker_blocks=7)
+        blob = path.read_bytes()
+        if b"\xff\xdd" in blob:                                             # Pillow wrote a DRI segment
+            d = np.abs(_decode(tool, path, tmp_path).astype(int) - np.asarray(Image.open(path)).astype(int))
+            assert d.max() <= 2
+    except TypeError:
+        pass                                                                # this Pillow cannot write restart markers
+    prog = tmp_path / "p.jpg"
+    Image.fromarray(g).save(prog, quality=90, progressive=True)
+    with pytest.raises(RuntimeError, match="progressive"):
+        _decode(tool, prog, tmp_path)
+
+
 def test_unsupported_files_are_refused_with_a_message(tool, tmp_path):
-    jpg = tmp_path / "x.jpg"
-    Image.fromarray(_grey(32, 32, 1)).save(jpg)
-    with pytest.raises(RuntimeError, match="JPEG input is not supported"):
-        _decode(tool, jpg, tmp_path)
     bad = tmp_path / "t.tif"
     bad.write_bytes(b"II*\x00\x08\x00\x00\x00\x00\x00")
     with pytest.raises(RuntimeError):

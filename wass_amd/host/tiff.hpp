@@ -8,6 +8,8 @@
 
 #include <zlib.h>
 
+#include "jpeg_read.hpp"
+
 #include <cstdint>
 #include <cstring>
 #include <fstream>
@@ -183,14 +185,14 @@ inline Image decode_tiff_gray(const std::vector<uint8_t>& f, const std::string& 
     return img;
 }
 
-// any supported picture -> 8-bit grey (cv::imread(..., IMREAD_GRAYSCALE)): PNG or TIFF, told apart by their magic bytes
+// any supported picture -> 8-bit grey (cv::imread(..., IMREAD_GRAYSCALE)): PNG, TIFF or baseline JPEG, told apart by their magic bytes
 inline Image read_image_gray(const std::string& filename)
 {
     std::ifstream ifs(filename.c_str(), std::ios::binary);
     if (!ifs.is_open()) throw std::runtime_error("unable to open " + filename);
     std::vector<uint8_t> f((std::istreambuf_iterator<char>(ifs)), std::istreambuf_iterator<char>());
     if (is_tiff(f)) return decode_tiff_gray(f, filename);
-    if (f.size() >= 3 && f[0] == 0xFF && f[1] == 0xD8) throw std::runtime_error(filename + ": JPEG input is not supported (PNG and TIFF are)");
+    if (is_jpeg(f)) return decode_jpeg_gray(f, filename);
     return read_png_gray(filename);
 }
 

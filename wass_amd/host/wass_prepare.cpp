@@ -7,8 +7,8 @@
 // Same options, exit codes, calibdir inputs (intrinsics_0X.xml, distortion_0X.xml, ext_R.xml, ext_T.xml,
 // prepare_config.txt), workdir outputs (undistorted/0000000X.png, intrinsics_0000000X.xml, ext_R.xml, ext_T.xml), stdout
 // progress markers and log lines as the reference.  Out of scope and rejected loudly: the polarimetric camera branch
-// (--demosaic / --hdr / --dolp-aolp / --save-channels / --save-stokes, :100-255) and JPEG input (PNG and TIFF are read:
-// hostio.hpp, tiff.hpp).
+// (--demosaic / --hdr / --dolp-aolp / --save-channels / --save-stokes, :100-255).  Inputs: PNG, TIFF and baseline JPEG
+// (hostio.hpp, tiff.hpp, jpeg_read.hpp), the formats wasscli accepts (wasscli.py:47).
 // There is NO CPU implementation of the image work: without a GPU (or libwassgpu.so) the program fails with exit -1.
 #include <sys/stat.h>
 #include <sys/types.h>
@@ -80,7 +80,7 @@ bool process_image(Gpu& gpu, const std::string& filename, const Mat& K, const Ma
 {
     WLOGI << "Processing " << filename;
     Image img;
-    try { img = read_image_gray(filename); } catch (const std::exception& e) { WLOGE << e.what(); return false; }     // PNG or TIFF
+    try { img = read_image_gray(filename); } catch (const std::exception& e) { WLOGE << e.what(); return false; }     // PNG, TIFF or baseline JPEG
     WLOGI << "Input image size: " << img.w << "x" << img.h;
     if (!gpu.ctx) {
         const char* dev = getenv("WASS_DEVICE");
