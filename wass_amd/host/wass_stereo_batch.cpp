@@ -133,7 +133,9 @@ int main(int argc, char* argv[])
 {
     if (argc < 3) {
         std::cout << "Usage:\n  wass_stereo_batch <config_file> <workdir>... [--gpus G] [--procs-per-gpu P] [--out <dir>] [--verbose] [--skip-existing] [--debug-images]\n"
-                     "  wass_stereo_batch <config_file> --sequence <output_dir> [--gpus G] ...\n";
+                     "  wass_stereo_batch <config_file> --sequence <output_dir> [--gpus G] ...\n"
+                     "  --procs-per-gpu P   worker processes per GPU (default 1).  The host side of a worker (PNG decoding, text files) is\n"
+                     "                      the limit, not the GPU: 4 workers give about 2.5 times the frames per second of one.\n";
         return argc == 1 ? 0 : -1;
     }
     const char* cfg = argv[1];
