@@ -22,6 +22,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=8)
 ap.add_argument("--config", default="B")
 ap.add_argument("--procs", default="1,2,4", help="worker processes per GPU to try with wass_stereo_batch")
+ap.add_argument("--threads", default="1", help="threads per worker process to try (each combined with every --procs value)")
 ap.add_argument("--replicate", type=int, default=1, help="extra copies of every workdir (inputs symlinked) so that a long sequence is cheap to set up")
 ap.add_argument("--skip-single", action="store_true", help="skip the one-process-per-frame runs")
 args = ap.parse_args()
@@ -91,10 +92,10 @@ for dbg in (() if args.skip_single else ("1", "0")):
     print(f"wass_stereo, one process per frame, debug pictures {'on' if dbg == '1' else 'off'}: {min(ts):.2f} s/frame (best of {len(ts)})")
     if dbg == "0":
         print("  time table of the last run:\n" + "\n".join(l for l in r.stdout.splitlines() if "|" in l and "P|" not in l))
-for procs in [int(x) for x in args.procs.split(",")]:
-    t, r = timed([build.BATCH, cfg, "--sequence", seq, "--procs-per-gpu", str(procs)])
+for procs, thr in [(int(x), int(y)) for x in args.procs.split(",") for y in args.threads.split(",")]:
+    t, r = timed([build.BATCH, cfg, "--sequence", seq, "--procs-per-gpu", str(procs), "--threads-per-proc", str(thr)])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    print(f"wass_stereo_batch, {procs} worker process(es) on one GPU, {nframes} frames: {t:.2f} s total = {t / nframes:.3f} s/frame = "
+    print(f"wass_stereo_batch, {procs} worker process(es) x {thr} thread(s) on one GPU, {nframes} frames: {t:.2f} s total = {t / nframes:.3f} s/frame = "
           f"{nframes / t:.2f} frames/s")
 log = open(os.path.join(seq, "%06d_wd" % (nframes - 1), "wass_stereo_log.txt")).read()
 print("  time table of the last frame of the batch (persistent context):\n" + "\n".join(l for l in log.splitlines() if "|" in l and "P|" not in l))

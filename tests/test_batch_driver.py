@@ -76,25 +76,31 @@ def test_failed_frame_is_reported_and_left_out(exes, tmp_path):
 
 
 @pytest.mark.gpu
-def test_batch_equals_one_process_per_frame(exes, tmp_path):
+@pytest.mark.parametrize("layout", [("--procs-per-gpu", "2"), ("--threads-per-proc", "3"), ("--procs-per-gpu", "2", "--threads-per-proc", "2")])
+def test_batch_equals_one_process_per_frame(exes, tmp_path, layout):
+    """Worker processes and / or threads (each thread a context of its own inside one process): the files of every workdir are
+    those of one wass_stereo process per frame, byte for byte, and the per-frame log goes to the right workdir."""
     cli, batch = exes
     w, h, D = 320, 240, 64
     seq_a, seq_b = tmp_path / "a", tmp_path / "b"
     cfg = None
-    for i in range(3):
+    nframes = 5
+    for i in range(nframes):
         t = tmp_path / f"mk{i}"
         t.mkdir()
         wd, cfg_i, *_ = make_workdir(str(t), w, h, D, frame=i)
         for seq in (seq_a, seq_b):
             shutil.copytree(wd, seq / ("%06d_wd" % i))
         cfg = cfg_i
-    for i in range(3):                                                   # the reference's way: one process per frame
+    for i in range(nframes):                                             # the reference's way: one process per frame
         r = subprocess.run([cli, cfg, str(seq_a / ("%06d_wd" % i))], capture_output=True, text=True)
         assert r.returncode == 0, r.stdout
-    r = subprocess.run([batch, cfg, "--sequence", str(seq_b), "--gpus", "1", "--procs-per-gpu", "2"], capture_output=True, text=True)
+    r = subprocess.run([batch, cfg, "--sequence", str(seq_b), "--gpus", "1", *layout], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     expect = ""
-    for i in range(3):
+    for i in range(nframes):
+        log = (seq_b / ("%06d_wd" % i) / "wass_stereo_log.txt").read_text()
+        assert log.count("Reconstructing") == 1 and ("%06d_wd" % i) in log and "estimated plane coeffs" in log
         for name in ("mesh_cam.xyzC", "plane.txt", "P0cam.txt", "Cam1_poseT.txt", "plane_refinement_inliers.xyz"):
             a = (seq_a / ("%06d_wd" % i) / name).read_bytes()
             assert a == (seq_b / ("%06d_wd" % i) / name).read_bytes(), f"frame {i}: {name} differs"

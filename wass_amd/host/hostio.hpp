@@ -26,7 +26,7 @@ namespace wasshost {
 struct LogState {
     std::string scope;
     std::unique_ptr<std::ofstream> file;
-    static LogState& get() { static LogState s; return s; }
+    static LogState& get() { static thread_local LogState s; return s; }     // per thread: a sequence driver runs frames on several threads
 };
 inline void setup_logger(const std::string& filename = std::string())
 {

@@ -23,6 +23,9 @@
 
 #include <algorithm>
 
+#include <mutex>
+#include <thread>
+
 #include "wass_frame.hpp"
 
 using namespace wassframe;
@@ -70,46 +73,65 @@ bool read_plane_txt(const std::string& wd, FrameSummary& fs)
 }
 
 int worker(int rank, int world, int device, bool distinct_gpus, const unsigned char* uid, const char* cfg,
-           const std::vector<std::string>& wds, bool verbose, bool skip_existing, bool debug_images, int fd)
+           const std::vector<std::string>& wds, bool verbose, bool skip_existing, bool debug_images, int fd, int threads)
 {
     if (!verbose) {                       // per-frame logs still go to <workdir>/wass_stereo_log.txt
         const int nul = open("/dev/null", O_WRONLY);
         if (nul >= 0) { dup2(nul, 1); close(nul); }
     }
-    wass_ctx* ctx = nullptr;
+    wass_ctx* ctx = nullptr;                                     // thread 0's context: also carries the RCCL collective below
     double acc[5] = { 0, 0, 0, 0, 0 };
-    // the next frame's PNGs are inflated on a host thread while this frame is being processed
-    Preload pre[2];
-    AsyncWriter writer;                                          // a frame's mesh_cam.xyzC is written while the next frame runs
-    std::thread loader;
-    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{ loader };     // also on the early returns
-    auto done = [&](size_t k) { return skip_existing && (exists(path_join(wds[k], "mesh_cam.xyzC")) || exists(path_join(wds[k], "mesh_cam.xyzbin"))); };
-    auto start_load = [&](size_t k, int slot) {
-        if (k < wds.size() && exists(wds[k]) && !done(k)) loader = std::thread([&, k, slot]() { preload_images(wds[k], pre[slot]); });
+    std::mutex mu;                                               // the pipe and the running plane sum
+    int status = 0;
+    // Frames rank, rank + world, ... of this worker are dealt round-robin to `threads` host threads, each with a context of
+    // its own (own streams and buffers): kernels of different frames then overlap on the GPU inside ONE process, which
+    // processes sharing a GPU do not do nearly as well.
+    auto run = [&](int tid) {
+        wass_ctx* my = nullptr;
+        // the next frame's PNGs are inflated on a host thread while this frame is being processed
+        Preload pre[2];
+        AsyncWriter writer;                                      // a frame's mesh_cam.xyzC is written while the next frame runs
+        std::thread loader;
+        struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{ loader };     // also on the early returns
+        const size_t stride = (size_t)world * (size_t)threads, first = (size_t)rank + (size_t)tid * (size_t)world;
+        auto done = [&](size_t k) { return skip_existing && (exists(path_join(wds[k], "mesh_cam.xyzC")) || exists(path_join(wds[k], "mesh_cam.xyzbin"))); };
+        auto start_load = [&](size_t k, int slot) {
+            if (k < wds.size() && exists(wds[k]) && !done(k)) loader = std::thread([&, k, slot]() { preload_images(wds[k], pre[slot]); });
+        };
+        start_load(first, 0);
+        int slot = 0;
+        for (size_t i = first; i < wds.size(); i += stride, slot ^= 1) {
+            Record r = {};
+            r.index = (int)i;
+            const double t0 = now();
+            FrameSummary fs;
+            if (loader.joinable()) loader.join();                 // this frame's pictures (slot) are in memory now
+            start_load(i + stride, slot ^ 1);
+            if (done(i) && read_plane_txt(wds[i], fs))
+                r.rc = 0;
+            else
+                r.rc = exists(wds[i]) ? wass_run_frame(cfg, wds[i], nullptr, device, &my, &fs, debug_images, &pre[slot], &writer) : -1;
+            r.seconds = now() - t0;
+            r.have_plane = r.rc == 0 && fs.have_plane;
+            r.n_points = fs.n_points;
+            for (int k = 0; k < 4; ++k) r.plane[k] = r.have_plane ? fs.plane[k] : std::nan("");
+            std::lock_guard<std::mutex> lk(mu);
+            if (r.rc == 0) wass_planes_mean_accumulate(r.plane, 1, acc);     // NaN planes are skipped (nanmean)
+            if (!write_all(fd, &r, sizeof r)) { status = 2; break; }
+        }
+        if (loader.joinable()) loader.join();
+        writer.wait();
+        std::lock_guard<std::mutex> lk(mu);
+        if (writer.failed && !status) status = 4;
+        if (tid == 0) ctx = my; else if (my) wass_ctx_destroy(my);
     };
-    start_load((size_t)rank, 0);
-    int slot = 0;
-    for (size_t i = (size_t)rank; i < wds.size(); i += (size_t)world, slot ^= 1) {
-        Record r = {};
-        r.index = (int)i;
-        const double t0 = now();
-        FrameSummary fs;
-        if (loader.joinable()) loader.join();                     // this frame's pictures (slot) are in memory now
-        start_load(i + (size_t)world, slot ^ 1);
-        if (done(i) && read_plane_txt(wds[i], fs))
-            r.rc = 0;
-        else
-            r.rc = exists(wds[i]) ? wass_run_frame(cfg, wds[i], nullptr, device, &ctx, &fs, debug_images, &pre[slot], &writer) : -1;
-        r.seconds = now() - t0;
-        r.have_plane = r.rc == 0 && fs.have_plane;
-        r.n_points = fs.n_points;
-        for (int k = 0; k < 4; ++k) r.plane[k] = r.have_plane ? fs.plane[k] : std::nan("");
-        if (r.rc == 0) wass_planes_mean_accumulate(r.plane, 1, acc);     // NaN planes are skipped (nanmean)
-        if (!write_all(fd, &r, sizeof r)) return 2;
+    {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < threads; ++t) pool.emplace_back(run, t);
+        run(0);
+        for (auto& th : pool) th.join();
     }
-    if (loader.joinable()) loader.join();
-    writer.wait();
-    if (writer.failed) return 4;
+    if (status) return status;
     Tail t = {};
     t.magic = 0x57415353;
     if (world > 1 && distinct_gpus) {
@@ -134,6 +156,7 @@ int main(int argc, char* argv[])
     if (argc < 3) {
         std::cout << "Usage:\n  wass_stereo_batch <config_file> <workdir>... [--gpus G] [--procs-per-gpu P] [--out <dir>] [--verbose] [--skip-existing] [--debug-images]\n"
                      "  wass_stereo_batch <config_file> --sequence <output_dir> [--gpus G] ...\n"
+                     "  --threads-per-proc T  frames in flight per worker process, each on a thread and a context of its own (default 1)\n"
                      "  --procs-per-gpu P   worker processes per GPU (default 1).  The host side of a worker (PNG decoding, text files) is\n"
                      "                      the limit, not the GPU: 4 workers give about 2.5 times the frames per second of one.\n";
         return argc == 1 ? 0 : -1;
@@ -141,12 +164,13 @@ int main(int argc, char* argv[])
     const char* cfg = argv[1];
     std::vector<std::string> wds;
     std::string outdir;
-    int gpus = 1, ppg = 1;
+    int gpus = 1, ppg = 1, tpp = 1;
     bool verbose = false, skip_existing = false, debug_images = false;
     for (int i = 2; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "--gpus" && i + 1 < argc) gpus = atoi(argv[++i]);
         else if (a == "--procs-per-gpu" && i + 1 < argc) ppg = atoi(argv[++i]);
+        else if (a == "--threads-per-proc" && i + 1 < argc) tpp = atoi(argv[++i]);
         else if (a == "--out" && i + 1 < argc) outdir = argv[++i];
         else if (a == "--verbose") verbose = true;
         else if (a == "--skip-existing") skip_existing = true;
@@ -167,7 +191,7 @@ int main(int argc, char* argv[])
         } else if (a.rfind("--", 0) == 0) { std::cerr << "unknown option " << a << std::endl; return -1; }
         else wds.push_back(a);
     }
-    if (gpus < 1 || ppg < 1 || wds.empty()) { std::cerr << "Invalid arguments" << std::endl; return -1; }
+    if (gpus < 1 || ppg < 1 || tpp < 1 || wds.empty()) { std::cerr << "Invalid arguments" << std::endl; return -1; }
     { std::ifstream ifs(cfg); if (!ifs.is_open()) { std::cerr << "Unable to load " << cfg << std::endl; return -1; } }
     if (outdir.empty()) outdir = ".";
     const int world = gpus * ppg;
@@ -178,7 +202,7 @@ int main(int argc, char* argv[])
         return -1;
     }
 
-    std::cout << "wass_stereo_batch: " << wds.size() << " frame(s), " << world << " worker process(es) on " << gpus << " GPU(s)" << std::endl;
+    std::cout << "wass_stereo_batch: " << wds.size() << " frame(s), " << world << " worker process(es) x " << tpp << " thread(s) on " << gpus << " GPU(s)" << std::endl;
     const double t0 = now();
     std::vector<pid_t> pids(world);
     std::vector<int> fds(world);
@@ -190,7 +214,7 @@ int main(int argc, char* argv[])
         if (pid == 0) {
             close(pfd[0]);
             for (int q = 0; q < r; ++q) close(fds[q]);
-            _exit(worker(r, world, r / ppg, distinct, uid, cfg, wds, verbose, skip_existing, debug_images, pfd[1]));
+            _exit(worker(r, world, r / ppg, distinct, uid, cfg, wds, verbose, skip_existing, debug_images, pfd[1], tpp));
         }
         close(pfd[1]);
         pids[r] = pid; fds[r] = pfd[0];
