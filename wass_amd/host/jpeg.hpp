@@ -78,13 +78,12 @@ struct BitWriter {
 // forward 8x8 DCT-II of a level-shifted block, separable, in double
 inline void fdct8x8(const double in[64], double out[64])
 {
-    static double c[8][8];
-    static bool init = false;
-    if (!init) {
-        for (int k = 0; k < 8; ++k)
-            for (int x = 0; x < 8; ++x) c[k][x] = (k == 0 ? std::sqrt(0.125) : 0.5) * std::cos((2 * x + 1) * k * 3.14159265358979323846 / 16.0);
-        init = true;
-    }
+    struct Table {                                            // built once, thread-safe (function-local static)
+        double v[8][8];
+        Table() { for (int k = 0; k < 8; ++k) for (int x = 0; x < 8; ++x) v[k][x] = (k == 0 ? std::sqrt(0.125) : 0.5) * std::cos((2 * x + 1) * k * 3.14159265358979323846 / 16.0); }
+    };
+    static const Table tab;
+    const double (&c)[8][8] = tab.v;
     double tmp[64];
     for (int y = 0; y < 8; ++y)
         for (int k = 0; k < 8; ++k) { double s = 0; for (int x = 0; x < 8; ++x) s += c[k][x] * in[y * 8 + x]; tmp[y * 8 + k] = s; }

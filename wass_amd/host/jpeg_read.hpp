@@ -70,13 +70,12 @@ inline int extend(int v, int t) { return t == 0 ? 0 : (v < (1 << (t - 1)) ? v - 
 
 inline void idct8x8(const double in[64], uint8_t* out, size_t stride, int wlim, int hlim)
 {
-    static double c[8][8];
-    static bool init = false;
-    if (!init) {
-        for (int k = 0; k < 8; ++k)
-            for (int x = 0; x < 8; ++x) c[k][x] = (k == 0 ? std::sqrt(0.125) : 0.5) * std::cos((2 * x + 1) * k * 3.14159265358979323846 / 16.0);
-        init = true;
-    }
+    struct Table {                                            // built once, thread-safe (function-local static)
+        double v[8][8];
+        Table() { for (int k = 0; k < 8; ++k) for (int x = 0; x < 8; ++x) v[k][x] = (k == 0 ? std::sqrt(0.125) : 0.5) * std::cos((2 * x + 1) * k * 3.14159265358979323846 / 16.0); }
+    };
+    static const Table tab;
+    const double (&c)[8][8] = tab.v;
     double tmp[64];
     for (int v = 0; v < 8; ++v)
         for (int x = 0; x < 8; ++x) { double s = 0; for (int u = 0; u < 8; ++u) s += c[u][x] * in[v * 8 + u]; tmp[v * 8 + x] = s; }
