@@ -200,48 +200,6 @@ def test_overflow_is_reported(gpu_ctx):
     assert e.value.code == -5
 
 
-@pytest.mark.parametrize("ndirs", [5, 8])
-def test_pipelined_strip_schedule_is_bit_exact(gpu_ctx, oracle, ndirs, monkeypatch):
-    """WASS_AGG=trio: the alternative aggregation schedule (neighbour hand-off through HBM) gives the same bits."""
-    monkeypatch.setenv("WASS_AGG", "trio")
-    for (w, h, D) in ((160, 120, 32), (300, 40, 160), (340, 32, 272)):
-        right, left = synth.make_pair(w, h, D, frame_idx=77)
-        p = default_sgm_params(D, ndirs=ndirs)
-        gpu_ctx.set_debug(True)
-        try:
-            got = gpu_ctx.sgm_disparity(right, left, p)
-            _, Sg, _ = gpu_ctx.sgm_debug_fetch(w, h, p, want=("S",))
-        finally:
-            gpu_ctx.set_debug(False)
-        R, L = _pad(right, left, D)
-        disp, st, Co, So, rawo = oracle.sgbm_compute(R, L, _oracle_params(oracle, p), dump=True)
-        np.testing.assert_array_equal(Sg, So)
-        np.testing.assert_array_equal(got, disp[:, D:D + w])
-
-
-@pytest.mark.parametrize("w,h,D,ndirs,win,mind,off", [c for c in CASES if c[:3] in {
-    (64, 48, 16), (160, 120, 32), (200, 90, 64), (150, 70, 128), (131, 77, 48), (320, 64, 256), (300, 40, 160), (340, 32, 272),
-    (560, 24, 512), (700, 20, 640), (40, 300, 16), (33, 29, 16), (1100, 10, 1024), (75, 41, 32)}])
-def test_tile_fused_schedule_is_bit_exact(gpu_ctx, oracle, monkeypatch, w, h, D, ndirs, win, mind, off):
-    """WASS_AGG=tile (sgm_tile.hip): edge sweeps + tile kernels with S kept in LDS -- quad-layout kernels for complete
-    tiles at D <= 512, one-pixel-per-wave kernels for the border tiles and for larger D.  Same bits as the oracle."""
-    monkeypatch.setenv("WASS_AGG", "tile")
-    right, left = synth.make_pair(w, h, D, frame_idx=w + h + D)
-    p = default_sgm_params(D, ndirs=ndirs, win=win, min_disp=mind, disp_offset=off)
-    gpu_ctx.set_debug(True)
-    try:
-        got = gpu_ctx.sgm_disparity(right, left, p)
-        _, Sg, rawg = gpu_ctx.sgm_debug_fetch(w, h, p, want=("S", "raw"))
-    finally:
-        gpu_ctx.set_debug(False)
-    np.testing.assert_array_equal(gpu_ctx.sgm_disparity(right, left, p), got)      # production mode: S never leaves LDS
-    R, L = _pad(right, left, D, off)
-    disp, st, Co, So, rawo = oracle.sgbm_compute(R, L, _oracle_params(oracle, p), dump=True)
-    np.testing.assert_array_equal(Sg, So, err_msg="aggregated volume S")
-    np.testing.assert_array_equal(rawg, rawo, err_msg="raw disparity")
-    np.testing.assert_array_equal(got, disp[:, D:D + w])
-
-
 def test_random_parameter_sets_match_the_oracle(gpu_ctx, oracle):
     """SGBM parameters away from the WASS defaults (uniqueness ratio, disp12MaxDiff, pre-filter cap, P1/P2, window,
     minimum disparity, path count), drawn at random: final fixed-point disparity bit-exact against the oracle."""

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libwassgpu.so")
+# WASS_GPU_LIB: another build of the same library (A/B measurements); there is still no fallback of any kind
+SO_PATH = os.environ.get("WASS_GPU_LIB") or os.path.join(_HERE, "libwassgpu.so")
 
 WASS_OK = 0
 WASS_ERR_COST_OVERFLOW = -5

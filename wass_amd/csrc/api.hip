@@ -96,7 +96,6 @@ int wass_ctx_create(int device_id, wass_ctx** out)
     c->device = device_id;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
-    if (hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
     if (hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
     if (hipStreamCreateWithFlags(&c->tail, hipStreamNonBlocking) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
     if (hipEventCreateWithFlags(&c->ev_post, hipEventDisableTiming) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
@@ -106,7 +105,6 @@ int wass_ctx_create(int device_id, wass_ctx** out)
         for (auto& e : set)
             if (hipEventCreate(&e) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
     if (hipEventCreateWithFlags(&c->ev_cost, hipEventDisableTiming) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
-    if (hipEventCreateWithFlags(&c->ev_cols, hipEventDisableTiming) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
     for (auto& e : c->ev_ckpt)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
     if (ensure(c, c->flags, 64) != WASS_OK) { wass_ctx_destroy(c); return WASS_ERR_NO_MEMORY; }
@@ -126,15 +124,13 @@ void wass_ctx_destroy(wass_ctx* c)
     coll_release(c);
     mesh_pool_ctx_alive(c, false);
     mesh_pool_purge(c);
-    for (Buf* b : { &c->img1, &c->img2, &c->bt1, &c->bt2, &c->hsum, &c->C, &c->S, &c->S2, &c->halo, &c->ckpt, &c->edges, &c->sel_d16, &c->sel_key, &c->raw,
+    for (Buf* b : { &c->img1, &c->img2, &c->bt1, &c->bt2, &c->hsum, &c->C, &c->S, &c->ckpt, &c->sel_d16, &c->sel_key, &c->raw,
                     &c->flags, &c->tmp_in0, &c->tmp_in1, &c->tmp_out, &c->tmp_mask, &c->fA, &c->fB, &c->fC, &c->fD, &c->fE, &c->uf, &c->rs_r, &c->rs_l, &c->raw2, &c->grid, &c->scratch, &c->counters, &c->dstate, &c->rect_tab, &c->rect_mx, &c->rect_my, &c->xyzc, &c->limits })
         release(*b);
     for (auto& set : c->evs) for (auto& e : set) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_ckpt) if (e) (void)hipEventDestroy(e);
     if (c->ev_cost) (void)hipEventDestroy(c->ev_cost);
-    if (c->ev_cols) (void)hipEventDestroy(c->ev_cols);
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
-    if (c->side2) { (void)hipStreamSynchronize(c->side2); (void)hipStreamDestroy(c->side2); }
     if (c->copy) { (void)hipStreamSynchronize(c->copy); (void)hipStreamDestroy(c->copy); }
     if (c->tail) { (void)hipStreamSynchronize(c->tail); (void)hipStreamDestroy(c->tail); }
     if (c->ev_post) (void)hipEventDestroy(c->ev_post);
@@ -220,8 +216,7 @@ int wass_sgm_disparity_dev(wass_ctx* c, const uint8_t* d_right, const uint8_t* d
     if ((rc = ensure(c, c->img1, npad)) || (rc = ensure(c, c->img2, npad)) ||
         (rc = ensure(c, c->bt1, npad * 8)) || (rc = ensure(c, c->bt2, (size_t)d.h * 6 * bt2_pitch(d.Wp) * 2 + 8192)) ||
         (rc = ensure(c, c->hsum, vol)) || (rc = ensure(c, c->C, vol)) ||
-        (!tile_schedule_enabled() && (rc = ensure(c, c->S, vol))) ||      // the tile schedule keeps S in LDS
-
+        (rc = ensure(c, c->S, vol)) ||
         (rc = ensure(c, c->sel_d16, (size_t)d.width1 * d.h * 2)) ||
         (rc = ensure(c, c->sel_key, (size_t)d.width1 * d.h * 4)) || (rc = ensure(c, c->raw, npad * 2)))
         return rc;
@@ -243,7 +238,7 @@ int wass_sgm_disparity_dev(wass_ctx* c, const uint8_t* d_right, const uint8_t* d
     if ((rc = launch_cost_volume(c, d))) return rc;
     WASS_HIP(c, hipEventRecord(c->ev[2], s));
     int nl = 0;
-    if ((rc = tile_schedule_enabled() ? launch_aggregate_tile(c, d, &nl) : launch_aggregate(c, d, &nl))) return rc;
+    if ((rc = launch_aggregate(c, d, &nl))) return rc;
     WASS_HIP(c, hipEventRecord(c->ev[3], s));
     if ((rc = launch_select(c, d))) return rc;
     WASS_HIP(c, hipEventRecord(c->ev[4], s));
@@ -290,10 +285,6 @@ static int read_timings(wass_ctx* c, unsigned long long call, wass_sgm_timings* 
     t.aggregate_launches = c->launches[set];
     c->timings = t;
     *out = t;
-    if (fl & 2) {
-        c->halo_dirty = true;
-        return set_err(c, WASS_ERR_DEVICE, "aggregation pipeline timed out waiting for a neighbouring strip");
-    }
     return WASS_OK;
 }
 
@@ -332,10 +323,6 @@ int wass_sgm_disparity(wass_ctx* c, const uint8_t* right, const uint8_t* left, i
     WASS_HIP(c, hipMemcpyAsync(disp16_out, c->tmp_out.p, no * 2, hipMemcpyDeviceToHost, c->stream));
     WASS_HIP(c, hipStreamSynchronize(c->stream));
     const uint32_t fl = c->h_flags[4 * (int)((c->nsgm - 1) & 1)];
-    if (fl & 2) {
-        c->halo_dirty = true;
-        return set_err(c, WASS_ERR_DEVICE, "aggregation pipeline timed out waiting for a neighbouring strip");
-    }
     if (fl & 1)
         return set_err(c, WASS_ERR_COST_OVERFLOW,
                        "block cost + P2 exceeded 32767: outside the range where the reference is well defined");

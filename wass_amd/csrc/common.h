@@ -113,10 +113,6 @@ struct wass_ctx {
     wass::Buf bt1, bt2;            // BT interval records: bt1 8 B/pixel; bt2 six mirrored u16 planes per row
     wass::Buf hsum, C, S;          // u16 volumes [h][width1][Dp]
     wass::Buf ckpt;                // forward-path checkpoints of k_pair (1/K of a volume)
-    wass::Buf edges;               // tile schedule: states with which every path enters every tile (sgm_tile.hip)
-    wass::Buf S2;                  // second partial-sum volume (pipelined-strip schedule)
-    wass::Buf halo;                // boundary vectors handed between neighbouring strips (two sweeps)
-    bool halo_dirty = false;       // a time-out left the halo buffer in an unknown state
     wass::Buf sel_d16, sel_key;    // per (y,x): raw fixed-point disparity / (minS<<16|d)
     wass::Buf raw;                 // padded-width raw disparity [h][Wp] int16
     wass::Buf flags;               // u32[4]: [0] = cost overflow
@@ -163,8 +159,8 @@ struct wass_ctx {
     hipEvent_t* ev = evs[0];       // set of the last call
     unsigned long long nsgm = 0;   // SGM calls so far
     int launches[2] = {};
-    hipStream_t side = nullptr, side2 = nullptr;   // checkpoint sweeps run ahead here
-    hipEvent_t ev_cost = nullptr, ev_ckpt[4] = {}, ev_cols = nullptr;
+    hipStream_t side = nullptr;    // checkpoint sweeps run ahead here
+    hipEvent_t ev_cost = nullptr, ev_ckpt[4] = {};
     void* coll_comm = nullptr;     // ncclComm_t of wass_coll_init (coll.hip); coll_buf: 64 doubles of HBM for the all-reduce
     void* coll_buf = nullptr;
     int coll_world = 0;
@@ -207,7 +203,7 @@ int ensure(wass_ctx* c, Buf& b, size_t bytes);
 // forward checkpoints are produced by the cost stage itself (k_vsum_col walks whole columns top-down, which is
 // exactly that family's forward path), so its pair kernel can start the moment C is complete.
 // steps per checkpoint segment (and unroll depth of the sweeps) for NP packed pairs per lane: bounded by the register
-// budget of k_pair, which keeps 7 * K * NP vectors live
+// budget of k_pair, which keeps 4 * K * NP vectors live (two banks of cost vectors, the forward path costs and S)
 #ifndef WASS_K_SMALL
 #define WASS_K_SMALL 8
 #endif
@@ -225,23 +221,12 @@ struct CkptLayout {
     int dx[4] = {}, dy[4] = {}, smode[4] = {}, nch[4] = {}, mseg[4] = {};
     bool split[4] = {};              // family split in the middle (half_chain_geometry): nch counts sub-chains
     size_t off[5] = {};              // byte offsets into c->ckpt
+    size_t moff[4] = {};             // byte offsets of the per-step minima records (K u16 per segment) into c->ckpt
+    size_t total = 0;                // bytes of c->ckpt
     bool cols_from_cost = false;     // family 0 is the column family and its checkpoints come from k_vsum_col
     bool path2_from_cost = false;    // 5-path mode: k_vsum_col has already written S = L_2 (path 2 has no partner)
 };
 CkptLayout ckpt_layout(const SgmDims& d);
-
-// Tile-fused schedule (sgm_tile.hip, tile_geom.h).  Tile edge length for NP packed pairs per lane: the cost tile and the S
-// tile, T*T vectors of 256*NP bytes each, share the 160 KiB of LDS of one CU; one wave per tile row.
-constexpr int tile_size(int NP) { return NP <= 2 ? 12 : (NP <= 4 ? 8 : (NP <= 6 ? 7 : 6)); }
-struct EdgeLayout {
-    int T = 0, ntx = 0, nty = 0;
-    bool has[4][2] = {};             // [family][0 forward / 1 backward]: is the path aggregated at all?
-    size_t off_row[4][2] = {}, off_col[4][2] = {};   // byte offsets into c->edges ((size_t)-1: no such array)
-    size_t total = 0;
-};
-EdgeLayout edge_layout(const SgmDims& d);
-bool tile_schedule_enabled();        // WASS_AGG=tile
-int launch_aggregate_tile(wass_ctx* c, const SgmDims& d, int* n_launches);
 
 void coll_release(wass_ctx* c);               // coll.hip
 // post_opt.hip: optional parts of sgbm_dense_stereo (row a9)
@@ -261,10 +246,5 @@ int launch_select(wass_ctx* c, const SgmDims& d);
 int launch_median_crop(wass_ctx* c, const SgmDims& d, int16_t* d_out);
 int wait_uploads(wass_ctx* c, const void* p, hipStream_t s);   // order s after the pending uploads that cover p
 int launch_median_full(wass_ctx* c, const SgmDims& d, int16_t* d_padded_out);   // the whole padded map (speckle filter path)
-// pipelined column-strip sweeps (sgm_trio.hip)
-size_t trio_halo_bytes(const SgmDims& d);
-int launch_trio(wass_ctx* c, const SgmDims& d, uint32_t* Sout, unsigned long long* halo, int xdir, int ydir, bool has_v,
-                hipStream_t stream);
-int launch_wta_sum(wass_ctx* c, const SgmDims& d, const uint32_t* S, const uint32_t* S2, hipStream_t stream);
 
 }  // namespace wass

@@ -1961,7 +1961,6 @@ int wass_ctx_frame_result(wass_ctx* c, wass_frame_result* out)
         const uint32_t fl = c->h_flags[4 * (int)((c->frame_sgm_call - 1) & 1)];
         out->sgm_cost_overflow = (int)(fl & 1);
         out->sgm_timeout = (int)((fl >> 1) & 1);
-        if (fl & 2) c->halo_dirty = true;
     } else {
         out->sgm_cost_overflow = out->sgm_timeout = -1;      // unknown: no SGM call of this context fed the frame
     }

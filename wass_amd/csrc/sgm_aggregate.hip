@@ -20,13 +20,11 @@
 // Each step touches one contiguous 256*NP-byte vector of C and of S.
 #include "sgm_step.h"
 
-#include <stdlib.h>
-
 namespace wass {
 
-// One path, every chain.  SMODE 0: S = L_r (first path)   1: S += L_r   2: last path -- S is read, finished in
-// registers and handed to wta_batch (stored only if keepS).  Loads of the next U steps are in flight while the
-// current U steps compute.
+// One path, every chain (5-path mode: paths 1 and 3, which have no partner).  SMODE 0: S = L_r (first path)
+// 1: S += L_r   2: last path -- S is read, finished in registers and handed to wta_batch (stored only if keepS).
+// Loads of the next U steps are in flight while the current U steps compute.
 template <int NP, int SMODE, int U>
 __global__ void __launch_bounds__(256) k_sweep(const uint32_t* __restrict__ C, uint32_t* __restrict__ S,
                                                int width1, int h, int dx, int dy, int P1, int P2, int nchains, int D,
@@ -101,26 +99,24 @@ __global__ void __launch_bounds__(256) k_sweep(const uint32_t* __restrict__ C, u
 }
 
 // ---------------------------------------------------------------------------
-// Two opposite paths of one chain family in one launch, S touched once.
-//   phase 1: forward path over the chain; only the normalised state N at the
-//            end of every K-step segment is kept (checkpoint, 1/K of a volume).
-//   phase 2: the chain in reverse, one segment at a time: load its K cost
-//            vectors once, recompute the forward path from the checkpoint into
-//            registers, run the backward path over the same registers, and
-//            add both to S.
-// SMODE 0: S = Lf+Lb (first family)   1: S += Lf+Lb   2: last family -- S is
-// read, finished in registers and handed to wta_batch; it is stored only if
-// keepS (debug fetch).
+// Two opposite paths of one chain family, S touched once (k_ckpt + k_pair).
+//   k_ckpt: forward path over the chain; only the normalised state N at the
+//           end of every K-step segment is kept (checkpoint, 1/K of a volume),
+//           plus the scalar min_d L after every step (2 bytes per pixel).
+//   k_pair: the chain in reverse, one segment at a time: recompute the forward
+//           path from the checkpoint into registers, run the backward path over
+//           the same cost vectors, and add both to S.
 // ---------------------------------------------------------------------------
-// Phase 1 of a chain-family pair: the forward path over every chain, keeping only the (normalised)
-// state at the end of each K-step segment -- 1/K of a volume.  Reads C once, touches nothing else, so
-// the checkpoint sweeps of all families can run concurrently with any other kernel.
+// Reads C once, touches nothing else, so the checkpoint sweeps of all families run ahead on the side stream while the
+// main stream accumulates S.  The K cost vectors of a segment sit in a register ring that is refilled in place: the
+// slot of step u is reloaded with step u of the NEXT segment as soon as it has been consumed (prefetch distance exactly
+// K steps, no second buffer, no register copies).
 // endstate != nullptr: the family is split in the middle (half_chain_geometry): c counts sub-chains, the sweep runs to the
 // end of its half and leaves its final state in endstate[c] for the pair kernel of the other half.
 template <int NP, int K>
 __global__ void __launch_bounds__(256) k_ckpt(const uint32_t* __restrict__ C, uint32_t* __restrict__ ckpt,
-                                              int width1, int h, int dx, int dy, int P1, int P2, int nchains,
-                                              int maxseg, uint32_t* __restrict__ endstate)
+                                              uint16_t* __restrict__ mins, int width1, int h, int dx, int dy, int P1, int P2,
+                                              int nchains, int maxseg, uint32_t* __restrict__ endstate)
 {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
@@ -128,91 +124,163 @@ __global__ void __launch_bounds__(256) k_ckpt(const uint32_t* __restrict__ C, ui
     int x0, y0, n;
     if (endstate) half_chain_geometry(c, dx, dy, width1, h, x0, y0, n);
     else chain_geometry(c, dx, dy, width1, h, x0, y0, n);
+    constexpr int VB = 256 * NP;                   // bytes per pixel vector
     const long long vec = 64 * NP;
-    const long long step = ((long long)dy * width1 + dx) * vec;
-    const uint32_t* cp0 = C + ((long long)y0 * width1 + x0) * vec + lane * NP;
-    uint32_t* ck = ckpt + ((long long)c * maxseg) * vec + lane * NP;
+    ChainAddr a;
+    a.pixstep = (long long)dy * width1 + dx;
+    a.pix0 = (long long)y0 * width1 + x0;
+    a.sstep = (int)a.pixstep * VB;
+    const uint32_t voff = lane * NP * 4;
+    const uint32_t bK = a.bias(K);
     const us2 P1v = pk_splat(P1);
     const int F = n / K, r = n - F * K;            // F full segments, then a tail of r steps
     // checkpoints needed: end of segments 0 .. ncp-1 (a split family also needs the state at the very end)
     const int ncp = endstate ? F : F - (r > 0 ? 0 : 1);
-    {
-        PathState<NP> st;
-        st.reset();
-        us2 cb[K][NP], cn[K][NP];
-        const uint32_t* cp = cp0;
-        if (ncp > 0) load_seg<NP, K, false>(cp, step, K, cb);
-        for (int s = 0; s < ncp; ++s) {
-            if (s + 1 < ncp) load_seg<NP, K, false>(cp + K * step, step, K, cn);
-            else if (endstate && r > 0) load_seg<NP, K, true>(cp + K * step, step, r, cn);
+    const rsrc_t ckr = mk_rsrc(ckpt + (long long)c * maxseg * vec);
+    uint32_t* mrow = (uint32_t*)(mins + (size_t)c * maxseg * K);
+
+    PathState<NP> st;
+    st.reset();
+    us2 ring[K][NP];
+    if (ncp > 0) {
+        const rsrc_t r0 = a.run<NP>(C, 0, K);
 #pragma unroll
-            for (int u = 0; u < K; ++u) {
-                us2 L[NP];
-                sgm_step<NP>(st, cb[u], L, P1v, P2);
-            }
-            st.store_normalised(ck + (long long)s * vec);
-            copy_seg<NP, K>(cb, cn);
-            cp += K * step;
+        for (int u = 0; u < K; ++u) buf_ld<NP>(r0, voff, bK + u * a.sstep, ring[u]);
+    }
+    for (int s = 0; s < ncp; ++s) {
+        uint32_t ms[K];                            // min_d L after every step of the segment
+        // refill from the next full segment; past the last one the slots are re-read from it (never consumed)
+        const rsrc_t rn = a.run<NP>(C, (long long)min(s + 1, F - 1) * K, K);
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            us2 L[NP];
+            sgm_step<NP>(st, ring[u], L, P1v, P2);
+            ms[u] = st.m;
+            buf_ld<NP>(rn, voff, bK + u * a.sstep, ring[u]);
         }
-        if (endstate) {
-            if (ncp == 0 && r > 0) load_seg<NP, K, true>(cp, step, r, cb);
+        {
+            const us2 mvv = pk_splat(st.m);
+            us2 nrm[NP];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) nrm[j] = st.L[j] - mvv;
+            buf_st<NP>(ckr, voff, (uint32_t)s * VB, nrm);
+        }
+        store_minima<K>(mrow + (size_t)s * (K / 2), ms, lane);
+    }
+    if (endstate) {
+        if (r > 0) {
+            const rsrc_t rt = a.run<NP>(C, (long long)F * K, r);
+            const uint32_t br = a.bias(r);
+#pragma unroll
+            for (int u = 0; u < K; ++u)
+                if (u < r) buf_ld<NP>(rt, voff, br + u * a.sstep, ring[u]);
 #pragma unroll
             for (int u = 0; u < K; ++u)
                 if (u < r) {
                     us2 L[NP];
-                    sgm_step<NP>(st, cb[u], L, P1v, P2);
+                    sgm_step<NP>(st, ring[u], L, P1v, P2);
                 }
-            st.store_normalised(endstate + (long long)c * vec + lane * NP);
         }
+        st.store_normalised(endstate + (long long)c * vec + lane * NP);
     }
-
 }
 
-// SMODE 3: like 2, but the partial sums of the earlier sweeps arrive in two volumes (S + S2).
-// SMODE 4: like 1 with two inputs: S = S + S2 + Lf + Lb.
-template <int NP, int K, int SMODE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_pair(const uint32_t* __restrict__ C, uint32_t* __restrict__ S,
-                                              const uint32_t* __restrict__ S2,
-                                              uint32_t* __restrict__ ckpt, int width1, int h, int dx, int dy,
-                                              int P1, int P2, int nchains, int maxseg, int D, int minD, int uniq,
-                                              int keepS, int16_t* __restrict__ sel_d16,
-                                              uint32_t* __restrict__ sel_key, const uint32_t* __restrict__ endstate)
+// ---------------------------------------------------------------------------
+// k_pair: on-chip storage of one wave
+//   registers: two rings that are refilled IN PLACE, exactly K steps ahead (no staging buffer, no register copies,
+//     one loop shape): cf[u] -- the cost vector the forward recomputation consumes at step u; it is reloaded with
+//     element u of the next (lower) segment as soon as it has been used; sr[v] -- S of the element the backward path is
+//     at, reloaded with the same element of the next segment.
+//   LDS (8 KiB per wave, private to the wave: no barriers): the hand-over from the forward recomputation to the backward
+//     path, which visits the same segment one iteration later in the opposite order: K cost vectors and K forward path
+//     cost vectors.  The slot the backward path has just drained at step u (element K-1-u of segment s) receives
+//     element u of segment s-1, so the slot order flips every iteration -- in LDS that is an address, not a register
+//     assignment: two iteration shapes (ODD = slot order reversed) instead of a rotating register file.
+// ---------------------------------------------------------------------------
+template <int NP>
+__device__ __forceinline__ void lds_st(uint32_t* p, const us2 (&v)[NP])
 {
+    if constexpr (NP % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < NP; j += 4) *(wass_u32x4*)(p + j) = wass_u32x4{ as_u32(v[j]), as_u32(v[j + 1]), as_u32(v[j + 2]), as_u32(v[j + 3]) };
+    } else if constexpr (NP % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < NP; j += 2) *(wass_u32x2*)(p + j) = wass_u32x2{ as_u32(v[j]), as_u32(v[j + 1]) };
+    } else {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) p[j] = as_u32(v[j]);
+    }
+}
+template <int NP>
+__device__ __forceinline__ void lds_ld(const uint32_t* p, us2 (&v)[NP])
+{
+    if constexpr (NP % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < NP; j += 4) {
+            const wass_u32x4 t = *(const wass_u32x4*)(p + j);
+            v[j] = as_us2(t.x); v[j + 1] = as_us2(t.y); v[j + 2] = as_us2(t.z); v[j + 3] = as_us2(t.w);
+        }
+    } else if constexpr (NP % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < NP; j += 2) {
+            const wass_u32x2 t = *(const wass_u32x2*)(p + j);
+            v[j] = as_us2(t.x); v[j + 1] = as_us2(t.y);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) v[j] = as_us2(p[j]);
+    }
+}
+
+template <int K>
+__device__ __forceinline__ uint32_t min_before(const uint32_t (&mrec)[K / 2], int u)
+{
+    // minimum of the forward path costs BEFORE step u of a segment: 0 for the normalised checkpoint state, otherwise
+    // what the checkpoint sweep recorded after step u - 1
+    return u == 0 ? 0u : ((mrec[(u - 1) >> 1] >> (((u - 1) & 1) * 16)) & 0xFFFFu);
+}
+
+// Occupancy is capped at four waves per SIMD (the hand-over buffers of four workgroups are 128 of the CU's 160 KiB of LDS):
+// with a fifth workgroup per CU the frame tail of the previous frame, which runs underneath on its own stream and needs
+// LDS for its tile kernels, starves until a pair kernel drains (measured: frame period 9.7 ms against an SGM stage of 8.7).
+#ifndef WASS_PAIR_WAVES
+#define WASS_PAIR_WAVES 4
+#endif
+// SMODE 0: S = Lf+Lb (first family)   1: S += Lf+Lb   2: last family -- S is read, finished (sat16) in registers and
+// handed to wta_batch; it is stored only if keepS (debug fetch).
+template <int NP, int K, int SMODE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WASS_PAIR_WAVES, WASS_PAIR_WAVES)))
+k_pair(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t* __restrict__ ckpt,
+       const uint16_t* __restrict__ mins, int width1, int h, int dx, int dy, int P1, int P2, int nchains, int maxseg, int D,
+       int minD, int uniq, int keepS, int16_t* __restrict__ sel_d16, uint32_t* __restrict__ sel_key,
+       const uint32_t* __restrict__ endstate)
+{
+    static_assert(K % 2 == 0, "the minima records are read as dwords");
+    constexpr int VW = 64 * NP;                    // dwords per pixel vector
+    __shared__ __attribute__((aligned(16))) uint32_t hand[4][2][K][VW];   // per wave: [0] cost vectors, [1] forward path costs
     const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = blockIdx.x * 4 + wv;             // wave-uniform
     if (c >= nchains) return;
     int x0, y0, n;
     if (endstate) half_chain_geometry(c, dx, dy, width1, h, x0, y0, n);    // split family: c counts sub-chains (k_ckpt)
     else chain_geometry(c, dx, dy, width1, h, x0, y0, n);
-    const long long vec = 64 * NP;
-    const long long step = ((long long)dy * width1 + dx) * vec;
-    const long long pixstep = (long long)dy * width1 + dx;
-    const long long base = ((long long)y0 * width1 + x0) * vec + lane * NP;
-    const long long pix0 = (long long)y0 * width1 + x0;
-    const uint32_t* cp0 = C + base;
-    uint32_t* sp0 = S + base;
-    const uint32_t* tp0 = S2 + base;
-    uint32_t* ck = ckpt + ((long long)c * maxseg) * vec + lane * NP;
+    constexpr int VB = 256 * NP;
+    constexpr bool LAST = SMODE == 2;
+    const long long vec = VW;
+    ChainAddr a;
+    a.pixstep = (long long)dy * width1 + dx;
+    a.pix0 = (long long)y0 * width1 + x0;
+    a.sstep = (int)a.pixstep * VB;
+    const uint32_t voff = lane * NP * 4;
+    const uint32_t bK = a.bias(K);
     const us2 P1v = pk_splat(P1), cap = pk_splat(0x7FFF);
     const int F = n / K, r = n - F * K;            // F full segments, then a tail of r steps
-    constexpr bool LAST = SMODE == 2 || SMODE == 3, TWO = SMODE == 3 || SMODE == 4;
+    const rsrc_t ckr = mk_rsrc(ckpt + (long long)c * maxseg * vec);
+    const uint32_t* mrow = (const uint32_t*)(mins + (size_t)c * maxseg * K);       // K / 2 dwords per segment
+    uint32_t* hc = &hand[wv][0][0][lane * NP];     // slot e: hc + e * VW
+    uint32_t* hl = &hand[wv][1][0][lane * NP];
 
-    // one finished backward step: S handling + optional winner-take-all
-    auto finish = [&](const us2 (&lf)[NP], const us2 (&lb)[NP], const us2 (&sin)[NP], const us2 (&sin2)[NP], uint32_t* sp,
-                      us2 (&sv)[NP]) {
-#pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const us2 both = pk_adds(lf[j], lb[j]);
-            us2 acc = SMODE == 0 ? both : pk_adds(sin[j], both);
-            if (TWO) acc = pk_adds(acc, sin2[j]);
-            sv[j] = pk_min(acc, cap);
-        }
-        if (!LAST || keepS) {
-            st_stream_vec<NP>(sp, sv);
-        }
-    };
-
-    // ---- phase 2: the chain in reverse ------------------------------------------------------------
     PathState<NP> bw;
     bw.reset();
     if (endstate) {                                // the backward path arrives from the other half of the chain
@@ -220,18 +288,30 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
         ld_stream_vec<NP>(endstate + (long long)(c ^ 1) * vec + lane * NP, nv);
         bw.load_normalised(nv);
     }
+    // S of one finished backward step
+    auto finish = [&](const us2 (&lf)[NP], const us2 (&lb)[NP], const us2 (&sin)[NP], us2 (&sv)[NP]) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const us2 both = pk_adds(lf[j], lb[j]);
+            const us2 acc = SMODE == 0 ? both : pk_adds(sin[j], both);
+            sv[j] = LAST ? pk_min(acc, cap) : acc;                 // sat16 once, at the end: every term is >= 0
+        }
+    };
     if (r > 0) {                                   // tail segment F (guarded, not pipelined)
-        const uint32_t* cp = cp0 + (long long)F * K * step;
-        uint32_t* sp = sp0 + (long long)F * K * step;
-        us2 cb[K][NP], lf[K][NP], sb[K][NP], tb[K][NP];
-        load_seg<NP, K, true>(cp, step, r, cb);
-        if (SMODE != 0) load_seg<NP, K, true>(sp, step, r, sb);
-        if (TWO) load_seg<NP, K, true>(tp0 + (long long)F * K * step, step, r, tb);
+        const rsrc_t rc = a.run<NP>(C, (long long)F * K, r), rs = a.run<NP>(S, (long long)F * K, r);
+        const uint32_t br = a.bias(r);
+        us2 cb[K][NP], lf[K][NP], sb[K][NP];
+#pragma unroll
+        for (int u = 0; u < K; ++u)
+            if (u < r) {
+                buf_ld<NP>(rc, voff, br + u * a.sstep, cb[u]);
+                if (SMODE != 0) buf_ld<NP>(rs, voff, br + u * a.sstep, sb[u]);
+            }
         PathState<NP> fw;
         fw.reset();
         if (F > 0) {
             us2 nv[NP];
-            ld_stream_vec<NP>(ck + (long long)(F - 1) * vec, nv);
+            buf_ld<NP>(ckr, voff, (uint32_t)(F - 1) * VB, nv);
             fw.load_normalised(nv);
         }
 #pragma unroll
@@ -245,181 +325,163 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
             if (u < r) {
                 us2 L[NP];
                 sgm_step<NP>(bw, cb[u], L, P1v, P2);
-                finish(lf[u], L, sb[u], tb[u], sp + u * step, fin[u]);
+                finish(lf[u], L, sb[u], fin[u]);
+                if (!LAST || keepS) buf_st<NP>(rs, voff, br + u * a.sstep, fin[u]);
             }
         }
-        if (LAST) wta_batch<NP, K>(fin, r, lane, D, minD, uniq, sel_d16, sel_key, pix0 + (long long)F * K * pixstep, pixstep);
+        if (LAST) wta_batch<NP, K>(fin, r, lane, D, minD, uniq, sel_d16, sel_key, a.pix0 + (long long)F * K * a.pixstep, a.pixstep);
     }
     if (F == 0) return;
 
-    // software pipeline over the full segments s = F-1 .. 0:
-    //   iteration s:  backward(s)  ||  forward recompute(s-1)  ||  loads of C(s-2), S(s-1), ckpt(s-3) in flight
-    us2 cA[K][NP], cB[K][NP], cC[K][NP];           // cost vectors of segments s, s-1, s-2
-    us2 lA[K][NP], lB[K][NP];                      // forward path costs of segments s, s-1
-    us2 sA[K][NP], sB[K][NP];                      // S of segments s, s-1
-    us2 tA[K][NP], tB[K][NP];                      // S2 of segments s, s-1 (SMODE 3)
-    us2 nvB[NP], nvC[NP];                          // checkpoints entering segments s-1, s-2
+    // prologue: the forward path over segment F-1 (with its reductions: once per chain) into the hand-over slots in
+    // natural order, segment F-2 into the forward ring, the first S vectors
+    us2 cf[K][NP], sr[K][NP];
+    PathState<NP> fw;
+    us2 nvB[NP];                                   // checkpoint entering the segment the next forward recomputation covers
+    uint32_t mB[K / 2];                            // ... and that segment's minima record
     {
         const int s = F - 1;
-        load_seg<NP, K, false>(cp0 + (long long)s * K * step, step, K, cA);
-        if (SMODE != 0) load_seg<NP, K, false>(sp0 + (long long)s * K * step, step, K, sA);
-        if (TWO) load_seg<NP, K, false>(tp0 + (long long)s * K * step, step, K, tA);
-        if (s >= 1) load_seg<NP, K, false>(cp0 + (long long)(s - 1) * K * step, step, K, cB);
-        PathState<NP> fw;
+        const rsrc_t rc = a.run<NP>(C, (long long)s * K, K), rs = a.run<NP>(S, (long long)s * K, K);
+        const rsrc_t rc2 = a.run<NP>(C, (long long)max(s - 1, 0) * K, K);
+        us2 c0[K][NP];
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            buf_ld<NP>(rc, voff, bK + u * a.sstep, c0[u]);
+            if (SMODE != 0) buf_ld<NP>(rs, voff, bK + u * a.sstep, sr[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < K; ++u) buf_ld<NP>(rc2, voff, bK + u * a.sstep, cf[u]);
         fw.reset();
         if (s >= 1) {
             us2 nv[NP];
-            ld_stream_vec<NP>(ck + (long long)(s - 1) * vec, nv);
+            buf_ld<NP>(ckr, voff, (uint32_t)(s - 1) * VB, nv);
             fw.load_normalised(nv);
         }
+        if (s >= 2) buf_ld<NP>(ckr, voff, (uint32_t)(s - 2) * VB, nvB);
+        else {
 #pragma unroll
-        for (int j = 0; j < NP; ++j) nvB[j] = s >= 2 ? as_us2(ld_stream(ck + (long long)(s - 2) * vec + j)) : pk_splat(0);
+            for (int j = 0; j < NP; ++j) nvB[j] = pk_splat(0);
+        }
 #pragma unroll
-        for (int u = 0; u < K; ++u) sgm_step<NP>(fw, cA[u], lA[u], P1v, P2);
-    }
-    for (int s = F - 1; s >= 1; --s) {
-        // prefetch for the next iterations
-        if (s >= 2) load_seg<NP, K, false>(cp0 + (long long)(s - 2) * K * step, step, K, cC);
-        if (SMODE != 0) load_seg<NP, K, false>(sp0 + (long long)(s - 1) * K * step, step, K, sB);
-        if (TWO) load_seg<NP, K, false>(tp0 + (long long)(s - 1) * K * step, step, K, tB);
-#pragma unroll
-        for (int j = 0; j < NP; ++j) nvC[j] = s >= 3 ? as_us2(ld_stream(ck + (long long)(s - 3) * vec + j)) : pk_splat(0);
-        PathState<NP> fw;
-        fw.load_normalised(nvB);                   // zeros when s-1 == 0
-        uint32_t* sp = sp0 + (long long)s * K * step;
-        const long long pixs = pix0 + (long long)s * K * pixstep;
-        // two independent dependency chains in one block: the scheduler interleaves them
-        us2 fin[K][NP];
+        for (int i = 0; i < K / 2; ++i) mB[i] = mrow[(size_t)max(s - 1, 0) * (K / 2) + i];
 #pragma unroll
         for (int u = 0; u < K; ++u) {
-            const int v = K - 1 - u;
             us2 L[NP];
-            sgm_step_pair<NP>(fw, cB[u], lB[u], bw, cA[v], L, P1v, P2);
-            finish(lA[v], L, sA[v], tA[v], sp + v * step, fin[v]);
+            sgm_step<NP>(fw, c0[u], L, P1v, P2);
+            lds_st<NP>(hc + u * VW, c0[u]);
+            lds_st<NP>(hl + u * VW, L);
         }
-        if (LAST) wta_batch<NP, K>(fin, K, lane, D, minD, uniq, sel_d16, sel_key, pixs, pixstep);
-        copy_seg<NP, K>(cA, cB);
-        copy_seg<NP, K>(cB, cC);
-        copy_seg<NP, K>(lA, lB);
-        if (SMODE != 0) copy_seg<NP, K>(sA, sB);
-        if (TWO) copy_seg<NP, K>(tA, tB);
-#pragma unroll
-        for (int j = 0; j < NP; ++j) nvB[j] = nvC[j];
     }
-    {                                              // epilogue: backward over segment 0
-        us2 fin[K][NP];
-#pragma unroll
-        for (int v = K - 1; v >= 0; --v) {
-            us2 L[NP];
-            sgm_step<NP>(bw, cA[v], L, P1v, P2);
-            finish(lA[v], L, sA[v], tA[v], sp0 + v * step, fin[v]);
-        }
-        if (LAST) wta_batch<NP, K>(fin, K, lane, D, minD, uniq, sel_d16, sel_key, pix0, pixstep);
+
+    // One iteration for segment s_ >= 1: backward path over segment s_ (elements K-1 .. 0, read from the hand-over slots)
+    // || forward recomputation of segment s_-1 (elements 0 .. K-1, from the ring; results into the slots just drained)
+    // || refills: C of segment s_-2, S of segment s_-1.  ODD_: the slots hold segment s_ in reversed order.
+#define WASS_PAIR_ITER(ODD_, s_)                                                                                        \
+    {                                                                                                                   \
+        const rsrc_t rcN = a.run<NP>(C, (long long)max((s_) - 2, 0) * K, K);   /* past the chain start: a harmless re-read */ \
+        const rsrc_t rsN = a.run<NP>(S, (long long)((s_) - 1) * K, K), rsO = a.run<NP>(S, (long long)(s_) * K, K);         \
+        us2 nvC[NP];                                                                                                    \
+        uint32_t mC[K / 2];                                                                                             \
+        if ((s_) >= 3) buf_ld<NP>(ckr, voff, (uint32_t)((s_) - 3) * VB, nvC);                                            \
+        else {                                                                                                          \
+            _Pragma("unroll") for (int j = 0; j < NP; ++j) nvC[j] = pk_splat(0);                                         \
+        }                                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < K / 2; ++i) mC[i] = mrow[(size_t)max((s_) - 2, 0) * (K / 2) + i];         \
+        fw.load_normalised(nvB);                   /* zeros when s-1 == 0 */                                            \
+        us2 cbn[NP], lfn[NP];                      /* hand-over vectors of the NEXT step, in flight */                  \
+        lds_ld<NP>(hc + ((ODD_) ? 0 : K - 1) * VW, cbn);                                                                 \
+        lds_ld<NP>(hl + ((ODD_) ? 0 : K - 1) * VW, lfn);                                                                 \
+        _Pragma("unroll") for (int u = 0; u < K; ++u) {                                                                 \
+            const int v = K - 1 - u;               /* element of segment s_ the backward path is at */                  \
+            const int slot = (ODD_) ? u : v, nslot = (ODD_) ? u + 1 : v - 1;                                             \
+            us2 cb[NP], lfv[NP], Lf[NP], Lb[NP], sv[NP];                                                                \
+            _Pragma("unroll") for (int j = 0; j < NP; ++j) { cb[j] = cbn[j]; lfv[j] = lfn[j]; }                          \
+            if (u + 1 < K) {                                                                                            \
+                lds_ld<NP>(hc + nslot * VW, cbn);                                                                       \
+                lds_ld<NP>(hl + nslot * VW, lfn);                                                                       \
+            }                                                                                                           \
+            sgm_step_fb<NP>(fw, min_before<K>(mB, u), cf[u], Lf, bw, cb, Lb, P1v, P2);                                   \
+            finish(lfv, Lb, sr[v], sv);                                                                                 \
+            if (!LAST || keepS) buf_st<NP>(rsO, voff, bK + v * a.sstep, sv);                                             \
+            if (LAST) { _Pragma("unroll") for (int j = 0; j < NP; ++j) fin[v][j] = sv[j]; }                              \
+            lds_st<NP>(hc + slot * VW, cf[u]);                                                                          \
+            lds_st<NP>(hl + slot * VW, Lf);                                                                             \
+            buf_ld<NP>(rcN, voff, bK + u * a.sstep, cf[u]);                                                              \
+            if (SMODE != 0) buf_ld<NP>(rsN, voff, bK + v * a.sstep, sr[v]);                                              \
+        }                                                                                                               \
+        if (LAST) wta_batch<NP, K>(fin, K, lane, D, minD, uniq, sel_d16, sel_key, a.pix0 + (long long)(s_) * K * a.pixstep, a.pixstep); \
+        _Pragma("unroll") for (int j = 0; j < NP; ++j) nvB[j] = nvC[j];                                                 \
+        _Pragma("unroll") for (int i = 0; i < K / 2; ++i) mB[i] = mC[i];                                                \
     }
+    // the backward path over segment 0: nothing left to recompute or to prefetch
+#define WASS_PAIR_LAST(ODD_)                                                                                            \
+    {                                                                                                                   \
+        const rsrc_t rsO = a.run<NP>(S, 0, K);                                                                          \
+        _Pragma("unroll") for (int u = 0; u < K; ++u) {                                                                 \
+            const int v = K - 1 - u;                                                                                    \
+            const int slot = (ODD_) ? u : v;                                                                            \
+            us2 cb[NP], lfv[NP], Lb[NP], sv[NP];                                                                        \
+            lds_ld<NP>(hc + slot * VW, cb);                                                                             \
+            lds_ld<NP>(hl + slot * VW, lfv);                                                                            \
+            sgm_step<NP>(bw, cb, Lb, P1v, P2);                                                                          \
+            finish(lfv, Lb, sr[v], sv);                                                                                 \
+            if (!LAST || keepS) buf_st<NP>(rsO, voff, bK + v * a.sstep, sv);                                             \
+            if (LAST) { _Pragma("unroll") for (int j = 0; j < NP; ++j) fin[v][j] = sv[j]; }                              \
+        }                                                                                                               \
+        if (LAST) wta_batch<NP, K>(fin, K, lane, D, minD, uniq, sel_d16, sel_key, a.pix0, a.pixstep);                    \
+    }
+    us2 fin[K][NP];
+    int s = F - 1;
+    for (;;) {
+        if (s < 1) { WASS_PAIR_LAST(false) break; }
+        WASS_PAIR_ITER(false, s)
+        --s;
+        if (s < 1) { WASS_PAIR_LAST(true) break; }
+        WASS_PAIR_ITER(true, s)
+        --s;
+    }
+#undef WASS_PAIR_ITER
+#undef WASS_PAIR_LAST
 }
 
 CkptLayout ckpt_layout(const SgmDims& d)
 {
     CkptLayout L;
     L.K = ckpt_k(d.NP);
-    const char* agg = getenv("WASS_AGG");
-    const bool legacy = agg && (!strcmp(agg, "trio") || !strcmp(agg, "concurrent") || !strcmp(agg, "rowsfirst"));
-    const char* sp = getenv("WASS_SPLIT_ROWS");
-    const bool split_rows = !legacy && (!sp || atoi(sp) != 0);
-    const char* sdg = getenv("WASS_SPLIT_DIAG");
-    const bool split_diag = !legacy && (!sdg || atoi(sdg) != 0);
-    const char* sc = getenv("WASS_SPLIT_COLS");
-    const bool split_cols = !legacy && d.ndirs == 8 && (!sc || atoi(sc) != 0);      // only the family that k_vsum_col produces
     auto add = [&](int dx, int dy, int smode) {
         const int f = L.nfam++;
         L.dx[f] = dx; L.dy[f] = dy; L.smode[f] = smode;
         L.nch[f] = dy == 0 ? d.h : (dx == 0 ? d.width1 : d.width1 + d.h - 1);
         int maxlen = dy == 0 ? d.width1 : (dx == 0 ? d.h : (d.width1 < d.h ? d.width1 : d.h));
-        // rows: 2 058 chains are two waves per SIMD -- split them in the middle (half_chain_geometry) for twice the waves.
-        // Measured at config B, same box, three runs each: columns split 1.40 -> 1.11 ms (k_vsum_col), diagonals split
-        // 7.90 -> 7.60 ms (aggregation): twice the waves, and the longest chain of a diagonal family halves.
-        L.split[f] = (split_rows && dy == 0) || (split_cols && dx == 0) || (split_diag && dx != 0 && dy != 0);
+        // Every family is split in the middle (half_chain_geometry) for twice the waves: 2 058 rows / 2 456 columns are
+        // two waves per SIMD, and the longest chain of a diagonal family halves.  Measured at config B, same box, three
+        // runs each: columns split 1.40 -> 1.11 ms (k_vsum_col), diagonals split 7.90 -> 7.60 ms (aggregation).
+        // The column family is only split when the cost stage produces it (8 paths).
+        L.split[f] = dx != 0 || d.ndirs == 8;
         if (L.split[f]) { L.nch[f] *= 2; maxlen = maxlen - maxlen / 2; }
         L.mseg[f] = (maxlen + L.K - 1) / L.K;
         const size_t b = (size_t)L.nch[f] * (L.mseg[f] + (L.split[f] ? 1 : 0)) * (64 * d.NP) * sizeof(uint32_t);   // + the end states
         L.off[f + 1] = L.off[f] + ((b + 255) & ~(size_t)255);
     };
-    // The kernel that carries the winner-take-all goes last and should have the most chains (the WTA adds ~60
+    // The kernel that carries the winner-take-all goes last and should have the most chains (the WTA adds ~50
     // instructions per pixel): the anti-diagonals (width1 + h - 1 chains).
-    if (d.ndirs == 8 && !legacy) {
+    if (d.ndirs == 8) {
         L.cols_from_cost = true;
         add(0, 1, 0);                // columns:        paths 2 + 6   (S written)
         add(1, 0, 1);                // rows:           paths 0 + 4
         add(1, 1, 1);                // diagonals:      paths 1 + 7
         add(-1, 1, 2);               // anti-diagonals: paths 3 + 5, winner-take-all fused
-    } else if (d.ndirs == 5 && !legacy) {
+    } else {
         L.path2_from_cost = true;
         add(1, 0, 1);                // rows: paths 0 + 4, added to the S = L_2 that the cost stage left behind
-    } else {
-        add(1, 0, 0);                // rows (S written)
-        if (d.ndirs == 8) { add(0, 1, 1); add(1, 1, 1); add(-1, 1, 2); }
     }
+    size_t o = L.off[L.nfam];
+    for (int f = 0; f < L.nfam; ++f) {
+        L.moff[f] = o;
+        o += ((size_t)L.nch[f] * L.mseg[f] * L.K * sizeof(uint16_t) + 255) & ~(size_t)255;
+    }
+    L.total = o;
     return L;
-}
-
-// Pipelined-strip schedule (sgm_trio.hip): paths {0,1,2} and {4,7,6} (MODE_HH) / {4,3} (MODE_SGBM) as two
-// concurrent three-path sweeps writing S and S2; MODE_HH finishes with the anti-diagonal pair {3,5} + fused
-// winner-take-all reading both volumes, MODE_SGBM with a plain S + S2 selection kernel.
-template <int NP>
-static int launch_aggregate_trio(wass_ctx* c, const SgmDims& d, int* n_launches)
-{
-    constexpr int K = ckpt_k(NP);
-    const uint32_t* C = (const uint32_t*)c->C.p;
-    uint32_t* S = (uint32_t*)c->S.p;
-    int rc;
-    const size_t vol = d.cells() * sizeof(uint16_t), hb = trio_halo_bytes(d);
-    if ((rc = ensure(c, c->S2, vol))) return rc;
-    // boundary buffers of the two sweeps; (re)allocation or a previous time-out leaves them in an unknown state
-    const size_t before = c->halo.cap;
-    if ((rc = ensure(c, c->halo, 2 * hb))) return rc;
-    if (c->halo.cap != before || c->halo_dirty) {
-        WASS_HIP(c, hipMemsetAsync(c->halo.p, 0xFF, c->halo.cap, c->stream));
-        c->halo_dirty = false;
-    }
-    uint32_t* S2 = (uint32_t*)c->S2.p;
-    unsigned long long* haloA = (unsigned long long*)c->halo.p;
-    unsigned long long* haloB = (unsigned long long*)((char*)c->halo.p + hb);
-    int nl = 0;
-    WASS_HIP(c, hipEventRecord(c->ev_cost, c->stream));
-    WASS_HIP(c, hipStreamWaitEvent(c->side, c->ev_cost, 0));
-    if ((rc = launch_trio(c, d, S, haloA, +1, +1, true, c->stream))) return rc;                   // paths 0, 1, 2 -> S
-    ++nl;
-    if (d.ndirs == 8) {
-        if ((rc = launch_trio(c, d, S2, haloB, -1, -1, true, c->side))) return rc;               // paths 4, 7, 6 -> S2
-        ++nl;
-        WASS_HIP(c, hipEventRecord(c->ev_ckpt[0], c->side));
-        // anti-diagonals: checkpoint sweep on the second side stream, then the pair + selection
-        WASS_HIP(c, hipStreamWaitEvent(c->side2, c->ev_cost, 0));
-        const int nch = d.width1 + d.h - 1, mlen = d.width1 < d.h ? d.width1 : d.h, mseg = (mlen + K - 1) / K;
-        const size_t cb = (size_t)nch * mseg * (64 * NP) * sizeof(uint32_t);
-        if ((rc = ensure(c, c->ckpt, cb))) return rc;
-        uint32_t* ck = (uint32_t*)c->ckpt.p;
-        hipLaunchKernelGGL((k_ckpt<NP, K>), dim3((nch + 3) / 4), dim3(256), 0, c->side2, C, ck, d.width1, d.h, -1, 1, d.P1, d.P2,
-                           nch, mseg, (uint32_t*)nullptr);
-        ++nl;
-        WASS_HIP(c, hipEventRecord(c->ev_ckpt[1], c->side2));
-        WASS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_ckpt[0], 0));
-        WASS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_ckpt[1], 0));
-        hipLaunchKernelGGL((k_pair<NP, K, 3>), dim3((nch + 3) / 4), dim3(256), 0, c->stream, C, S, (const uint32_t*)S2, ck,
-                           d.width1, d.h, -1, 1, d.P1, d.P2, nch, mseg, d.D, d.minD, d.uniq, c->debug ? 1 : 0,
-                           (int16_t*)c->sel_d16.p, (uint32_t*)c->sel_key.p, (const uint32_t*)nullptr);
-        ++nl;
-    } else {
-        if ((rc = launch_trio(c, d, S2, haloB, -1, +1, false, c->side))) return rc;              // paths 4, 3 -> S2
-        ++nl;
-        WASS_HIP(c, hipEventRecord(c->ev_ckpt[0], c->side));
-        WASS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_ckpt[0], 0));
-        if ((rc = launch_wta_sum(c, d, S, S2, c->stream))) return rc;
-        ++nl;
-    }
-    if (n_launches) *n_launches = nl;
-    WASS_HIP(c, hipGetLastError());
-    return WASS_OK;
 }
 
 template <int NP>
@@ -435,52 +497,30 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
     int16_t* sd = (int16_t*)c->sel_d16.p;
     uint32_t* sk = (uint32_t*)c->sel_key.p;
     int nl = 0;
-    // WASS_AGG=trio selects the pipelined column-strip schedule (sgm_trio.hip).  It moves 40 % fewer bytes and is
-    // bit-exact, but measured slower on MI355X (10-12 ms vs 8.1 ms at config B): a strip is ONE wave walking
-    // 2058 rows x 12 dependent path steps, and a lone wave issues only ~1 VALU instruction per 16 cycles.
-    const char* agg = getenv("WASS_AGG");
-    if (agg && !strcmp(agg, "trio")) return launch_aggregate_trio<NP>(c, d, n_launches);
     auto nchains = [&](int dx, int dy) { return dy == 0 ? d.h : (dx == 0 ? d.width1 : d.width1 + d.h - 1); };
     // every family has its own checkpoint region so that all checkpoint sweeps (which only read C) can run ahead
     // on the side stream while the main stream accumulates S
     const CkptLayout lay = ckpt_layout(d);
     const int nf = lay.nfam;
-    struct Fam { int dx, dy, smode; };
-    Fam fam[4];
-    size_t off[5];
-    for (int f = 0; f < nf; ++f) { fam[f] = { lay.dx[f], lay.dy[f], lay.smode[f] }; off[f] = lay.off[f]; }
-    off[nf] = lay.off[nf];
-    int rc = ensure(c, c->ckpt, off[nf]);
+    int rc = ensure(c, c->ckpt, lay.total);
     if (rc) return rc;
 
     WASS_HIP(c, hipEventRecord(c->ev_cost, c->stream));
     WASS_HIP(c, hipStreamWaitEvent(c->side, c->ev_cost, 0));
-    WASS_HIP(c, hipStreamWaitEvent(c->side2, c->ev_cost, 0));
     for (int f = 0; f < nf; ++f) {
         if (f == 0 && lay.cols_from_cost) {         // written by k_vsum_col on the main stream already
             WASS_HIP(c, hipEventRecord(c->ev_ckpt[f], c->stream));
             continue;
         }
-        const int dx = fam[f].dx, dy = fam[f].dy;
         const int nch = lay.nch[f], mseg = lay.mseg[f];
-        static const bool two = getenv("WASS_SIDE_STREAMS") && atoi(getenv("WASS_SIDE_STREAMS")) == 2;
-        hipStream_t ss = (two && (f & 1)) ? c->side2 : c->side;
-        uint32_t* ckf = (uint32_t*)((char*)c->ckpt.p + off[f]);
-        hipLaunchKernelGGL((k_ckpt<NP, K>), dim3((nch + 3) / 4), dim3(256), 0, ss, C, ckf, d.width1, d.h, dx, dy, d.P1, d.P2, nch, mseg,
+        uint32_t* ckf = (uint32_t*)((char*)c->ckpt.p + lay.off[f]);
+        hipLaunchKernelGGL((k_ckpt<NP, K>), dim3((nch + 3) / 4), dim3(256), 0, c->side, C, ckf, (uint16_t*)((char*)c->ckpt.p + lay.moff[f]),
+                           d.width1, d.h, lay.dx[f], lay.dy[f], d.P1, d.P2, nch, mseg,
                            lay.split[f] ? ckf + (size_t)nch * mseg * (64 * NP) : (uint32_t*)nullptr);
-        WASS_HIP(c, hipEventRecord(c->ev_ckpt[f], ss));
+        WASS_HIP(c, hipEventRecord(c->ev_ckpt[f], c->side));
         ++nl;
     }
 
-    // WASS_AGG=concurrent (experiment): the row and the column family, which have the fewest chains, run
-    // concurrently, each writing its own volume (S, S2), and the first diagonal family folds the two together.
-    // Same bytes as the serial order and, measured, the same time (8.3 vs 8.2 ms): the family is bandwidth-bound.
-    const bool conc = d.ndirs == 8 && getenv("WASS_AGG") && !strcmp(getenv("WASS_AGG"), "concurrent");
-    if (conc) {
-        int rc2 = ensure(c, c->S2, d.cells() * sizeof(uint16_t));
-        if (rc2) return rc2;
-    }
-    const uint32_t* S2 = conc ? (const uint32_t*)c->S2.p : (const uint32_t*)S;
     if (lay.path2_from_cost) {       // path 1 needs no checkpoints: it runs while the row checkpoints are produced
         const int nch = nchains(1, 1);
         hipLaunchKernelGGL((k_sweep<NP, 1, U>), dim3((nch + 3) / 4), dim3(256), 0, c->stream, C, S, d.width1, d.h, 1, 1, d.P1, d.P2,
@@ -488,45 +528,27 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
         ++nl;
     }
     for (int f = 0; f < nf; ++f) {
-        const int dx = fam[f].dx, dy = fam[f].dy;
         const int nch = lay.nch[f], mseg = lay.mseg[f];
-        uint32_t* ck = (uint32_t*)((char*)c->ckpt.p + off[f]);
+        const uint32_t* ck = (const uint32_t*)((char*)c->ckpt.p + lay.off[f]);
+        const uint16_t* mn = (const uint16_t*)((char*)c->ckpt.p + lay.moff[f]);
         const dim3 grid((nch + 3) / 4), block(256);
-#define WASS_PAIR(SMODE, STREAM, SOUT)                                                                       \
-        hipLaunchKernelGGL((k_pair<NP, K, SMODE>), grid, block, 0, STREAM, C, SOUT, S2, ck, d.width1, d.h, dx, dy, \
-                           d.P1, d.P2, nch, mseg, d.D, d.minD, d.uniq, c->debug ? 1 : 0, sd, sk,                \
+        WASS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_ckpt[f], 0));
+#define WASS_PAIR(SMODE)                                                                                         \
+        hipLaunchKernelGGL((k_pair<NP, K, SMODE>), grid, block, 0, c->stream, C, S, ck, mn, d.width1, d.h, lay.dx[f],  \
+                           lay.dy[f], d.P1, d.P2, nch, mseg, d.D, d.minD, d.uniq, c->debug ? 1 : 0, sd, sk,            \
                            lay.split[f] ? (const uint32_t*)(ck + (size_t)nch * mseg * (64 * NP)) : (const uint32_t*)nullptr)
-        if (conc && f == 1) {                       // columns -> S2 on the second side stream, concurrent with the rows
-            WASS_HIP(c, hipStreamWaitEvent(c->side2, c->ev_ckpt[f], 0));
-            WASS_PAIR(0, c->side2, (uint32_t*)c->S2.p);
-            WASS_HIP(c, hipEventRecord(c->ev_cols, c->side2));
-        } else {
-            WASS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_ckpt[f], 0));
-            if (conc && f == 2) {                   // diagonals: S = S + S2 + pair
-                WASS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_cols, 0));
-                WASS_PAIR(4, c->stream, S);
-            } else if (fam[f].smode == 0) WASS_PAIR(0, c->stream, S);
-            else if (fam[f].smode == 1) WASS_PAIR(1, c->stream, S);
-            else WASS_PAIR(2, c->stream, S);
-        }
+        if (lay.smode[f] == 0) WASS_PAIR(0);
+        else if (lay.smode[f] == 1) WASS_PAIR(1);
+        else WASS_PAIR(2);
 #undef WASS_PAIR
         ++nl;
     }
-#define WASS_SWEEP(SMODE, dx, dy)                                                                            \
-    do {                                                                                                     \
-        const int nch = nchains(dx, dy);                                                                     \
-        hipLaunchKernelGGL((k_sweep<NP, SMODE, U>), dim3((nch + 3) / 4), dim3(256), 0, c->stream, C, S,      \
-                           d.width1, d.h, dx, dy, d.P1, d.P2, nch, d.D, d.minD, d.uniq, c->debug ? 1 : 0, sd, sk); \
-        ++nl;                                                                                                \
-    } while (0)
-    if (d.ndirs == 5 && !lay.path2_from_cost) {   // MODE_SGBM, legacy order: the three down-going paths as plain sweeps
-        WASS_SWEEP(1, 0, 1);         // path 2
-        WASS_SWEEP(1, 1, 1);         // path 1
-        WASS_SWEEP(2, -1, 1);        // path 3, winner-take-all fused
-    } else if (d.ndirs == 5) {
-        WASS_SWEEP(2, -1, 1);        // path 3, winner-take-all fused (paths 2, 1, 0 + 4 are in S by now)
+    if (d.ndirs == 5) {              // path 3, winner-take-all fused (paths 2, 1, 0 + 4 are in S by now)
+        const int nch = nchains(-1, 1);
+        hipLaunchKernelGGL((k_sweep<NP, 2, U>), dim3((nch + 3) / 4), dim3(256), 0, c->stream, C, S, d.width1, d.h, -1, 1, d.P1, d.P2,
+                           nch, d.D, d.minD, d.uniq, c->debug ? 1 : 0, sd, sk);
+        ++nl;
     }
-#undef WASS_SWEEP
     if (n_launches) *n_launches = nl;
     WASS_HIP(c, hipGetLastError());
     return WASS_OK;

@@ -11,7 +11,6 @@
 // 256*NP-byte vector per pixel -- fully coalesced -- and all arithmetic runs
 // on v_pk_*_u16.  Slots d >= D hold 0xFFFF in C and never win a minimum.
 #include "sgm_step.h"
-#include "tile_geom.h"
 
 #include <stdlib.h>
 
@@ -305,20 +304,21 @@ __global__ void __launch_bounds__(256) k_vsum(const uint32_t* __restrict__ hsum,
 // PATH2 (5-path mode, where path 2 has no partner): the path costs themselves are the first contribution to S and
 // are written out (S = L_2), which replaces that path's sweep (a read of C and a read-modify-write of S).
 // ---------------------------------------------------------------------------
-// ET > 0 (tile-fused schedule, sgm_tile.hip): instead of the checkpoints the wave stores the state with which path 2
-// enters every tile row (tile edge ET), i.e. it is that path's k_edge_sweep.
 // SPLIT (8-path pair schedule): the column family is cut in the middle like the row family (half_chain_geometry): wave
 // 2x walks rows 0 .. h/2-1 downwards with path 2, wave 2x+1 walks rows h-1 .. h/2 UPWARDS with path 6 -- the vertical
 // window sum does not care about the direction.  Both start from the all-zero state at an image border; each leaves its
 // final state in endstate[], where the pair kernel of the other half picks it up.  Twice the waves (2 456 columns are
 // only 2.4 waves per SIMD) for this kernel and for the family's pair kernel.
-template <int NP, int K, bool PATH2, int ET, bool SPLIT>
+// Besides the checkpoints the wave leaves the minimum of the path costs after every step of a checkpointed segment in
+// mins[] (K u16 per segment): the pair kernel's forward recomputation reads them back as scalars instead of repeating the
+// cross-lane reduction (sgm_step.h, sgm_step_fb).
+template <int NP, int K, bool PATH2, bool SPLIT>
 __global__ void __launch_bounds__(256) k_vsum_col(const uint32_t* __restrict__ hsum, int width1, int h, int D, int SH2,
                                                   int P1, int P2, uint32_t* __restrict__ C, uint32_t* __restrict__ ckpt,
-                                                  int maxseg, uint32_t* __restrict__ S, uint32_t* __restrict__ flags,
-                                                  uint32_t* __restrict__ endstate)
+                                                  uint16_t* __restrict__ mins, int maxseg, uint32_t* __restrict__ S,
+                                                  uint32_t* __restrict__ flags, uint32_t* __restrict__ endstate)
 {
-    static_assert(!SPLIT || (!PATH2 && ET == 0), "only the pair schedule's column family is split");
+    static_assert(!SPLIT || !PATH2, "only the pair schedule's column family is split");
     extern __shared__ __attribute__((aligned(16))) uint32_t ringbuf[];   // [4 waves][WIN][NP][64]
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -335,16 +335,12 @@ __global__ void __launch_bounds__(256) k_vsum_col(const uint32_t* __restrict__ h
     const size_t vec = 64 * NP, rowstride = (size_t)width1 * vec;
     const uint32_t* hp = hsum + (size_t)x * vec + lane * NP;
     uint32_t* cp = C + (size_t)x * vec + lane * NP;
-    uint32_t* ck = ET > 0 ? ckpt + (size_t)x * vec + lane * NP       // row-edge array of path 2: [tile row][x]
-                          : ckpt + (size_t)c2 * maxseg * vec + lane * NP;
+    uint32_t* ck = ckpt + (size_t)c2 * maxseg * vec + lane * NP;
+    uint32_t* mrow = (uint32_t*)(mins + (size_t)c2 * maxseg * K);
+    uint32_t ms[K];                                                   // min_d L after every step of the current segment
+#pragma unroll
+    for (int u = 0; u < K; ++u) ms[u] = 0;
     uint32_t* sp = S + (size_t)x * vec + lane * NP;
-    // the state after row y enters the next tile row at y + 1
-    auto edge = [&](const PathState<NP>& s_, int y) {
-        if (ET > 0) {
-            const int ny = y + 1;
-            if (ny < h && ny % (ET > 0 ? ET : 1) == 0) s_.store_normalised(ck + (size_t)(ny / (ET > 0 ? ET : 1)) * rowstride);
-        }
-    };
     const int dlane = lane * 2 * NP;
     const us2 lim = pk_splat(32767 - P2), P1v = pk_splat(P1), cap = pk_splat(0x7FFF);
 
@@ -373,7 +369,7 @@ __global__ void __launch_bounds__(256) k_vsum_col(const uint32_t* __restrict__ h
 #pragma unroll
         for (int u = 0; u < K; ++u) ld_stream_vec<NP>(hp + (size_t)yrow(tb + u + SH2 + 1) * rowstride, dst[u]);
     };
-    auto row = [&](int t, const us2 (&in)[NP]) {
+    auto row = [&](int t, const us2 (&in)[NP], int u) {
         const int y = ystart + dir * t;
         us2 cv[NP], L[NP];
 #pragma unroll
@@ -386,7 +382,8 @@ __global__ void __launch_bounds__(256) k_vsum_col(const uint32_t* __restrict__ h
             cp[(size_t)y * rowstride + j] = as_u32(v);
         }
         sgm_step<NP>(st, cv, L, P1v, P2);
-        edge(st, y);
+#pragma unroll
+        for (int i = 0; i < K; ++i) ms[i] = i == u ? st.m : ms[i];         // u is a constant wherever row() is inlined
         if (PATH2) {
 #pragma unroll
             for (int j = 0; j < NP; ++j) sp[(size_t)y * rowstride + j] = as_u32(pk_min(L[j], cap));
@@ -434,7 +431,7 @@ __global__ void __launch_bounds__(256) k_vsum_col(const uint32_t* __restrict__ h
         for (int u = 0; u < K; ++u) {
             us2 L[NP];
             sgm_step<NP>(st, cv[u], L, P1v, P2);
-            edge(st, ystart + dir * (t0 + u));
+            ms[u] = st.m;
             if (PATH2) {
                 us2 s2[NP];
 #pragma unroll
@@ -453,14 +450,17 @@ __global__ void __launch_bounds__(256) k_vsum_col(const uint32_t* __restrict__ h
             group(s * K, nb);
         } else {
 #pragma unroll
-            for (int u = 0; u < K; ++u) row(s * K + u, nb[u]);
+            for (int u = 0; u < K; ++u) row(s * K + u, nb[u], u);
         }
-        if (ET == 0 && !PATH2 && s < ncp) st.store_normalised(ck + (size_t)s * vec);
+        if (!PATH2 && s < ncp) {
+            st.store_normalised(ck + (size_t)s * vec);
+            store_minima<K>(mrow + (size_t)s * (K / 2), ms, lane);
+        }
         copy_seg<NP, K>(nb, nn);
     }
 #pragma unroll
     for (int u = 0; u < K; ++u)
-        if (u < r) row(F * K + u, nb[u]);
+        if (u < r) row(F * K + u, nb[u], u);
     if (SPLIT) st.store_normalised(endstate + (size_t)c2 * vec + lane * NP);
     if (__any(over) && lane == 0) atomicOr(flags, 1u);
 }
@@ -487,43 +487,29 @@ static int launch_cost_np(wass_ctx* c, const SgmDims& d)
     const int YSEG = 128;
     const size_t lds2 = (size_t)4 * (2 * d.SW2 + 1) * NP * 64 * sizeof(uint32_t);
     if (lds2 > 160 * 1024) return set_err(c, WASS_ERR_UNSUPPORTED, "WINSIZE %d too large for the LDS ring", 2 * d.SW2 + 1);
-    if (tile_schedule_enabled()) {
-        // the column walk doubles as the edge sweep of path 2 (forward column path) in both path modes
-        constexpr int K = ckpt_k(NP);
-        constexpr int T = tile_size(NP);
-        const EdgeLayout el = edge_layout(d);
-        int rc = ensure(c, c->edges, el.total);
-        if (rc) return rc;
-        WASS_HIP(c, hipFuncSetAttribute((const void*)k_vsum_col<NP, K, false, T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-        hipLaunchKernelGGL((k_vsum_col<NP, K, false, T, false>), dim3((d.width1 + 3) / 4), dim3(256), lds2, c->stream, (const uint32_t*)c->hsum.p,
-                           d.width1, d.h, d.D, d.SW2, d.P1, d.P2, (uint32_t*)c->C.p,
-                           (uint32_t*)((char*)c->edges.p + el.off_row[FAM_COLS][0]), 0, (uint32_t*)nullptr, (uint32_t*)c->flags.p,
-                           (uint32_t*)nullptr);
-        WASS_HIP(c, hipGetLastError());
-        return WASS_OK;
-    }
     const CkptLayout lay = ckpt_layout(d);
     if (lay.cols_from_cost || lay.path2_from_cost) {
         constexpr int K = ckpt_k(NP);
-        int rc = ensure(c, c->ckpt, lay.off[lay.nfam]);
+        int rc = ensure(c, c->ckpt, lay.total);
         if (rc) return rc;
         const dim3 grid((d.width1 + 3) / 4), block(256);
         if (lay.cols_from_cost && lay.split[0]) {
             uint32_t* ckf = (uint32_t*)((char*)c->ckpt.p + lay.off[0]);
-            WASS_HIP(c, hipFuncSetAttribute((const void*)k_vsum_col<NP, K, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-            hipLaunchKernelGGL((k_vsum_col<NP, K, false, 0, true>), dim3((2 * d.width1 + 3) / 4), block, lds2, c->stream, (const uint32_t*)c->hsum.p,
-                               d.width1, d.h, d.D, d.SW2, d.P1, d.P2, (uint32_t*)c->C.p, ckf, lay.mseg[0], (uint32_t*)c->S.p,
-                               (uint32_t*)c->flags.p, ckf + (size_t)lay.nch[0] * lay.mseg[0] * (64 * NP));
+            WASS_HIP(c, hipFuncSetAttribute((const void*)k_vsum_col<NP, K, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            hipLaunchKernelGGL((k_vsum_col<NP, K, false, true>), dim3((2 * d.width1 + 3) / 4), block, lds2, c->stream, (const uint32_t*)c->hsum.p,
+                               d.width1, d.h, d.D, d.SW2, d.P1, d.P2, (uint32_t*)c->C.p, ckf, (uint16_t*)((char*)c->ckpt.p + lay.moff[0]), lay.mseg[0],
+                               (uint32_t*)c->S.p, (uint32_t*)c->flags.p, ckf + (size_t)lay.nch[0] * lay.mseg[0] * (64 * NP));
         } else if (lay.cols_from_cost) {
-            WASS_HIP(c, hipFuncSetAttribute((const void*)k_vsum_col<NP, K, false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-            hipLaunchKernelGGL((k_vsum_col<NP, K, false, 0, false>), grid, block, lds2, c->stream, (const uint32_t*)c->hsum.p, d.width1, d.h, d.D,
-                               d.SW2, d.P1, d.P2, (uint32_t*)c->C.p, (uint32_t*)((char*)c->ckpt.p + lay.off[0]), lay.mseg[0],
-                               (uint32_t*)c->S.p, (uint32_t*)c->flags.p, (uint32_t*)nullptr);
-        } else {
-            WASS_HIP(c, hipFuncSetAttribute((const void*)k_vsum_col<NP, K, true, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-            hipLaunchKernelGGL((k_vsum_col<NP, K, true, 0, false>), grid, block, lds2, c->stream, (const uint32_t*)c->hsum.p, d.width1, d.h, d.D,
-                               d.SW2, d.P1, d.P2, (uint32_t*)c->C.p, (uint32_t*)c->ckpt.p, 0, (uint32_t*)c->S.p, (uint32_t*)c->flags.p,
+            WASS_HIP(c, hipFuncSetAttribute((const void*)k_vsum_col<NP, K, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            hipLaunchKernelGGL((k_vsum_col<NP, K, false, false>), grid, block, lds2, c->stream, (const uint32_t*)c->hsum.p, d.width1, d.h, d.D,
+                               d.SW2, d.P1, d.P2, (uint32_t*)c->C.p, (uint32_t*)((char*)c->ckpt.p + lay.off[0]),
+                               (uint16_t*)((char*)c->ckpt.p + lay.moff[0]), lay.mseg[0], (uint32_t*)c->S.p, (uint32_t*)c->flags.p,
                                (uint32_t*)nullptr);
+        } else {
+            WASS_HIP(c, hipFuncSetAttribute((const void*)k_vsum_col<NP, K, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            hipLaunchKernelGGL((k_vsum_col<NP, K, true, false>), grid, block, lds2, c->stream, (const uint32_t*)c->hsum.p, d.width1, d.h, d.D,
+                               d.SW2, d.P1, d.P2, (uint32_t*)c->C.p, (uint32_t*)c->ckpt.p, (uint16_t*)c->ckpt.p, 0, (uint32_t*)c->S.p,
+                               (uint32_t*)c->flags.p, (uint32_t*)nullptr);
         }
         WASS_HIP(c, hipGetLastError());
         return WASS_OK;

@@ -1,5 +1,5 @@
-// sgm_step.h -- the path-cost recurrence and its helpers, shared by every aggregation kernel
-// (sgm_aggregate.hip: chain sweeps / pairs; sgm_trio.hip: pipelined column strips).
+// sgm_step.h -- the path-cost recurrence and its helpers, shared by the aggregation kernels (sgm_aggregate.hip) and the
+// column walk of the cost stage (sgm_cost.hip).
 #pragma once
 
 #include "common.h"
@@ -91,6 +91,81 @@ __device__ __forceinline__ void st_stream_vec(uint32_t* __restrict__ p, const us
         for (int j = 0; j < NP; ++j) st_stream(p + j, as_u32(src[j]));
     }
 }
+
+// ---------------------------------------------------------------------------
+// Buffer addressing for the chain kernels: address = descriptor base (SGPRs, re-based per segment with scalar
+// arithmetic) + scalar byte offset + per-lane byte offset.  global_load/store with a runtime stride needs a 64-bit VALU
+// add per access (v_lshl_add_u64: 5 % of the pair kernel's vector instructions); buffer_load ... offen takes the scalar
+// offset as an operand and needs none.  Raw buffer (stride 0), 4 GiB window, no swizzle; aux 2 = nt.
+// ---------------------------------------------------------------------------
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef uint32_t wass_v2u __attribute__((__vector_size__(2 * sizeof(uint32_t))));
+typedef uint32_t wass_v4u __attribute__((__vector_size__(4 * sizeof(uint32_t))));
+__device__ __forceinline__ rsrc_t mk_rsrc(const void* p)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xFFFFFFFF, 0x00020000);
+}
+template <int NP>
+__device__ __forceinline__ void buf_ld(rsrc_t r, uint32_t voff, uint32_t soff, us2 (&dst)[NP])
+{
+    if constexpr (NP % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < NP; j += 4) {
+            const wass_v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, voff + 4 * j, soff, WASS_NT ? 2 : 0);
+            dst[j] = as_us2(v[0]); dst[j + 1] = as_us2(v[1]); dst[j + 2] = as_us2(v[2]); dst[j + 3] = as_us2(v[3]);
+        }
+    } else if constexpr (NP % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < NP; j += 2) {
+            const wass_v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, voff + 4 * j, soff, WASS_NT ? 2 : 0);
+            dst[j] = as_us2(v[0]); dst[j + 1] = as_us2(v[1]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) dst[j] = as_us2(__builtin_amdgcn_raw_buffer_load_b32(r, voff + 4 * j, soff, WASS_NT ? 2 : 0));
+    }
+}
+template <int NP>
+__device__ __forceinline__ void buf_st(rsrc_t r, uint32_t voff, uint32_t soff, const us2 (&src)[NP])
+{
+    if constexpr (NP % 4 == 0) {
+        // A 128-bit buffer store whose scalar offset is an SGPR fetches its data registers late (the ISA manual lists
+        // buffer_store_dwordx3/x4 with an SGPR offset as needing a wait state before a VALU overwrites the data; under
+        // memory back-pressure the window is far longer and an LDS read or a load landing in the same registers also
+        // corrupts the store -- measured: ~1e-4 of the pixels wrong at D = 512, run to run different, only with x4
+        // stores, never with x4 loads or x2 stores).  The offset therefore goes into the VGPR: one v_add per store.
+        const uint32_t vo = voff + soff;
+#pragma unroll
+        for (int j = 0; j < NP; j += 4) {
+            const wass_v4u v = { as_u32(src[j]), as_u32(src[j + 1]), as_u32(src[j + 2]), as_u32(src[j + 3]) };
+            __builtin_amdgcn_raw_buffer_store_b128(v, r, vo + 4 * j, 0, WASS_NT ? 2 : 0);
+        }
+    } else if constexpr (NP % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < NP; j += 2) {
+            const wass_v2u v = { as_u32(src[j]), as_u32(src[j + 1]) };
+            __builtin_amdgcn_raw_buffer_store_b64(v, r, voff + 4 * j, soff, WASS_NT ? 2 : 0);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) __builtin_amdgcn_raw_buffer_store_b32(as_u32(src[j]), r, voff + 4 * j, soff, WASS_NT ? 2 : 0);
+    }
+}
+
+// One chain as the kernels address it: element t lies at pixel pix0 + t * pixstep.  A run of `count` elements starting
+// at element `first` is addressed from its lowest address (descriptor base) with the scalar offset bias + e * sstep for
+// its e-th element (sstep is negative for chains that walk towards lower addresses).
+struct ChainAddr {
+    long long pix0, pixstep;
+    int sstep;                       // pixstep * bytes per vector
+    template <int NP>
+    __device__ __forceinline__ rsrc_t run(const uint32_t* vol, long long first, int count) const
+    {
+        const long long lp = pix0 + (first + (pixstep < 0 ? count - 1 : 0)) * pixstep;
+        return mk_rsrc(vol + lp * (64 * NP));
+    }
+    __device__ __forceinline__ uint32_t bias(int count) const { return pixstep < 0 ? (uint32_t)(-(count - 1) * sstep) : 0u; }
+};
 
 template <int NP>
 struct PathState {
@@ -191,6 +266,63 @@ __device__ __forceinline__ void sgm_step_pair(PathState<NP>& a, const us2 (&ca)[
     uint32_t ra = min((uint32_t)am.x, (uint32_t)am.y), rb = min((uint32_t)bm.x, (uint32_t)bm.y);
     wave_min2_u32(ra, rb);
     a.m = ra; b.m = rb;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) { a.L[j] = La[j]; b.L[j] = Lb[j]; }
+}
+
+// The K minima of a checkpointed segment (wave-uniform scalars) -> one record of K u16 in HBM, written as K/2 dwords
+// by lanes 0 .. K/2-1 (a handful of instructions per SEGMENT; the pair kernel reads the record back with scalar loads).
+template <int K>
+__device__ __forceinline__ void store_minima(uint32_t* __restrict__ rec, const uint32_t (&ms)[K], int lane)
+{
+    static_assert(K % 2 == 0, "records are dwords");
+    uint32_t v = ms[0] | (ms[1] << 16);
+#pragma unroll
+    for (int i = 1; i < K / 2; ++i) v = lane == i ? (ms[2 * i] | (ms[2 * i + 1] << 16)) : v;
+    if (lane < K / 2) rec[lane] = v;
+}
+
+// The main-loop step of k_pair: chain a is a forward RE-computation whose minimum before the step is known (am: the
+// checkpoint sweep recorded it, sgm_aggregate.hip / k_vsum_col), chain b is the backward path proper.  Same arithmetic as
+// sgm_step_pair; chain a simply has no cross-lane reduction (6 DPP stages + v_readlane per step saved).
+template <int NP>
+__device__ __forceinline__ void sgm_step_fb(PathState<NP>& a, const uint32_t am, const us2 (&ca)[NP], us2 (&La)[NP],
+                                            PathState<NP>& b, const us2 (&cb)[NP], us2 (&Lb)[NP],
+                                            const us2 P1v, const uint32_t P2)
+{
+    a.shr = dpp_mov<DPP_WAVE_SHR1>(a.shr, as_u32(a.L[NP - 1]));
+    b.shr = dpp_mov<DPP_WAVE_SHR1>(b.shr, as_u32(b.L[NP - 1]));
+    a.shl = dpp_mov<DPP_WAVE_SHL1>(a.shl, as_u32(a.L[0]));
+    b.shl = dpp_mov<DPP_WAVE_SHL1>(b.shl, as_u32(b.L[0]));
+    const us2 amv = pk_splat(am), amp2 = pk_splat(am + P2);
+    const us2 bmv = pk_splat(b.m), bmp2 = pk_splat(b.m + P2);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const uint32_t alo = j == 0 ? a.shr : as_u32(a.L[j - 1]);
+        const uint32_t blo = j == 0 ? b.shr : as_u32(b.L[j - 1]);
+        const uint32_t ahi = j == NP - 1 ? a.shl : as_u32(a.L[j + 1]);
+        const uint32_t bhi = j == NP - 1 ? b.shl : as_u32(b.L[j + 1]);
+        const us2 anl = as_us2(__builtin_amdgcn_alignbit(as_u32(a.L[j]), alo, 16));
+        const us2 bnl = as_us2(__builtin_amdgcn_alignbit(as_u32(b.L[j]), blo, 16));
+        const us2 anr = as_us2(__builtin_amdgcn_alignbit(ahi, as_u32(a.L[j]), 16));
+        const us2 bnr = as_us2(__builtin_amdgcn_alignbit(bhi, as_u32(b.L[j]), 16));
+        us2 ax = pk_min(anl, anr);
+        us2 bx = pk_min(bnl, bnr);
+        ax = pk_adds(ax, P1v);
+        bx = pk_adds(bx, P1v);
+        ax = pk_min(a.L[j], ax);
+        bx = pk_min(b.L[j], bx);
+        ax = pk_min(ax, amp2);
+        bx = pk_min(bx, bmp2);
+        ax = ax - amv;
+        bx = bx - bmv;
+        La[j] = pk_adds(ca[j], ax);
+        Lb[j] = pk_adds(cb[j], bx);
+    }
+    us2 bm = Lb[0];
+#pragma unroll
+    for (int j = 1; j < NP; ++j) bm = pk_min(bm, Lb[j]);
+    b.m = wave_min_u32(min((uint32_t)bm.x, (uint32_t)bm.y));
 #pragma unroll
     for (int j = 0; j < NP; ++j) { a.L[j] = La[j]; b.L[j] = Lb[j]; }
 }
