@@ -169,6 +169,11 @@ int wass_ctx_wait_for_stream(wass_ctx* c, void* producer_stream)
 {
     if (!c) return WASS_ERR_INVALID_ARG;
     WASS_HIP(c, hipSetDevice(c->device));
+    // An idle producer has nothing to wait for.  This is not only a shortcut: the runtime multiplexes every stream of the
+    // process onto four hardware queues, and an event recorded on an idle stream that happens to share its queue with the
+    // context's tail stream completes only behind the previous frame's tail -- the SGM stage of the next frame, which
+    // waits for that event, then starts after the tail instead of beside it (measured: frame period = SGM + tail).
+    if (hipStreamQuery((hipStream_t)producer_stream) == hipSuccess) return WASS_OK;
     if (!c->ev_producer) WASS_HIP(c, hipEventCreateWithFlags(&c->ev_producer, hipEventDisableTiming));
     WASS_HIP(c, hipEventRecord(c->ev_producer, (hipStream_t)producer_stream));
     WASS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_producer, 0));

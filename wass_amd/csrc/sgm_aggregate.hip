@@ -113,8 +113,13 @@ __global__ void __launch_bounds__(256) k_sweep(const uint32_t* __restrict__ C, u
 // K steps, no second buffer, no register copies).
 // endstate != nullptr: the family is split in the middle (half_chain_geometry): c counts sub-chains, the sweep runs to the
 // end of its half and leaves its final state in endstate[c] for the pair kernel of the other half.
+// At most WASS_CKPT_WAVES waves per SIMD: a sweep needs 26 VGPRs and would otherwise take every wave slot the pair kernel
+// leaves (4 + 4 of 8), which locks the previous frame's tail kernels out of the GPU for as long as both run.
+#ifndef WASS_CKPT_WAVES
+#define WASS_CKPT_WAVES 3
+#endif
 template <int NP, int K>
-__global__ void __launch_bounds__(256) k_ckpt(const uint32_t* __restrict__ C, uint32_t* __restrict__ ckpt,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, WASS_CKPT_WAVES))) k_ckpt(const uint32_t* __restrict__ C, uint32_t* __restrict__ ckpt,
                                               uint16_t* __restrict__ mins, int width1, int h, int dx, int dy, int P1, int P2,
                                               int nchains, int maxseg, uint32_t* __restrict__ endstate)
 {
