@@ -224,6 +224,9 @@ struct CkptLayout {
     size_t moff[4] = {};             // byte offsets of the per-step minima records (K u16 per segment) into c->ckpt
     size_t total = 0;                // bytes of c->ckpt
     bool cols_from_cost = false;     // family 0 is the column family and its checkpoints come from k_vsum_col
+    bool rows_fused = false;         // 8 paths: the row family is folded into the column family's pair kernel (k_pairx)
+    int nbx = 0;                     // ... blocks of 8 columns per row
+    size_t roff[4] = {};             // ... byte offsets into c->ckpt: entry states of paths 0 / 4, minima of paths 0 / 4
     bool path2_from_cost = false;    // 5-path mode: k_vsum_col has already written S = L_2 (path 2 has no partner)
 };
 CkptLayout ckpt_layout(const SgmDims& d);

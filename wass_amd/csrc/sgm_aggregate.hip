@@ -449,6 +449,372 @@ k_pair(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t*
 #undef WASS_PAIR_LAST
 }
 
+// ---------------------------------------------------------------------------
+// 8-path mode: the ROW family rides on the column family's pair kernel, so that S is written once for both (an S
+// read-modify-write pass less: -4 B/cell of HBM traffic, -2 B/cell of writes).
+//   k_rowsweep (x2, pure read streams): paths 0 and 4 over every row, keeping only the state with which the path enters
+//     each block of XB columns and min_d L after every step.
+//   k_pairx: k_pair of the column family with a workgroup of XB ADJACENT columns walking in lock-step.  What a wave hands
+//     from its forward recomputation to its backward path (cost vectors + forward path costs of a K-row segment, in LDS)
+//     is, over the XB waves, a K x XB block of the image: between the two uses wave r takes ROW r of the block, rebuilds
+//     both row paths across the XB columns from the entry states (no reductions: the minima are recorded) and adds
+//     L_0 + L_4 into the forward path costs waiting in LDS.  Two workgroup barriers per iteration.
+// ---------------------------------------------------------------------------
+// XB = 10: 2 * ceil(2455 / 10) = 492 workgroups of ten waves, two per CU (2 x 80 KiB of LDS, five waves per SIMD): all of
+// config B's columns are resident at once.  With XB = 8 there were 614 workgroups for 512 places and the kernel ran two
+// rounds, the second one a fifth full (2.85 ms).
+constexpr int XB = 10;
+
+// MB ? path 4 (walking -x) : path 0 (walking +x).  ent[y][b]: normalised state entering block b (undefined for the block
+// the path starts in); M[y][x]: min_d L after the step at x.
+template <int NP, bool MB>
+__device__ __forceinline__ void rowsweep(const uint32_t* __restrict__ C, uint32_t* __restrict__ ent, uint16_t* __restrict__ M, int width1, int h,
+                                         int P1, int P2, int nbx)
+{
+    const int lane = threadIdx.x & 63;
+    const int y = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
+    if (y >= h) return;
+    constexpr int VB = 256 * NP;
+    const long long vec = 64 * NP;
+    const int n = width1;
+    ChainAddr a;
+    a.pixstep = MB ? -1 : 1;
+    a.pix0 = (long long)y * width1 + (MB ? n - 1 : 0);
+    a.sstep = (int)a.pixstep * VB;
+    const uint32_t voff = lane * NP * 4;
+    const us2 P1v = pk_splat(P1);
+    const int cnt_last = n - (nbx - 1) * XB;               // columns of block nbx-1 (1 .. XB)
+    // processing order p = 0 .. nbx-1: block b(p), its first chain element t0(p), its size
+    auto blk = [&](int p) { return MB ? nbx - 1 - p : p; };
+    auto cnt = [&](int p) { return blk(p) == nbx - 1 ? cnt_last : XB; };
+    auto t0 = [&](int p) { return MB ? (p == 0 ? 0 : cnt_last + (p - 1) * XB) : p * XB; };
+    uint32_t* mrow = (uint32_t*)(M + (size_t)y * nbx * XB);
+    uint32_t* erow = ent + (size_t)y * nbx * vec + lane * NP;
+
+    PathState<NP> st;
+    st.reset();
+    us2 ring[XB][NP];
+    {
+        const int c0 = cnt(0);
+        const rsrc_t r0 = a.run<NP>(C, 0, c0);
+        const uint32_t b0 = a.bias(c0);
+#pragma unroll
+        for (int u = 0; u < XB; ++u)
+            if (u < c0) buf_ld<NP>(r0, voff, b0 + u * a.sstep, ring[u]);
+    }
+    for (int p = 0; p < nbx; ++p) {
+        const int b = blk(p), cn = cnt(p);
+        if (p > 0) st.store_normalised(erow + (size_t)b * vec);
+        uint32_t ms[XB];                                   // minima in x order within the block
+#pragma unroll
+        for (int i = 0; i < XB; ++i) ms[i] = 0;
+        if (cn == XB) {
+            // refill from the next block; its elements past the row end (only the last block of path 0 can be short)
+            // are clamped to the row's last pixel and never consumed
+            const bool more = p + 1 < nbx;
+            const int cnn = more ? cnt(p + 1) : XB;
+            const rsrc_t rn = a.run<NP>(C, more ? t0(p + 1) : t0(p), cnn);
+            const uint32_t bn = a.bias(cnn);
+#pragma unroll
+            for (int u = 0; u < XB; ++u) {
+                us2 L[NP];
+                sgm_step<NP>(st, ring[u], L, P1v, P2);
+                ms[MB ? XB - 1 - u : u] = st.m;
+                buf_ld<NP>(rn, voff, bn + min(u, cnn - 1) * a.sstep, ring[u]);
+            }
+        } else {
+            // the one short block: the last one of path 0, the first one of path 4 (followed by full blocks)
+#pragma unroll
+            for (int u = 0; u < XB; ++u)
+                if (u < cn) {
+                    us2 L[NP];
+                    sgm_step<NP>(st, ring[u], L, P1v, P2);
+                    const int xi = MB ? cn - 1 - u : u;
+#pragma unroll
+                    for (int i = 0; i < XB; ++i) ms[i] = i == xi ? st.m : ms[i];
+                }
+            if (p + 1 < nbx) {
+                const rsrc_t rn = a.run<NP>(C, t0(p + 1), XB);
+                const uint32_t bn = a.bias(XB);
+#pragma unroll
+                for (int u = 0; u < XB; ++u) buf_ld<NP>(rn, voff, bn + u * a.sstep, ring[u]);
+            }
+        }
+        store_minima<XB>(mrow + (size_t)b * (XB / 2), ms, lane);
+    }
+}
+
+// both paths in one launch (blockIdx.y = 0: path 0, 1: path 4).  2h chains are about four waves per SIMD at config B and every
+// chain is as long as a row: all of them must be resident at once (with three per SIMD the launch took two rounds, 1.3 ms)
+template <int NP>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 6)))
+k_rowsweep(const uint32_t* __restrict__ C, uint32_t* __restrict__ entF, uint32_t* __restrict__ entB, uint16_t* __restrict__ MF,
+           uint16_t* __restrict__ MB, int width1, int h, int P1, int P2, int nbx)
+{
+    if (blockIdx.y == 0) rowsweep<NP, false>(C, entF, MF, width1, h, P1, P2, nbx);
+    else rowsweep<NP, true>(C, entB, MB, width1, h, P1, P2, nbx);
+}
+
+struct RowSide {                     // what k_rowsweep left behind
+    const uint32_t* entF; const uint32_t* entB;
+    const uint16_t* MF; const uint16_t* MB;
+    int nbx;
+};
+
+template <int NP, int K>
+__global__ void __launch_bounds__(64 * XB) __attribute__((amdgpu_waves_per_eu(5, 5)))
+k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t* __restrict__ ckpt, const uint16_t* __restrict__ mins,
+        const RowSide rs, int width1, int h, int P1, int P2, int maxseg, const uint32_t* __restrict__ endstate)
+{
+    static_assert(K % 2 == 0 && K <= XB, "one wave per row of a K-row segment");
+    constexpr int VW = 64 * NP, VB = 256 * NP;
+    extern __shared__ __attribute__((aligned(16))) uint32_t hand_raw[];   // [XB][2][K][VW]: per wave (column): [0] cost vectors, [1] forward path costs
+    uint32_t (*hand)[2][K][VW] = (uint32_t (*)[2][K][VW])hand_raw;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bx = blockIdx.x >> 1, half = blockIdx.x & 1;
+    const int X0 = bx * XB, ncol = min(XB, width1 - X0);
+    const bool colact = wv < ncol;                         // this wave owns a column (the last block of a row may be short)
+    const int x = colact ? X0 + wv : X0;
+    const int c = 2 * x + half;                            // sub-chain index of the split column family (half_chain_geometry)
+    int dx = 0, dy = 1, x0, y0, n;
+    half_chain_geometry(c, dx, dy, width1, h, x0, y0, n);  // the same n, y0, dy for every wave of the workgroup
+    if (n == 0) return;                                    // h == 1: the first half of every column is empty
+    const long long vec = VW;
+    ChainAddr a;
+    a.pixstep = (long long)dy * width1;
+    a.pix0 = (long long)y0 * width1 + x0;
+    a.sstep = (int)a.pixstep * VB;
+    const uint32_t voff = lane * NP * 4;
+    const uint32_t bK = a.bias(K);
+    const us2 P1v = pk_splat(P1);
+    const int F = n / K, r = n - F * K;
+    const int top = r > 0 ? F : F - 1;                     // the segment the forward pass starts with (n >= 1)
+    const rsrc_t ckr = mk_rsrc(ckpt + (long long)c * maxseg * vec);
+    const uint32_t* mrow = (const uint32_t*)(mins + (size_t)c * maxseg * K);
+    uint32_t* hc = &hand[wv][0][0][lane * NP];
+    uint32_t* hl = &hand[wv][1][0][lane * NP];
+
+    // ---- the row phase: wave e takes element e of the K-row segment seg, whose vectors lie in slot (rev ? K-1-e : e) of
+    // every wave's hand-over region
+    // what the row phase of a segment needs from HBM: requested before the column phase that precedes it
+    us2 eF[NP], eB[NP];
+    uint32_t mf[XB / 2], mb[XB / 2];
+    auto row_fetch = [&](int seg, int cnt) {
+        if (wv < cnt) {
+            const int yrow = y0 + (seg * K + wv) * dy;
+            if (bx >= 1) ld_stream_vec<NP>(rs.entF + ((size_t)yrow * rs.nbx + bx) * vec + lane * NP, eF);
+            else {
+#pragma unroll
+                for (int j = 0; j < NP; ++j) eF[j] = pk_splat(0);
+            }
+            if (bx + 1 < rs.nbx) ld_stream_vec<NP>(rs.entB + ((size_t)yrow * rs.nbx + bx) * vec + lane * NP, eB);
+            else {
+#pragma unroll
+                for (int j = 0; j < NP; ++j) eB[j] = pk_splat(0);
+            }
+            const uint32_t* pf = (const uint32_t*)(rs.MF + ((size_t)yrow * rs.nbx + bx) * XB);
+            const uint32_t* pb = (const uint32_t*)(rs.MB + ((size_t)yrow * rs.nbx + bx) * XB);
+#pragma unroll
+            for (int i = 0; i < XB / 2; ++i) { mf[i] = pf[i]; mb[i] = pb[i]; }
+        }
+    };
+    auto row_phase = [&](int seg, int cnt, bool rev) {
+        __syncthreads();
+        if (wv < cnt) {
+            const int e = wv, slot = rev ? K - 1 - e : e;
+            auto mat = [](const uint32_t (&m)[XB / 2], int i) { return (m[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu; };
+            us2 cj[XB][NP], part[XB][NP];
+#pragma unroll
+            for (int j = 0; j < XB; ++j)
+                if (j < ncol) lds_ld<NP>(&hand[j][0][slot][lane * NP], cj[j]);
+            PathState<NP> fa, fb;
+            fa.load_normalised(eF);
+            fb.load_normalised(eB);
+            if (ncol == XB) {
+#pragma unroll
+                for (int u = 0; u < XB; ++u) {
+                    const int jf = u, jb = XB - 1 - u;
+                    us2 Lf[NP], Lb[NP];
+                    // minimum before the step: what the sweep recorded after the previous pixel of the path (0 behind an entry state)
+                    sgm_step_ff<NP>(fa, u == 0 ? 0u : mat(mf, jf - 1), cj[jf], Lf, fb, u == 0 ? 0u : mat(mb, jb + 1), cj[jb], Lb, P1v, P2);
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) {
+                        part[jf][j] = u < XB / 2 ? Lf[j] : pk_adds(part[jf][j], Lf[j]);
+                        part[jb][j] = u < XB / 2 ? Lb[j] : pk_adds(part[jb][j], Lb[j]);
+                    }
+                }
+            } else {                                        // the short block at the right image border
+#pragma unroll
+                for (int j = 0; j < XB; ++j)
+                    if (j < ncol) sgm_step_f<NP>(fa, j == 0 ? 0u : mat(mf, j - 1), cj[j], part[j], P1v, P2);
+#pragma unroll
+                for (int j = XB - 1; j >= 0; --j)
+                    if (j < ncol) {
+                        us2 Lb[NP];
+                        sgm_step_f<NP>(fb, j == ncol - 1 ? 0u : mat(mb, j + 1), cj[j], Lb, P1v, P2);
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) part[j][q] = pk_adds(part[j][q], Lb[q]);
+                    }
+            }
+#pragma unroll
+            for (int j = 0; j < XB; ++j)
+                if (j < ncol) {
+                    uint32_t* lp = &hand[j][1][slot][lane * NP];
+                    us2 t[NP];
+                    lds_ld<NP>(lp, t);
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) t[q] = pk_adds(t[q], part[j][q]);
+                    lds_st<NP>(lp, t);
+                }
+        }
+        __syncthreads();
+    };
+
+    PathState<NP> bw, fw;
+    us2 cf[K][NP];                                         // ring: cost vectors of the segment the forward recomputation covers next
+    us2 nvB[NP];
+    uint32_t mB[K / 2];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) nvB[j] = pk_splat(0);
+#pragma unroll
+    for (int i = 0; i < K / 2; ++i) mB[i] = 0;
+    // ---- iteration 0: the forward path over segment `top` (with its reductions: once per chain), natural slot order
+    {
+        const int cn = top == F ? r : K;
+        row_fetch(top, cn);
+        if (colact) {
+            bw.reset();
+            {                                              // the backward path arrives from the other half of the chain
+                us2 nv[NP];
+                ld_stream_vec<NP>(endstate + (long long)(c ^ 1) * vec + lane * NP, nv);
+                bw.load_normalised(nv);
+            }
+            const rsrc_t rc = a.run<NP>(C, (long long)top * K, cn);
+            const uint32_t bc = a.bias(cn);
+            us2 c0[K][NP];
+#pragma unroll
+            for (int u = 0; u < K; ++u)
+                if (u < cn) buf_ld<NP>(rc, voff, bc + u * a.sstep, c0[u]);
+            fw.reset();
+            if (top >= 1) {
+                us2 nv[NP];
+                buf_ld<NP>(ckr, voff, (uint32_t)(top - 1) * VB, nv);
+                fw.load_normalised(nv);
+                const rsrc_t rc2 = a.run<NP>(C, (long long)(top - 1) * K, K);
+#pragma unroll
+                for (int u = 0; u < K; ++u) buf_ld<NP>(rc2, voff, bK + u * a.sstep, cf[u]);
+#pragma unroll
+                for (int i = 0; i < K / 2; ++i) mB[i] = mrow[(size_t)(top - 1) * (K / 2) + i];
+            }
+            if (top >= 2) buf_ld<NP>(ckr, voff, (uint32_t)(top - 2) * VB, nvB);
+#pragma unroll
+            for (int u = 0; u < K; ++u)
+                if (u < cn) {
+                    us2 L[NP];
+                    sgm_step<NP>(fw, c0[u], L, P1v, P2);
+                    lds_st<NP>(hc + u * VW, c0[u]);
+                    lds_st<NP>(hl + u * VW, L);
+                }
+        }
+    }
+
+    // ---- iterations t = 1, 2, ...: backward path over segment s = top, top-1, ..., 0 || forward recomputation of segment
+    // s-1 || refill of the ring with segment s-2.  NAT_: the slots hold segment s in natural order (element e in slot e); the
+    // forward results go into the slots as they are drained, i.e. in reversed order, and so on alternately.
+    // The common case, complete segments on both sides:
+#define WASS_PX_FAST(NAT_, s_)                                                                                         \
+    if (colact) {                                                                                                       \
+        const rsrc_t rcN = a.run<NP>(C, (long long)max((s_) - 2, 0) * K, K);                                              \
+        const rsrc_t rsO = a.run<NP>(S, (long long)(s_) * K, K);                                                          \
+        us2 nvC[NP];                                                                                                    \
+        uint32_t mC[K / 2];                                                                                             \
+        if ((s_) >= 3) buf_ld<NP>(ckr, voff, (uint32_t)((s_) - 3) * VB, nvC);                                            \
+        else {                                                                                                          \
+            _Pragma("unroll") for (int j = 0; j < NP; ++j) nvC[j] = pk_splat(0);                                         \
+        }                                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < K / 2; ++i) mC[i] = mrow[(size_t)max((s_) - 2, 0) * (K / 2) + i];         \
+        fw.load_normalised(nvB);                                                                                        \
+        us2 cbn[NP], lfn[NP];                                                                                           \
+        lds_ld<NP>(hc + ((NAT_) ? K - 1 : 0) * VW, cbn);                                                                \
+        lds_ld<NP>(hl + ((NAT_) ? K - 1 : 0) * VW, lfn);                                                                \
+        _Pragma("unroll") for (int u = 0; u < K; ++u) {                                                                 \
+            const int v = K - 1 - u;                                                                                    \
+            const int slot = (NAT_) ? v : u, nslot = (NAT_) ? v - 1 : u + 1;                                           \
+            us2 cb[NP], lfv[NP], Lf[NP], Lb[NP], sv[NP];                                                                \
+            _Pragma("unroll") for (int j = 0; j < NP; ++j) { cb[j] = cbn[j]; lfv[j] = lfn[j]; }                          \
+            if (u + 1 < K) {                                                                                            \
+                lds_ld<NP>(hc + nslot * VW, cbn);                                                                       \
+                lds_ld<NP>(hl + nslot * VW, lfn);                                                                       \
+            }                                                                                                           \
+            sgm_step_fb<NP>(fw, min_before<K>(mB, u), cf[u], Lf, bw, cb, Lb, P1v, P2);                                   \
+            _Pragma("unroll") for (int j = 0; j < NP; ++j) sv[j] = pk_adds(lfv[j], Lb[j]);                               \
+            buf_st<NP>(rsO, voff, bK + v * a.sstep, sv);                                                                \
+            lds_st<NP>(hc + slot * VW, cf[u]);                                                                          \
+            lds_st<NP>(hl + slot * VW, Lf);                                                                             \
+            buf_ld<NP>(rcN, voff, bK + u * a.sstep, cf[u]);                                                              \
+        }                                                                                                               \
+        _Pragma("unroll") for (int j = 0; j < NP; ++j) nvB[j] = nvC[j];                                                 \
+        _Pragma("unroll") for (int i = 0; i < K / 2; ++i) mB[i] = mC[i];                                                \
+    }
+    // Guarded form: the backward path over the short tail segment (cb_ < K elements) and/or no segment left to recompute
+#define WASS_PX_SLOW(nat_, s_, cb_, hasfw_)                                                                             \
+    if (colact) {                                                                                                       \
+        const rsrc_t rcN = a.run<NP>(C, (long long)max((s_) - 2, 0) * K, K);                                              \
+        const rsrc_t rsO = a.run<NP>(S, (long long)(s_) * K, (cb_));                                                      \
+        const uint32_t bO = a.bias(cb_);                                                                                \
+        us2 nvC[NP];                                                                                                    \
+        uint32_t mC[K / 2];                                                                                             \
+        if ((s_) >= 3) buf_ld<NP>(ckr, voff, (uint32_t)((s_) - 3) * VB, nvC);                                            \
+        else {                                                                                                          \
+            _Pragma("unroll") for (int j = 0; j < NP; ++j) nvC[j] = pk_splat(0);                                         \
+        }                                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < K / 2; ++i) mC[i] = mrow[(size_t)max((s_) - 2, 0) * (K / 2) + i];         \
+        fw.load_normalised(nvB);                                                                                        \
+        _Pragma("unroll") for (int u = 0; u < K; ++u) {                                                                 \
+            const int v = K - 1 - u;                                                                                    \
+            const int slot = (nat_) ? v : u;                                                                             \
+            us2 Lf[NP];                                                                                                 \
+            if (v < (cb_)) {                                                                                            \
+                us2 cb[NP], lfv[NP], Lb[NP], sv[NP];                                                                    \
+                lds_ld<NP>(hc + slot * VW, cb);                                                                         \
+                lds_ld<NP>(hl + slot * VW, lfv);                                                                        \
+                sgm_step<NP>(bw, cb, Lb, P1v, P2);                                                                      \
+                _Pragma("unroll") for (int j = 0; j < NP; ++j) sv[j] = pk_adds(lfv[j], Lb[j]);                           \
+                buf_st<NP>(rsO, voff, bO + v * a.sstep, sv);                                                            \
+            }                                                                                                           \
+            if (hasfw_) {                                                                                               \
+                sgm_step_f<NP>(fw, min_before<K>(mB, u), cf[u], Lf, P1v, P2);                                            \
+                lds_st<NP>(hc + slot * VW, cf[u]);                                                                      \
+                lds_st<NP>(hl + slot * VW, Lf);                                                                         \
+                buf_ld<NP>(rcN, voff, bK + u * a.sstep, cf[u]);                                                          \
+            }                                                                                                           \
+        }                                                                                                               \
+        _Pragma("unroll") for (int j = 0; j < NP; ++j) nvB[j] = nvC[j];                                                 \
+        _Pragma("unroll") for (int i = 0; i < K / 2; ++i) mB[i] = mC[i];                                                \
+    }
+    // One call site for the row phase and one for each form of the column phase: the loop must stay well inside the 64 KB
+    // instruction cache two CUs share (with the row phase inlined three times the kernel was 50 KB).
+    int s = top, rseg = top, rcnt = top == F ? r : K;
+    bool nat = true, rrev = false;                         // iteration 0 filled the slots in natural order
+    for (;;) {
+        row_phase(rseg, rcnt, rrev);
+        const bool hasfw = s >= 1;
+        const int cbw = s == F ? r : K;
+        if (hasfw) row_fetch(s - 1, K);
+        if (hasfw && cbw == K) {
+            if (nat) { WASS_PX_FAST(true, s) }
+            else { WASS_PX_FAST(false, s) }
+        } else { WASS_PX_SLOW(nat, s, cbw, hasfw) }
+        if (!hasfw) break;
+        rseg = s - 1; rcnt = K; rrev = nat;               // the forward results went into the slots as they were drained
+        nat = !nat;
+        --s;
+    }
+#undef WASS_PX_FAST
+#undef WASS_PX_SLOW
+}
+
 CkptLayout ckpt_layout(const SgmDims& d)
 {
     CkptLayout L;
@@ -472,8 +838,8 @@ CkptLayout ckpt_layout(const SgmDims& d)
     // instructions per pixel): the anti-diagonals (width1 + h - 1 chains).
     if (d.ndirs == 8) {
         L.cols_from_cost = true;
-        add(0, 1, 0);                // columns:        paths 2 + 6   (S written)
-        add(1, 0, 1);                // rows:           paths 0 + 4
+        L.rows_fused = true;
+        add(0, 1, 0);                // columns + rows: paths 2 + 6 and 0 + 4 (k_pairx, S written)
         add(1, 1, 1);                // diagonals:      paths 1 + 7
         add(-1, 1, 2);               // anti-diagonals: paths 3 + 5, winner-take-all fused
     } else {
@@ -484,6 +850,15 @@ CkptLayout ckpt_layout(const SgmDims& d)
     for (int f = 0; f < L.nfam; ++f) {
         L.moff[f] = o;
         o += ((size_t)L.nch[f] * L.mseg[f] * L.K * sizeof(uint16_t) + 255) & ~(size_t)255;
+    }
+    if (L.rows_fused) {              // k_rowsweep: entry states per block of XB columns and minima per pixel, both row paths
+        L.nbx = (d.width1 + XB - 1) / XB;
+        const size_t eb = ((size_t)d.h * L.nbx * (64 * d.NP) * sizeof(uint32_t) + 255) & ~(size_t)255;
+        const size_t mb = ((size_t)d.h * L.nbx * XB * sizeof(uint16_t) + 255) & ~(size_t)255;
+        L.roff[0] = o; o += eb;
+        L.roff[1] = o; o += eb;
+        L.roff[2] = o; o += mb;
+        L.roff[3] = o; o += mb;
     }
     L.total = o;
     return L;
@@ -512,6 +887,14 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
 
     WASS_HIP(c, hipEventRecord(c->ev_cost, c->stream));
     WASS_HIP(c, hipStreamWaitEvent(c->side, c->ev_cost, 0));
+    char* const ckb = (char*)c->ckpt.p;
+    if (lay.rows_fused) {                            // the row sweeps come first: the first kernel on the main stream needs them
+        hipLaunchKernelGGL((k_rowsweep<NP>), dim3((d.h + 3) / 4, 2), dim3(256), 0, c->side, C, (uint32_t*)(ckb + lay.roff[0]),
+                           (uint32_t*)(ckb + lay.roff[1]), (uint16_t*)(ckb + lay.roff[2]), (uint16_t*)(ckb + lay.roff[3]), d.width1, d.h,
+                           d.P1, d.P2, lay.nbx);
+        WASS_HIP(c, hipEventRecord(c->ev_ckpt[3], c->side));
+        ++nl;
+    }
     for (int f = 0; f < nf; ++f) {
         if (f == 0 && lay.cols_from_cost) {         // written by k_vsum_col on the main stream already
             WASS_HIP(c, hipEventRecord(c->ev_ckpt[f], c->stream));
@@ -519,10 +902,14 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
         }
         const int nch = lay.nch[f], mseg = lay.mseg[f];
         uint32_t* ckf = (uint32_t*)((char*)c->ckpt.p + lay.off[f]);
-        hipLaunchKernelGGL((k_ckpt<NP, K>), dim3((nch + 3) / 4), dim3(256), 0, c->side, C, ckf, (uint16_t*)((char*)c->ckpt.p + lay.moff[f]),
+        // (Tried: the first of these sweeps on the main stream, beside the row sweeps, which keep the main stream waiting.  The
+        // row chains are the longest in the image, 2 455 dependent steps, and sharing their SIMDs stretched them from 0.7 to
+        // 1.9 ms: they run alone.)
+        hipStream_t ss = c->side;
+        hipLaunchKernelGGL((k_ckpt<NP, K>), dim3((nch + 3) / 4), dim3(256), 0, ss, C, ckf, (uint16_t*)((char*)c->ckpt.p + lay.moff[f]),
                            d.width1, d.h, lay.dx[f], lay.dy[f], d.P1, d.P2, nch, mseg,
                            lay.split[f] ? ckf + (size_t)nch * mseg * (64 * NP) : (uint32_t*)nullptr);
-        WASS_HIP(c, hipEventRecord(c->ev_ckpt[f], c->side));
+        WASS_HIP(c, hipEventRecord(c->ev_ckpt[f], ss));
         ++nl;
     }
 
@@ -542,7 +929,15 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
         hipLaunchKernelGGL((k_pair<NP, K, SMODE>), grid, block, 0, c->stream, C, S, ck, mn, d.width1, d.h, lay.dx[f],  \
                            lay.dy[f], d.P1, d.P2, nch, mseg, d.D, d.minD, d.uniq, c->debug ? 1 : 0, sd, sk,            \
                            lay.split[f] ? (const uint32_t*)(ck + (size_t)nch * mseg * (64 * NP)) : (const uint32_t*)nullptr)
-        if (lay.smode[f] == 0) WASS_PAIR(0);
+        if (f == 0 && lay.rows_fused) {
+            WASS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_ckpt[3], 0));
+            const RowSide rs = { (const uint32_t*)(ckb + lay.roff[0]), (const uint32_t*)(ckb + lay.roff[1]),
+                                 (const uint16_t*)(ckb + lay.roff[2]), (const uint16_t*)(ckb + lay.roff[3]), lay.nbx };
+            const size_t ldsx = (size_t)XB * 2 * K * (64 * NP) * sizeof(uint32_t);
+            WASS_HIP(c, hipFuncSetAttribute((const void*)k_pairx<NP, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx));
+            hipLaunchKernelGGL((k_pairx<NP, K>), dim3(2 * lay.nbx), dim3(64 * XB), ldsx, c->stream, C, S, ck, mn, rs, d.width1, d.h, d.P1,
+                               d.P2, mseg, (const uint32_t*)(ck + (size_t)nch * mseg * (64 * NP)));
+        } else if (lay.smode[f] == 0) WASS_PAIR(0);
         else if (lay.smode[f] == 1) WASS_PAIR(1);
         else WASS_PAIR(2);
 #undef WASS_PAIR

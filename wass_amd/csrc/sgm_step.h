@@ -327,6 +327,67 @@ __device__ __forceinline__ void sgm_step_fb(PathState<NP>& a, const uint32_t am,
     for (int j = 0; j < NP; ++j) { a.L[j] = La[j]; b.L[j] = Lb[j]; }
 }
 
+// Two forward RE-computations side by side (the row paths inside a block of k_pairx): both minima are known scalars,
+// no reduction at all.
+template <int NP>
+__device__ __forceinline__ void sgm_step_ff(PathState<NP>& a, const uint32_t am, const us2 (&ca)[NP], us2 (&La)[NP],
+                                            PathState<NP>& b, const uint32_t bm, const us2 (&cb)[NP], us2 (&Lb)[NP],
+                                            const us2 P1v, const uint32_t P2)
+{
+    a.shr = dpp_mov<DPP_WAVE_SHR1>(a.shr, as_u32(a.L[NP - 1]));
+    b.shr = dpp_mov<DPP_WAVE_SHR1>(b.shr, as_u32(b.L[NP - 1]));
+    a.shl = dpp_mov<DPP_WAVE_SHL1>(a.shl, as_u32(a.L[0]));
+    b.shl = dpp_mov<DPP_WAVE_SHL1>(b.shl, as_u32(b.L[0]));
+    const us2 amv = pk_splat(am), amp2 = pk_splat(am + P2);
+    const us2 bmv = pk_splat(bm), bmp2 = pk_splat(bm + P2);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const uint32_t alo = j == 0 ? a.shr : as_u32(a.L[j - 1]);
+        const uint32_t blo = j == 0 ? b.shr : as_u32(b.L[j - 1]);
+        const uint32_t ahi = j == NP - 1 ? a.shl : as_u32(a.L[j + 1]);
+        const uint32_t bhi = j == NP - 1 ? b.shl : as_u32(b.L[j + 1]);
+        const us2 anl = as_us2(__builtin_amdgcn_alignbit(as_u32(a.L[j]), alo, 16));
+        const us2 bnl = as_us2(__builtin_amdgcn_alignbit(as_u32(b.L[j]), blo, 16));
+        const us2 anr = as_us2(__builtin_amdgcn_alignbit(ahi, as_u32(a.L[j]), 16));
+        const us2 bnr = as_us2(__builtin_amdgcn_alignbit(bhi, as_u32(b.L[j]), 16));
+        us2 ax = pk_min(anl, anr);
+        us2 bx = pk_min(bnl, bnr);
+        ax = pk_adds(ax, P1v);
+        bx = pk_adds(bx, P1v);
+        ax = pk_min(a.L[j], ax);
+        bx = pk_min(b.L[j], bx);
+        ax = pk_min(ax, amp2);
+        bx = pk_min(bx, bmp2);
+        ax = ax - amv;
+        bx = bx - bmv;
+        La[j] = pk_adds(ca[j], ax);
+        Lb[j] = pk_adds(cb[j], bx);
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) { a.L[j] = La[j]; b.L[j] = Lb[j]; }
+}
+// ... and one alone (partial blocks)
+template <int NP>
+__device__ __forceinline__ void sgm_step_f(PathState<NP>& a, const uint32_t am, const us2 (&ca)[NP], us2 (&La)[NP], const us2 P1v,
+                                           const uint32_t P2)
+{
+    a.shr = dpp_mov<DPP_WAVE_SHR1>(a.shr, as_u32(a.L[NP - 1]));
+    a.shl = dpp_mov<DPP_WAVE_SHL1>(a.shl, as_u32(a.L[0]));
+    const us2 amv = pk_splat(am), amp2 = pk_splat(am + P2);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const uint32_t alo = j == 0 ? a.shr : as_u32(a.L[j - 1]);
+        const uint32_t ahi = j == NP - 1 ? a.shl : as_u32(a.L[j + 1]);
+        const us2 anl = as_us2(__builtin_amdgcn_alignbit(as_u32(a.L[j]), alo, 16));
+        const us2 anr = as_us2(__builtin_amdgcn_alignbit(ahi, as_u32(a.L[j]), 16));
+        us2 ax = pk_adds(pk_min(anl, anr), P1v);
+        ax = pk_min(pk_min(a.L[j], ax), amp2) - amv;
+        La[j] = pk_adds(ca[j], ax);
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) a.L[j] = La[j];
+}
+
 // chain c of direction (dx,dy): start cell and length
 __device__ __forceinline__ void chain_geometry(int c, int dx, int dy, int width1, int h, int& x0, int& y0, int& n)
 {
