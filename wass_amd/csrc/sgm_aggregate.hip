@@ -465,11 +465,16 @@ k_pair(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t*
 // rounds, the second one a fifth full (2.85 ms).
 constexpr int XB = 10;
 
-// MB ? path 4 (walking -x) : path 0 (walking +x).  ent[y][b]: normalised state entering block b (undefined for the block
-// the path starts in); M[y][x]: min_d L after the step at x.
-template <int NP, bool MB>
-__device__ __forceinline__ void rowsweep(const uint32_t* __restrict__ C, uint32_t* __restrict__ ent, uint16_t* __restrict__ M, int width1, int h,
-                                         int P1, int P2, int nbx)
+// One wave per row walks BOTH paths at once, path 0 from the left border and path 4 from the right border, the two
+// recurrences interleaved statement by statement (sgm_step_pair): the row chains are the longest in the image (2 455
+// dependent steps) and the main stream waits for this kernel, so what counts is the latency of a step, and a second,
+// independent chain fills the wait states of the first (one chain per wave: 1.2 ms; this form: see DESIGN.md).
+//   entF[y][b] / entB[y][b]: normalised state with which path 0 / path 4 enters block b of XB columns (undefined for the
+//   block the path starts in);  MF[y][x] / MB[y][x]: min_d L after the step at x.
+template <int NP>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4)))
+k_rowsweep(const uint32_t* __restrict__ C, uint32_t* __restrict__ entF, uint32_t* __restrict__ entB, uint16_t* __restrict__ MF,
+           uint16_t* __restrict__ MB, int width1, int h, int P1, int P2, int nbx)
 {
     const int lane = threadIdx.x & 63;
     const int y = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
@@ -477,82 +482,95 @@ __device__ __forceinline__ void rowsweep(const uint32_t* __restrict__ C, uint32_
     constexpr int VB = 256 * NP;
     const long long vec = 64 * NP;
     const int n = width1;
-    ChainAddr a;
-    a.pixstep = MB ? -1 : 1;
-    a.pix0 = (long long)y * width1 + (MB ? n - 1 : 0);
-    a.sstep = (int)a.pixstep * VB;
+    ChainAddr af, ab;                                       // step t: path 0 is at x = t, path 4 at x = n-1-t
+    af.pixstep = 1;  af.pix0 = (long long)y * width1;           af.sstep = VB;
+    ab.pixstep = -1; ab.pix0 = (long long)y * width1 + n - 1;   ab.sstep = -VB;
     const uint32_t voff = lane * NP * 4;
     const us2 P1v = pk_splat(P1);
-    const int cnt_last = n - (nbx - 1) * XB;               // columns of block nbx-1 (1 .. XB)
-    // processing order p = 0 .. nbx-1: block b(p), its first chain element t0(p), its size
-    auto blk = [&](int p) { return MB ? nbx - 1 - p : p; };
-    auto cnt = [&](int p) { return blk(p) == nbx - 1 ? cnt_last : XB; };
-    auto t0 = [&](int p) { return MB ? (p == 0 ? 0 : cnt_last + (p - 1) * XB) : p * XB; };
-    uint32_t* mrow = (uint32_t*)(M + (size_t)y * nbx * XB);
-    uint32_t* erow = ent + (size_t)y * nbx * vec + lane * NP;
+    const int cb = n % XB;                                  // path 4 enters a new block at the steps t = cb (mod XB)
+    uint32_t* mfrow = (uint32_t*)(MF + (size_t)y * nbx * XB);
+    uint16_t* mbrow = MB + (size_t)y * nbx * XB;
+    uint32_t* efrow = entF + (size_t)y * nbx * vec + lane * NP;
+    uint32_t* ebrow = entB + (size_t)y * nbx * vec + lane * NP;
 
-    PathState<NP> st;
-    st.reset();
-    us2 ring[XB][NP];
-    {
-        const int c0 = cnt(0);
-        const rsrc_t r0 = a.run<NP>(C, 0, c0);
-        const uint32_t b0 = a.bias(c0);
+    PathState<NP> sf, sb;
+    sf.reset();
+    sb.reset();
+    us2 rf[XB][NP], rb[XB][NP];
+    const int G = n / XB, rem = n - G * XB;                 // G groups of XB steps, then rem steps
+    if (G > 0) {
+        const rsrc_t r0 = af.run<NP>(C, 0, XB), r1 = ab.run<NP>(C, 0, XB);
+        const uint32_t b1 = ab.bias(XB);
 #pragma unroll
-        for (int u = 0; u < XB; ++u)
-            if (u < c0) buf_ld<NP>(r0, voff, b0 + u * a.sstep, ring[u]);
+        for (int u = 0; u < XB; ++u) {
+            buf_ld<NP>(r0, voff, u * VB, rf[u]);
+            buf_ld<NP>(r1, voff, b1 + u * ab.sstep, rb[u]);
+        }
     }
-    for (int p = 0; p < nbx; ++p) {
-        const int b = blk(p), cn = cnt(p);
-        if (p > 0) st.store_normalised(erow + (size_t)b * vec);
-        uint32_t ms[XB];                                   // minima in x order within the block
+    for (int g = 0; g < G; ++g) {
+        const int t0 = g * XB;
+        // refill from the next group; steps past the end of the row re-read its last pixel and are never consumed
+        const int nxt = min(t0 + XB, n - 1), cnn = min(XB, n - nxt);
+        const rsrc_t rnf = af.run<NP>(C, nxt, cnn), rnb = ab.run<NP>(C, nxt, cnn);
+        const uint32_t bnb = ab.bias(cnn);
+        uint32_t msf[XB], msb[XB];
 #pragma unroll
-        for (int i = 0; i < XB; ++i) ms[i] = 0;
-        if (cn == XB) {
-            // refill from the next block; its elements past the row end (only the last block of path 0 can be short)
-            // are clamped to the row's last pixel and never consumed
-            const bool more = p + 1 < nbx;
-            const int cnn = more ? cnt(p + 1) : XB;
-            const rsrc_t rn = a.run<NP>(C, more ? t0(p + 1) : t0(p), cnn);
-            const uint32_t bn = a.bias(cnn);
+        for (int u = 0; u < XB; ++u) {
+            const int t = t0 + u;
+            if (u == 0 && g > 0) sf.store_normalised(efrow + (size_t)g * vec);                  // path 0 enters block g
+            if (u == cb && t > 0) sb.store_normalised(ebrow + (size_t)((n - 1 - t) / XB) * vec); // path 4 enters block (n-1-t)/XB
+            us2 Lf[NP], Lb[NP];
+            sgm_step_pair<NP>(sf, rf[u], Lf, sb, rb[u], Lb, P1v, P2);
+            msf[u] = sf.m;
+            msb[XB - 1 - u] = sb.m;                         // in x order: x = n-1-t0-u
+            const int uc = min(u, cnn - 1);
+            buf_ld<NP>(rnf, voff, uc * VB, rf[u]);
+            buf_ld<NP>(rnb, voff, bnb + uc * ab.sstep, rb[u]);
+        }
+        store_minima<XB>(mfrow + (size_t)g * (XB / 2), msf, lane);
+        {                                                   // path 4's minima cover x = n-t0-XB .. n-1-t0: not block aligned
+            uint32_t v = msb[0];
 #pragma unroll
-            for (int u = 0; u < XB; ++u) {
-                us2 L[NP];
-                sgm_step<NP>(st, ring[u], L, P1v, P2);
-                ms[MB ? XB - 1 - u : u] = st.m;
-                buf_ld<NP>(rn, voff, bn + min(u, cnn - 1) * a.sstep, ring[u]);
-            }
-        } else {
-            // the one short block: the last one of path 0, the first one of path 4 (followed by full blocks)
+            for (int i = 1; i < XB; ++i) v = lane == i ? msb[i] : v;
+            if (lane < XB) mbrow[n - t0 - XB + lane] = (uint16_t)v;
+        }
+    }
+    if (rem > 0) {                                          // the last rem steps, guarded
+        const int t0 = G * XB;
+        if (G == 0) {
+            const rsrc_t r0 = af.run<NP>(C, 0, rem), r1 = ab.run<NP>(C, 0, rem);
+            const uint32_t b1 = ab.bias(rem);
 #pragma unroll
             for (int u = 0; u < XB; ++u)
-                if (u < cn) {
-                    us2 L[NP];
-                    sgm_step<NP>(st, ring[u], L, P1v, P2);
-                    const int xi = MB ? cn - 1 - u : u;
-#pragma unroll
-                    for (int i = 0; i < XB; ++i) ms[i] = i == xi ? st.m : ms[i];
+                if (u < rem) {
+                    buf_ld<NP>(r0, voff, u * VB, rf[u]);
+                    buf_ld<NP>(r1, voff, b1 + u * ab.sstep, rb[u]);
                 }
-            if (p + 1 < nbx) {
-                const rsrc_t rn = a.run<NP>(C, t0(p + 1), XB);
-                const uint32_t bn = a.bias(XB);
-#pragma unroll
-                for (int u = 0; u < XB; ++u) buf_ld<NP>(rn, voff, bn + u * a.sstep, ring[u]);
-            }
         }
-        store_minima<XB>(mrow + (size_t)b * (XB / 2), ms, lane);
+        uint32_t msf[XB], msb[XB];
+#pragma unroll
+        for (int i = 0; i < XB; ++i) msf[i] = msb[i] = 0;
+#pragma unroll
+        for (int u = 0; u < XB; ++u)
+            if (u < rem) {
+                const int t = t0 + u;
+                if (u == 0 && G > 0) sf.store_normalised(efrow + (size_t)G * vec);
+                if (u == cb && t > 0) sb.store_normalised(ebrow + (size_t)((n - 1 - t) / XB) * vec);
+                us2 Lf[NP], Lb[NP];
+                sgm_step_pair<NP>(sf, rf[u], Lf, sb, rb[u], Lb, P1v, P2);
+                msf[u] = sf.m;
+                // x = rem-1-u
+#pragma unroll
+                for (int i = 0; i < XB; ++i) msb[i] = i == rem - 1 - u ? sb.m : msb[i];
+            }
+        store_minima<XB>(mfrow + (size_t)G * (XB / 2), msf, lane);
+        {
+            uint32_t v = msb[0];
+#pragma unroll
+            for (int i = 1; i < XB; ++i) v = lane == i ? msb[i] : v;
+            if (lane < rem) mbrow[lane] = (uint16_t)v;
+        }
     }
-}
-
-// both paths in one launch (blockIdx.y = 0: path 0, 1: path 4).  2h chains are about four waves per SIMD at config B and every
-// chain is as long as a row: all of them must be resident at once (with three per SIMD the launch took two rounds, 1.3 ms)
-template <int NP>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 6)))
-k_rowsweep(const uint32_t* __restrict__ C, uint32_t* __restrict__ entF, uint32_t* __restrict__ entB, uint16_t* __restrict__ MF,
-           uint16_t* __restrict__ MB, int width1, int h, int P1, int P2, int nbx)
-{
-    if (blockIdx.y == 0) rowsweep<NP, false>(C, entF, MF, width1, h, P1, P2, nbx);
-    else rowsweep<NP, true>(C, entB, MB, width1, h, P1, P2, nbx);
 }
 
 struct RowSide {                     // what k_rowsweep left behind
@@ -889,7 +907,7 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
     WASS_HIP(c, hipStreamWaitEvent(c->side, c->ev_cost, 0));
     char* const ckb = (char*)c->ckpt.p;
     if (lay.rows_fused) {                            // the row sweeps come first: the first kernel on the main stream needs them
-        hipLaunchKernelGGL((k_rowsweep<NP>), dim3((d.h + 3) / 4, 2), dim3(256), 0, c->side, C, (uint32_t*)(ckb + lay.roff[0]),
+        hipLaunchKernelGGL((k_rowsweep<NP>), dim3((d.h + 3) / 4), dim3(256), 0, c->side, C, (uint32_t*)(ckb + lay.roff[0]),
                            (uint32_t*)(ckb + lay.roff[1]), (uint16_t*)(ckb + lay.roff[2]), (uint16_t*)(ckb + lay.roff[3]), d.width1, d.h,
                            d.P1, d.P2, lay.nbx);
         WASS_HIP(c, hipEventRecord(c->ev_ckpt[3], c->side));
