@@ -78,6 +78,17 @@ def test_dense_scale_sgm_and_cleanup(gpu_ctx, oracle, scale):
     ref, st = oracle.dense_disparity16(r2, l2, _oracle_params(oracle, p))
     assert not st.overflow
     np.testing.assert_array_equal(got, ref)
+    # the device-pointer entry allocates / checks its output at the size of the RESIZED inputs (a (h, w) tensor would be
+    # overrun by the median / crop kernel for scale > 1)
+    import torch
+    dev = torch.device("cuda", gpu_ctx.device_id)
+    d = gpu_ctx.sgm_disparity_dev(torch.from_numpy(right).to(dev), torch.from_numpy(left).to(dev), p)
+    gpu_ctx.synchronize()
+    assert tuple(d.shape) == r2.shape
+    np.testing.assert_array_equal(d.cpu().numpy(), ref)
+    with pytest.raises(ValueError):
+        gpu_ctx.sgm_disparity_dev(torch.from_numpy(right).to(dev), torch.from_numpy(left).to(dev), p,
+                                  torch.empty((h, w), dtype=torch.int16, device=dev))
     for cc in (0, 30):
         f = gpu_ctx.disparity_postprocess_ex(got, p, w, h, cc_threshold=cc)
         np.testing.assert_array_equal(f, oracle.disparity_postprocess_ex(ref, 1, D, w, h, dense_scale=scale, cc_threshold=cc))

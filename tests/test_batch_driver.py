@@ -60,6 +60,26 @@ def test_planes_txt_and_mean_from_finished_workdirs(exes, tmp_path, workers):
         assert f"[frame {i}]" in r.stdout
 
 
+def test_long_sequences_do_not_fill_the_worker_pipes(exes, tmp_path):
+    """More records per worker than a 64 KiB pipe holds (~1000 of 64 bytes): the parent has to drain every worker as it
+    goes -- draining them one after the other blocks workers 1.. in write() and, with an all-reduce before the tail,
+    deadlocks the run."""
+    out = tmp_path / "output"
+    out.mkdir()
+    n = 2 * 1300
+    for i in range(n):
+        _finished_workdir(str(out), i, "0.1 0.2 0.3 %d" % i)
+    cfg = tmp_path / "cfg.txt"
+    cfg.write_text("MAX_DISPARITY=64\n")
+    r = subprocess.run([exes[1], str(cfg), "--sequence", str(out), "--gpus", "1", "--procs-per-gpu", "2", "--skip-existing"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr
+    lines = (out / "planes.txt").read_text().strip().split("\n")
+    assert len(lines) == n and lines[0].split()[3] == "0" and lines[-1].split()[3] == str(n - 1)
+    mean = np.array([float(x) for x in (out / "planes_mean.txt").read_text().split()])
+    np.testing.assert_allclose(mean, [0.1, 0.2, 0.3, (n - 1) / 2], rtol=1e-12)
+
+
 def test_failed_frame_is_reported_and_left_out(exes, tmp_path):
     out = tmp_path / "output"
     out.mkdir()

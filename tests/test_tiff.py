@@ -123,3 +123,67 @@ def test_unsupported_files_are_refused_with_a_message(tool, tmp_path):
     bad.write_bytes(b"II*\x00\x08\x00\x00\x00\x00\x00")
     with pytest.raises(RuntimeError):
         _decode(tool, bad, tmp_path)
+
+
+@pytest.fixture(scope="module")
+def tool_asan():
+    """The same driver under AddressSanitizer + UBSan: a malformed file must end in an error message, not in an out-of-bounds read."""
+    src = os.path.join(HERE, "native", "tiff_check.cpp")
+    deps = [src] + [os.path.join(HERE, "..", "wass_amd", "host", f) for f in ("tiff.hpp", "hostio.hpp", "jpeg_read.hpp")]
+    out_dir = os.path.join(HERE, "native", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    exe = os.path.join(out_dir, "tiff_check_asan")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                               "-Wno-unused-function", src, "-o", exe, "-lz"])
+    return exe
+
+
+def _segments(blob):
+    """(marker, offset of the marker's 0xFF, segment length incl. the length field) of the header segments of a JPEG file"""
+    out, p = [], 2
+    while p + 4 <= len(blob):
+        assert blob[p] == 0xFF
+        m = blob[p + 1]
+        ln = (blob[p + 2] << 8) | blob[p + 3]
+        out.append((m, p, ln))
+        if m == 0xDA:
+            break
+        p += 2 + ln
+    return out
+
+
+def test_malformed_jpeg_headers_are_refused_not_read_out_of_bounds(tool_asan, tmp_path):
+    """Bad table selectors in the scan header (Td / Ta up to 15 index four-entry arrays), segments that end in the middle of
+    a table, frame headers shorter than their component list, plus random corruption of the header bytes."""
+    img = _grey(96, 64, 3)
+    good = tmp_path / "good.jpg"
+    Image.fromarray(np.dstack([img, img // 2, 255 - img])).save(good, quality=90)
+    blob = bytearray(good.read_bytes())
+    seg = {m: (p, ln) for m, p, ln in _segments(blob)}
+    cases = {}
+    sos, _ = seg[0xDA]
+    b = bytearray(blob); b[sos + 6] = 0xF0; cases["td15"] = b                  # first component: Td = 15
+    b = bytearray(blob); b[sos + 6] = 0x0F; cases["ta15"] = b                  # Ta = 15
+    dht, ln = seg[0xC4]
+    b = bytearray(blob); b[dht + 2:dht + 4] = (10).to_bytes(2, "big"); cases["dht_cut"] = b      # counts run past the segment
+    dqt, ln = seg[0xDB]
+    b = bytearray(blob); b[dqt + 4] |= 0x10; cases["dqt16_cut"] = b            # 16-bit entries in a segment sized for 8-bit ones
+    sof, ln = seg[0xC0]
+    b = bytearray(blob); b[sof + 2:sof + 4] = (9).to_bytes(2, "big"); cases["sof_short"] = b
+    b = bytearray(blob); b[sof + 2:sof + 4] = (1).to_bytes(2, "big"); cases["len1"] = b
+    cases["cut_in_header"] = bytearray(blob[:sos + 3])
+    rng = np.random.default_rng(5)
+    for k in range(150):
+        b = bytearray(blob)
+        for _ in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(2, sos + 14))] = int(rng.integers(0, 256))
+        cases["rnd%d" % k] = b
+    env = dict(os.environ, ASAN_OPTIONS="exitcode=99:detect_leaks=0", UBSAN_OPTIONS="halt_on_error=1:exitcode=98")
+    for name, data in cases.items():
+        path = tmp_path / (name + ".jpg")
+        path.write_bytes(bytes(data))
+        r = subprocess.run([tool_asan, str(path), str(tmp_path / "o.raw")], capture_output=True, text=True, env=env, timeout=60)
+        assert r.returncode in (0, 1), (name, r.returncode, r.stderr[-1500:])
+        if name in ("td15", "ta15", "dht_cut", "dqt16_cut", "sof_short", "len1", "cut_in_header"):
+            assert r.returncode == 1 and r.stderr.strip(), name

@@ -51,6 +51,10 @@ class FramePipeline:
                  ransac_rounds=400, random_seed=12345, ransac_thr=1.0, plane_max_distance=1.5, refine=None,
                  tail_overlap=True):
         import torch
+        if params.dense_scale != 1.0:
+            # the pipelined chain keeps every map at the crop size; DENSE_SCALE != 1 goes through the stage-by-stage calls
+            # (Context.sgm_disparity + disparity_postprocess with the scale), as the drop-in wass_stereo does
+            raise ValueError("FramePipeline supports DENSE_SCALE = 1 only")
         self.ctx, self.w, self.h, self.params, self.geom = ctx, width, height, params, geom
         self.roi_l = tuple(roi_l) if roi_l is not None else (0, 0, width, height)
         self.roi_r = tuple(roi_r) if roi_r is not None else (0, 0, width, height)

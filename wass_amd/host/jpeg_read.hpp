@@ -102,6 +102,9 @@ inline Image decode_jpeg_gray(const std::vector<uint8_t>& f, const std::string& 
     int ncomp = 0, W = 0, H = 0, restart = 0;
     size_t p = 2;
     auto u16 = [&](size_t o) { if (o + 2 > f.size()) throw std::runtime_error(name + ": truncated JPEG"); return (int)((f[o] << 8) | f[o + 1]); };
+    // every byte of a marker segment is read through these: nothing is taken from beyond the segment's own end
+    auto s8 = [&](size_t o, size_t end) { if (o >= end) throw std::runtime_error(name + ": truncated JPEG segment"); return (int)f[o]; };
+    auto s16 = [&](size_t o, size_t end) { if (o + 2 > end) throw std::runtime_error(name + ": truncated JPEG segment"); return (int)((f[o] << 8) | f[o + 1]); };
     for (;;) {
         if (p + 4 > f.size()) throw std::runtime_error(name + ": no scan in JPEG file");
         if (f[p] != 0xFF) { ++p; continue; }
@@ -111,20 +114,20 @@ inline Image decode_jpeg_gray(const std::vector<uint8_t>& f, const std::string& 
         if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
         const int len = u16(p);
         const size_t seg = p + 2, end = p + len;
-        if (end > f.size()) throw std::runtime_error(name + ": truncated JPEG segment");
+        if (len < 2 || end > f.size()) throw std::runtime_error(name + ": truncated JPEG segment");
         if (m == 0xDB) {                                         // DQT
             for (size_t q = seg; q < end;) {
-                const int pq = f[q] >> 4, tq = f[q] & 15; ++q;
-                if (tq > 3) throw std::runtime_error(name + ": bad quantisation table");
-                for (int i = 0; i < 64; ++i) { qt[tq][kZigzag[i]] = (uint16_t)(pq ? u16(q) : f[q]); q += pq ? 2 : 1; }
+                const int pq = s8(q, end) >> 4, tq = f[q] & 15; ++q;
+                if (tq > 3 || pq > 1) throw std::runtime_error(name + ": bad quantisation table");
+                for (int i = 0; i < 64; ++i) { qt[tq][kZigzag[i]] = (uint16_t)(pq ? s16(q, end) : s8(q, end)); q += pq ? 2 : 1; }
             }
         } else if (m == 0xC4) {                                  // DHT
             for (size_t q = seg; q < end;) {
-                const int tc = f[q] >> 4, th = f[q] & 15; ++q;
+                const int tc = s8(q, end) >> 4, th = f[q] & 15; ++q;
                 if (tc > 1 || th > 3) throw std::runtime_error(name + ": bad Huffman table");
                 HuffTable& h = tc ? hac[th] : hdc[th];
                 int counts[17], total = 0;
-                for (int l = 1; l <= 16; ++l) { counts[l] = f[q++]; total += counts[l]; }
+                for (int l = 1; l <= 16; ++l) { counts[l] = s8(q++, end); total += counts[l]; }
                 if (total > 256 || q + total > end) throw std::runtime_error(name + ": bad Huffman table");
                 for (int i = 0; i < total; ++i) h.vals[i] = f[q++];
                 int code = 0, k = 0;
@@ -137,20 +140,27 @@ inline Image decode_jpeg_gray(const std::vector<uint8_t>& f, const std::string& 
                 h.present = true;
             }
         } else if (m == 0xC0 || m == 0xC1) {                     // SOF0 / SOF1: sequential, Huffman
-            if (f[seg] != 8) throw std::runtime_error(name + ": only 8-bit JPEG files are supported");
-            H = u16(seg + 1); W = u16(seg + 3); ncomp = f[seg + 5];
+            if (len < 8) throw std::runtime_error(name + ": truncated JPEG frame header");
+            if (s8(seg, end) != 8) throw std::runtime_error(name + ": only 8-bit JPEG files are supported");
+            H = s16(seg + 1, end); W = s16(seg + 3, end); ncomp = s8(seg + 5, end);
             if ((ncomp != 1 && ncomp != 3) || W <= 0 || H <= 0) throw std::runtime_error(name + ": unsupported JPEG layout");
-            for (int i = 0; i < ncomp; ++i) { comp[i].id = f[seg + 6 + 3 * i]; comp[i].h = f[seg + 7 + 3 * i] >> 4; comp[i].v = f[seg + 7 + 3 * i] & 15; comp[i].tq = f[seg + 8 + 3 * i] & 3; }
+            if (len < 8 + 3 * ncomp) throw std::runtime_error(name + ": truncated JPEG frame header");
+            for (int i = 0; i < ncomp; ++i) {
+                comp[i].id = s8(seg + 6 + 3 * i, end); comp[i].h = s8(seg + 7 + 3 * i, end) >> 4; comp[i].v = f[seg + 7 + 3 * i] & 15;
+                comp[i].tq = s8(seg + 8 + 3 * i, end);
+                if (comp[i].tq > 3) throw std::runtime_error(name + ": bad quantisation table");
+            }
         } else if (m == 0xC2 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) {
             throw std::runtime_error(name + ": progressive / lossless / arithmetic-coded JPEG files are not supported (baseline ones are)");
-        } else if (m == 0xDD) restart = u16(seg);
+        } else if (m == 0xDD) restart = s16(seg, end);
         else if (m == 0xDA) {                                    // SOS
             if (!W) throw std::runtime_error(name + ": scan before frame header");
-            const int ns = f[seg];
+            const int ns = s8(seg, end);
             if (ns != ncomp) throw std::runtime_error(name + ": multi-scan JPEG files are not supported");
             for (int i = 0; i < ns; ++i) {
-                const int cid = f[seg + 1 + 2 * i], tt = f[seg + 2 + 2 * i];
-                for (int k = 0; k < ncomp; ++k) if (comp[k].id == cid) { comp[k].td = tt >> 4; comp[k].ta = tt & 3; }
+                const int cid = s8(seg + 1 + 2 * i, end), tt = s8(seg + 2 + 2 * i, end);
+                if ((tt >> 4) > 3 || (tt & 15) > 3) throw std::runtime_error(name + ": bad Huffman table");       // only four tables of each class exist
+                for (int k = 0; k < ncomp; ++k) if (comp[k].id == cid) { comp[k].td = tt >> 4; comp[k].ta = tt & 15; }
             }
             p = end;
             break;
@@ -181,6 +191,7 @@ inline Image decode_jpeg_gray(const std::vector<uint8_t>& f, const std::string& 
                     for (int bx = 0; bx < c.h; ++bx) {
                         double blk[64] = {};
                         const int t = decode_symbol(br, hdc[c.td]);
+                        if (t > 16) throw std::runtime_error(name + ": corrupt JPEG entropy data");     // a DC category, not a byte of a damaged table
                         c.pred += extend(br.bits(t), t);
                         blk[0] = (double)c.pred * qt[c.tq][0];
                         for (int k = 1; k < 64;) {

@@ -632,9 +632,18 @@ inline int wass_run_frame(const char* config_path, const std::string& workdir, c
             void* bytes = nullptr; size_t nb = 0;
             gpu_check(ctx, wass_mesh_encode_xyzc(ctx, mesh, have_plane ? plane : nullptr, &bytes, &nb), "wass_mesh_encode_xyzc");
             const std::string xyzc_path = path_join(env.workdir, "mesh_cam.xyzC");
+            // written under a temporary name and renamed: a worker killed in the middle of the (possibly asynchronous) write
+            // must not leave a truncated mesh_cam.xyzC behind that --skip-existing would take for a finished frame
             auto write_xyzc = [xyzc_path, bytes, nb]() {
-                std::ofstream ofs(xyzc_path.c_str(), std::ios::binary);
-                const bool ok = !ofs.fail() && ofs.write((const char*)bytes, (std::streamsize)nb).good();
+                const std::string tmp = xyzc_path + ".tmp";
+                bool ok;
+                {
+                    std::ofstream ofs(tmp.c_str(), std::ios::binary);
+                    ok = !ofs.fail() && ofs.write((const char*)bytes, (std::streamsize)nb).good();
+                    ofs.close();
+                    ok = ok && !ofs.fail();
+                }
+                ok = ok && rename(tmp.c_str(), xyzc_path.c_str()) == 0;
                 wass_free(bytes);
                 if (!ok) fprintf(stderr, "wass_stereo [error] unable to save %s\n", xyzc_path.c_str());
                 return ok;

@@ -83,7 +83,7 @@ bool process_image(Gpu& gpu, const std::string& filename, const Mat& K, const Ma
     try { img = read_image_gray(filename); } catch (const std::exception& e) { WLOGE << e.what(); return false; }     // PNG, TIFF or baseline JPEG
     WLOGI << "Input image size: " << img.w << "x" << img.h;
     if (!gpu.ctx) {
-        const char* dev = getenv("WASS_DEVICE");
+        const char* dev = getenv("WASS_GPU_DEVICE");      // the same variable wass_stereo and wass_stereo_batch read
         if (wass_ctx_create(dev ? atoi(dev) : 0, &gpu.ctx) != WASS_OK) {
             WLOGE << "unable to open the GPU: " << wass_last_error(gpu.ctx);
             return false;

@@ -18,7 +18,9 @@
 // mesh_cam.xyzbin exist is not recomputed, its plane is read back from plane.txt.
 #include <dirent.h>
 #include <fcntl.h>
+#include <sys/stat.h>
 #include <sys/wait.h>
+#include <poll.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -94,7 +96,15 @@ int worker(int rank, int world, int device, bool distinct_gpus, const unsigned c
         std::thread loader;
         struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{ loader };     // also on the early returns
         const size_t stride = (size_t)world * (size_t)threads, first = (size_t)rank + (size_t)tid * (size_t)world;
-        auto done = [&](size_t k) { return skip_existing && (exists(path_join(wds[k], "mesh_cam.xyzC")) || exists(path_join(wds[k], "mesh_cam.xyzbin"))); };
+        // finished = the point cloud file is there and at least as long as its header (148 bytes, PovMesh.cpp:377-460; the file
+        // only gets its name once it is complete) -- plane.txt is checked by the caller
+        auto done = [&](size_t k) {
+            if (!skip_existing) return false;
+            struct stat sb;
+            const std::string a = path_join(wds[k], "mesh_cam.xyzC");
+            if (stat(a.c_str(), &sb) == 0) return sb.st_size >= 148;
+            return exists(path_join(wds[k], "mesh_cam.xyzbin"));
+        };
         auto start_load = [&](size_t k, int slot) {
             if (k < wds.size() && exists(wds[k]) && !done(k)) loader = std::thread([&, k, slot]() { preload_images(wds[k], pre[slot]); });
         };
@@ -223,20 +233,57 @@ int main(int argc, char* argv[])
     std::vector<char> got(wds.size(), 0);
     std::vector<Tail> tails(world);
     bool ok = true;
-    for (int r = 0; r < world; ++r) {
-        const size_t mine = (wds.size() + world - 1 - r) / world;
-        for (size_t k = 0; k < mine; ++k) {
-            Record rec;
-            if (!read_all(fds[r], &rec, sizeof rec) || rec.index < 0 || (size_t)rec.index >= wds.size()) { ok = false; break; }
-            recs[rec.index] = rec; got[rec.index] = 1;
-            std::cout << "[frame " << rec.index << "] " << wds[rec.index] << "  rc=" << rec.rc << "  " << rec.seconds << " s  "
-                      << rec.n_points << " pts" << (rec.have_plane ? "" : "  (no plane)") << std::endl;
+    // Every worker's pipe is drained as it fills (poll): a worker blocks in write() once the 64 KiB pipe holds ~1000
+    // records, and with one worker per GPU rank 0 only sends its tail after the RCCL all-reduce, which needs EVERY rank --
+    // draining the workers one after the other would deadlock sequences of more than ~1000 frames per worker.
+    {
+        struct Chan { std::vector<unsigned char> buf; size_t nrec = 0, want = 0; bool tail = false, open = true; };
+        std::vector<Chan> ch(world);
+        for (int r = 0; r < world; ++r) ch[r].want = (wds.size() + world - 1 - r) / world;
+        int live = world;
+        while (live > 0) {
+            std::vector<pollfd> pf;
+            std::vector<int> who;
+            for (int r = 0; r < world; ++r)
+                if (ch[r].open) { pf.push_back({ fds[r], POLLIN, 0 }); who.push_back(r); }
+            if (poll(pf.data(), pf.size(), -1) < 0) { if (errno == EINTR) continue; perror("poll"); ok = false; break; }
+            for (size_t q = 0; q < pf.size(); ++q) {
+                if (!(pf[q].revents & (POLLIN | POLLHUP | POLLERR))) continue;
+                Chan& c = ch[who[q]];
+                unsigned char tmp[16384];
+                const ssize_t n = read(pf[q].fd, tmp, sizeof tmp);
+                if (n < 0 && (errno == EINTR || errno == EAGAIN)) continue;
+                if (n > 0) c.buf.insert(c.buf.end(), tmp, tmp + n);
+                size_t off = 0;
+                while (c.nrec < c.want && c.buf.size() - off >= sizeof(Record)) {
+                    Record rec;
+                    memcpy(&rec, c.buf.data() + off, sizeof rec);
+                    off += sizeof rec;
+                    ++c.nrec;
+                    if (rec.index < 0 || (size_t)rec.index >= wds.size()) { ok = false; continue; }
+                    recs[rec.index] = rec; got[rec.index] = 1;
+                    std::cout << "[frame " << rec.index << "] " << wds[rec.index] << "  rc=" << rec.rc << "  " << rec.seconds << " s  "
+                              << rec.n_points << " pts" << (rec.have_plane ? "" : "  (no plane)") << std::endl;
+                }
+                if (c.nrec == c.want && !c.tail && c.buf.size() - off >= sizeof(Tail)) {
+                    memcpy(&tails[who[q]], c.buf.data() + off, sizeof(Tail));
+                    off += sizeof(Tail);
+                    c.tail = true;
+                }
+                c.buf.erase(c.buf.begin(), c.buf.begin() + off);
+                if (n <= 0 || c.tail) {                     // end of stream (worker gone) or everything received
+                    if (!c.tail || tails[who[q]].magic != 0x57415353) ok = false;
+                    c.open = false;
+                    --live;
+                    close(pf[q].fd);
+                }
+            }
         }
-        if (!read_all(fds[r], &tails[r], sizeof(Tail)) || tails[r].magic != 0x57415353) ok = false;
-        close(fds[r]);
-        int st = 0;
-        waitpid(pids[r], &st, 0);
-        if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) { std::cerr << "worker " << r << " failed (status " << st << ")" << std::endl; ok = false; }
+        for (int r = 0; r < world; ++r) {
+            int st = 0;
+            waitpid(pids[r], &st, 0);
+            if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) { std::cerr << "worker " << r << " failed (status " << st << ")" << std::endl; ok = false; }
+        }
     }
     // planes.txt as wasscli builds it: the lines of plane.txt joined by single blanks, successful frames only (:341-343)
     std::ofstream fpl(path_join(outdir, "planes.txt").c_str());

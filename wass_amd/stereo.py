@@ -100,10 +100,12 @@ class Context:
         if d_left.shape != d_right.shape or d_left.stride(0) != d_right.stride(0):
             raise ValueError("d_right and d_left must have the same shape and pitch")
         h, w = d_right.shape
+        # DENSE_SCALE != 1: the library resizes the crops first and writes the map at THAT size (wass_dense_input_size)
+        ws, hs = dense_input_size(w, h, params.dense_scale) if params.dense_scale != 1.0 else (w, h)
         if d_out is None:
-            d_out = torch.empty((h, w), dtype=torch.int16, device=d_right.device)
-        elif d_out.dtype != torch.int16 or not d_out.is_contiguous() or tuple(d_out.shape) != (h, w):
-            raise ValueError("d_out: expected a contiguous int16 tensor of the image size")
+            d_out = torch.empty((hs, ws), dtype=torch.int16, device=d_right.device)
+        elif d_out.dtype != torch.int16 or not d_out.is_contiguous() or tuple(d_out.shape) != (hs, ws):
+            raise ValueError(f"d_out: expected a contiguous int16 tensor of shape ({hs}, {ws}) (the size of the resized inputs)")
         rc = self._lib.wass_sgm_disparity_dev(self._h, d_right.data_ptr(), d_left.data_ptr(), w, h,
                                               d_right.stride(0), C.byref(params), d_out.data_ptr())
         self._check(rc)
