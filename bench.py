@@ -90,20 +90,88 @@ def _cpu_frame(job):
             "bytes": len(blob), "overflow": int(st.overflow)}
 
 
-def cpu_baseline(config: str, max_procs: int = 32):
-    """the CPU restatement in 5-path mode on the SAME workload (one full frame per process), (i) one
-    thread, (ii) one process per host core like wasscli's fan-out (cli/wasscli/wasscli.py:346).  ~1-1.5 minutes at config B."""
+def _physical_cores():
+    """distinct (physical id, core id) pairs of /proc/cpuinfo -- SMT siblings count once"""
+    cores, phys, core = set(), None, None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    return len(cores) or (os.cpu_count() or 1)
+
+
+def _cpu_quota():
+    """CPUs this container may actually burn: the cgroup CPU quota (cpu.max, v2 / cfs_quota_us, v1) and the affinity mask.  The GPU
+    boxes of this pool show 256 hardware threads and grant 16 CPUs' worth of time: 128 processes measured 13.6x slower EACH than
+    one alone (profiles/r03a_bench_driver_args_cpu128.json), i.e. they were time-sliced, not memory-bound."""
+    q = float("inf")
+    try:
+        a, b = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if a != "max":
+            q = float(a) / float(b)
+    except (OSError, ValueError):
+        try:
+            a = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            b = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if a > 0:
+                q = a / b
+        except (OSError, ValueError):
+            pass
+    try:
+        q = min(q, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    return q
+
+
+def _native_oracle():
+    """The oracle's C sources compiled for THIS machine (-O3 -march=native, still without FMA contraction): the portable
+    .so in oracle/ was built in another container.  Returns (path, flags) or (None, reason)."""
+    import subprocess
+    import tempfile
+    src = [os.path.join(ROOT, "oracle", f) for f in ("sgbm_oracle.c", "wass_oracle.c", "rectify_oracle.c", "a9_oracle.c", "clahe_oracle.c")]
+    flags = ["-O3", "-march=native", "-std=c99", "-fPIC", "-ffp-contract=off", "-fno-fast-math"]
+    out = os.path.join(tempfile.gettempdir(), f"libwass_oracle_native_{os.getpid()}.so")
+    try:
+        subprocess.check_call([os.environ.get("CC", "gcc"), *flags, "-shared", "-o", out, *src, "-lm"], stderr=subprocess.DEVNULL)
+        return out, " ".join(flags)
+    except Exception as e:                                            # no compiler on the box: fall back to the portable build
+        return None, f"native build failed ({type(e).__name__})"
+
+
+def cpu_baseline(config: str):
+    """SURVEY.md 8(d) / BASELINE.md section 3: the CPU restatement in 5-path mode (what the reference runs) on the SAME workload,
+    one full frame per process, (i) on one thread and (ii) with one process per PHYSICAL host core at once, like wasscli's
+    fan-out (cli/wasscli/wasscli.py:346); the oracle is compiled for this machine first (-O3 -march=native)."""
     import multiprocessing as mp
     w, h, D = CONFIGS[config]
+    so, cflags = _native_oracle()
+    if so:
+        os.environ["WASS_ORACLE_LIB"] = so                             # inherited by the spawned workers
     one = _cpu_frame((w, h, D, 5000))
-    nproc = os.cpu_count() or 1
-    n = max(1, min(nproc, max_procs))
+    threads = os.cpu_count() or 1
+    phys, quota = _physical_cores(), _cpu_quota()
+    n = max(1, int(min(phys, quota)))                             # one process per physical core the container may use
     ctx = mp.get_context("spawn")
     with ctx.Pool(n) as pool:
         pool.map(abs, range(n))                                   # processes up before the clock starts
         t0 = time.perf_counter()
         res = pool.map(_cpu_frame, [(w, h, D, 5001 + i) for i in range(n)], chunksize=1)
         wall = time.perf_counter() - t0
+    if so:
+        os.environ.pop("WASS_ORACLE_LIB", None)
+        try:
+            os.remove(so)
+        except OSError:
+            pass
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -112,22 +180,16 @@ def cpu_baseline(config: str, max_procs: int = 32):
                 break
     except OSError:
         pass
-    cflags = "unknown"
-    try:
-        for line in open(os.path.join(ROOT, "oracle", "Makefile")):
-            if line.startswith("CFLAGS"):
-                cflags = line.split("=", 1)[1].strip()
-                break
-    except OSError:
-        pass
     cells = w * h * D
     return {
         "value": round(n / wall, 4), "unit": "pairs/s", "cores": n, "kind": "port",
         "mdisp_per_sec": round(n / wall * cells / 1e6, 1),
         "sample": f"config {config} ({w}x{h}, D={D}), 5-path MODE_SGBM (what the reference runs), whole path a1-a20 with the scalar C "
-                  f"oracle: one full frame per process, {n} processes at once on {nproc} host cores ({wall:.1f} s wall incl. "
-                  f"input synthesis), after one full frame on one thread ({one['total_s']:.1f} s)",
-        "host_cores": nproc, "cpu_model": model, "cflags": cflags,
+                  f"oracle: one full frame per process, {n} processes at once = one per usable physical core ({phys} physical cores, "
+                  f"{threads} hardware threads, cgroup CPU quota {quota:g}) "
+                  f"({wall:.1f} s wall incl. input synthesis), after one full frame on one thread ({one['total_s']:.1f} s)",
+        "physical_cores": phys, "hardware_threads": threads, "cpu_quota": (None if quota == float("inf") else quota),
+        "cpu_model": model, "cflags": cflags,
         "single_thread": {"s_per_frame": round(one["total_s"], 2), "pairs_per_sec": round(1.0 / one["total_s"], 4),
                           "mdisp_per_sec": round(cells / one["total_s"] / 1e6, 1),
                           "stage_s": {k: round(v, 2) for k, v in zip(STAGES, one["stage_s"])}},
@@ -168,6 +230,45 @@ def measured_traffic(config: str, ndirs: int):
     return best
 
 
+def config_e_record(dev_index: int, ndirs: int, steps: int = 5, warmup: int = 2):
+    """BASELINE.json configs[4] (3840x2160, D=512; the HBM-bound stress case) inside the default run: a few frames through the
+    SGM stage a1-a6 with resident inputs, the same hipEvent brackets as the headline, so that the driver's BENCH record carries
+    config E's aggregation time and roofline fraction next to config B's."""
+    import torch
+    import wass_amd
+    from wass_amd import synth
+    w, h, D = CONFIGS["E"]
+    dev = torch.device("cuda", dev_index)
+    params = wass_amd.default_sgm_params(D, ndirs=ndirs)
+    frames = [synth.make_pair_torch(w, h, D, frame_idx=900000 + k, device=dev) for k in range(2)]
+    out = torch.empty((h, w), dtype=torch.int16, device=dev)
+    ctx = wass_amd.Context(dev_index)
+    agg, tot, cost = [], [], []
+    try:
+        for i in range(warmup + steps):
+            r, l = frames[i & 1]
+            ctx.sgm_disparity_dev(r, l, params, out)
+            if i >= warmup:
+                ctx.synchronize()
+                t = ctx.sgm_timings()
+                agg.append(t.aggregate_ms); tot.append(t.total_ms); cost.append(t.cost_ms)
+        ctx.synchronize()
+        overflow = ctx.sgm_timings().cost_overflow
+    finally:
+        ctx.close()
+    cells = w * h * D
+    alg = cells * (2 * ndirs + 4)
+    t_agg = float(np.mean(agg)) * 1e-3
+    traffic = measured_traffic("E", ndirs)
+    return {"workload": f"config E: {w}x{h}, D={D}, {ndirs}-path, SGM stage a1-a6, resident inputs, {steps} frames after {warmup}",
+            "aggregate_ms": round(t_agg * 1e3, 3), "sgm_total_ms": round(float(np.mean(tot)), 3), "cost_volume_ms": round(float(np.mean(cost)), 3),
+            "pairs_per_sec_sgm_stage": round(1e3 / float(np.mean(tot)), 2),
+            "roofline": {"bound": "hbm", "achieved": round(alg / t_agg / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg / t_agg / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": alg,
+                         "traffic": int(traffic[0]) if traffic else None, "traffic_source": traffic[1] if traffic else None},
+            "cost_overflow": int(overflow)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,6 +278,7 @@ def main():
     ap.add_argument("--config", default="B", choices=sorted(CONFIGS))
     ap.add_argument("--frames", type=int, default=64, help="distinct frames per rank (cycled when steps exceed it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config-e", action="store_true", help="skip the short config E (3840x2160, D=512) sub-record of the default run")
     ap.add_argument("--no-tail-overlap", action="store_true",
                     help="run the post-SGM stages on the SGM stream instead of the context's tail stream")
     ap.add_argument("--resident-inputs", action="store_true",
@@ -239,7 +341,8 @@ def main():
 
     # distinct frames per rank, synthesised on the GPU (wass_amd.synth.make_pair_torch == make_pair), parked in pinned
     # host memory: the timed region uploads them like a sequence driver would after decoding the PNGs
-    nf = max(2, min(args.frames, args.steps + args.warmup))
+    # every frame of the timed region comes round at least twice (repeat_check), also at the driver's --steps 20
+    nf = max(2, min(args.frames, max(2, args.steps // 2)))
     host = []
     for k in range(nf):
         r, l = synth.make_pair_torch(w, h, D, frame_idx=rank * 100000 + k, device=dev)
@@ -322,10 +425,37 @@ def main():
     # Coll-1: sequence mean plane = NaN-aware mean over every rank's frames (5 doubles all-reduced over RCCL)
     acc = wass_amd.planes_mean_accumulate(np.array(planes).reshape(-1, 4)) if planes else np.zeros(5)
     rank_rates = [args.steps / elapsed]
+    coll_info = None
     if dist is not None:
         acc_t = torch.tensor(acc, dtype=torch.float64, device=coll_dev)
         dist.all_reduce(acc_t, op=dist.ReduceOp.SUM)
-        acc = acc_t.cpu().numpy()
+        acc_torch = acc_t.cpu().numpy()
+        if dist.get_backend() == "nccl":
+            # Coll-1 as the product does it (wass_stereo_batch): ncclCommInitRank + ncclAllReduce(ncclSum, ncclDouble) through the
+            # C ABI, on the context's own stream; the unique id travels over the process group.  The torch all-reduce above is
+            # only the cross-check.
+            import ctypes as C
+            from wass_amd import _lib
+            lib = _lib.load()
+            uid_t = torch.zeros(128, dtype=torch.uint8, device=coll_dev)
+            if rank == 0:
+                uid = (C.c_ubyte * 128)()
+                if lib.wass_coll_unique_id(uid) != 0:
+                    sys.exit("bench.py: wass_coll_unique_id failed (librccl not loadable)")
+                uid_t = torch.tensor(list(uid), dtype=torch.uint8, device=coll_dev)
+            dist.broadcast(uid_t, 0)
+            uid = (C.c_ubyte * 128)(*uid_t.cpu().tolist())
+            a5 = (C.c_double * 5)(*acc.tolist())
+            t0c = time.perf_counter()
+            if lib.wass_coll_init(ctx._h, rank, world, uid) != 0 or lib.wass_coll_allreduce_sum_f64(ctx._h, a5, 5) != 0:
+                sys.exit(f"bench.py: rank {rank}: wass_coll all-reduce failed: " + lib.wass_last_error(ctx._h).decode())
+            coll_ms = (time.perf_counter() - t0c) * 1e3
+            acc = np.array(a5[:])
+            coll_info = {"path": "wass_coll_allreduce_sum_f64 (RCCL via the C ABI)", "ranks": world, "ms_incl_comm_init": round(coll_ms, 2),
+                         "matches_torch_distributed": bool(np.array_equal(acc, acc_torch))}
+        else:
+            acc = acc_torch
+            coll_info = {"path": "torch.distributed gloo (shared-GPU functional test: RCCL refuses two ranks on one device)", "ranks": world}
     mean_plane, n_planes = wass_amd.planes_mean_finish(acc)
     if dist is not None:
         mine = torch.tensor([args.steps / elapsed], dtype=torch.float64, device=coll_dev)
@@ -392,18 +522,24 @@ def main():
             "stage_ms": {"cost_volume": round(float(np.mean(cost_ms)), 3), "vertical_sum_and_path2": round(t_vs * 1e3, 3), "aggregate": round(t_agg * 1e3, 3),
                          "select": round(float(np.mean(sel_ms)), 3), "sgm_total": round(float(np.mean(sgm_ms)), 3)},
             "mean_plane": [None if x != x else round(float(x), 9) for x in mean_plane], "planes_averaged": n_planes,
+            "plane_allreduce": coll_info,
             "points_per_frame": int(np.mean(npts_hist)) if npts_hist else None,
             "xyzc_bytes_per_frame": int(np.mean(nbytes_hist)) if nbytes_hist else None,
             "cost_overflow": int(overflow),
             "repeat_check": repeat_check(planes, npts_hist, args.warmup, nf),
         }
+        if world == 1 and args.config == "B" and args.stage == "full" and not args.no_config_e:
+            ctx.close()
+            ctx = None
+            line["config_E"] = config_e_record(dev_index, args.ndirs)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.config)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
 
 
 if __name__ == "__main__":

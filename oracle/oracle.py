@@ -63,8 +63,13 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = C.CDLL(_SO)
+        # WASS_ORACLE_LIB: another build of the same sources (bench.py's cpu_baseline leg times one compiled with
+        # -march=native on the box it runs on); the tests always use the portable build next to this file
+        so = os.environ.get("WASS_ORACLE_LIB")
+        if not so:
+            build()
+            so = _SO
+        _lib = C.CDLL(so)
         _lib.orc_zgap_percentile.restype = C.c_double
         for f in ("orc_triangulate", "orc_keep_biggest_component", "orc_crop_plane",
                   "orc_refine_plane", "orc_encode_xyzc"):
