@@ -854,10 +854,19 @@ CkptLayout ckpt_layout(const SgmDims& d)
     };
     // The kernel that carries the winner-take-all goes last and should have the most chains (the WTA adds ~50
     // instructions per pixel): the anti-diagonals (width1 + h - 1 chains).
-    if (d.ndirs == 8) {
+    if (d.ndirs == 8 && d.NP <= 2) {
         L.cols_from_cost = true;
         L.rows_fused = true;
         add(0, 1, 0);                // columns + rows: paths 2 + 6 and 0 + 4 (k_pairx, S written)
+        add(1, 1, 1);                // diagonals:      paths 1 + 7
+        add(-1, 1, 2);               // anti-diagonals: paths 3 + 5, winner-take-all fused
+    } else if (d.ndirs == 8) {
+        // D > 256: a pixel vector is 1 KiB or more, a checkpoint segment only 4 or 2 rows, so the fused kernel would run its
+        // two barriers every few pixels with most waves idle in the row phase (measured at config E: 13.5 ms against
+        // 4.3 + 5.4 ms for the two kernels it replaces).  One pair kernel per family.
+        L.cols_from_cost = true;
+        add(0, 1, 0);                // columns:        paths 2 + 6   (S written)
+        add(1, 0, 1);                // rows:           paths 0 + 4
         add(1, 1, 1);                // diagonals:      paths 1 + 7
         add(-1, 1, 2);               // anti-diagonals: paths 3 + 5, winner-take-all fused
     } else {
