@@ -4,8 +4,15 @@ Follows gridding/wassgridsurface/wassgridsurface.py:316-365 (_grid_task, algorit
 (compute_sea_plane_RT / align_on_sea_plane_RT) and IDWInterpolator.py:23-58; the inverse-distance step calls
 scipy.signal.convolve2d exactly as the reference does.  cv.morphologyEx(MORPH_CLOSE, 5x5 ones) is OpenCV (absent here):
 restated as a 5x5 dilation followed by a 5x5 erosion that ignore what lies outside the image (OpenCV's default border
-values for the two operations).  The reference's randomised cell value (nanmedian of ten random sub-samples with a
-last-writer-wins scatter, :330-345) is replaced by the mean of the cell's points, as in grid.hip."""
+values for the two operations).
+
+Cell statistic.  The reference fills a cell with the nanmedian of ten random sub-samples scattered last-writer-wins
+(:330-345): the result depends on numpy's global random state and on the order of the points.  Two modes:
+  cell="mean"              the mean of the cell's points in plain float64 (np.add.at) -- what grid.hip computes up to its
+                           fixed-point accumulation; nothing here mirrors the GPU's arithmetic, the test tolerance follows
+                           from the GPU's 2^-24 quantisation and its float32 output;
+  cell="subsample_median"  the reference's statistic restated line by line (np.random.seed(seed) first), so that the GPU
+                           grid can also be compared with what the reference would have produced for one seed."""
 import numpy as np
 import scipy.signal
 
@@ -18,7 +25,36 @@ def compute_sea_plane_RT(plane):
     return R, T
 
 
-def grid_idw(points, plane, baseline, xmin, xmax, ymin, ymax, width, height):
+def cell_values(px, py, pz, width, height, cell="mean", seed=0, subsample_percent=100):
+    """(height, width) float64 map of the binned points, NaN where a cell is empty."""
+    if cell == "mean":
+        cnt = np.zeros((height, width), np.float64)
+        ssum = np.zeros((height, width), np.float64)
+        np.add.at(cnt, (py, px), 1.0)
+        np.add.at(ssum, (py, px), pz)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return np.where(cnt > 0, ssum / cnt, np.nan)
+    if cell == "subsample_median":                       # wassgridsurface.py:319,330-345, verbatim order of the random draws
+        np.random.seed(seed)
+        perm = np.random.permutation(px.shape[0])        # :319 (the permutation of the aligned mesh, here of its in-grid points)
+        px, py, pz = px[perm], py[perm], pz[perm]
+        NREPS = 10
+        ZZ = np.ones([height, width, NREPS], dtype=np.float32) * np.nan
+        indices = np.arange(px.shape[0])
+        n_pts = int(px.shape[0] * subsample_percent // 100)
+        for ii in range(NREPS):
+            np.random.shuffle(indices)
+            curr_indices = np.copy(indices[:n_pts])
+            ZZ[py[indices[curr_indices]], px[indices[curr_indices]], ii] = pz[indices[curr_indices]]
+        with np.errstate(all="ignore"):
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)
+                return np.nanmedian(ZZ, axis=-1).astype(np.float64)
+    raise ValueError(cell)
+
+
+def grid_idw(points, plane, baseline, xmin, xmax, ymin, ymax, width, height, cell="mean", seed=0, subsample_percent=100):
     """points: (3, N) camera-frame cloud.  Returns (Zi float64 with NaN outside the mask, mask uint8)."""
     R, T = compute_sea_plane_RT(plane)
     m = R @ points + T
@@ -28,12 +64,7 @@ def grid_idw(points, plane, baseline, xmin, xmax, ymin, ymax, width, height):
     py = np.floor((m[1] - ymin) / (ymax - ymin) * (height - 1) + 0.5)
     good = (px >= 0) & (px < width) & (py >= 0) & (py < height)
     px, py, pz = px[good].astype(np.int64), py[good].astype(np.int64), m[2, good]
-    cnt = np.zeros((height, width), np.int64)
-    ssum = np.zeros((height, width), np.int64)
-    np.add.at(cnt, (py, px), 1)
-    np.add.at(ssum, (py, px), np.rint(pz * 16777216.0).astype(np.int64))       # the GPU's 2^-24 fixed point
-    with np.errstate(invalid="ignore", divide="ignore"):
-        ZZ = np.where(cnt > 0, ssum / 16777216.0 / cnt, np.nan)
+    ZZ = cell_values(px, py, pz, width, height, cell, seed, subsample_percent)
     # IDWInterpolator(KSIZE=5, exp=2.4, reps=1)
     KS = 5
     Kd = np.array([(k - KS // 2) for k in range(KS)], dtype=np.float64)
