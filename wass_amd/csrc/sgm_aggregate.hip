@@ -237,13 +237,53 @@ __device__ __forceinline__ void lds_ld(const uint32_t* p, us2 (&v)[NP])
     }
 }
 
-template <int K>
-__device__ __forceinline__ uint32_t min_before(const uint32_t (&mrec)[K / 2], int u)
-{
+// A minima record (N u16 values, N / 2 dwords) is held in ONE VGPR, dword i in lane i, and read back with v_readlane.
+// Scalar loads would be the obvious form, but SMEM returns out of order: while one is outstanding every wait for an LDS
+// read becomes lgkmcnt(0), so the first hand-over read of an iteration stalled for a full HBM round trip (k_pairx, cycle
+// counters: column phase 12.3k cycles per iteration in the waves that had just requested their row records, 6.0k in the
+// two waves that had not -- and the other eight waiting for them at the barrier).  Vector loads count on vmcnt, in order,
+// behind ring refills that are waited for anyway.
+// A minima record (N u16 values, N / 2 dwords).  VEC = false: N / 2 SGPRs filled by scalar loads.  VEC = true: ONE VGPR,
+// dword i in lane i, read back with v_readlane.  SMEM returns out of order, so while a scalar load is outstanding every
+// wait for an LDS read becomes lgkmcnt(0); in k_pairx, where a wave requests its row records right before the column
+// phase, the first hand-over read of that phase then stalls for a full HBM round trip -- and nine other waves wait for it
+// at the barrier.  Vector loads count on vmcnt, in order, behind ring refills that are waited for anyway.
+// The compiler fence in load() keeps the vector load where it is written.  Without it k_pair<2, 8, 1> was MISCOMPILED
+// (rocm 7.2 clang, -O3: the load is sunk past the loop-exit test into the next half-iteration and S comes out wrong in
+// segment 0 of short diagonal chains -- 232 cells of the 320 x 64, D = 256 test; bit-exact again with the fence, with any
+// of -mllvm -disable-machine-sink, -mllvm -disable-machine-licm, -O1, or with a scalar load of the same record kept alive
+// beside the vector one; forcing every s_waitcnt to zero did NOT help, so it is not a missing wait, and scripts/micro/
+// order.hip shows vmcnt counting in order across global / buffer / scratch loads and stores.  DESIGN.md 4.3).
+#ifndef WASS_VREC
+#define WASS_VREC 7                                // bit 0: k_pair, bit 1: k_pairx column records, bit 2: k_pairx row records
+#endif
+template <int N, bool VEC>
+struct Rec {
+    uint32_t v[VEC ? 1 : N / 2];
+    __device__ __forceinline__ void clear()
+    {
+#pragma unroll
+        for (int i = 0; i < (VEC ? 1 : N / 2); ++i) v[i] = 0;
+    }
+    __device__ __forceinline__ void load(const uint32_t* p, int lane)
+    {
+        if constexpr (VEC) {
+            v[0] = p[min(lane, N / 2 - 1)];
+            asm volatile("" ::: "memory");
+        } else {
+#pragma unroll
+            for (int i = 0; i < N / 2; ++i) v[i] = p[i];
+        }
+    }
+    __device__ __forceinline__ uint32_t at(int i) const
+    {
+        if constexpr (VEC) return (__builtin_amdgcn_readlane(v[0], i >> 1) >> ((i & 1) * 16)) & 0xFFFFu;
+        else return (v[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu;
+    }
     // minimum of the forward path costs BEFORE step u of a segment: 0 for the normalised checkpoint state, otherwise
     // what the checkpoint sweep recorded after step u - 1
-    return u == 0 ? 0u : ((mrec[(u - 1) >> 1] >> (((u - 1) & 1) * 16)) & 0xFFFFu);
-}
+    __device__ __forceinline__ uint32_t before(int u) const { return u == 0 ? 0u : at(u - 1); }
+};
 
 // Occupancy is capped at four waves per SIMD (the hand-over buffers of four workgroups are 128 of the CU's 160 KiB of LDS):
 // with a fifth workgroup per CU the frame tail of the previous frame, which runs underneath on its own stream and needs
@@ -343,7 +383,8 @@ k_pair(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t*
     us2 cf[K][NP], sr[K][NP];
     PathState<NP> fw;
     us2 nvB[NP];                                   // checkpoint entering the segment the next forward recomputation covers
-    uint32_t mB[K / 2];                            // ... and that segment's minima record
+    Rec<K, (WASS_VREC & 1) != 0> mB;               // ... and that segment's minima record
+    mB.clear();
     {
         const int s = F - 1;
         const rsrc_t rc = a.run<NP>(C, (long long)s * K, K), rs = a.run<NP>(S, (long long)s * K, K);
@@ -367,8 +408,7 @@ k_pair(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t*
 #pragma unroll
             for (int j = 0; j < NP; ++j) nvB[j] = pk_splat(0);
         }
-#pragma unroll
-        for (int i = 0; i < K / 2; ++i) mB[i] = mrow[(size_t)max(s - 1, 0) * (K / 2) + i];
+        mB.load(mrow + (size_t)max(s - 1, 0) * (K / 2), lane);
 #pragma unroll
         for (int u = 0; u < K; ++u) {
             us2 L[NP];
@@ -386,12 +426,12 @@ k_pair(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t*
         const rsrc_t rcN = a.run<NP>(C, (long long)max((s_) - 2, 0) * K, K);   /* past the chain start: a harmless re-read */ \
         const rsrc_t rsN = a.run<NP>(S, (long long)((s_) - 1) * K, K), rsO = a.run<NP>(S, (long long)(s_) * K, K);         \
         us2 nvC[NP];                                                                                                    \
-        uint32_t mC[K / 2];                                                                                             \
+        Rec<K, (WASS_VREC & 1) != 0> mC;                                                                                                    \
         if ((s_) >= 3) buf_ld<NP>(ckr, voff, (uint32_t)((s_) - 3) * VB, nvC);                                            \
         else {                                                                                                          \
             _Pragma("unroll") for (int j = 0; j < NP; ++j) nvC[j] = pk_splat(0);                                         \
         }                                                                                                               \
-        _Pragma("unroll") for (int i = 0; i < K / 2; ++i) mC[i] = mrow[(size_t)max((s_) - 2, 0) * (K / 2) + i];         \
+        mC.load(mrow + (size_t)max((s_) - 2, 0) * (K / 2), lane);                                                \
         fw.load_normalised(nvB);                   /* zeros when s-1 == 0 */                                            \
         us2 cbn[NP], lfn[NP];                      /* hand-over vectors of the NEXT step, in flight */                  \
         lds_ld<NP>(hc + ((ODD_) ? 0 : K - 1) * VW, cbn);                                                                 \
@@ -405,7 +445,7 @@ k_pair(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t*
                 lds_ld<NP>(hc + nslot * VW, cbn);                                                                       \
                 lds_ld<NP>(hl + nslot * VW, lfn);                                                                       \
             }                                                                                                           \
-            sgm_step_fb<NP>(fw, min_before<K>(mB, u), cf[u], Lf, bw, cb, Lb, P1v, P2);                                   \
+            sgm_step_fb<NP>(fw, mB.before(u), cf[u], Lf, bw, cb, Lb, P1v, P2);                                   \
             finish(lfv, Lb, sr[v], sv);                                                                                 \
             if (!LAST || keepS) buf_st<NP>(rsO, voff, bK + v * a.sstep, sv);                                             \
             if (LAST) { _Pragma("unroll") for (int j = 0; j < NP; ++j) fin[v][j] = sv[j]; }                              \
@@ -416,7 +456,7 @@ k_pair(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t*
         }                                                                                                               \
         if (LAST) wta_batch<NP, K>(fin, K, lane, D, minD, uniq, sel_d16, sel_key, a.pix0 + (long long)(s_) * K * a.pixstep, a.pixstep); \
         _Pragma("unroll") for (int j = 0; j < NP; ++j) nvB[j] = nvC[j];                                                 \
-        _Pragma("unroll") for (int i = 0; i < K / 2; ++i) mB[i] = mC[i];                                                \
+        mB = mC;                                                                                                        \
     }
     // the backward path over segment 0: nothing left to recompute or to prefetch
 #define WASS_PAIR_LAST(ODD_)                                                                                            \
@@ -617,7 +657,7 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
     // every wave's hand-over region
     // what the row phase of a segment needs from HBM: requested before the column phase that precedes it
     us2 eF[NP], eB[NP];
-    uint32_t mf[XB / 2], mb[XB / 2];
+    Rec<XB, (WASS_VREC & 4) != 0> mf, mb;                  // minima records of the row
     auto row_fetch = [&](int seg, int cnt) {
         if (wv < cnt) {
             const int yrow = y0 + (seg * K + wv) * dy;
@@ -633,15 +673,15 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
             }
             const uint32_t* pf = (const uint32_t*)(rs.MF + ((size_t)yrow * rs.nbx + bx) * XB);
             const uint32_t* pb = (const uint32_t*)(rs.MB + ((size_t)yrow * rs.nbx + bx) * XB);
-#pragma unroll
-            for (int i = 0; i < XB / 2; ++i) { mf[i] = pf[i]; mb[i] = pb[i]; }
+            mf.load(pf, lane);
+            mb.load(pb, lane);
         }
     };
     auto row_phase = [&](int seg, int cnt, bool rev) {
         __syncthreads();
         if (wv < cnt) {
             const int e = wv, slot = rev ? K - 1 - e : e;
-            auto mat = [](const uint32_t (&m)[XB / 2], int i) { return (m[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu; };
+            auto mat = [](const Rec<XB, (WASS_VREC & 4) != 0>& m, int i) { return m.at(i); };
             us2 cj[XB][NP], part[XB][NP];
 #pragma unroll
             for (int j = 0; j < XB; ++j)
@@ -692,14 +732,19 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
     PathState<NP> bw, fw;
     us2 cf[K][NP];                                         // ring: cost vectors of the segment the forward recomputation covers next
     us2 nvB[NP];
-    uint32_t mB[K / 2];
+    Rec<K, (WASS_VREC & 2) != 0> mB;
+    mB.clear();
 #pragma unroll
     for (int j = 0; j < NP; ++j) nvB[j] = pk_splat(0);
-#pragma unroll
-    for (int i = 0; i < K / 2; ++i) mB[i] = 0;
-    // ---- iteration 0: the forward path over segment `top` (with its reductions: once per chain), natural slot order
+    // ---- iteration 0: the forward path over segment `top` (with its reductions: once per chain), natural slot order.
+    // What the LOOP consumes first (checkpoint and minima record of the next segment) is requested first: vmcnt counts in
+    // order, and the waits inside the loop are computed for the worst of its predecessors.
     {
         const int cn = top == F ? r : K;
+        if (colact) {
+            if (top >= 2) buf_ld<NP>(ckr, voff, (uint32_t)(top - 2) * VB, nvB);
+            if (top >= 1) mB.load(mrow + (size_t)(top - 1) * (K / 2), lane);
+        }
         row_fetch(top, cn);
         if (colact) {
             bw.reset();
@@ -722,10 +767,7 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
                 const rsrc_t rc2 = a.run<NP>(C, (long long)(top - 1) * K, K);
 #pragma unroll
                 for (int u = 0; u < K; ++u) buf_ld<NP>(rc2, voff, bK + u * a.sstep, cf[u]);
-#pragma unroll
-                for (int i = 0; i < K / 2; ++i) mB[i] = mrow[(size_t)(top - 1) * (K / 2) + i];
             }
-            if (top >= 2) buf_ld<NP>(ckr, voff, (uint32_t)(top - 2) * VB, nvB);
 #pragma unroll
             for (int u = 0; u < K; ++u)
                 if (u < cn) {
@@ -741,39 +783,42 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
     // s-1 || refill of the ring with segment s-2.  NAT_: the slots hold segment s in natural order (element e in slot e); the
     // forward results go into the slots as they are drained, i.e. in reversed order, and so on alternately.
     // The common case, complete segments on both sides:
-#define WASS_PX_FAST(NAT_, s_)                                                                                         \
+#define WASS_PX_FAST(s_)                                                                                               \
     if (colact) {                                                                                                       \
         const rsrc_t rcN = a.run<NP>(C, (long long)max((s_) - 2, 0) * K, K);                                              \
         const rsrc_t rsO = a.run<NP>(S, (long long)(s_) * K, K);                                                          \
         us2 nvC[NP];                                                                                                    \
-        uint32_t mC[K / 2];                                                                                             \
+        Rec<K, (WASS_VREC & 2) != 0> mC;                                                                                                    \
         if ((s_) >= 3) buf_ld<NP>(ckr, voff, (uint32_t)((s_) - 3) * VB, nvC);                                            \
         else {                                                                                                          \
             _Pragma("unroll") for (int j = 0; j < NP; ++j) nvC[j] = pk_splat(0);                                         \
         }                                                                                                               \
-        _Pragma("unroll") for (int i = 0; i < K / 2; ++i) mC[i] = mrow[(size_t)max((s_) - 2, 0) * (K / 2) + i];         \
+        mC.load(mrow + (size_t)max((s_) - 2, 0) * (K / 2), lane);                                                \
         fw.load_normalised(nvB);                                                                                        \
+        const int stp = nat ? -VW : VW;            /* the slots are drained from the end they were filled last */      \
+        uint32_t* pc = hc + (nat ? (K - 1) * VW : 0);                                                                   \
         us2 cbn[NP], lfn[NP];                                                                                           \
-        lds_ld<NP>(hc + ((NAT_) ? K - 1 : 0) * VW, cbn);                                                                \
-        lds_ld<NP>(hl + ((NAT_) ? K - 1 : 0) * VW, lfn);                                                                \
+        lds_ld<NP>(pc, cbn);                                                                                            \
+        lds_ld<NP>(pc + K * VW, lfn);              /* hl = hc + K * VW */                                               \
         _Pragma("unroll") for (int u = 0; u < K; ++u) {                                                                 \
             const int v = K - 1 - u;                                                                                    \
-            const int slot = (NAT_) ? v : u, nslot = (NAT_) ? v - 1 : u + 1;                                           \
+            uint32_t* pn = pc + stp;                                                                                    \
             us2 cb[NP], lfv[NP], Lf[NP], Lb[NP], sv[NP];                                                                \
             _Pragma("unroll") for (int j = 0; j < NP; ++j) { cb[j] = cbn[j]; lfv[j] = lfn[j]; }                          \
             if (u + 1 < K) {                                                                                            \
-                lds_ld<NP>(hc + nslot * VW, cbn);                                                                       \
-                lds_ld<NP>(hl + nslot * VW, lfn);                                                                       \
+                lds_ld<NP>(pn, cbn);                                                                                    \
+                lds_ld<NP>(pn + K * VW, lfn);                                                                           \
             }                                                                                                           \
-            sgm_step_fb<NP>(fw, min_before<K>(mB, u), cf[u], Lf, bw, cb, Lb, P1v, P2);                                   \
+            sgm_step_fb<NP>(fw, mB.before(u), cf[u], Lf, bw, cb, Lb, P1v, P2);                                   \
             _Pragma("unroll") for (int j = 0; j < NP; ++j) sv[j] = pk_adds(lfv[j], Lb[j]);                               \
             buf_st<NP>(rsO, voff, bK + v * a.sstep, sv);                                                                \
-            lds_st<NP>(hc + slot * VW, cf[u]);                                                                          \
-            lds_st<NP>(hl + slot * VW, Lf);                                                                             \
+            lds_st<NP>(pc, cf[u]);                                                                                      \
+            lds_st<NP>(pc + K * VW, Lf);                                                                                \
             buf_ld<NP>(rcN, voff, bK + u * a.sstep, cf[u]);                                                              \
+            pc = pn;                                                                                                    \
         }                                                                                                               \
         _Pragma("unroll") for (int j = 0; j < NP; ++j) nvB[j] = nvC[j];                                                 \
-        _Pragma("unroll") for (int i = 0; i < K / 2; ++i) mB[i] = mC[i];                                                \
+        mB = mC;                                                                                                        \
     }
     // Guarded form: the backward path over the short tail segment (cb_ < K elements) and/or no segment left to recompute
 #define WASS_PX_SLOW(nat_, s_, cb_, hasfw_)                                                                             \
@@ -782,12 +827,12 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
         const rsrc_t rsO = a.run<NP>(S, (long long)(s_) * K, (cb_));                                                      \
         const uint32_t bO = a.bias(cb_);                                                                                \
         us2 nvC[NP];                                                                                                    \
-        uint32_t mC[K / 2];                                                                                             \
+        Rec<K, (WASS_VREC & 2) != 0> mC;                                                                                                    \
         if ((s_) >= 3) buf_ld<NP>(ckr, voff, (uint32_t)((s_) - 3) * VB, nvC);                                            \
         else {                                                                                                          \
             _Pragma("unroll") for (int j = 0; j < NP; ++j) nvC[j] = pk_splat(0);                                         \
         }                                                                                                               \
-        _Pragma("unroll") for (int i = 0; i < K / 2; ++i) mC[i] = mrow[(size_t)max((s_) - 2, 0) * (K / 2) + i];         \
+        mC.load(mrow + (size_t)max((s_) - 2, 0) * (K / 2), lane);                                                \
         fw.load_normalised(nvB);                                                                                        \
         _Pragma("unroll") for (int u = 0; u < K; ++u) {                                                                 \
             const int v = K - 1 - u;                                                                                    \
@@ -802,33 +847,39 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
                 buf_st<NP>(rsO, voff, bO + v * a.sstep, sv);                                                            \
             }                                                                                                           \
             if (hasfw_) {                                                                                               \
-                sgm_step_f<NP>(fw, min_before<K>(mB, u), cf[u], Lf, P1v, P2);                                            \
+                sgm_step_f<NP>(fw, mB.before(u), cf[u], Lf, P1v, P2);                                            \
                 lds_st<NP>(hc + slot * VW, cf[u]);                                                                      \
                 lds_st<NP>(hl + slot * VW, Lf);                                                                         \
                 buf_ld<NP>(rcN, voff, bK + u * a.sstep, cf[u]);                                                          \
             }                                                                                                           \
         }                                                                                                               \
         _Pragma("unroll") for (int j = 0; j < NP; ++j) nvB[j] = nvC[j];                                                 \
-        _Pragma("unroll") for (int i = 0; i < K / 2; ++i) mB[i] = mC[i];                                                \
+        mB = mC;                                                                                                        \
     }
-    // One call site for the row phase and one for each form of the column phase: the loop must stay well inside the 64 KB
-    // instruction cache two CUs share (with the row phase inlined three times the kernel was 50 KB).
-    int s = top, rseg = top, rcnt = top == F ? r : K;
-    bool nat = true, rrev = false;                         // iteration 0 filled the slots in natural order
-    for (;;) {
-        row_phase(rseg, rcnt, rrev);
+    // The hot loop holds ONLY the unguarded form.  With both forms in one loop the register allocator gave the ring
+    // different registers in each and copied at the join -- behind an s_waitcnt vmcnt(0), i.e. every refill requested
+    // during a column phase was waited for at its end and the row records requested before it at its start (cycle
+    // counters: 12.3k cycles per column phase in the eight waves with a row role, 6.0k in the two without).
+    int s = top;
+    bool nat = true;                                       // iteration 0 filled the slots in natural order
+    if (top == F) {                                        // r > 0: the backward path starts on the short tail segment
+        row_phase(s, r, !nat);
         const bool hasfw = s >= 1;
-        const int cbw = s == F ? r : K;
         if (hasfw) row_fetch(s - 1, K);
-        if (hasfw && cbw == K) {
-            if (nat) { WASS_PX_FAST(true, s) }
-            else { WASS_PX_FAST(false, s) }
-        } else { WASS_PX_SLOW(nat, s, cbw, hasfw) }
-        if (!hasfw) break;
-        rseg = s - 1; rcnt = K; rrev = nat;               // the forward results went into the slots as they were drained
+        WASS_PX_SLOW(nat, s, r, hasfw)
+        if (!hasfw) return;
+        nat = !nat;                                        // the forward results went into the slots as they were drained
+        --s;
+    }
+    while (s >= 1) {
+        row_phase(s, K, !nat);
+        row_fetch(s - 1, K);
+        WASS_PX_FAST(s)
         nat = !nat;
         --s;
     }
+    row_phase(0, K, !nat);
+    WASS_PX_SLOW(nat, 0, K, false)
 #undef WASS_PX_FAST
 #undef WASS_PX_SLOW
 }
