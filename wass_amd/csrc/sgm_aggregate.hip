@@ -389,7 +389,18 @@ k_pair(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t*
         const int s = F - 1;
         const rsrc_t rc = a.run<NP>(C, (long long)s * K, K), rs = a.run<NP>(S, (long long)s * K, K);
         const rsrc_t rc2 = a.run<NP>(C, (long long)max(s - 1, 0) * K, K);
+        // what the LOOP consumes first is requested first: vmcnt counts in order, and the waits inside the loop are computed
+        // for the worst of its predecessors (with these two loads last, the loop began every iteration with vmcnt(1))
+        if (s >= 2) buf_ld<NP>(ckr, voff, (uint32_t)(s - 2) * VB, nvB);
+        else {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) nvB[j] = pk_splat(0);
+        }
+        mB.load(mrow + (size_t)max(s - 1, 0) * (K / 2), lane);
         us2 c0[K][NP];
+        fw.reset();
+        us2 nv[NP];
+        if (s >= 1) buf_ld<NP>(ckr, voff, (uint32_t)(s - 1) * VB, nv);
 #pragma unroll
         for (int u = 0; u < K; ++u) {
             buf_ld<NP>(rc, voff, bK + u * a.sstep, c0[u]);
@@ -397,18 +408,7 @@ k_pair(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t*
         }
 #pragma unroll
         for (int u = 0; u < K; ++u) buf_ld<NP>(rc2, voff, bK + u * a.sstep, cf[u]);
-        fw.reset();
-        if (s >= 1) {
-            us2 nv[NP];
-            buf_ld<NP>(ckr, voff, (uint32_t)(s - 1) * VB, nv);
-            fw.load_normalised(nv);
-        }
-        if (s >= 2) buf_ld<NP>(ckr, voff, (uint32_t)(s - 2) * VB, nvB);
-        else {
-#pragma unroll
-            for (int j = 0; j < NP; ++j) nvB[j] = pk_splat(0);
-        }
-        mB.load(mrow + (size_t)max(s - 1, 0) * (K / 2), lane);
+        if (s >= 1) fw.load_normalised(nv);
 #pragma unroll
         for (int u = 0; u < K; ++u) {
             us2 L[NP];
@@ -418,75 +418,84 @@ k_pair(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t*
         }
     }
 
-    // One iteration for segment s_ >= 1: backward path over segment s_ (elements K-1 .. 0, read from the hand-over slots)
-    // || forward recomputation of segment s_-1 (elements 0 .. K-1, from the ring; results into the slots just drained)
-    // || refills: C of segment s_-2, S of segment s_-1.  ODD_: the slots hold segment s_ in reversed order.
-#define WASS_PAIR_ITER(ODD_, s_)                                                                                        \
-    {                                                                                                                   \
-        const rsrc_t rcN = a.run<NP>(C, (long long)max((s_) - 2, 0) * K, K);   /* past the chain start: a harmless re-read */ \
-        const rsrc_t rsN = a.run<NP>(S, (long long)((s_) - 1) * K, K), rsO = a.run<NP>(S, (long long)(s_) * K, K);         \
-        us2 nvC[NP];                                                                                                    \
-        Rec<K, (WASS_VREC & 1) != 0> mC;                                                                                                    \
-        if ((s_) >= 3) buf_ld<NP>(ckr, voff, (uint32_t)((s_) - 3) * VB, nvC);                                            \
-        else {                                                                                                          \
-            _Pragma("unroll") for (int j = 0; j < NP; ++j) nvC[j] = pk_splat(0);                                         \
-        }                                                                                                               \
-        mC.load(mrow + (size_t)max((s_) - 2, 0) * (K / 2), lane);                                                \
-        fw.load_normalised(nvB);                   /* zeros when s-1 == 0 */                                            \
-        us2 cbn[NP], lfn[NP];                      /* hand-over vectors of the NEXT step, in flight */                  \
-        lds_ld<NP>(hc + ((ODD_) ? 0 : K - 1) * VW, cbn);                                                                 \
-        lds_ld<NP>(hl + ((ODD_) ? 0 : K - 1) * VW, lfn);                                                                 \
-        _Pragma("unroll") for (int u = 0; u < K; ++u) {                                                                 \
-            const int v = K - 1 - u;               /* element of segment s_ the backward path is at */                  \
-            const int slot = (ODD_) ? u : v, nslot = (ODD_) ? u + 1 : v - 1;                                             \
-            us2 cb[NP], lfv[NP], Lf[NP], Lb[NP], sv[NP];                                                                \
-            _Pragma("unroll") for (int j = 0; j < NP; ++j) { cb[j] = cbn[j]; lfv[j] = lfn[j]; }                          \
-            if (u + 1 < K) {                                                                                            \
-                lds_ld<NP>(hc + nslot * VW, cbn);                                                                       \
-                lds_ld<NP>(hl + nslot * VW, lfn);                                                                       \
-            }                                                                                                           \
-            sgm_step_fb<NP>(fw, mB.before(u), cf[u], Lf, bw, cb, Lb, P1v, P2);                                   \
-            finish(lfv, Lb, sr[v], sv);                                                                                 \
-            if (!LAST || keepS) buf_st<NP>(rsO, voff, bK + v * a.sstep, sv);                                             \
-            if (LAST) { _Pragma("unroll") for (int j = 0; j < NP; ++j) fin[v][j] = sv[j]; }                              \
-            lds_st<NP>(hc + slot * VW, cf[u]);                                                                          \
-            lds_st<NP>(hl + slot * VW, Lf);                                                                             \
-            buf_ld<NP>(rcN, voff, bK + u * a.sstep, cf[u]);                                                              \
-            if (SMODE != 0) buf_ld<NP>(rsN, voff, bK + v * a.sstep, sr[v]);                                              \
-        }                                                                                                               \
-        if (LAST) wta_batch<NP, K>(fin, K, lane, D, minD, uniq, sel_d16, sel_key, a.pix0 + (long long)(s_) * K * a.pixstep, a.pixstep); \
-        _Pragma("unroll") for (int j = 0; j < NP; ++j) nvB[j] = nvC[j];                                                 \
-        mB = mC;                                                                                                        \
-    }
-    // the backward path over segment 0: nothing left to recompute or to prefetch
-#define WASS_PAIR_LAST(ODD_)                                                                                            \
-    {                                                                                                                   \
-        const rsrc_t rsO = a.run<NP>(S, 0, K);                                                                          \
-        _Pragma("unroll") for (int u = 0; u < K; ++u) {                                                                 \
-            const int v = K - 1 - u;                                                                                    \
-            const int slot = (ODD_) ? u : v;                                                                            \
-            us2 cb[NP], lfv[NP], Lb[NP], sv[NP];                                                                        \
-            lds_ld<NP>(hc + slot * VW, cb);                                                                             \
-            lds_ld<NP>(hl + slot * VW, lfv);                                                                            \
-            sgm_step<NP>(bw, cb, Lb, P1v, P2);                                                                          \
-            finish(lfv, Lb, sr[v], sv);                                                                                 \
-            if (!LAST || keepS) buf_st<NP>(rsO, voff, bK + v * a.sstep, sv);                                             \
-            if (LAST) { _Pragma("unroll") for (int j = 0; j < NP; ++j) fin[v][j] = sv[j]; }                              \
-        }                                                                                                               \
-        if (LAST) wta_batch<NP, K>(fin, K, lane, D, minD, uniq, sel_d16, sel_key, a.pix0, a.pixstep);                    \
-    }
+    // One iteration for segment s >= 1: backward path over segment s (elements K-1 .. 0, read from the hand-over slots) ||
+    // forward recomputation of segment s-1 (elements 0 .. K-1, from the ring; results into the slots just drained) ||
+    // refills: C of segment s-2, S of segment s-1.  odd: the slots hold segment s in reversed order; the direction in which
+    // they are walked is a run-time stride, so that the loop has ONE body: with two compile-time forms unrolled behind each
+    // other, the refills of the first had their only use behind the loop-exit test between them and the compiler sank
+    // them there -- K steps too late, the second form began by waiting for loads it had just issued.
     us2 fin[K][NP];
+    bool odd = false;
     int s = F - 1;
-    for (;;) {
-        if (s < 1) { WASS_PAIR_LAST(false) break; }
-        WASS_PAIR_ITER(false, s)
-        --s;
-        if (s < 1) { WASS_PAIR_LAST(true) break; }
-        WASS_PAIR_ITER(true, s)
+    while (s >= 1) {
+        const rsrc_t rcN = a.run<NP>(C, (long long)max(s - 2, 0) * K, K);      // past the chain start: a harmless re-read
+        const rsrc_t rsN = a.run<NP>(S, (long long)(s - 1) * K, K), rsO = a.run<NP>(S, (long long)s * K, K);
+        us2 nvC[NP];
+        Rec<K, (WASS_VREC & 1) != 0> mC;
+        if (s >= 3) buf_ld<NP>(ckr, voff, (uint32_t)(s - 3) * VB, nvC);
+        else {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) nvC[j] = pk_splat(0);
+        }
+        mC.load(mrow + (size_t)max(s - 2, 0) * (K / 2), lane);
+        fw.load_normalised(nvB);                   // zeros when s-1 == 0
+        const int stp = odd ? VW : -VW;
+        uint32_t* pc = hc + (odd ? 0 : (K - 1) * VW);
+        us2 cbn[NP], lfn[NP];                      // hand-over vectors of the NEXT step, in flight
+        lds_ld<NP>(pc, cbn);
+        lds_ld<NP>(pc + K * VW, lfn);              // hl = hc + K * VW
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            const int v = K - 1 - u;               // element of segment s the backward path is at
+            uint32_t* pn = pc + stp;
+            us2 cb[NP], lfv[NP], Lf[NP], Lb[NP], sv[NP];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) { cb[j] = cbn[j]; lfv[j] = lfn[j]; }
+            if (u + 1 < K) {
+                lds_ld<NP>(pn, cbn);
+                lds_ld<NP>(pn + K * VW, lfn);
+            }
+            sgm_step_fb<NP>(fw, mB.before(u), cf[u], Lf, bw, cb, Lb, P1v, P2);
+            finish(lfv, Lb, sr[v], sv);
+            if (!LAST || keepS) buf_st<NP>(rsO, voff, bK + v * a.sstep, sv);
+            if (LAST) {
+#pragma unroll
+                for (int j = 0; j < NP; ++j) fin[v][j] = sv[j];
+            }
+            lds_st<NP>(pc, cf[u]);
+            lds_st<NP>(pc + K * VW, Lf);
+            buf_ld<NP>(rcN, voff, bK + u * a.sstep, cf[u]);
+            if (SMODE != 0) buf_ld<NP>(rsN, voff, bK + v * a.sstep, sr[v]);
+            pc = pn;
+        }
+        if (LAST) wta_batch<NP, K>(fin, K, lane, D, minD, uniq, sel_d16, sel_key, a.pix0 + (long long)s * K * a.pixstep, a.pixstep);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) nvB[j] = nvC[j];
+        mB = mC;
+        odd = !odd;
         --s;
     }
-#undef WASS_PAIR_ITER
-#undef WASS_PAIR_LAST
+    {   // the backward path over segment 0: nothing left to recompute or to prefetch
+        const rsrc_t rsO = a.run<NP>(S, 0, K);
+        const int stp = odd ? VW : -VW;
+        uint32_t* pc = hc + (odd ? 0 : (K - 1) * VW);
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            const int v = K - 1 - u;
+            us2 cb[NP], lfv[NP], Lb[NP], sv[NP];
+            lds_ld<NP>(pc, cb);
+            lds_ld<NP>(pc + K * VW, lfv);
+            sgm_step<NP>(bw, cb, Lb, P1v, P2);
+            finish(lfv, Lb, sr[v], sv);
+            if (!LAST || keepS) buf_st<NP>(rsO, voff, bK + v * a.sstep, sv);
+            if (LAST) {
+#pragma unroll
+                for (int j = 0; j < NP; ++j) fin[v][j] = sv[j];
+            }
+            pc += stp;
+        }
+        if (LAST) wta_batch<NP, K>(fin, K, lane, D, minD, uniq, sel_d16, sel_key, a.pix0, a.pixstep);
+    }
 }
 
 // ---------------------------------------------------------------------------
