@@ -268,7 +268,8 @@ struct Rec {
     __device__ __forceinline__ void load(const uint32_t* p, int lane)
     {
         if constexpr (VEC) {
-            v[0] = p[min(lane, N / 2 - 1)];
+            // wave-uniform base in a descriptor + a small per-lane offset: no 64-bit per-lane address to keep alive
+            v[0] = __builtin_amdgcn_raw_buffer_load_b32(mk_rsrc(p), (uint32_t)min(lane, N / 2 - 1) * 4u, 0, 0);
             asm volatile("" ::: "memory");
         } else {
 #pragma unroll
@@ -279,6 +280,17 @@ struct Rec {
     {
         if constexpr (VEC) return (__builtin_amdgcn_readlane(v[0], i >> 1) >> ((i & 1) * 16)) & 0xFFFFu;
         else return (v[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu;
+    }
+    __device__ __forceinline__ uint32_t at_dyn(int i) const        // i: wave-uniform, not a compile-time constant
+    {
+        uint32_t w;
+        if constexpr (VEC) w = __builtin_amdgcn_readlane(v[0], i >> 1);
+        else {
+            w = v[0];
+#pragma unroll
+            for (int k = 1; k < N / 2; ++k) w = (i >> 1) == k ? v[k] : w;
+        }
+        return (w >> ((i & 1) * 16)) & 0xFFFFu;
     }
     // minimum of the forward path costs BEFORE step u of a segment: 0 for the normalised checkpoint state, otherwise
     // what the checkpoint sweep recorded after step u - 1
@@ -513,6 +525,9 @@ k_pair(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t*
 // config B's columns are resident at once.  With XB = 8 there were 614 workgroups for 512 places and the kernel ran two
 // rounds, the second one a fifth full (2.85 ms).
 constexpr int XB = 10;
+#ifndef WASS_FUSE_NP
+#define WASS_FUSE_NP 2
+#endif
 
 // One wave per row walks BOTH paths at once, path 0 from the left border and path 4 from the right border, the two
 // recurrences interleaved statement by statement (sgm_step_pair): the row chains are the longest in the image (2 455
@@ -635,8 +650,13 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
 {
     static_assert(K % 2 == 0 && K <= XB, "one wave per row of a K-row segment");
     constexpr int VW = 64 * NP, VB = 256 * NP;
-    extern __shared__ __attribute__((aligned(16))) uint32_t hand_raw[];   // [XB][2][K][VW]: per wave (column): [0] cost vectors, [1] forward path costs
-    uint32_t (*hand)[2][K][VW] = (uint32_t (*)[2][K][VW])hand_raw;
+    // hand-over slots [2][K][XB][VW]: [0] cost vectors, [1] forward path costs; slot (element of a K-row segment), column.
+    // The column is the INNER index: a row-phase wave reaches all ten columns of its slot, and a column-phase wave both
+    // kinds of a slot, with immediate offsets from one address register (with the column outermost the compiler kept
+    // four address registers per wave alive across the loop, and spilled them).
+    extern __shared__ __attribute__((aligned(16))) uint32_t hand_raw[];
+    constexpr int SS = XB * VW;                            // slot stride, dwords
+    constexpr int KS = K * XB * VW;                        // kind stride
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bx = blockIdx.x >> 1, half = blockIdx.x & 1;
@@ -659,8 +679,7 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
     const int top = r > 0 ? F : F - 1;                     // the segment the forward pass starts with (n >= 1)
     const rsrc_t ckr = mk_rsrc(ckpt + (long long)c * maxseg * vec);
     const uint32_t* mrow = (const uint32_t*)(mins + (size_t)c * maxseg * K);
-    uint32_t* hc = &hand[wv][0][0][lane * NP];
-    uint32_t* hl = &hand[wv][1][0][lane * NP];
+    uint32_t* hc = hand_raw + wv * VW + lane * NP;         // this wave's column: slot e at hc + e * SS, forward costs at + KS
 
     // ---- the row phase: wave e takes element e of the K-row segment seg, whose vectors lie in slot (rev ? K-1-e : e) of
     // every wave's hand-over region
@@ -670,12 +689,12 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
     auto row_fetch = [&](int seg, int cnt) {
         if (wv < cnt) {
             const int yrow = y0 + (seg * K + wv) * dy;
-            if (bx >= 1) ld_stream_vec<NP>(rs.entF + ((size_t)yrow * rs.nbx + bx) * vec + lane * NP, eF);
+            if (bx >= 1) buf_ld<NP>(mk_rsrc(rs.entF + ((size_t)yrow * rs.nbx + bx) * vec), voff, 0, eF);
             else {
 #pragma unroll
                 for (int j = 0; j < NP; ++j) eF[j] = pk_splat(0);
             }
-            if (bx + 1 < rs.nbx) ld_stream_vec<NP>(rs.entB + ((size_t)yrow * rs.nbx + bx) * vec + lane * NP, eB);
+            if (bx + 1 < rs.nbx) buf_ld<NP>(mk_rsrc(rs.entB + ((size_t)yrow * rs.nbx + bx) * vec), voff, 0, eB);
             else {
 #pragma unroll
                 for (int j = 0; j < NP; ++j) eB[j] = pk_splat(0);
@@ -691,49 +710,55 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
         if (wv < cnt) {
             const int e = wv, slot = rev ? K - 1 - e : e;
             auto mat = [](const Rec<XB, (WASS_VREC & 4) != 0>& m, int i) { return m.at(i); };
-            us2 cj[XB][NP], part[XB][NP];
-#pragma unroll
-            for (int j = 0; j < XB; ++j)
-                if (j < ncol) lds_ld<NP>(&hand[j][0][slot][lane * NP], cj[j]);
+            // Cost vectors are fetched from the slots when a path gets to them (twice per column) instead of all at the
+            // start, and a column's forward path costs are updated as soon as both row paths have been there: with the ten
+            // cost vectors and ten partial sums all live the kernel spilled, and every reload of a spilled register is a
+            // wait for ALL outstanding loads -- the ring refills of the column phase included.
+            uint32_t* rb = hand_raw + slot * SS + lane * NP;       // column j of the slot: rb + j * VW, its forward costs + KS
             PathState<NP> fa, fb;
             fa.load_normalised(eF);
             fb.load_normalised(eB);
+            auto add_into_lf = [&](int j, const us2 (&x)[NP]) {
+                uint32_t* lp = rb + KS + j * VW;
+                us2 t[NP];
+                lds_ld<NP>(lp, t);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) t[q] = pk_adds(t[q], x[q]);
+                lds_st<NP>(lp, t);
+            };
             if (ncol == XB) {
+                us2 cfn[NP], cbn[NP];
+                lds_ld<NP>(rb, cfn);
+                lds_ld<NP>(rb + (XB - 1) * VW, cbn);
 #pragma unroll
                 for (int u = 0; u < XB; ++u) {
                     const int jf = u, jb = XB - 1 - u;
-                    us2 Lf[NP], Lb[NP];
-                    // minimum before the step: what the sweep recorded after the previous pixel of the path (0 behind an entry state)
-                    sgm_step_ff<NP>(fa, u == 0 ? 0u : mat(mf, jf - 1), cj[jf], Lf, fb, u == 0 ? 0u : mat(mb, jb + 1), cj[jb], Lb, P1v, P2);
+                    us2 ca[NP], cb[NP], Lf[NP], Lb[NP];
 #pragma unroll
-                    for (int j = 0; j < NP; ++j) {
-                        part[jf][j] = u < XB / 2 ? Lf[j] : pk_adds(part[jf][j], Lf[j]);
-                        part[jb][j] = u < XB / 2 ? Lb[j] : pk_adds(part[jb][j], Lb[j]);
+                    for (int j = 0; j < NP; ++j) { ca[j] = cfn[j]; cb[j] = cbn[j]; }
+                    if (u + 1 < XB) {
+                        lds_ld<NP>(rb + (jf + 1) * VW, cfn);
+                        lds_ld<NP>(rb + (jb - 1) * VW, cbn);
                     }
+                    // minimum before the step: what the sweep recorded after the previous pixel of the path (0 behind an entry state)
+                    sgm_step_ff<NP>(fa, u == 0 ? 0u : mat(mf, jf - 1), ca, Lf, fb, u == 0 ? 0u : mat(mb, jb + 1), cb, Lb, P1v, P2);
+                    add_into_lf(jf, Lf);
+                    add_into_lf(jb, Lb);
                 }
             } else {                                        // the short block at the right image border
-#pragma unroll
-                for (int j = 0; j < XB; ++j)
-                    if (j < ncol) sgm_step_f<NP>(fa, j == 0 ? 0u : mat(mf, j - 1), cj[j], part[j], P1v, P2);
-#pragma unroll
-                for (int j = XB - 1; j >= 0; --j)
-                    if (j < ncol) {
-                        us2 Lb[NP];
-                        sgm_step_f<NP>(fb, j == ncol - 1 ? 0u : mat(mb, j + 1), cj[j], Lb, P1v, P2);
-#pragma unroll
-                        for (int q = 0; q < NP; ++q) part[j][q] = pk_adds(part[j][q], Lb[q]);
-                    }
-            }
-#pragma unroll
-            for (int j = 0; j < XB; ++j)
-                if (j < ncol) {
-                    uint32_t* lp = &hand[j][1][slot][lane * NP];
-                    us2 t[NP];
-                    lds_ld<NP>(lp, t);
-#pragma unroll
-                    for (int q = 0; q < NP; ++q) t[q] = pk_adds(t[q], part[j][q]);
-                    lds_st<NP>(lp, t);
+                for (int j = 0; j < ncol; ++j) {
+                    us2 cv[NP], L[NP];
+                    lds_ld<NP>(rb + j * VW, cv);
+                    sgm_step_f<NP>(fa, j == 0 ? 0u : mf.at_dyn(j - 1), cv, L, P1v, P2);
+                    add_into_lf(j, L);
                 }
+                for (int j = ncol - 1; j >= 0; --j) {
+                    us2 cv[NP], L[NP];
+                    lds_ld<NP>(rb + j * VW, cv);
+                    sgm_step_f<NP>(fb, j == ncol - 1 ? 0u : mb.at_dyn(j + 1), cv, L, P1v, P2);
+                    add_into_lf(j, L);
+                }
+            }
         }
         __syncthreads();
     };
@@ -782,10 +807,14 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
                 if (u < cn) {
                     us2 L[NP];
                     sgm_step<NP>(fw, c0[u], L, P1v, P2);
-                    lds_st<NP>(hc + u * VW, c0[u]);
-                    lds_st<NP>(hl + u * VW, L);
+                    lds_st<NP>(hc + u * SS, c0[u]);
+                    lds_st<NP>(hc + KS + u * SS, L);
                 }
         }
+        // Once per chain: nothing is in flight when the loop is entered, so that the waits inside it are the ones its own
+        // back-edge needs (they are computed for the worst predecessor; with guarded loads pending here that was "wait
+        // for everything" at the top of every row phase and every column phase).
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0), expcnt and lgkmcnt untouched
     }
 
     // ---- iterations t = 1, 2, ...: backward path over segment s = top, top-1, ..., 0 || forward recomputation of segment
@@ -804,11 +833,11 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
         }                                                                                                               \
         mC.load(mrow + (size_t)max((s_) - 2, 0) * (K / 2), lane);                                                \
         fw.load_normalised(nvB);                                                                                        \
-        const int stp = nat ? -VW : VW;            /* the slots are drained from the end they were filled last */      \
-        uint32_t* pc = hc + (nat ? (K - 1) * VW : 0);                                                                   \
+        const int stp = nat ? -SS : SS;            /* the slots are drained from the end they were filled last */      \
+        uint32_t* pc = hc + (nat ? (K - 1) * SS : 0);                                                                   \
         us2 cbn[NP], lfn[NP];                                                                                           \
         lds_ld<NP>(pc, cbn);                                                                                            \
-        lds_ld<NP>(pc + K * VW, lfn);              /* hl = hc + K * VW */                                               \
+        lds_ld<NP>(pc + KS, lfn);                                                                                       \
         _Pragma("unroll") for (int u = 0; u < K; ++u) {                                                                 \
             const int v = K - 1 - u;                                                                                    \
             uint32_t* pn = pc + stp;                                                                                    \
@@ -816,13 +845,13 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
             _Pragma("unroll") for (int j = 0; j < NP; ++j) { cb[j] = cbn[j]; lfv[j] = lfn[j]; }                          \
             if (u + 1 < K) {                                                                                            \
                 lds_ld<NP>(pn, cbn);                                                                                    \
-                lds_ld<NP>(pn + K * VW, lfn);                                                                           \
+                lds_ld<NP>(pn + KS, lfn);                                                                               \
             }                                                                                                           \
             sgm_step_fb<NP>(fw, mB.before(u), cf[u], Lf, bw, cb, Lb, P1v, P2);                                   \
             _Pragma("unroll") for (int j = 0; j < NP; ++j) sv[j] = pk_adds(lfv[j], Lb[j]);                               \
             buf_st<NP>(rsO, voff, bK + v * a.sstep, sv);                                                                \
             lds_st<NP>(pc, cf[u]);                                                                                      \
-            lds_st<NP>(pc + K * VW, Lf);                                                                                \
+            lds_st<NP>(pc + KS, Lf);                                                                                    \
             buf_ld<NP>(rcN, voff, bK + u * a.sstep, cf[u]);                                                              \
             pc = pn;                                                                                                    \
         }                                                                                                               \
@@ -849,16 +878,16 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
             us2 Lf[NP];                                                                                                 \
             if (v < (cb_)) {                                                                                            \
                 us2 cb[NP], lfv[NP], Lb[NP], sv[NP];                                                                    \
-                lds_ld<NP>(hc + slot * VW, cb);                                                                         \
-                lds_ld<NP>(hl + slot * VW, lfv);                                                                        \
+                lds_ld<NP>(hc + slot * SS, cb);                                                                         \
+                lds_ld<NP>(hc + KS + slot * SS, lfv);                                                                   \
                 sgm_step<NP>(bw, cb, Lb, P1v, P2);                                                                      \
                 _Pragma("unroll") for (int j = 0; j < NP; ++j) sv[j] = pk_adds(lfv[j], Lb[j]);                           \
                 buf_st<NP>(rsO, voff, bO + v * a.sstep, sv);                                                            \
             }                                                                                                           \
             if (hasfw_) {                                                                                               \
                 sgm_step_f<NP>(fw, mB.before(u), cf[u], Lf, P1v, P2);                                            \
-                lds_st<NP>(hc + slot * VW, cf[u]);                                                                      \
-                lds_st<NP>(hl + slot * VW, Lf);                                                                         \
+                lds_st<NP>(hc + slot * SS, cf[u]);                                                                      \
+                lds_st<NP>(hc + KS + slot * SS, Lf);                                                                    \
                 buf_ld<NP>(rcN, voff, bK + u * a.sstep, cf[u]);                                                          \
             }                                                                                                           \
         }                                                                                                               \
@@ -879,6 +908,10 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
         if (!hasfw) return;
         nat = !nat;                                        // the forward results went into the slots as they were drained
         --s;
+        // Everything this guarded form requested has landed before the loop is entered: the waits inside the loop are
+        // computed for the worst of its predecessors, and here that is "no refill was issued after the loads the loop
+        // consumes first" -- which put a vmcnt(0) at the top of every column phase.
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0), expcnt and lgkmcnt untouched
     }
     while (s >= 1) {
         row_phase(s, K, !nat);
@@ -914,7 +947,7 @@ CkptLayout ckpt_layout(const SgmDims& d)
     };
     // The kernel that carries the winner-take-all goes last and should have the most chains (the WTA adds ~50
     // instructions per pixel): the anti-diagonals (width1 + h - 1 chains).
-    if (d.ndirs == 8 && d.NP <= 2) {
+    if (d.ndirs == 8 && d.NP <= WASS_FUSE_NP) {
         L.cols_from_cost = true;
         L.rows_fused = true;
         add(0, 1, 0);                // columns + rows: paths 2 + 6 and 0 + 4 (k_pairx, S written)
