@@ -1024,7 +1024,8 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
         uint32_t* ckf = (uint32_t*)((char*)c->ckpt.p + lay.off[f]);
         // (Tried: the first of these sweeps on the main stream, beside the row sweeps, which keep the main stream waiting.  The
         // row chains are the longest in the image, 2 455 dependent steps, and sharing their SIMDs stretched them from 0.7 to
-        // 1.9 ms: they run alone.)
+        // 1.9 ms: they run alone.  Tried again with s_setprio 3 in k_rowsweep: priority alone changes nothing, the sweep beside
+        // it still costs 0.15-0.2 ms overall.)
         hipStream_t ss = c->side;
         hipLaunchKernelGGL((k_ckpt<NP, K>), dim3((nch + 3) / 4), dim3(256), 0, ss, C, ckf, (uint16_t*)((char*)c->ckpt.p + lay.moff[f]),
                            d.width1, d.h, lay.dx[f], lay.dy[f], d.P1, d.P2, nch, mseg,
