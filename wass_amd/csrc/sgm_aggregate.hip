@@ -439,6 +439,11 @@ k_pair(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t*
     us2 fin[K][NP];
     bool odd = false;
     int s = F - 1;
+    // Nothing in flight when the loop is entered: its waits are then the ones its own back-edge needs (with
+    // the prologue's loads pending the top of every trip waited for vmcnt(4) instead of 9 at K = 4; at K = 8 it stays at
+    // vmcnt(8) because the scheduler issues the refills in clumps of four or five.  Pinning them to their steps with
+    // sched_barrier costs more than it gains: 6.42 against 6.36 ms).
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0), expcnt and lgkmcnt untouched
     while (s >= 1) {
         const rsrc_t rcN = a.run<NP>(C, (long long)max(s - 2, 0) * K, K);      // past the chain start: a harmless re-read
         const rsrc_t rsN = a.run<NP>(S, (long long)(s - 1) * K, K), rsO = a.run<NP>(S, (long long)s * K, K);
@@ -570,6 +575,14 @@ k_rowsweep(const uint32_t* __restrict__ C, uint32_t* __restrict__ entF, uint32_t
             buf_ld<NP>(r0, voff, u * VB, rf[u]);
             buf_ld<NP>(r1, voff, b1 + u * ab.sstep, rb[u]);
         }
+        // Nothing in flight when the loop is entered ("waits are computed for the worst predecessor"): the
+        // scheduler reorders these twenty loads, the loop's first operands came out 7 and 3 from the end and every trip
+        // began with s_waitcnt vmcnt(7) / vmcnt(3); now vmcnt(19) / vmcnt(18) at every step.  (No measurable change in
+        // this kernel: what its two entry-state stores per block cost -- 1.41 ms against 1.08 without them, same
+        // arithmetic -- is not a wait at this point; ring depth 20 / 30, stores without nt, through a descriptor, to one
+        // address, or batched at the end of a block all leave it where it is.  Keeping the stored registers alive for a
+        // block gives 0.1 ms of it back in isolation and nothing in the frame.)
+        __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0), expcnt and lgkmcnt untouched
     }
     for (int g = 0; g < G; ++g) {
         const int t0 = g * XB;
