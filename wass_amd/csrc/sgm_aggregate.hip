@@ -656,7 +656,8 @@ struct RowSide {                     // what k_rowsweep left behind
     int nbx;
 };
 
-template <int NP, int K>
+// ACC: S already holds another family's sum (S += ...); otherwise this kernel writes S first.
+template <int NP, int K, bool ACC>
 __global__ void __launch_bounds__(64 * XB) __attribute__((amdgpu_waves_per_eu(5, 5)))
 k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t* __restrict__ ckpt, const uint16_t* __restrict__ mins,
         const RowSide rs, int width1, int h, int P1, int P2, int maxseg, const uint32_t* __restrict__ endstate)
@@ -778,6 +779,7 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
 
     PathState<NP> bw, fw;
     us2 cf[K][NP];                                         // ring: cost vectors of the segment the forward recomputation covers next
+    us2 sr[ACC ? K : 1][NP];                               // ring (ACC): S of the segment the backward path covers next
     us2 nvB[NP];
     Rec<K, (WASS_VREC & 2) != 0> mB;
     mB.clear();
@@ -806,6 +808,12 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
 #pragma unroll
             for (int u = 0; u < K; ++u)
                 if (u < cn) buf_ld<NP>(rc, voff, bc + u * a.sstep, c0[u]);
+            if constexpr (ACC) {
+                const rsrc_t rs0 = a.run<NP>(S, (long long)top * K, cn);
+#pragma unroll
+                for (int u = 0; u < K; ++u)
+                    if (u < cn) buf_ld<NP>(rs0, voff, bc + u * a.sstep, sr[u]);
+            }
             fw.reset();
             if (top >= 1) {
                 us2 nv[NP];
@@ -838,6 +846,7 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
     if (colact) {                                                                                                       \
         const rsrc_t rcN = a.run<NP>(C, (long long)max((s_) - 2, 0) * K, K);                                              \
         const rsrc_t rsO = a.run<NP>(S, (long long)(s_) * K, K);                                                          \
+        const rsrc_t rsN = a.run<NP>(S, (long long)((s_) - 1) * K, K);                                                    \
         us2 nvC[NP];                                                                                                    \
         Rec<K, (WASS_VREC & 2) != 0> mC;                                                                                                    \
         if ((s_) >= 3) buf_ld<NP>(ckr, voff, (uint32_t)((s_) - 3) * VB, nvC);                                            \
@@ -862,10 +871,12 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
             }                                                                                                           \
             sgm_step_fb<NP>(fw, mB.before(u), cf[u], Lf, bw, cb, Lb, P1v, P2);                                   \
             _Pragma("unroll") for (int j = 0; j < NP; ++j) sv[j] = pk_adds(lfv[j], Lb[j]);                               \
+            if constexpr (ACC) { _Pragma("unroll") for (int j = 0; j < NP; ++j) sv[j] = pk_adds(sv[j], sr[v][j]); }     \
             buf_st<NP>(rsO, voff, bK + v * a.sstep, sv);                                                                \
             lds_st<NP>(pc, cf[u]);                                                                                      \
             lds_st<NP>(pc + KS, Lf);                                                                                    \
             buf_ld<NP>(rcN, voff, bK + u * a.sstep, cf[u]);                                                              \
+            if constexpr (ACC) buf_ld<NP>(rsN, voff, bK + v * a.sstep, sr[v]);                                           \
             pc = pn;                                                                                                    \
         }                                                                                                               \
         _Pragma("unroll") for (int j = 0; j < NP; ++j) nvB[j] = nvC[j];                                                 \
@@ -877,6 +888,7 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
         const rsrc_t rcN = a.run<NP>(C, (long long)max((s_) - 2, 0) * K, K);                                              \
         const rsrc_t rsO = a.run<NP>(S, (long long)(s_) * K, (cb_));                                                      \
         const uint32_t bO = a.bias(cb_);                                                                                \
+        const rsrc_t rsN = a.run<NP>(S, (long long)max((s_) - 1, 0) * K, K);                                              \
         us2 nvC[NP];                                                                                                    \
         Rec<K, (WASS_VREC & 2) != 0> mC;                                                                                                    \
         if ((s_) >= 3) buf_ld<NP>(ckr, voff, (uint32_t)((s_) - 3) * VB, nvC);                                            \
@@ -895,9 +907,11 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
                 lds_ld<NP>(hc + KS + slot * SS, lfv);                                                                   \
                 sgm_step<NP>(bw, cb, Lb, P1v, P2);                                                                      \
                 _Pragma("unroll") for (int j = 0; j < NP; ++j) sv[j] = pk_adds(lfv[j], Lb[j]);                           \
+                if constexpr (ACC) { _Pragma("unroll") for (int j = 0; j < NP; ++j) sv[j] = pk_adds(sv[j], sr[v][j]); } \
                 buf_st<NP>(rsO, voff, bO + v * a.sstep, sv);                                                            \
             }                                                                                                           \
             if (hasfw_) {                                                                                               \
+                if constexpr (ACC) buf_ld<NP>(rsN, voff, bK + v * a.sstep, sr[v]);   /* segment s-1 is complete */       \
                 sgm_step_f<NP>(fw, mB.before(u), cf[u], Lf, P1v, P2);                                            \
                 lds_st<NP>(hc + slot * SS, cf[u]);                                                                      \
                 lds_st<NP>(hc + KS + slot * SS, Lf);                                                                    \
@@ -963,9 +977,13 @@ CkptLayout ckpt_layout(const SgmDims& d)
     if (d.ndirs == 8 && d.NP <= WASS_FUSE_NP) {
         L.cols_from_cost = true;
         L.rows_fused = true;
-        add(0, 1, 0);                // columns + rows: paths 2 + 6 and 0 + 4 (k_pairx, S written)
-        add(1, 1, 1);                // diagonals:      paths 1 + 7
-        add(-1, 1, 2);               // anti-diagonals: paths 3 + 5, winner-take-all fused
+        // Order of the pair kernels: diagonals, columns + rows, anti-diagonals.  The fused kernel needs the row sweeps, whose
+        // chains are the longest in the image (1.4 ms alone); with the diagonal family first the main stream has 2 ms of
+        // its own work to do while they run (launch_aggregate_np), and only one checkpoint sweep is left to run beside
+        // the fused kernel instead of two.  S: written by the diagonals, read-modify-written by k_pairx, read by the last.
+        add(0, 1, 1);                // columns + rows: paths 2 + 6 and 0 + 4 (k_pairx, S +=), second
+        add(1, 1, 0);                // diagonals:      paths 1 + 7 (S written), first
+        add(-1, 1, 2);               // anti-diagonals: paths 3 + 5, winner-take-all fused, last
     } else if (d.ndirs == 8) {
         // D > 256: a pixel vector is 1 KiB or more, a checkpoint segment only 4 or 2 rows, so the fused kernel would run its
         // two barriers every few pixels with most waves idle in the row phase (measured at config E: 13.5 ms against
@@ -1035,11 +1053,11 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
         }
         const int nch = lay.nch[f], mseg = lay.mseg[f];
         uint32_t* ckf = (uint32_t*)((char*)c->ckpt.p + lay.off[f]);
-        // (Tried: the first of these sweeps on the main stream, beside the row sweeps, which keep the main stream waiting.  The
-        // row chains are the longest in the image, 2 455 dependent steps, and sharing their SIMDs stretched them from 0.7 to
-        // 1.9 ms: they run alone.  Tried again with s_setprio 3 in k_rowsweep: priority alone changes nothing, the sweep beside
-        // it still costs 0.15-0.2 ms overall.)
-        hipStream_t ss = c->side;
+        // (The sweeps that run BESIDE the row sweeps stretch them -- 2 455 dependent steps per chain -- from 1.4 to 2.6 ms.
+        // That was a loss while the fused kernel, which needs them, came first; it is free now that the diagonal family's
+        // sweep and pair kernel, 2 ms of main-stream work, come first.  s_setprio in k_rowsweep changes nothing.)
+        // fused schedule: the diagonal sweep goes on the MAIN stream (its pair kernel follows it there), beside the row sweeps
+        hipStream_t ss = (lay.rows_fused && f == 1) ? c->stream : c->side;
         hipLaunchKernelGGL((k_ckpt<NP, K>), dim3((nch + 3) / 4), dim3(256), 0, ss, C, ckf, (uint16_t*)((char*)c->ckpt.p + lay.moff[f]),
                            d.width1, d.h, lay.dx[f], lay.dy[f], d.P1, d.P2, nch, mseg,
                            lay.split[f] ? ckf + (size_t)nch * mseg * (64 * NP) : (uint32_t*)nullptr);
@@ -1053,7 +1071,9 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
                            nch, d.D, d.minD, d.uniq, c->debug ? 1 : 0, sd, sk);
         ++nl;
     }
-    for (int f = 0; f < nf; ++f) {
+    for (int fi = 0; fi < nf; ++fi) {
+        const int fused_order[3] = { 1, 0, 2 };
+        const int f = lay.rows_fused ? fused_order[fi] : fi;
         const int nch = lay.nch[f], mseg = lay.mseg[f];
         const uint32_t* ck = (const uint32_t*)((char*)c->ckpt.p + lay.off[f]);
         const uint16_t* mn = (const uint16_t*)((char*)c->ckpt.p + lay.moff[f]);
@@ -1068,8 +1088,8 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
             const RowSide rs = { (const uint32_t*)(ckb + lay.roff[0]), (const uint32_t*)(ckb + lay.roff[1]),
                                  (const uint16_t*)(ckb + lay.roff[2]), (const uint16_t*)(ckb + lay.roff[3]), lay.nbx };
             const size_t ldsx = (size_t)XB * 2 * K * (64 * NP) * sizeof(uint32_t);
-            WASS_HIP(c, hipFuncSetAttribute((const void*)k_pairx<NP, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx));
-            hipLaunchKernelGGL((k_pairx<NP, K>), dim3(2 * lay.nbx), dim3(64 * XB), ldsx, c->stream, C, S, ck, mn, rs, d.width1, d.h, d.P1,
+            WASS_HIP(c, hipFuncSetAttribute((const void*)k_pairx<NP, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx));
+            hipLaunchKernelGGL((k_pairx<NP, K, true>), dim3(2 * lay.nbx), dim3(64 * XB), ldsx, c->stream, C, S, ck, mn, rs, d.width1, d.h, d.P1,
                                d.P2, mseg, (const uint32_t*)(ck + (size_t)nch * mseg * (64 * NP)));
         } else if (lay.smode[f] == 0) WASS_PAIR(0);
         else if (lay.smode[f] == 1) WASS_PAIR(1);
