@@ -202,13 +202,16 @@ int ensure(wass_ctx* c, Buf& b, size_t bytes);
 // Checkpoint regions of the chain families, in launch order.  With 8 paths the column family comes first: its
 // forward checkpoints are produced by the cost stage itself (k_vsum_col walks whole columns top-down, which is
 // exactly that family's forward path), so its pair kernel can start the moment C is complete.
-// steps per checkpoint segment (and unroll depth of the sweeps) for NP packed pairs per lane: bounded by the register
-// budget of k_pair, which keeps 4 * K * NP vectors live (two banks of cost vectors, the forward path costs and S)
+// steps per checkpoint segment (and unroll depth of the sweeps) for NP packed pairs per lane: bounded by k_pair, which
+// keeps 2 * K * NP vectors in registers (the cost and S rings) and 2 * K * NP per wave in LDS (the hand-over slots).
+// NP = 3, 4 (D = 384, 512): K = 8 since the end of round 3 -- 64 ring registers and 64 KiB of LDS per workgroup, i.e. two
+// workgroups per CU instead of four, and still faster than K = 4 (config E, alternating runs: aggregation 21.9 -> 21.2 ms,
+// cost stage 5.1 -> 4.8 ms): half the checkpoint traffic (126 -> 118 GB per frame) outweighs the occupancy.  K = 6: the same.
 #ifndef WASS_K_SMALL
 #define WASS_K_SMALL 8
 #endif
 #ifndef WASS_K_MID
-#define WASS_K_MID 4
+#define WASS_K_MID 8
 #endif
 #ifndef WASS_K_BIG
 #define WASS_K_BIG 2
