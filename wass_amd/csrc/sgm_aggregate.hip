@@ -985,9 +985,9 @@ CkptLayout ckpt_layout(const SgmDims& d)
         add(1, 1, 0);                // diagonals:      paths 1 + 7 (S written), first
         add(-1, 1, 2);               // anti-diagonals: paths 3 + 5, winner-take-all fused, last
     } else if (d.ndirs == 8) {
-        // D > 256: a pixel vector is 1 KiB or more, a checkpoint segment only 4 or 2 rows, so the fused kernel would run its
-        // two barriers every few pixels with most waves idle in the row phase (measured at config E: 13.5 ms against
-        // 4.3 + 5.4 ms for the two kernels it replaces).  One pair kernel per family.
+        // D > 256: a pixel vector is 1 KiB or more; the fused kernel's hand-over block (XB columns x K rows, two kinds) would
+        // be the CU's whole LDS at K = 8, and with K = 4, where it fits, it ran its two barriers every four rows with six of
+        // ten waves idle in the row phase (measured at config E: 28.1 against 23.3 ms).  One pair kernel per family.
         L.cols_from_cost = true;
         add(0, 1, 0);                // columns:        paths 2 + 6   (S written)
         add(1, 0, 1);                // rows:           paths 0 + 4
