@@ -34,6 +34,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     deps = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(_HERE, "..", "include", "wass_gpu.h")]
+    # objects built with other flags (WASS_EXTRA_FLAGS experiments) must not be mixed with fresh ones: the checkpoint
+    # distance, for one, is a compile-time constant shared by the cost stage and the aggregation
+    stamp = os.path.join(OBJ, ".flags")
+    flags_now = " ".join(FLAGS)
+    try:
+        same = open(stamp).read() == flags_now
+    except OSError:
+        same = False
+    if not same:
+        force = True
     objs, procs = [], []
     for s in srcs:
         o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
@@ -46,6 +56,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     failed = [s for s, p in procs if p.wait() != 0]
     if failed:
         raise RuntimeError("hipcc failed for: " + ", ".join(failed))
+    with open(stamp, "w") as f:
+        f.write(flags_now)
     if force or procs or not os.path.exists(SO):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO, *objs, "-ldl"]
         if verbose:
