@@ -16,11 +16,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 @pytest.fixture(scope="module")
 def model():
-    src = os.path.join(HERE, "native", "tile_model.cpp")
+    src = os.path.join(HERE, "tile_model.cpp")
     out_dir = os.path.join(HERE, "native", "_build")
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libtile_model.so")
-    hdr = os.path.join(HERE, "..", "wass_amd", "csrc", "tile_geom.h")
+    hdr = os.path.join(HERE, "tile_geom.h")
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", src, "-o", so])
     lib = ctypes.CDLL(so)

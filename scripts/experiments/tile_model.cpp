@@ -8,7 +8,7 @@
 
 #include <vector>
 
-#include "../../wass_amd/csrc/tile_geom.h"
+#include "tile_geom.h"
 
 using namespace wass;
 

@@ -51,6 +51,16 @@ CASES = [
     (1100, 10, 1024, 5, 13, 1, 0),    # NP = 8: the largest supported MAX_DISPARITY
     (257, 33, 96, 8, 11, 1, 0),       # (wider windows leave the int16 range of A.7 on textured input)
     (75, 41, 32, 5, 11, 3, 0),        # odd width, minD = 3, window wider than a checkpoint segment is tall
+    # every checkpoint regime with half chains of at least two full segments (F >= 2: the steady-state loop of k_pair runs for
+    # the column and diagonal families too), every NP from 4 up in 8-path mode
+    (600, 64, 512, 8, 13, 1, 0),      # NP = 4, K = 8
+    (720, 40, 640, 8, 13, 1, 0),      # NP = 5, K = 4
+    (800, 40, 768, 8, 13, 1, 0),      # NP = 6
+    (950, 40, 896, 8, 13, 1, 0),      # NP = 7 (no other case has it)
+    (1100, 40, 1024, 8, 13, 1, 0),    # NP = 8, 8-path
+    (460, 48, 384, 8, 13, 1, 0),      # NP = 3, K = 8, three segments per half chain
+    (460, 48, 384, 5, 13, 1, 0),
+    (950, 40, 896, 5, 13, 1, 0),
 ]
 
 
@@ -78,6 +88,36 @@ def test_stage_parity(gpu_ctx, oracle, w, h, D, ndirs, win, mind, off):
     # and the wass-level wrapper of the oracle agrees with itself
     d2, _ = oracle.dense_disparity16(right, left, _oracle_params(oracle, p), off)
     np.testing.assert_array_equal(got, d2)
+
+
+# Chain lengths around the checkpoint distance: an image of height h has column half-chains of h // 2 and h - h // 2 rows and
+# diagonal chains of every length 1 .. min(w, h), so heights 1 .. 2K + 1 (and a few beyond) put every combination of
+# "number of full segments F" and "tail length r" of k_ckpt / k_pair / k_pairx / k_sweep through the guarded prologues and
+# epilogues, for every NP (= every template instance that is launched) in both modes.  One known instance-specific
+# miscompile (k_pair<2, 8, 1>) showed only in segment 0 of short diagonal chains.
+_SHORT_H = [1, 2, 3, 4, 5, 7, 8, 9, 11, 15, 16, 17, 18, 23, 25, 33, 34]
+
+
+@pytest.mark.parametrize("ndirs", [5, 8])
+@pytest.mark.parametrize("D", [64, 128, 256, 384, 512, 640, 768, 896, 1024])
+def test_short_chains_every_instance(gpu_ctx, oracle, D, ndirs):
+    w = 48 + (D % 7)                                       # width1 = w + D - 1 ... a few blocks of ten columns plus a ragged one
+    gpu_ctx.set_debug(True)
+    try:
+        for h in _SHORT_H:
+            right, left = synth.make_pair(w, h, D, frame_idx=h * 31 + D)
+            p = default_sgm_params(D, ndirs=ndirs, win=5)
+            got = gpu_ctx.sgm_disparity(right, left, p, allow_overflow=True)
+            Cg, Sg, rawg = gpu_ctx.sgm_debug_fetch(w, h, p)
+            R, L = _pad(right, left, D)
+            disp, st, Co, So, rawo = oracle.sgbm_compute(R, L, _oracle_params(oracle, p), dump=True)
+            assert not st.overflow
+            np.testing.assert_array_equal(Cg, Co, err_msg=f"C, h={h}")
+            np.testing.assert_array_equal(Sg, So, err_msg=f"S, h={h}")
+            np.testing.assert_array_equal(rawg, rawo, err_msg=f"raw, h={h}")
+            np.testing.assert_array_equal(got, disp[:, D:D + w], err_msg=f"final, h={h}")
+    finally:
+        gpu_ctx.set_debug(False)
 
 
 def test_random_noise_images(gpu_ctx, oracle):

@@ -37,13 +37,24 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # objects built with other flags (WASS_EXTRA_FLAGS experiments) must not be mixed with fresh ones: the checkpoint
     # distance, for one, is a compile-time constant shared by the cost stage and the aggregation
     stamp = os.path.join(OBJ, ".flags")
-    flags_now = " ".join(FLAGS)
+    try:
+        hipcc_version = subprocess.run([HIPCC, "--version"], capture_output=True, text=True).stdout.strip().replace("\n", " | ")
+    except OSError:
+        hipcc_version = "?"
+    flags_now = " ".join(FLAGS) + " || " + hipcc_version
     try:
         same = open(stamp).read() == flags_now
     except OSError:
         same = False
     if not same:
+        # the stamp is only rewritten after a successful LINK: a build that dies between compiling and linking must not
+        # leave a stamp that matches while the old library (other flags) is still in place
         force = True
+        for stale in (stamp, SO):
+            try:
+                os.remove(stale)
+            except OSError:
+                pass
     objs, procs = [], []
     for s in srcs:
         o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
@@ -56,13 +67,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
     failed = [s for s, p in procs if p.wait() != 0]
     if failed:
         raise RuntimeError("hipcc failed for: " + ", ".join(failed))
-    with open(stamp, "w") as f:
-        f.write(flags_now)
     if force or procs or not os.path.exists(SO):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO, *objs, "-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(flags_now)
     return SO
 
 

@@ -270,7 +270,9 @@ struct Rec {
         if constexpr (VEC) {
             // wave-uniform base in a descriptor + a small per-lane offset: no 64-bit per-lane address to keep alive
             v[0] = __builtin_amdgcn_raw_buffer_load_b32(mk_rsrc(p), (uint32_t)min(lane, N / 2 - 1) * 4u, 0, 0);
-            asm volatile("" ::: "memory");
+            // the loaded REGISTER is an operand of the fence: a bare memory clobber does not formally order a read-only
+            // buffer-load intrinsic, a volatile asm that consumes its result does (it cannot be sunk past it)
+            asm volatile("" : "+v"(v[0]) :: "memory");
         } else {
 #pragma unroll
             for (int i = 0; i < N / 2; ++i) v[i] = p[i];
@@ -663,6 +665,7 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
         const RowSide rs, int width1, int h, int P1, int P2, int maxseg, const uint32_t* __restrict__ endstate)
 {
     static_assert(K % 2 == 0 && K <= XB, "one wave per row of a K-row segment");
+    static_assert((size_t)XB * 2 * K * 256 * NP <= 160 * 1024, "the hand-over block must fit a CU's LDS");
     constexpr int VW = 64 * NP, VB = 256 * NP;
     // hand-over slots [2][K][XB][VW]: [0] cost vectors, [1] forward path costs; slot (element of a K-row segment), column.
     // The column is the INNER index: a row-phase wave reaches all ten columns of its slot, and a column-phase wave both
@@ -1084,13 +1087,18 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
                            lay.dy[f], d.P1, d.P2, nch, mseg, d.D, d.minD, d.uniq, c->debug ? 1 : 0, sd, sk,            \
                            lay.split[f] ? (const uint32_t*)(ck + (size_t)nch * mseg * (64 * NP)) : (const uint32_t*)nullptr)
         if (f == 0 && lay.rows_fused) {
-            WASS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_ckpt[3], 0));
-            const RowSide rs = { (const uint32_t*)(ckb + lay.roff[0]), (const uint32_t*)(ckb + lay.roff[1]),
-                                 (const uint16_t*)(ckb + lay.roff[2]), (const uint16_t*)(ckb + lay.roff[3]), lay.nbx };
-            const size_t ldsx = (size_t)XB * 2 * K * (64 * NP) * sizeof(uint32_t);
-            WASS_HIP(c, hipFuncSetAttribute((const void*)k_pairx<NP, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx));
-            hipLaunchKernelGGL((k_pairx<NP, K, true>), dim3(2 * lay.nbx), dim3(64 * XB), ldsx, c->stream, C, S, ck, mn, rs, d.width1, d.h, d.P1,
-                               d.P2, mseg, (const uint32_t*)(ck + (size_t)nch * mseg * (64 * NP)));
+            // only the instances that can be launched are instantiated (the others would need more LDS than a CU has)
+            if constexpr (NP <= WASS_FUSE_NP) {
+                WASS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_ckpt[3], 0));
+                const RowSide rs = { (const uint32_t*)(ckb + lay.roff[0]), (const uint32_t*)(ckb + lay.roff[1]),
+                                     (const uint16_t*)(ckb + lay.roff[2]), (const uint16_t*)(ckb + lay.roff[3]), lay.nbx };
+                const size_t ldsx = (size_t)XB * 2 * K * (64 * NP) * sizeof(uint32_t);
+                WASS_HIP(c, hipFuncSetAttribute((const void*)k_pairx<NP, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx));
+                hipLaunchKernelGGL((k_pairx<NP, K, true>), dim3(2 * lay.nbx), dim3(64 * XB), ldsx, c->stream, C, S, ck, mn, rs, d.width1, d.h, d.P1,
+                                   d.P2, mseg, (const uint32_t*)(ck + (size_t)nch * mseg * (64 * NP)));
+            } else {
+                return set_err(c, WASS_ERR_UNSUPPORTED, "row fusion is not built for NP = %d", NP);
+            }
         } else if (lay.smode[f] == 0) WASS_PAIR(0);
         else if (lay.smode[f] == 1) WASS_PAIR(1);
         else WASS_PAIR(2);

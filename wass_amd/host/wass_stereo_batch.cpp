@@ -21,6 +21,7 @@
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <poll.h>
+#include <signal.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -246,8 +247,21 @@ int main(int argc, char* argv[])
             std::vector<int> who;
             for (int r = 0; r < world; ++r)
                 if (ch[r].open) { pf.push_back({ fds[r], POLLIN, 0 }); who.push_back(r); }
-            if (poll(pf.data(), pf.size(), -1) < 0) { if (errno == EINTR) continue; perror("poll"); ok = false; break; }
+            if (poll(pf.data(), pf.size(), -1) < 0) {
+                if (errno == EINTR) continue;
+                perror("poll");
+                ok = false;
+                // nobody will read the pipes any more: close them (a worker blocked in write() gets EPIPE and exits) and end
+                // the workers, so that the waitpid() below cannot hang
+                for (int r = 0; r < world; ++r)
+                    if (ch[r].open) { close(fds[r]); ch[r].open = false; kill(pids[r], SIGTERM); }
+                break;
+            }
             for (size_t q = 0; q < pf.size(); ++q) {
+                if (pf[q].revents & POLLNVAL) {             // not an open descriptor: would spin forever
+                    ch[who[q]].open = false; --live; ok = false;
+                    continue;
+                }
                 if (!(pf[q].revents & (POLLIN | POLLHUP | POLLERR))) continue;
                 Chan& c = ch[who[q]];
                 unsigned char tmp[16384];
