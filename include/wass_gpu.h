@@ -68,6 +68,13 @@ const char* wass_version(void);
  * buffer was last used by frame i-2) gets the transfer underneath frame i's kernels.  A kernel of the caller's own that
  * reads d_dst must be ordered by the caller (wass_ctx_synchronize, or pass the buffer through one of the calls above). */
 int wass_upload_async(wass_ctx* ctx, void* d_dst, const void* h_src, size_t nbytes);
+/* Device and pinned host memory for a host program that has no other GPU runtime of its own (the C++ sequence driver;
+ * bench.py and the tests use torch's allocator instead): hipMalloc / hipHostMalloc on the context's device.  Device
+ * memory comes back zero-filled.  Free with the matching call before the context is destroyed. */
+int wass_device_alloc(wass_ctx* ctx, size_t nbytes, void** d_out);
+void wass_device_free(wass_ctx* ctx, void* d_ptr);
+int wass_pinned_alloc(wass_ctx* ctx, size_t nbytes, void** h_out);
+void wass_pinned_free(wass_ctx* ctx, void* h_ptr);
 /* DISCARD_BURNED_AREAS (wass_stereo.cpp:1072,1086): d_mask[i] = d_img[i] <= 254, on the context's SGM stream; feeds the
  * left_mask / right_mask arguments of wass_triangulate_dev.  Both pointers 4-byte aligned. */
 int wass_burned_area_mask_dev(wass_ctx* ctx, const uint8_t* d_img, size_t n, uint8_t* d_mask);
@@ -307,10 +314,22 @@ typedef struct {
      * cannot return it): 1 = block cost + P2 left the int16 range where the reference is defined (the synchronous call
      * returns WASS_ERR_COST_OVERFLOW), -1 = unknown (the disparity did not come from this context's last two calls) */
     int      sgm_cost_overflow, sgm_timeout;
+    /* valid points the last wass_triangulate[_dev] call of this context produced ("N valid points found",
+     * wass_stereo.cpp:1374; the MIN_TRIANGULATED_POINTS test of :1993) -- counted on the device, no synchronisation */
+    uint64_t n_triangulated;
+    /* points written to inliers_dst by wass_mesh_finish_frame_async_ex (0 for the plain form or when RANSAC failed) */
+    uint64_t n_inliers_out;
 } wass_frame_result;
 int wass_mesh_finish_frame_async(wass_ctx* ctx, wass_mesh* m, double percentile, const int32_t* uv_triplets, int rounds,
                                  double ransac_thr, const wass_refine_params* rp, double max_distance, void* dst,
                                  size_t capacity);
+/* The same, and additionally what main() writes to plane_refinement_inliers.xyz (wass_stereo.cpp:2077-2085): every
+ * `inliers_every`-th refinement inlier (PovMesh.cpp:590-606) in raster order, selected on the device between the
+ * refinement and the final crop and downloaded next to the file image -- inliers_dst: pinned host memory for
+ * inliers_capacity points of 3 doubles (ceil(width*height / inliers_every) is always enough); NULL: not wanted. */
+int wass_mesh_finish_frame_async_ex(wass_ctx* ctx, wass_mesh* m, double percentile, const int32_t* uv_triplets, int rounds,
+                                    double ransac_thr, const wass_refine_params* rp, double max_distance, void* dst,
+                                    size_t capacity, double* inliers_dst, size_t inliers_capacity, int inliers_every);
 int wass_ctx_frame_result(wass_ctx* ctx, wass_frame_result* out);
 
 /* RT_from_plane (:1044-1069); pure host math */

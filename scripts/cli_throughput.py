@@ -25,6 +25,10 @@ ap.add_argument("--procs", default="1,2,4", help="worker processes per GPU to tr
 ap.add_argument("--threads", default="1", help="threads per worker process to try (each combined with every --procs value)")
 ap.add_argument("--replicate", type=int, default=1, help="extra copies of every workdir (inputs symlinked) so that a long sequence is cheap to set up")
 ap.add_argument("--skip-single", action="store_true", help="skip the one-process-per-frame runs")
+ap.add_argument("--decode", default="6", help="decode threads per worker to try (pipelined chain)")
+ap.add_argument("--writers", default="4", help="writer threads per worker to try")
+ap.add_argument("--stage-by-stage", action="store_true", help="also time the synchronous per-stage workers")
+ap.add_argument("--tmp", default=None, help="where the sequence lives (default: a fresh directory under the system's temp dir)")
 args = ap.parse_args()
 import numpy as np  # noqa: E402
 from test_cli import _write_xml  # noqa: E402
@@ -48,7 +52,7 @@ def _write_png(path, img):                      # zlib level 1: the inputs only 
 
 w, h, D = bench.CONFIGS[args.config]
 cli = build.build_host()
-tmp = tempfile.mkdtemp(prefix="wass_cli_")
+tmp = tempfile.mkdtemp(prefix="wass_cli_", dir=args.tmp)
 seq = os.path.join(tmp, "output")
 rig = synth.rig_geometry(w, h)
 cfg = os.path.join(tmp, "stereo_config.txt")
@@ -92,10 +96,32 @@ for dbg in (() if args.skip_single else ("1", "0")):
     print(f"wass_stereo, one process per frame, debug pictures {'on' if dbg == '1' else 'off'}: {min(ts):.2f} s/frame (best of {len(ts)})")
     if dbg == "0":
         print("  time table of the last run:\n" + "\n".join(l for l in r.stdout.splitlines() if "|" in l and "P|" not in l))
-for procs, thr in [(int(x), int(y)) for x in args.procs.split(",") for y in args.threads.split(",")]:
-    t, r = timed([build.BATCH, cfg, "--sequence", seq, "--procs-per-gpu", str(procs), "--threads-per-proc", str(thr)])
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    print(f"wass_stereo_batch, {procs} worker process(es) x {thr} thread(s) on one GPU, {nframes} frames: {t:.2f} s total = {t / nframes:.3f} s/frame = "
-          f"{nframes / t:.2f} frames/s")
+def clean():
+    for i in range(nframes):
+        for f in ("mesh_cam.xyzC", "plane.txt", "plane_refinement_inliers.xyz"):
+            try:
+                os.remove(os.path.join(seq, "%06d_wd" % i, f))
+            except OSError:
+                pass
+
+
+for procs in [int(x) for x in args.procs.split(",")]:
+    for dec in [int(x) for x in args.decode.split(",")]:
+        for wr in [int(x) for x in args.writers.split(",")]:
+            for extra in ((), ("--no-inliers-file",)):
+                clean()
+                t, r = timed([build.BATCH, cfg, "--sequence", seq, "--procs-per-gpu", str(procs), "--decode-threads", str(dec), "--writer-threads", str(wr), *extra])
+                assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+                print(f"wass_stereo_batch pipelined, {procs} worker(s), {dec} decode + {wr} writer threads{' ' + extra[0] if extra else ''}, {nframes} frames: "
+                      f"{t:.2f} s total = {nframes / t:.2f} frames/s   [{r.stdout.strip().splitlines()[-1]}]")
+if args.stage_by_stage:
+    for procs, thr in [(int(x), int(y)) for x in args.procs.split(",") for y in args.threads.split(",")]:
+        clean()
+        t, r = timed([build.BATCH, cfg, "--sequence", seq, "--procs-per-gpu", str(procs), "--threads-per-proc", str(thr), "--stage-by-stage"])
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        print(f"wass_stereo_batch stage by stage, {procs} worker process(es) x {thr} thread(s) on one GPU, {nframes} frames: {t:.2f} s total = "
+              f"{nframes / t:.2f} frames/s")
 log = open(os.path.join(seq, "%06d_wd" % (nframes - 1), "wass_stereo_log.txt")).read()
-print("  time table of the last frame of the batch (persistent context):\n" + "\n".join(l for l in log.splitlines() if "|" in l and "P|" not in l))
+print("  time table of the last frame of the last run:\n" + "\n".join(l for l in log.splitlines() if "|" in l and "P|" not in l))
+import shutil  # noqa: E402
+shutil.rmtree(tmp, ignore_errors=True)

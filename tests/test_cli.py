@@ -190,7 +190,68 @@ def test_no_gpu_is_a_loud_failure(cli, tmp_path):
     assert not os.path.exists(os.path.join(wd, "mesh_cam.xyzC"))
 
 
+def test_no_gpu_is_a_loud_failure_in_the_pipelined_chain_too(cli, tmp_path):
+    """WASS_DEBUG_IMAGES=0 sends the frame through the device-resident chain (frame_pipeline.hpp): same loud failure, same
+    host-side files (they are written before the GPU is needed), a log in the workdir."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    wd, cfg, *_ = make_workdir(str(tmp_path), 64, 48, 16)
+    r = subprocess.run([cli, cfg, wd], capture_output=True, text=True, env=dict(os.environ, WASS_DEBUG_IMAGES="0"))
+    assert r.returncode == 255 and "no usable MI355X GPU" in r.stdout and "[P|10|100]" in r.stdout
+    assert not os.path.exists(os.path.join(wd, "mesh_cam.xyzC"))
+    log = open(os.path.join(wd, "wass_stereo_log.txt")).read()
+    assert "no usable MI355X GPU" in log and "load_data [info ] image 0 loaded, Size: 64x48" in log and "[P|" not in log
+    for name in ("P0cam.txt", "Cam1_poseT.txt", "H0_rect.txt", "stereo_config.txt", "K0_small.txt", "scale.txt", "00000000_s.png"):
+        assert os.path.exists(os.path.join(wd, name)), name
+
+
 # ------------------------------------------------------------------ GPU: BASELINE config A through the CLI
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", ["", "USE_CUSTOM_STEREORECTIFY=false\n", "DENSE_PATHS=8\nMEDIAN_FILTER_WSIZE=3\nDISCARD_BURNED_AREAS=false\n"])
+def test_pipelined_chain_writes_the_files_of_the_stage_by_stage_calls(cli, tmp_path, extra):
+    """wass_stereo runs a frame through the host-sync-free device chain when the debug pictures are off and through the
+    synchronous per-stage calls when they are on: every file a tool reads must come out the same, byte for byte, and the
+    log must carry the same numbers."""
+    import shutil
+    w, h, D = 400, 300, 64
+    wd, cfg, *_ = make_workdir(str(tmp_path), w, h, D, extra_cfg=extra)
+    wd2 = os.path.join(str(tmp_path), "pipelined_wd")
+    shutil.copytree(wd, wd2)
+    a = subprocess.run([cli, cfg, wd], capture_output=True, text=True, env=dict(os.environ, WASS_DEBUG_IMAGES="1"))
+    b = subprocess.run([cli, cfg, wd2], capture_output=True, text=True, env=dict(os.environ, WASS_DEBUG_IMAGES="0"))
+    assert a.returncode == 0 and b.returncode == 0, a.stdout[-2000:] + b.stdout[-2000:]
+    assert "GPU pipeline" in b.stdout and "GPU pipeline" not in a.stdout          # which path ran is visible in the time table
+    for name in ("mesh_cam.xyzC", "plane.txt", "plane_refinement_inliers.xyz", "P0cam.txt", "P1cam.txt", "Cam0_poseR.txt", "Cam1_poseT.txt",
+                 "K0_small.txt", "K1_small.txt", "scale.txt", "00000000_s.png", "00000001_s.png", "stereo_config.txt") + \
+            (() if "USE_CUSTOM_STEREORECTIFY=false" in extra else ("H0_rect.txt", "H1_rect.txt")):
+        assert open(os.path.join(wd, name), "rb").read() == open(os.path.join(wd2, name), "rb").read(), name
+    for marker in ("[P|10|100]", "[P|20|100]", "[P|40|100]", "[P|60|100]", "[P|80|100]", "[P|90|100]", "[P|100|100]", "All done."):
+        assert marker in b.stdout
+    import re
+    def numbers(out):                                          # the log lines that carry results
+        keep = ("valid points found", "biggest component size", "ransac rounds", "ransac plane coeffs", "refinement inliers",
+                "estimated plane coeffs", "number of points after plane cropping", "total data size", "rectification map generated")
+        return [l for l in out.splitlines() if any(k in l for k in keep)]
+    assert numbers(a.stdout) == numbers(b.stdout) and len(numbers(a.stdout)) == 9
+    log = open(os.path.join(wd2, "wass_stereo_log.txt")).read()
+    assert "[P|" not in log and log.count("Reconstructing") == 1 and "All done." in log
+
+
+@pytest.mark.gpu
+def test_pipelined_chain_too_few_points(cli, tmp_path):
+    """Untextured input through the device chain: the point count arrives with the result record, the frame fails like the
+    reference (:1993) and leaves no plane.txt / mesh_cam.xyzC behind."""
+    wd, cfg, *_ = make_workdir(str(tmp_path), 160, 120, 32)
+    flat = np.full((120, 160), 90, np.uint8)
+    _write_png(os.path.join(wd, "undistorted", "00000000.png"), flat)
+    _write_png(os.path.join(wd, "undistorted", "00000001.png"), flat)
+    r = subprocess.run([cli, cfg, wd], capture_output=True, text=True, env=dict(os.environ, WASS_DEBUG_IMAGES="0"))
+    assert r.returncode == 255 and "Too few points triangulated" in r.stdout
+    assert not os.path.exists(os.path.join(wd, "mesh_cam.xyzC")) and not os.path.exists(os.path.join(wd, "plane.txt"))
+
+
+
 @pytest.mark.gpu
 def test_config_a_end_to_end_matches_oracle_chain(cli, tmp_path, oracle):
     w, h, D = 640, 480, 64

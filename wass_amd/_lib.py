@@ -42,7 +42,8 @@ class FrameResult(C.Structure):
                 ("refine_ok", C.c_int), ("ransac_plane", C.c_double * 4), ("ransac_inliers", C.c_uint64),
                 ("plane", C.c_double * 4), ("refine_inliers", C.c_uint64), ("kept_after_ransac_crop", C.c_uint64),
                 ("kept_final", C.c_uint64), ("n_points", C.c_uint64), ("xyzc_bytes", C.c_uint64),
-                ("sgm_cost_overflow", C.c_int), ("sgm_timeout", C.c_int)]
+                ("sgm_cost_overflow", C.c_int), ("sgm_timeout", C.c_int), ("n_triangulated", C.c_uint64),
+                ("n_inliers_out", C.c_uint64)]
 
 
 class GridSetup(C.Structure):
@@ -130,7 +131,13 @@ SYMBOLS = {
     "wass_mesh_encode_xyzc_to": (_i, [_vp, _vp, C.POINTER(C.c_double), _vp, _sz, C.POINTER(_sz)]),
     "wass_mesh_encode_xyzc_async": (_i, [_vp, _vp, C.POINTER(C.c_double), _vp, _sz, C.POINTER(_sz)]),
     "wass_mesh_finish_frame_async": (_i, [_vp, _vp, C.c_double, _vp, _i, C.c_double, C.POINTER(RefineParams), C.c_double, _vp, _sz]),
+    "wass_mesh_finish_frame_async_ex": (_i, [_vp, _vp, C.c_double, _vp, _i, C.c_double, C.POINTER(RefineParams), C.c_double, _vp, _sz,
+                                             _vp, _sz, _i]),
     "wass_ctx_frame_result": (_i, [_vp, C.POINTER(FrameResult)]),
+    "wass_device_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "wass_device_free": (None, [_vp, _vp]),
+    "wass_pinned_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "wass_pinned_free": (None, [_vp, _vp]),
     "wass_free": (None, [_vp]),
     "wass_mesh_grid_idw": (_i, [_vp, _vp, C.POINTER(GridSetup), _vp, _vp]),
     "wass_planes_mean_accumulate": (None, [C.POINTER(C.c_double), _i, C.POINTER(C.c_double)]),

@@ -125,7 +125,7 @@ void wass_ctx_destroy(wass_ctx* c)
     mesh_pool_ctx_alive(c, false);
     mesh_pool_purge(c);
     for (Buf* b : { &c->img1, &c->img2, &c->bt1, &c->bt2, &c->hsum, &c->C, &c->S, &c->ckpt, &c->sel_d16, &c->sel_key, &c->raw,
-                    &c->flags, &c->tmp_in0, &c->tmp_in1, &c->tmp_out, &c->tmp_mask, &c->fA, &c->fB, &c->fC, &c->fD, &c->fE, &c->uf, &c->rs_r, &c->rs_l, &c->raw2, &c->grid, &c->scratch, &c->counters, &c->dstate, &c->rect_tab, &c->rect_mx, &c->rect_my, &c->xyzc, &c->limits })
+                    &c->flags, &c->tmp_in0, &c->tmp_in1, &c->tmp_out, &c->tmp_mask, &c->fA, &c->fB, &c->fC, &c->fD, &c->fE, &c->uf, &c->rs_r, &c->rs_l, &c->raw2, &c->grid, &c->scratch, &c->counters, &c->tri_cnt, &c->inl, &c->dstate, &c->rect_tab, &c->rect_mx, &c->rect_my, &c->xyzc, &c->limits })
         release(*b);
     for (auto& set : c->evs) for (auto& e : set) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_ckpt) if (e) (void)hipEventDestroy(e);
@@ -179,6 +179,36 @@ int wass_ctx_wait_for_stream(wass_ctx* c, void* producer_stream)
     WASS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_producer, 0));
     WASS_HIP(c, hipStreamWaitEvent(c->tail, c->ev_producer, 0));
     return WASS_OK;
+}
+
+int wass_device_alloc(wass_ctx* c, size_t nbytes, void** d_out)
+{
+    if (!c || !d_out || nbytes == 0) return set_err(c, WASS_ERR_INVALID_ARG, "bad argument");
+    WASS_HIP(c, hipSetDevice(c->device));
+    *d_out = nullptr;
+    if (hipMalloc(d_out, nbytes) != hipSuccess) { *d_out = nullptr; return set_err(c, WASS_ERR_NO_MEMORY, "hipMalloc(%zu) failed", nbytes); }
+    WASS_HIP(c, hipMemset(*d_out, 0, nbytes));
+    return WASS_OK;
+}
+void wass_device_free(wass_ctx* c, void* d_ptr)
+{
+    if (!c || !d_ptr) return;
+    (void)hipSetDevice(c->device);
+    (void)hipFree(d_ptr);
+}
+int wass_pinned_alloc(wass_ctx* c, size_t nbytes, void** h_out)
+{
+    if (!c || !h_out || nbytes == 0) return set_err(c, WASS_ERR_INVALID_ARG, "bad argument");
+    WASS_HIP(c, hipSetDevice(c->device));
+    *h_out = nullptr;
+    if (hipHostMalloc(h_out, nbytes, hipHostMallocDefault) != hipSuccess) { *h_out = nullptr; return set_err(c, WASS_ERR_NO_MEMORY, "hipHostMalloc(%zu) failed", nbytes); }
+    return WASS_OK;
+}
+void wass_pinned_free(wass_ctx* c, void* h_ptr)
+{
+    if (!c || !h_ptr) return;
+    (void)hipSetDevice(c->device);
+    (void)hipHostFree(h_ptr);
 }
 
 int wass_ctx_set_tail_overlap(wass_ctx* c, int on)

@@ -126,12 +126,15 @@ struct wass_ctx {
     wass::Buf raw2;                // speckle filter: median-filtered padded disparity
     wass::Buf grid;                // wass_mesh_grid_idw: accumulators and maps of the surface grid (grid.hip)
     wass::Buf counters;            // striped atomics of the mesh stages
+    wass::Buf tri_cnt;             // striped count of the points the last triangulation produced (read by the frame tail)
+    wass::Buf inl;                 // every n-th refinement inlier of the frame tail (plane_refinement_inliers.xyz)
     wass::Buf dstate;              // device-resident scalar record + radix histogram (mesh.hip DevState)
     wass::Buf scratch;             // mesh stages: gaps / labels / partial sums / packed output
     wass::Buf xyzc;                // packed u16 triples of mesh_cam.xyzC (own buffer: downloaded asynchronously)
     wass::Buf limits;              // striped min/max keys of the frame tail
     void* h_frame = nullptr;       // pinned: device state record of the last wass_mesh_finish_frame_async
     bool frame_pending = false;
+    int frame_inl_every = 0;       // > 0: the pending frame also selected every n-th refinement inlier
     unsigned long long frame_sgm_call = 0;   // 1-based index of the SGM call whose disparity the pending frame was built from
     void* h_stage = nullptr;       // pinned source images of the frame tail's small H2D copies (mesh.hip host_stage)
     hipEvent_t ev_stage = nullptr;

@@ -391,6 +391,8 @@ struct DevState {
     double mn[3], sc[3];
     unsigned int npts, have_plane;
     unsigned long long kept1, kept2;
+    unsigned long long ntri;                              // valid points the triangulation produced
+    unsigned int ninl_sel, pad2;                          // refinement inliers seen by the selection for plane_refinement_inliers.xyz
 };
 
 // z gaps computed on the fly (no gap array): histogram of one 11-bit digit of the fp64 bit patterns that match the
@@ -1204,8 +1206,12 @@ int wass_triangulate_dev(wass_ctx* c, const float* d_disp, int W, int H, const i
     memcpy(gd.P1, g->P1, sizeof gd.P1); memcpy(gd.P2, g->P2, sizeof gd.P2);
     memcpy(gd.HLi, g->HLi, sizeof gd.HLi); memcpy(gd.HRi, g->HRi, sizeof gd.HRi);
     gd.comp_over_scale = g->disparity_compensation / g->dense_scale;
+    // counted into a buffer of its own: the frame tail (wass_mesh_finish_frame_async) reports it, long after the shared
+    // counters have been reused by the plane stages
     unsigned long long* cnt = nullptr;
-    if ((rc = counters_reset(c, &cnt))) { wass_mesh_destroy(m); return rc; }
+    if ((rc = ensure(c, c->tri_cnt, (size_t)NSLOT * 8))) { wass_mesh_destroy(m); return rc; }
+    cnt = (unsigned long long*)c->tri_cnt.p;
+    if (hipMemsetAsync(cnt, 0, (size_t)NSLOT * 8, c->ts()) != hipSuccess) { wass_mesh_destroy(m); return set_err(c, WASS_ERR_DEVICE, "memset failed"); }
     dim3 grid((m->w + 255) / 256, std::min(m->h, 512));
     hipLaunchKernelGGL(k_triangulate, grid, dim3(256), 0, c->ts(), d_disp, W, H, roi_l[0], roi_r[0], roi_r[1], m->w, m->h,
                        gd, d_right_img, img_w, img_h, d_lmask, d_rmask, tp->min_angle_deg, tp->bbox[0], tp->bbox[1],
@@ -1411,14 +1417,15 @@ __global__ void __launch_bounds__(256) k_crop_limits_counts_dev(uint8_t* __restr
 }
 // frame tail: limits -> scale factors, and the 148-byte header of the file image (PovMesh.cpp:417-436)
 __global__ void k_frame_header(DevState* __restrict__ ds, const unsigned long long* __restrict__ lim, const unsigned int* __restrict__ total,
-                               const unsigned long long* __restrict__ kept /* [2][NSLOT] */, unsigned char* __restrict__ img)
+                               const unsigned long long* __restrict__ kept /* [2][NSLOT] */, unsigned char* __restrict__ img,
+                               const unsigned long long* __restrict__ tri /* [NSLOT] or null */, const unsigned int* __restrict__ inl_total /* or null */)
 {
     if (blockIdx.x) return;
     {
-        unsigned long long k1 = 0, k2 = 0;
-        for (int i = threadIdx.x; i < NSLOT; i += 64) { k1 += kept[i]; k2 += kept[NSLOT + i]; }
-        for (int o = 32; o > 0; o >>= 1) { k1 += __shfl_down(k1, o); k2 += __shfl_down(k2, o); }
-        if (threadIdx.x == 0) { ds->kept1 = k1; ds->kept2 = k2; }
+        unsigned long long k1 = 0, k2 = 0, k3 = 0;
+        for (int i = threadIdx.x; i < NSLOT; i += 64) { k1 += kept[i]; k2 += kept[NSLOT + i]; k3 += tri ? tri[i] : 0ull; }
+        for (int o = 32; o > 0; o >>= 1) { k1 += __shfl_down(k1, o); k2 += __shfl_down(k2, o); k3 += __shfl_down(k3, o); }
+        if (threadIdx.x == 0) { ds->kept1 = k1; ds->kept2 = k2; ds->ntri = k3; ds->ninl_sel = inl_total && ds->ransac_found ? *inl_total : 0u; }
     }
     unsigned long long hl[6] = { ~0ull, ~0ull, ~0ull, 0, 0, 0 };
     for (int i = threadIdx.x; i < NSLOT; i += 64)
@@ -1895,7 +1902,15 @@ int wass_mesh_fit_plane(wass_ctx* c, wass_mesh* m, const int32_t* uv, int rounds
 int wass_mesh_finish_frame_async(wass_ctx* c, wass_mesh* m, double percentile, const int32_t* uv, int rounds, double ransac_thr,
                                  const wass_refine_params* rp, double max_distance, void* dst, size_t capacity)
 {
+    return wass_mesh_finish_frame_async_ex(c, m, percentile, uv, rounds, ransac_thr, rp, max_distance, dst, capacity, nullptr, 0, 0);
+}
+
+int wass_mesh_finish_frame_async_ex(wass_ctx* c, wass_mesh* m, double percentile, const int32_t* uv, int rounds, double ransac_thr,
+                                    const wass_refine_params* rp, double max_distance, void* dst, size_t capacity,
+                                    double* inliers_dst, size_t inliers_capacity, int inliers_every)
+{
     if (!c || !m || !dst) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    if (inliers_dst && (inliers_every <= 0 || inliers_capacity == 0)) return set_err(c, WASS_ERR_INVALID_ARG, "bad inlier selection");
     WASS_HIP(c, hipSetDevice(c->device));
     const size_t n = m->n();
     if (capacity < 148 + n * 6)
@@ -1913,6 +1928,31 @@ int wass_mesh_finish_frame_async(wass_ctx* c, wass_mesh* m, double percentile, c
     const size_t need = 64 + (size_t)nb * 4 + 16;
     if (c->scratch.cap < need && (rc = ensure(c, c->scratch, need))) return rc;
     hipStream_t s = c->ts();
+    // plane_refinement_inliers.xyz: the refinement inliers are the points that survived the crop by the RANSAC plane, which
+    // enqueue_fit_plane has just applied; the final crop (below) has not run yet -- the point main() collects them at
+    size_t inl_copy = 0;
+    unsigned int* inl_total = nullptr;
+    if (inliers_dst) {
+        RefineDev rd;
+        rd.xmin = rp->xmin; rd.xmax = rp->xmax; rd.ymin = rp->ymin; rd.ymax = rp->ymax; rd.maxd = rp->max_distance;
+        rd.weighted = rp->weight_by_distance;
+        rd.umin = rp->central_third_only ? m->w / 4 : 0;
+        rd.umax = rp->central_third_only ? m->w * 3 / 4 : m->w - 1;
+        rd.vmin = rp->central_third_only ? m->h / 4 : 0;
+        rd.vmax = rp->central_third_only ? m->h * 2 / 3 : m->h - 1;
+        const size_t cap = (n + (size_t)inliers_every - 1) / (size_t)inliers_every;
+        if (inliers_capacity < cap) return set_err(c, WASS_ERR_INVALID_ARG, "inliers_dst must hold %zu points", cap);
+        if ((rc = ensure(c, c->inl, cap * 24 + 256))) return rc;
+        inl_total = (unsigned int*)c->inl.p;                       // [0]: number of refinement inliers; points from byte 256
+        unsigned int* bc = (unsigned int*)((char*)c->scratch.p + 64);
+        double* dout = (double*)((char*)c->inl.p + 256);
+        WASS_HIP(c, hipStreamWaitEvent(s, c->ev_copy, 0));        // the previous frame's download of this buffer
+        hipLaunchKernelGGL(k_inlier_counts, dim3(nb), dim3(256), 0, s, m->valid, m->x, m->y, m->z, m->w, n, rd, bc);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, bc, (int)nb, inl_total);
+        hipLaunchKernelGGL(k_inlier_pack, dim3(nb), dim3(256), 0, s, m->valid, m->x, m->y, m->z, m->w, n, rd, (const unsigned int*)bc,
+                           (unsigned)inliers_every, dout);
+        inl_copy = cap * 24;
+    }
     hipLaunchKernelGGL(k_frame_rt, dim3(1), dim3(64), 0, s, ds);
     unsigned char* stage = nullptr;
     if ((rc = host_stage(c, &stage))) return rc;
@@ -1927,7 +1967,7 @@ int wass_mesh_finish_frame_async(wass_ctx* c, wass_mesh* m, double percentile, c
                        (const DevState*)ds, max_distance, kept1 + NSLOT, lim, bcnt, nb);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, bcnt, (int)nb, total);
     hipLaunchKernelGGL(k_frame_header, dim3(1), dim3(64), 0, s, ds, (const unsigned long long*)lim, (const unsigned int*)total,
-                       (const unsigned long long*)kept1, img);
+                       (const unsigned long long*)kept1, img, (const unsigned long long*)c->tri_cnt.p, (const unsigned int*)inl_total);
     hipLaunchKernelGGL(k_xyzc_pack_dev, dim3(nb), dim3(256), 0, s, m->valid, m->x, m->y, m->z, n, (const DevState*)ds,
                        (const unsigned int*)bcnt, (uint16_t*)(img + 148));
     WASS_HIP(c, hipGetLastError());
@@ -1935,7 +1975,9 @@ int wass_mesh_finish_frame_async(wass_ctx* c, wass_mesh* m, double percentile, c
     WASS_HIP(c, hipStreamWaitEvent(c->copy, c->ev_pack, 0));
     WASS_HIP(c, hipMemcpyAsync(c->h_frame, ds, sizeof(DevState), hipMemcpyDeviceToHost, c->copy));
     WASS_HIP(c, hipMemcpyAsync(dst, img, 148 + n * 6, hipMemcpyDeviceToHost, c->copy));
+    if (inl_copy) WASS_HIP(c, hipMemcpyAsync(inliers_dst, (const char*)c->inl.p + 256, inl_copy, hipMemcpyDeviceToHost, c->copy));
     WASS_HIP(c, hipEventRecord(c->ev_copy, c->copy));
+    c->frame_inl_every = inliers_dst ? inliers_every : 0;
     c->frame_pending = true;
     c->frame_sgm_call = c->nsgm;              // the SGM call that fed this frame is the last one enqueued (0: none)
     return WASS_OK;
@@ -1955,6 +1997,8 @@ int wass_ctx_frame_result(wass_ctx* c, wass_frame_result* out)
     if (h.ransac_found) { out->kept_after_ransac_crop = h.kept1; out->kept_final = h.kept2; out->refine_inliers = (uint64_t)(h.ninl + 0.5); }
     out->n_points = h.npts;
     out->xyzc_bytes = 148 + (uint64_t)h.npts * 6;
+    out->n_triangulated = h.ntri;
+    out->n_inliers_out = c->frame_inl_every > 0 ? ((uint64_t)h.ninl_sel + (uint64_t)c->frame_inl_every - 1) / (uint64_t)c->frame_inl_every : 0;
     if (c->frame_sgm_call > 0 && c->nsgm - c->frame_sgm_call < 2) {
         // status word of the frame's SGM call: copied to pinned memory in stream order long before the download this
         // function has just waited for; the slot is reused two calls later

@@ -337,6 +337,10 @@ static int launch_resample(wass_ctx* c, bool cubic, const uint8_t* d_src, int sw
     }
     int rc = ensure_tables(c);
     if (rc) return rc;
+    // a source (or a map) that is still on its way up through wass_upload_async
+    if ((rc = wait_uploads(c, d_src, c->stream)) || (d_mx && (rc = wait_uploads(c, d_mx, c->stream))) ||
+        (d_my && (rc = wait_uploads(c, d_my, c->stream))))
+        return rc;
     const dim3 block(64, 4), grid((ow + 63) / 64, (oh + 3) / 4);
     const short* tab = (const short*)c->rect_tab.p;
     if (cubic) {

@@ -1,0 +1,586 @@
+// frame_pipeline.hpp -- the device-resident, host-sync-free frame chain of the C++ drop-in: what wass_stereo's main()
+// (/root/reference/src/wass_stereo/wass_stereo.cpp:1833-2147) does with one workdir, cut into three phases that run on
+// different threads for different frames at the same time:
+//
+//   prepare(job)   any thread   configuration echo, calibration, PNG inflation, previews, camera files, the rectification's
+//                               decisions (rectify_plan) -- host only, nothing of it touches the GPU
+//   submit(job)    owner thread both pictures to HBM (wass_upload_async, one frame ahead), rectification resampling
+//                               (wass_warp_perspective_dev / wass_remap_cubic_dev), wass_sgm_disparity_dev, disparity clean-up,
+//                               wass_triangulate_dev and the whole mesh tail (wass_mesh_finish_frame_async_ex) enqueued on the
+//                               context's streams WITHOUT a host synchronisation; hands back the PREVIOUS frame, whose one
+//                               result record and file image have arrived meanwhile
+//   finish(job)    any thread   the log lines that carry numbers (from the result record), plane.txt,
+//                               plane_refinement_inliers.xyz, mesh_cam.xyzC, the time table, wass_stereo_log.txt
+//
+// Same files, byte for byte, as the stage-by-stage wass_run_frame (tests/test_batch_driver.py, tests/test_cli.py); used by
+// wass_stereo_batch for every frame and by wass_stereo for its single frame whenever the configuration allows it
+// (pipeline_eligible: the options that need an intermediate mesh or map on the host keep the stage-by-stage calls).
+#pragma once
+
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+
+#include "wass_frame.hpp"
+
+namespace wassframe {
+
+inline bool pipeline_eligible(const Config& cfg, std::string* why = nullptr)
+{
+    auto no = [&](const char* w) { if (why) *why = w; return false; };
+    if (cfg.get_double("DENSE_SCALE") != 1.0) return no("DENSE_SCALE != 1 (maps of two sizes)");
+    if (cfg.get_bool("SAVE_FULL_MESH")) return no("SAVE_FULL_MESH (the mesh before the plane stages goes to the host)");
+    if (cfg.get_bool("SAVE_AS_PLY")) return no("SAVE_AS_PLY (the whole mesh goes to the host)");
+    if (!cfg.get_bool("SAVE_COMPRESSED")) return no("SAVE_COMPRESSED=false (the whole mesh goes to the host)");
+    if (cfg.get_string("LEFT_MASK_IMAGE") != "none" || cfg.get_string("RIGHT_MASK_IMAGE") != "none") return no("mask images");
+    const int rounds = cfg.get_int("PLANE_RANSAC_ROUNDS");
+    if (rounds <= 0 || rounds > 1800) return no("PLANE_RANSAC_ROUNDS outside 1..1800");
+    return true;
+}
+
+struct FrameJob {
+    size_t index = 0;
+    std::string workdir;
+    Env env;
+    std::string log;                 // the frame's wass_stereo_log.txt, in the order the reference writes it
+    int rc = 0;                      // -1: the frame failed (the log says why)
+    bool skipped = false;            // --skip-existing: nothing to do, summary read back from plane.txt
+    bool staged = false;
+    unsigned int ransac_seed = 0;
+    int in_slot = -1, out_slot = -1;
+    long long sgm_call = -1;         // which wass_sgm_disparity_dev call of the pipeline's context produced the frame's disparity
+    double t_prepare0 = 0, t_loaded = 0, t_planned = 0, t_submit0 = 0, t_submitted = 0, t_result = 0;
+    wass_frame_result res{};
+    wass_sgm_timings sgm{};
+    bool have_sgm = false;
+    FrameSummary summary;
+};
+
+class FramePipeline {
+public:
+    static constexpr int NIN = 3;    // input sets: frame n+1 is uploaded while frame n runs and frame n-1's tail still reads its picture
+    struct Options {
+        int out_slots = 4;           // pinned output sets (file image + inlier points) that writer threads may hold at once
+        bool inliers_file = true;    // plane_refinement_inliers.xyz (a debug artefact of the reference; 14 MB of text per 5-megapixel frame)
+        bool live = false;           // single-frame executable: echo log and progress markers to stdout as the phases end
+    };
+
+    // The context is created on `device` when the first frame needs the GPU (as wass_stereo does: a sequence whose frames
+    // are all finished, or all unreadable, never initialises HIP); a frame that finds no GPU fails loudly.
+    FramePipeline(int device, const Config& cfg, const std::string& config_path, const Options& opt)
+        : device_(device), cfg_(cfg), config_path_(config_path), opt_(opt)
+    {
+        sp_.min_disp = cfg.get_int("MIN_DISPARITY");
+        sp_.num_disp = cfg.get_int("MAX_DISPARITY");
+        sp_.win = cfg.get_int("WINSIZE");
+        sp_.P1 = cfg.get_int("DENSE_P1_MULT") * sp_.win * sp_.win;
+        sp_.P2 = cfg.get_int("DENSE_P2_MULT") * sp_.win * sp_.win;
+        sp_.uniq_ratio = cfg.get_int("DENSE_UNIQUENESS_RATIO");
+        sp_.disp12_max_diff = cfg.get_int("DENSE_DISP12MAXDIFF");
+        sp_.prefilter_cap = cfg.get_int("DENSE_PREFILTER_CAP");
+        sp_.speckle_win = cfg.get_int("DENSE_SPECKLE_WINDOW_SIZE");
+        sp_.speckle_range = cfg.get_int("DENSE_SPECKLE_RANGE");
+        sp_.ndirs = cfg.get_int("DENSE_PATHS");
+        sp_.disp_offset = cfg.get_int("DISPARITY_OFFSET");
+        sp_.dense_scale = cfg.get_double("DENSE_SCALE");
+        rp_.xmin = cfg.get_double("PLANE_REFINE_XMIN"); rp_.xmax = cfg.get_double("PLANE_REFINE_XMAX");
+        rp_.ymin = cfg.get_double("PLANE_REFINE_YMIN"); rp_.ymax = cfg.get_double("PLANE_REFINE_YMAX");
+        rp_.max_distance = cfg.get_double("PLANE_REFINEMENT_MAX_DISTANCE");
+        rp_.weight_by_distance = cfg.get_bool("PLANE_WEIGHT_PROPORTIONAL_TO_DISTANCE");
+        rp_.central_third_only = cfg.get_bool("PLANE_USE_CENTRAL_THIRD_ONLY");
+        out_free_.assign((size_t)std::max(1, opt_.out_slots), true);
+        out_.resize(out_free_.size());
+    }
+    ~FramePipeline()
+    {
+        if (!ctx_) return;
+        (void)wass_ctx_synchronize(ctx_);
+        release_buffers();
+        for (auto& o : out_) { if (o.xyzc) wass_pinned_free(ctx_, o.xyzc); if (o.inl) wass_pinned_free(ctx_, o.inl); }
+        wass_ctx_destroy(ctx_);
+    }
+    // the pipeline's context, created if need be (owner thread); nullptr when there is no usable GPU
+    wass_ctx* context()
+    {
+        if (!ctx_ && !ctx_failed_) {
+            if (wass_ctx_create(device_, &ctx_) != WASS_OK) { ctx_ = nullptr; ctx_failed_ = true; }
+            else if (wass_ctx_set_tail_overlap(ctx_, 1) != WASS_OK) { wass_ctx_destroy(ctx_); ctx_ = nullptr; ctx_failed_ = true; }
+        }
+        return ctx_;
+    }
+    FramePipeline(const FramePipeline&) = delete;
+    FramePipeline& operator=(const FramePipeline&) = delete;
+
+    // ---- phase 1 (any thread, host only): wass_stereo.cpp:1840-1908 without the resampling
+    void prepare(FrameJob& job) const
+    {
+        LogSinkScope sink(&job.log);
+        job.t_prepare0 = Timer::now();
+        job.env.workdir = job.workdir;
+        Env& env = job.env;
+        WLOG_SCOPE("wass_stereo");
+        try {
+            WLOGI << "Loading configuration file " << config_path_;
+            if (save_configuration(cfg_, path_join(env.workdir, "stereo_config.txt")) != 0) WLOGE << "Unable to save stereo configuration file";
+            job.ransac_seed = (unsigned int)time(0);
+            if (cfg_.get_int("RANDOM_SEED") != -1) { job.ransac_seed = (unsigned int)cfg_.get_int("RANDOM_SEED"); WLOGI << "random seed set to: " << cfg_.get_int("RANDOM_SEED"); }
+            WLOGI << "Reconstructing " << env.workdir;
+            env.timer.start();
+            env.cam_distance = 1.0;
+            if (!load_data(env, cfg_, nullptr, nullptr)) { job.rc = -1; return; }
+            job.t_loaded = Timer::now();
+            marker(job, 10);
+            auto save_cams = [&]() {
+                save_matrix_txt(path_join(env.workdir, "P0cam.txt"), env.P0);
+                save_matrix_txt(path_join(env.workdir, "P1cam.txt"), env.P1);
+                save_matrix_txt(path_join(env.workdir, "Cam0_poseR.txt"), env.Rpose0);
+                save_matrix_txt(path_join(env.workdir, "Cam0_poseT.txt"), env.Tpose0);
+                save_matrix_txt(path_join(env.workdir, "Cam1_poseR.txt"), env.Rpose1);
+                save_matrix_txt(path_join(env.workdir, "Cam1_poseT.txt"), env.Tpose1);
+            };
+            save_cams();
+            if (!rectify_plan(env, cfg_)) { job.rc = -1; return; }
+            save_cams();
+            job.t_planned = Timer::now();
+        } catch (const std::exception& e) {
+            WLOG_SCOPE("wass_stereo");
+            WLOGE << e.what();
+            job.rc = -1;
+        }
+    }
+
+    // May the frame be staged AHEAD of its turn?  Only with the buffers as they are: a change of picture or ROI size
+    // re-allocates them, which must wait until the frames staged before it have been submitted.
+    bool same_geometry(const FrameJob& job) const
+    {
+        const Env& e = job.env;
+        return e.left.w == W_ && e.left.h == H_ && e.roi_l.width == cwl_ && e.roi_l.height == chl_ && e.roi_r.width == cwr_ && e.roi_r.height == chr_;
+    }
+    // ---- phase 2 (owner thread): the frame's pictures into the pinned ring and on their way to HBM.  Called for frame n+1
+    // right before frame n is submitted (when frame n+1 is ready by then), so that the transfer runs underneath frame n.
+    void stage(FrameJob& job)
+    {
+        if (job.staged || job.rc != 0 || job.skipped) return;
+        LogSinkScope sink(&job.log);
+        try {
+            const Env& env = job.env;
+            if (!context()) throw std::runtime_error("no usable MI355X GPU / HIP runtime (libwassgpu has no CPU fallback)");
+            ensure_buffers(env.left.w, env.left.h, env.roi_l, env.roi_r);
+            const int k = next_in_;
+            next_in_ = (next_in_ + 1) % NIN;
+            const size_t n = (size_t)W_ * H_;
+            memcpy(in_[k].h_l, env.left.px.data(), n);
+            memcpy(in_[k].h_r, env.right.px.data(), n);
+            check(wass_upload_async(ctx_, in_[k].d_l, in_[k].h_l, n), "wass_upload_async");
+            check(wass_upload_async(ctx_, in_[k].d_r, in_[k].h_r, n), "wass_upload_async");
+            job.in_slot = k;
+            job.staged = true;
+        } catch (const std::exception& e) {
+            WLOG_SCOPE("wass_stereo");
+            WLOGE << e.what();
+            job.rc = -1;
+        }
+    }
+
+    // Enqueues the frame and appends to `done` the frames that are complete as far as the GPU is concerned (at most the
+    // previous frame, and `job` itself if it cannot run), in submission order.  They go to finish().
+    void submit(FrameJob& job, std::vector<FrameJob*>& done)
+    {
+        if (job.rc != 0 || job.skipped) {                 // nothing to enqueue: keep the order
+            if (FrameJob* p = collect()) done.push_back(p);
+            done.push_back(&job);
+            return;
+        }
+        stage(job);
+        if (job.rc != 0) { if (FrameJob* p = collect()) done.push_back(p); done.push_back(&job); return; }
+        LogSinkScope sink(&job.log);
+        job.t_submit0 = Timer::now();
+        Env& env = job.env;
+        wass_mesh* mesh = nullptr;
+        try {
+            const int k = job.in_slot;
+            const int rl[4] = { env.roi_l.x, env.roi_l.y, env.roi_l.width, env.roi_l.height };
+            const int rr[4] = { env.roi_r.x, env.roi_r.y, env.roi_r.width, env.roi_r.height };
+            // ---- rectify(): the resampling (:515-528, 600-607), ROI crop fused, from the device-resident pictures
+            WLOG_SCOPE("rectify");
+            if (env.use_custom) {
+                check(wass_warp_perspective_dev(ctx_, in_[k].d_l, W_, H_, (size_t)W_, env.HL.d.data(), W_, H_, rl, in_[k].d_cl), "wass_warp_perspective");
+                check(wass_warp_perspective_dev(ctx_, in_[k].d_r, W_, H_, (size_t)W_, env.HR.d.data(), W_, H_, rl, in_[k].d_cr), "wass_warp_perspective");
+            } else {
+                ensure_maps(env);
+                check(wass_remap_cubic_dev(ctx_, in_[k].d_l, W_, H_, (size_t)W_, d_map_[0], d_map_[1], W_, H_, rl, in_[k].d_cl), "wass_remap_cubic");
+                check(wass_remap_cubic_dev(ctx_, in_[k].d_r, W_, H_, (size_t)W_, d_map_[2], d_map_[3], W_, H_, rr, in_[k].d_cr), "wass_remap_cubic");
+            }
+            WLOGI << "rectification map generated. Size: " << rl[2] << "x" << rl[3];
+            marker(job, 20);
+            const bool burned = cfg_.get_bool("DISCARD_BURNED_AREAS");
+            if (burned) {                                   // :1072,1086 -- the masks of the ORIGINAL pictures
+                const size_t n = (size_t)W_ * H_;
+                check(wass_burned_area_mask_dev(ctx_, in_[k].d_l, n, in_[k].d_ml), "wass_burned_area_mask");
+                check(wass_burned_area_mask_dev(ctx_, in_[k].d_r, n, in_[k].d_mr), "wass_burned_area_mask");
+            }
+            // ---- sgbm_dense_stereo (:764-1020)
+            WLOG_SCOPE("sgbm_dense_stereo");
+            const int cw = rr[2], ch = rr[3];
+            const int cc_threshold = cfg_.get_int("DENSE_DISPARITY_BIGGEST_COMPONENT_THRESHOLD");
+            WLOGI << "Disparity offset: " << sp_.disp_offset << " px";
+            env.disparity_compensation = sp_.disp_offset > 0 ? 0 : -sp_.disp_offset;
+            WLOGI << "Dense-stereo input resize: [" << cw << " x " << ch << "] -> [" << cw << " x " << ch << "]";
+            WLOGI << "computing dense disparity map... (may take a while)";
+            int16_t* d16 = d_disp16_[nsub_ & 1];
+            check(wass_sgm_disparity_dev(ctx_, in_[k].d_cr, in_[k].d_cl, cw, ch, (size_t)cw, &sp_, d16), "wass_sgm_disparity");
+            job.sgm_call = ++sgm_calls_;
+            const int dil = cfg_.get_int("DISP_DILATE_STEPS"), ero = cfg_.get_int("DISP_EROSION_STEPS"), med = cfg_.get_int("MEDIAN_FILTER_WSIZE");
+            if (dil > 0) WLOGI << "applying dilate filter (" << dil << " steps)"; else WLOGI << "dilate filter skipped.";
+            if (ero > 0) WLOGI << "applying erode filter (" << ero << " steps)"; else WLOGI << "erode filter skipped.";
+            if (med >= 3) WLOGI << "applying median filter (window size " << med << " px.)";
+            if (cc_threshold > 0) {
+                WLOGI << "extracting the biggest connected component from the disparity map";
+                WLOGI << "assuming a sq gradient magnitude of " << cc_threshold;
+            }
+            check(wass_disparity_postprocess_ex_dev(ctx_, d16, cw, ch, &sp_, dil, ero, med, cc_threshold, cw, ch, d_dispf_), "wass_disparity_postprocess");
+            WLOGI << "dense stereo completed successfully";
+            marker(job, 40);
+            // ---- triangulate (:1039-1386)
+            WLOG_SCOPE("triangulate");
+            wass_geom g;
+            memset(&g, 0, sizeof g);
+            auto put = [](double* dst, const Mat& m, int n) { for (int i = 0; i < n; ++i) dst[i] = m.d[i]; };
+            put(g.K_left, env.K_left, 9); put(g.K_right, env.K_right, 9); put(g.R, env.R, 9); put(g.T, env.T, 3);
+            g.use_custom = env.use_custom ? 1 : 0;
+            if (env.use_custom) { put(g.HLi, env.HLi, 9); put(g.HRi, env.HRi, 9); }
+            else { memcpy(g.R1, env.rec_R1, sizeof g.R1); memcpy(g.R2, env.rec_R2, sizeof g.R2); memcpy(g.P1, env.rec_P1, sizeof g.P1); memcpy(g.P2, env.rec_P2, sizeof g.P2); }
+            g.disparity_compensation = env.disparity_compensation;
+            g.dense_scale = sp_.dense_scale;
+            wass_tri_params tp;
+            tp.min_angle_deg = cfg_.get_double("TRIANG_MIN_ANGLE");
+            tp.bbox[0] = 0; tp.bbox[1] = 0; tp.bbox[2] = W_; tp.bbox[3] = H_;
+            if (cfg_.get_double("TRIANG_BBOX_TOP") >= 0 && cfg_.get_double("TRIANG_BBOX_LEFT") >= 0 && cfg_.get_double("TRIANG_BBOX_BOTTOM") >= 0 &&
+                cfg_.get_double("TRIANG_BBOX_RIGHT") >= 0) {
+                tp.bbox[0] = cfg_.get_double("TRIANG_BBOX_LEFT"); tp.bbox[1] = cfg_.get_double("TRIANG_BBOX_TOP");
+                tp.bbox[2] = cfg_.get_double("TRIANG_BBOX_RIGHT"); tp.bbox[3] = cfg_.get_double("TRIANG_BBOX_BOTTOM");
+            }
+            tp.cam_distance = env.cam_distance;
+            WLOGI << "triangulating disparity map";
+            check(wass_triangulate_dev(ctx_, d_dispf_, W_, H_, rl, rr, &g, in_[k].d_r, W_, H_, burned ? in_[k].d_ml : nullptr,
+                                       burned ? in_[k].d_mr : nullptr, &tp, &mesh, nullptr), "wass_triangulate");
+            WLOGI << "... 100%";
+            // ---- the previous frame: its record and file image have arrived while this one was being enqueued
+            if (FrameJob* p = collect()) done.push_back(p);
+            // ---- the mesh tail (:2046-2123), decided on the device
+            const int rounds = cfg_.get_int("PLANE_RANSAC_ROUNDS");
+            if (uv_.empty() || uv_seed_ != job.ransac_seed || uv_w_ != rr[2] || uv_h_ != rr[3]) {
+                uv_.assign((size_t)rounds * 6, 0);
+                if (wass_ransac_sample_seeded(job.ransac_seed, rr[2], rr[3], rounds, uv_.data()) != WASS_OK) throw std::runtime_error("invalid PLANE_RANSAC_ROUNDS / mesh size");
+                uv_seed_ = job.ransac_seed; uv_w_ = rr[2]; uv_h_ = rr[3];
+            }
+            const int slot = acquire_out((size_t)rr[2] * rr[3]);
+            job.out_slot = slot;
+            check(wass_mesh_finish_frame_async_ex(ctx_, mesh, cfg_.get_double("ZGAP_PERCENTILE"), uv_.data(), rounds, cfg_.get_double("PLANE_RANSAC_THRESHOLD"),
+                                                  &rp_, cfg_.get_double("PLANE_MAX_DISTANCE"), out_[slot].xyzc, out_[slot].xyzc_cap,
+                                                  opt_.inliers_file ? out_[slot].inl : nullptr, opt_.inliers_file ? out_[slot].inl_cap : 0, 10),
+                  "wass_mesh_finish_frame_async");
+            wass_mesh_destroy(mesh);                        // back to the context's pool; the kernels enqueued on it run in stream order
+            mesh = nullptr;
+            pending_ = &job;
+            ++nsub_;
+            job.t_submitted = Timer::now();
+        } catch (const std::exception& e) {
+            if (mesh) wass_mesh_destroy(mesh);
+            WLOG_SCOPE("wass_stereo");
+            WLOGE << e.what();
+            job.rc = -1;
+            if (job.out_slot >= 0) { release_out(job.out_slot); job.out_slot = -1; }
+            if (FrameJob* p = collect()) done.push_back(p);
+            done.push_back(&job);
+        }
+    }
+
+    // the last submitted frame (waits for it)
+    void flush(std::vector<FrameJob*>& done) { if (FrameJob* p = collect()) done.push_back(p); }
+
+    // ---- phase 3 (any thread): everything that is written from the result record (:1374, 1993, 2046-2139)
+    void finish(FrameJob& job)
+    {
+        LogSinkScope sink(&job.log);
+        WLOG_SCOPE("wass_stereo");
+        Env& env = job.env;
+        const double t0 = Timer::now();
+        if (job.rc == 0 && !job.skipped) {
+            try {
+                const wass_frame_result& r = job.res;
+                WLOG_SCOPE("triangulate");
+                WLOGI << r.n_triangulated << " valid points found";
+                job.summary.n_points = r.n_triangulated;
+                marker(job, 60);
+                WLOG_SCOPE("wass_stereo");
+                if (r.sgm_cost_overflow == 1) WLOGE << "matching costs exceeded the int16 range; the disparity is outside the reference's defined behaviour";
+                if ((long long)r.n_triangulated < cfg_.get_int("MIN_TRIANGULATED_POINTS")) { WLOGE << "Too few points triangulated, aborting"; throw GpuError("too few points"); }
+                WLOG_SCOPE("cluster");
+                WLOGI << "biggest component size: " << r.component_size << " (px)";
+                marker(job, 80);
+                WLOG_SCOPE("wass_stereo");
+                WLOGI << "estimating best fitting plane...";
+                const int rounds = cfg_.get_int("PLANE_RANSAC_ROUNDS");
+                WLOG_SCOPE("ransac_find_plane");
+                WLOGI << rounds << " ransac rounds, " << r.ransac_inliers << " best inliers";
+                WLOGI << "ransac plane coeffs: " << r.ransac_plane[0] << " " << r.ransac_plane[1] << " " << r.ransac_plane[2] << " " << r.ransac_plane[3];
+                WLOG_SCOPE("wass_stereo");
+                bool have_plane = false;
+                if (r.found) {
+                    marker(job, 90);
+                    WLOGI << "refining plane";
+                    if (!r.refine_ok) {
+                        char msg[128];
+                        snprintf(msg, sizeof msg, "wass_mesh_refine_plane: plane refinement has %g inliers", (double)r.refine_inliers);
+                        throw GpuError(msg);
+                    }
+                    WLOG_SCOPE("refine_plane");
+                    WLOGI << "refinement inliers (after cropping): " << r.refine_inliers;
+                    WLOGI << "estimated plane coeffs: " << r.plane[0] << " " << r.plane[1] << " " << r.plane[2] << " " << r.plane[3];
+                    WLOG_SCOPE("wass_stereo");
+                    if (opt_.inliers_file) write_inliers_xyz(path_join(env.workdir, "plane_refinement_inliers.xyz"), out_[job.out_slot].inl, (size_t)r.n_inliers_out);
+                    WLOG_SCOPE("crop_plane");
+                    WLOGI << "number of points after plane cropping: " << r.kept_final;
+                    WLOG_SCOPE("wass_stereo");
+                    std::ofstream ofs(path_join(env.workdir, "plane.txt").c_str());
+                    ofs << std::setprecision(20);
+                    for (int i = 0; i < 4; ++i) ofs << r.plane[i] << std::endl;
+                    have_plane = true;
+                    job.summary.have_plane = 1;
+                    for (int i = 0; i < 4; ++i) job.summary.plane[i] = r.plane[i];
+                } else {
+                    WLOGE << "ransac failed. I'll continue anyway but plane data won't be available!";
+                    std::ofstream ofs(path_join(env.workdir, "plane.txt").c_str());
+                    ofs << "nan nan nan nan" << std::endl;
+                }
+                (void)have_plane;
+                WLOGI << "Exporting point cloud data";
+                {
+                    WLOG_SCOPE("save_as_xyz_compressed");
+                    WLOGI << "saving mesh as compressed xyz file...";
+                    const std::string xyzc_path = path_join(env.workdir, "mesh_cam.xyzC"), tmp = xyzc_path + ".tmp";
+                    bool ok;
+                    {
+                        std::ofstream ofs(tmp.c_str(), std::ios::binary);
+                        ok = !ofs.fail() && ofs.write((const char*)out_[job.out_slot].xyzc, (std::streamsize)r.xyzc_bytes).good();
+                        ofs.close();
+                        ok = ok && !ofs.fail();
+                    }
+                    ok = ok && rename(tmp.c_str(), xyzc_path.c_str()) == 0;
+                    if (!ok) { WLOGE << "unable to save mesh data"; throw GpuError("write failed"); }
+                    WLOGI << "total data size: " << ((double)r.xyzc_bytes / 1E6) << " MB";
+                    WLOG_SCOPE("wass_stereo");
+                }
+                marker(job, 100);
+                // the time table (render.hpp:175-191).  A pipelined frame has no per-stage wall times: its GPU stages run
+                // underneath its neighbours'.  "Dense Stereo" is the GPU time of the SGM stage (hipEvents); "GPU pipeline" the
+                // wall time from submission to the arrival of the result record, queueing behind the previous frame included.
+                Timer t;
+                t.events.emplace_back(job.t_loaded - job.t_prepare0, "Data load");
+                t.events.emplace_back(job.t_planned - job.t_prepare0, "Rectification");
+                double at = job.t_planned - job.t_prepare0;
+                t.events.emplace_back(at += job.t_submitted - job.t_submit0, "Submission");
+                if (job.have_sgm) t.events.emplace_back(at += job.sgm.total_ms / 1e3, "Dense Stereo (GPU)");
+                t.events.emplace_back(at += job.t_result - job.t_submitted, "GPU pipeline");
+                t.events.emplace_back(at += Timer::now() - t0, "Output");
+                t.t0 = 0; t.tend = at;
+                show_time_stats(t);
+                WLOGI << "All done.";
+            } catch (const GpuError& e) {
+                WLOG_SCOPE("wass_stereo");
+                WLOGE << e.what();
+                job.rc = -1;
+            } catch (const std::exception& e) {
+                WLOG_SCOPE("wass_stereo");
+                WLOGE << e.what();
+                job.rc = -1;
+            }
+        }
+        if (job.out_slot >= 0) { release_out(job.out_slot); job.out_slot = -1; }
+        if (!job.skipped) {
+            flush_live(job);
+            std::ofstream lf(path_join(job.workdir, "wass_stereo_log.txt").c_str(), std::ios::binary);
+            write_log(lf, job.log);
+        }
+    }
+
+    // log text with the progress markers (lines starting with \x01) removed / kept
+    static void write_log(std::ostream& os, const std::string& log)
+    {
+        size_t p = 0;
+        while (p < log.size()) {
+            size_t e = log.find('\n', p);
+            if (e == std::string::npos) e = log.size(); else ++e;
+            if (log[p] != '\x01') os.write(log.data() + p, (std::streamsize)(e - p));
+            p = e;
+        }
+    }
+    // single-frame executable: what the phases have logged since the last call goes to stdout, markers included
+    void flush_live(FrameJob& job)
+    {
+        if (!opt_.live) return;
+        size_t p = live_pos_;
+        const std::string& log = job.log;
+        while (p < log.size()) {
+            size_t e = log.find('\n', p);
+            if (e == std::string::npos) e = log.size(); else ++e;
+            if (log[p] == '\x01') std::cout.write(log.data() + p + 1, (std::streamsize)(e - p - 1));
+            else std::cout.write(log.data() + p, (std::streamsize)(e - p));
+            p = e;
+        }
+        std::cout.flush();
+        live_pos_ = log.size();
+    }
+
+    int frames_submitted() const { return nsub_; }
+
+private:
+    struct InSet { uint8_t *h_l = nullptr, *h_r = nullptr, *d_l = nullptr, *d_r = nullptr, *d_cl = nullptr, *d_cr = nullptr, *d_ml = nullptr, *d_mr = nullptr; };
+    struct OutSet { void* xyzc = nullptr; size_t xyzc_cap = 0; double* inl = nullptr; size_t inl_cap = 0; };
+
+    void check(int rc, const char* what) const { if (rc != WASS_OK) throw GpuError(std::string(what) + ": " + wass_last_error(ctx_)); }
+    void marker(FrameJob& job, int pct) const
+    {
+        if (!opt_.live) return;
+        char b[32];
+        snprintf(b, sizeof b, "\x01[P|%d|100]\n", pct);
+        job.log += b;
+    }
+
+    FrameJob* collect()
+    {
+        if (!pending_) return nullptr;
+        FrameJob* j = pending_;
+        pending_ = nullptr;
+        LogSinkScope sink(&j->log);
+        WLOG_SCOPE("wass_stereo");
+        if (wass_ctx_frame_result(ctx_, &j->res) != WASS_OK) { WLOGE << "wass_ctx_frame_result: " << wass_last_error(ctx_); j->rc = -1; }
+        j->t_result = Timer::now();
+        // stage times of the frame's SGM call: the last call, or the last but one if another frame has been enqueued since
+        const long long behind = sgm_calls_ - j->sgm_call;
+        j->have_sgm = behind == 0 ? wass_sgm_last_timings(ctx_, &j->sgm) == WASS_OK : (behind == 1 && wass_sgm_prev_timings(ctx_, &j->sgm) == WASS_OK);
+        return j;
+    }
+
+    void release_buffers()
+    {
+        for (auto& s : in_) {
+            for (uint8_t** p : { &s.d_l, &s.d_r, &s.d_cl, &s.d_cr, &s.d_ml, &s.d_mr }) { if (*p) wass_device_free(ctx_, *p); *p = nullptr; }
+            for (uint8_t** p : { &s.h_l, &s.h_r }) { if (*p) wass_pinned_free(ctx_, *p); *p = nullptr; }
+        }
+        for (auto& p : d_disp16_) { if (p) wass_device_free(ctx_, p); p = nullptr; }
+        if (d_dispf_) wass_device_free(ctx_, d_dispf_);
+        d_dispf_ = nullptr;
+        for (auto& p : d_map_) { if (p) wass_device_free(ctx_, p); p = nullptr; }
+        map_valid_ = false;
+    }
+    // (re)allocated when the pictures or the ROIs change size -- once per sequence in practice
+    void ensure_buffers(int W, int H, const Rect& roi_l, const Rect& roi_r)
+    {
+        if (W == W_ && H == H_ && roi_l.width == cwl_ && roi_l.height == chl_ && roi_r.width == cwr_ && roi_r.height == chr_) return;
+        check(wass_ctx_synchronize(ctx_), "wass_ctx_synchronize");
+        release_buffers();
+        W_ = W; H_ = H; cwl_ = roi_l.width; chl_ = roi_l.height; cwr_ = roi_r.width; chr_ = roi_r.height;
+        const size_t n = (size_t)W * H + 4;
+        auto dev = [&](size_t bytes) { void* p = nullptr; check(wass_device_alloc(ctx_, bytes, &p), "wass_device_alloc"); return p; };
+        auto pin = [&](size_t bytes) { void* p = nullptr; check(wass_pinned_alloc(ctx_, bytes, &p), "wass_pinned_alloc"); return p; };
+        for (auto& s : in_) {
+            s.h_l = (uint8_t*)pin(n); s.h_r = (uint8_t*)pin(n);
+            s.d_l = (uint8_t*)dev(n); s.d_r = (uint8_t*)dev(n); s.d_ml = (uint8_t*)dev(n); s.d_mr = (uint8_t*)dev(n);
+            s.d_cl = (uint8_t*)dev((size_t)cwl_ * chl_ + 4); s.d_cr = (uint8_t*)dev((size_t)cwr_ * chr_ + 4);
+        }
+        for (auto& p : d_disp16_) p = (int16_t*)dev((size_t)cwr_ * chr_ * 2);
+        d_dispf_ = (float*)dev((size_t)cwr_ * chr_ * 4);
+    }
+    // cv::initUndistortRectifyMap (:600-601): rig constants, computed and uploaded when the calibration changes
+    void ensure_maps(const Env& env)
+    {
+        std::vector<double> key;
+        auto add = [&](const double* p, int n) { key.insert(key.end(), p, p + n); };
+        add(env.K_left.d.data(), 9); add(env.rec_R1, 9); add(env.rec_P1, 12); add(env.K_right.d.data(), 9); add(env.rec_R2, 9); add(env.rec_P2, 12);
+        key.push_back(W_); key.push_back(H_);
+        if (map_valid_ && key == map_key_) return;
+        check(wass_ctx_synchronize(ctx_), "wass_ctx_synchronize");          // a frame in flight may still read the old maps
+        const size_t n = (size_t)W_ * H_;
+        std::vector<float> mx(n), my(n);
+        void* h = nullptr;
+        check(wass_pinned_alloc(ctx_, n * 4 * 4, &h), "wass_pinned_alloc");
+        float* hp = (float*)h;
+        for (int cam = 0; cam < 2; ++cam) {
+            const int rc = cam == 0 ? wass_init_rectify_map(env.K_left.d.data(), env.rec_R1, env.rec_P1, W_, H_, hp, hp + n)
+                                    : wass_init_rectify_map(env.K_right.d.data(), env.rec_R2, env.rec_P2, W_, H_, hp + 2 * n, hp + 3 * n);
+            if (rc != WASS_OK) { wass_pinned_free(ctx_, h); throw std::runtime_error("singular rectification"); }
+        }
+        for (int i = 0; i < 4; ++i) {
+            if (!d_map_[i]) { void* p = nullptr; check(wass_device_alloc(ctx_, n * 4, &p), "wass_device_alloc"); d_map_[i] = (float*)p; }
+            check(wass_upload_async(ctx_, d_map_[i], hp + (size_t)i * n, n * 4), "wass_upload_async");
+        }
+        check(wass_ctx_synchronize(ctx_), "wass_ctx_synchronize");          // the staging buffer goes away
+        wass_pinned_free(ctx_, h);
+        map_key_ = key;
+        map_valid_ = true;
+    }
+
+    int acquire_out(size_t npts)
+    {
+        std::unique_lock<std::mutex> lk(out_mu_);
+        out_cv_.wait(lk, [&]() { for (bool f : out_free_) if (f) return true; return false; });
+        int slot = 0;
+        while (!out_free_[(size_t)slot]) ++slot;
+        out_free_[(size_t)slot] = false;
+        lk.unlock();
+        OutSet& o = out_[(size_t)slot];
+        const size_t need = 148 + 6 * npts, icap = (npts + 9) / 10;
+        if (o.xyzc_cap < need) {
+            if (o.xyzc) wass_pinned_free(ctx_, o.xyzc);
+            o.xyzc = nullptr; o.xyzc_cap = 0;
+            check(wass_pinned_alloc(ctx_, need, &o.xyzc), "wass_pinned_alloc");
+            o.xyzc_cap = need;
+        }
+        if (opt_.inliers_file && o.inl_cap < icap) {
+            if (o.inl) wass_pinned_free(ctx_, o.inl);
+            o.inl = nullptr; o.inl_cap = 0;
+            void* p = nullptr;
+            check(wass_pinned_alloc(ctx_, icap * 24, &p), "wass_pinned_alloc");
+            o.inl = (double*)p; o.inl_cap = icap;
+        }
+        return slot;
+    }
+    void release_out(int slot)
+    {
+        { std::lock_guard<std::mutex> lk(out_mu_); out_free_[(size_t)slot] = true; }
+        out_cv_.notify_one();
+    }
+
+    int device_ = 0;
+    wass_ctx* ctx_ = nullptr;
+    bool ctx_failed_ = false;
+    const Config& cfg_;
+    std::string config_path_;
+    Options opt_;
+    wass_sgm_params sp_{};
+    wass_refine_params rp_{};
+    int W_ = 0, H_ = 0, cwl_ = 0, chl_ = 0, cwr_ = 0, chr_ = 0;
+    InSet in_[NIN];
+    int next_in_ = 0;
+    int16_t* d_disp16_[2] = { nullptr, nullptr };
+    float* d_dispf_ = nullptr;
+    float* d_map_[4] = { nullptr, nullptr, nullptr, nullptr };
+    std::vector<double> map_key_;
+    bool map_valid_ = false;
+    std::vector<int32_t> uv_;
+    unsigned int uv_seed_ = 0;
+    int uv_w_ = 0, uv_h_ = 0;
+    std::vector<OutSet> out_;
+    std::vector<bool> out_free_;
+    std::mutex out_mu_;
+    std::condition_variable out_cv_;
+    FrameJob* pending_ = nullptr;
+    int nsub_ = 0;
+    long long sgm_calls_ = 0;
+    size_t live_pos_ = 0;
+};
+
+}  // namespace wassframe

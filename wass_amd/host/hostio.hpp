@@ -8,6 +8,7 @@
 
 #include <zlib.h>
 
+#include <charconv>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -26,7 +27,16 @@ namespace wasshost {
 struct LogState {
     std::string scope;
     std::unique_ptr<std::ofstream> file;
+    // set: lines are collected here instead of going to stdout / the file.  The pipelined sequence driver works on one frame
+    // from three threads at different times (decode, GPU submission, output); each binds the frame's buffer while it does,
+    // and the frame's wass_stereo_log.txt is written once, in order, when the frame is finished.
+    std::string* sink = nullptr;
     static LogState& get() { static thread_local LogState s; return s; }     // per thread: a sequence driver runs frames on several threads
+};
+struct LogSinkScope {                      // binds a frame's log buffer to the calling thread for the lifetime of the object
+    std::string* prev_sink; std::string prev_scope;
+    explicit LogSinkScope(std::string* s) : prev_sink(LogState::get().sink), prev_scope(LogState::get().scope) { LogState::get().sink = s; }
+    ~LogSinkScope() { LogState::get().sink = prev_sink; LogState::get().scope = prev_scope; }
 };
 inline void setup_logger(const std::string& filename = std::string())
 {
@@ -35,10 +45,20 @@ inline void setup_logger(const std::string& filename = std::string())
 class LogLine {
 public:
     explicit LogLine(const char* sev) { emit(LogState::get().scope + " [" + sev + "] "); }
-    ~LogLine() { std::cout << std::endl; auto& f = LogState::get().file; if (f) (*f) << std::endl; }
+    ~LogLine()
+    {
+        auto& st = LogState::get();
+        if (st.sink) { st.sink->push_back('\n'); return; }
+        std::cout << std::endl; auto& f = st.file; if (f) (*f) << std::endl;
+    }
     template <typename T> LogLine& operator<<(const T& v) { std::ostringstream os; os << v; emit(os.str()); return *this; }
 private:
-    static void emit(const std::string& s) { std::cout << s; auto& f = LogState::get().file; if (f) (*f) << s; }
+    static void emit(const std::string& s)
+    {
+        auto& st = LogState::get();
+        if (st.sink) { st.sink->append(s); return; }
+        std::cout << s; auto& f = st.file; if (f) (*f) << s;
+    }
 };
 #define WLOG_SCOPE(name) (wasshost::LogState::get().scope = std::string(name))
 #define WLOGI wasshost::LogLine("info ")
@@ -292,6 +312,49 @@ inline bool write_png_gray(const std::string& filename, const Image& img)
     chunk("IDAT", comp.data(), (uint32_t)clen);
     chunk("IEND", nullptr, 0);
     return !ofs.fail();
+}
+
+// ------------------------------------------------------------------ "%g" of a double, fast
+// plane_refinement_inliers.xyz holds ~1.4 million numbers per 5-megapixel frame in the stream's default format (what
+// printf("%g") prints: six significant digits, trailing zeros removed, scientific outside [1e-4, 1e6)).  std::to_chars
+// is exact but costs ~0.3 us per number -- 0.4 s of CPU per frame.  fmt_g6 takes the common case in ~25 ns: scale into
+// [1e5, 1e6) by an exactly representable power of ten (one rounding, relative error <= 2^-53), round to an integer, and
+// accept the result only when the scaled value is far enough from a rounding boundary that neither that error nor a tie
+// can change the digits; everything else (boundaries, tiny / huge / non-finite values) goes to std::to_chars, which is
+// specified to produce printf's digits.  tests/test_hostio.py compares the two on tens of millions of values.
+inline char* fmt_g6(char* out, char* end, double v)
+{
+    static const double P10[11] = { 1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10 };
+    auto slow = [&]() { return std::to_chars(out, end, v, std::chars_format::general, 6).ptr; };
+    const double a = std::fabs(v);
+    if (!(a >= 1e-4 && a < 999999.0)) {                     // zero, subnormal-ish, scientific range, inf, nan
+        if (v == 0.0) { char* q = out; if (std::signbit(v)) *q++ = '-'; *q++ = '0'; return q; }
+        return slow();
+    }
+    if (end - out < 16) return slow();
+    int e;                                                   // decimal exponent: 10^e <= a < 10^(e+1)
+    if (a >= 1.0) e = a < 1e1 ? 0 : a < 1e2 ? 1 : a < 1e3 ? 2 : a < 1e4 ? 3 : a < 1e5 ? 4 : 5;
+    else e = a >= 1e-1 ? -1 : a >= 1e-2 ? -2 : a >= 1e-3 ? -3 : -4;
+    const double sc = a * P10[5 - e];                       // in [1e5, 1e6) up to one rounding
+    const double fl = std::floor(sc), fr = sc - fl;
+    if (std::fabs(fr - 0.5) < 1e-7 || sc < 100000.0 || sc >= 999999.5) return slow();     // boundary cases: exact path
+    uint32_t m = (uint32_t)fl + (fr > 0.5 ? 1u : 0u);       // six digits
+    char dg[6];
+    for (int i = 5; i >= 0; --i) { dg[i] = (char)('0' + m % 10); m /= 10; }
+    int nd = 6;
+    while (nd > 1 && dg[nd - 1] == '0') --nd;               // %g strips trailing zeros
+    char* q = out;
+    if (v < 0) *q++ = '-';
+    if (e >= 0) {
+        const int ip = e + 1;                                // digits in front of the point
+        for (int i = 0; i < ip; ++i) *q++ = dg[i];           // (zeros that belong to the integer part are never stripped: nd < ip is padded)
+        if (nd > ip) { *q++ = '.'; for (int i = ip; i < nd; ++i) *q++ = dg[i]; }
+    } else {
+        *q++ = '0'; *q++ = '.';
+        for (int i = 0; i < -e - 1; ++i) *q++ = '0';
+        for (int i = 0; i < nd; ++i) *q++ = dg[i];
+    }
+    return q;
 }
 
 // ------------------------------------------------------------------ point-cloud writers (host copies of the mesh)

@@ -167,7 +167,11 @@ bool load_data(Env& env, const Config& cfg, Preload* pre = nullptr, BgTask* bg =
     return true;
 }
 
-bool rectify(Env& env, const Config& cfg, wass_ctx* ctx)                                  // :447-613
+// rectify() in two steps: what it DECIDES (left/right swap, homographies or cv::stereoRectify's matrices, the ROIs: host
+// math on the calibration, no pixel touched) and the resampling of the two pictures.  The stage-by-stage executable runs one
+// after the other; the pipelined sequence driver takes the decisions on a decode thread and resamples on the GPU from
+// device-resident inputs (frame_pipeline.hpp).
+bool rectify_plan(Env& env, const Config& cfg)                                            // :447-599
 {
     WLOG_SCOPE("rectify");
     WLOGI << "rectifying...";
@@ -186,7 +190,6 @@ bool rectify(Env& env, const Config& cfg, wass_ctx* ctx)                        
     }
     const int W = env.left.w, H = env.left.h;
     auto roi_ok = [&](const Rect& r) { return r.x >= 0 && r.y >= 0 && r.width > 0 && r.height > 0 && r.x + r.width <= W && r.y + r.height <= H; };
-    auto gpu = [&](int rc, const char* what) { if (rc != WASS_OK) throw std::runtime_error(std::string(what) + ": " + wass_last_error(ctx)); };
     env.use_custom = cfg.get_bool("USE_CUSTOM_STEREORECTIFY");
     if (env.use_custom) {
         const double ang = cfg.get_double("RECTIFY_ANGLE");
@@ -200,11 +203,6 @@ bool rectify(Env& env, const Config& cfg, wass_ctx* ctx)                        
         env.roi_l = env.roi_r = roi;
         if (cfg.get_bool("DISABLE_RECTIFY_ROI")) { env.roi_l = env.roi_r = Rect{ 0, 0, W, H }; }
         if (!roi_ok(env.roi_l)) { WLOGE << "rectification ROI is empty or outside the image"; return false; }
-        // cv::warpPerspective (:515-516) and the ROI .clone() (:526-528) in one GPU pass per camera
-        const int rl[4] = { env.roi_l.x, env.roi_l.y, env.roi_l.width, env.roi_l.height };
-        env.left_crop = Image(rl[2], rl[3]); env.right_crop = Image(rl[2], rl[3]);
-        gpu(wass_warp_perspective(ctx, env.left.px.data(), W, H, (size_t)W, env.HL.d.data(), W, H, rl, env.left_crop.px.data()), "wass_warp_perspective");
-        gpu(wass_warp_perspective(ctx, env.right.px.data(), W, H, (size_t)W, env.HR.d.data(), W, H, rl, env.right_crop.px.data()), "wass_warp_perspective");
     } else {
         WLOGI << "Rectifying via cv::stereoRectify";
         int roi_left[4], roi_right[4];
@@ -230,6 +228,22 @@ bool rectify(Env& env, const Config& cfg, wass_ctx* ctx)                        
         env.roi_r = Rect{ roi_right[0], ymin, roi_right[2], ymax - ymin };
         if (env.roi_l.width > env.roi_r.width) env.roi_l.width = env.roi_r.width; else env.roi_r.width = env.roi_l.width;
         if (!roi_ok(env.roi_l) || !roi_ok(env.roi_r)) { WLOGE << "rectification ROI is empty or outside the image"; return false; }
+    }
+    return true;
+}
+
+bool rectify_resample(Env& env, wass_ctx* ctx)                                            // :515-528, 600-613
+{
+    WLOG_SCOPE("rectify");
+    const int W = env.left.w, H = env.left.h;
+    auto gpu = [&](int rc, const char* what) { if (rc != WASS_OK) throw std::runtime_error(std::string(what) + ": " + wass_last_error(ctx)); };
+    if (env.use_custom) {
+        // cv::warpPerspective (:515-516) and the ROI .clone() (:526-528) in one GPU pass per camera
+        const int rl[4] = { env.roi_l.x, env.roi_l.y, env.roi_l.width, env.roi_l.height };
+        env.left_crop = Image(rl[2], rl[3]); env.right_crop = Image(rl[2], rl[3]);
+        gpu(wass_warp_perspective(ctx, env.left.px.data(), W, H, (size_t)W, env.HL.d.data(), W, H, rl, env.left_crop.px.data()), "wass_warp_perspective");
+        gpu(wass_warp_perspective(ctx, env.right.px.data(), W, H, (size_t)W, env.HR.d.data(), W, H, rl, env.right_crop.px.data()), "wass_warp_perspective");
+    } else {
         // cv::initUndistortRectifyMap (:600-601), cv::remap INTER_CUBIC (:603-604), ROI .clone() (:606-607)
         std::vector<float> mx((size_t)W * H), my((size_t)W * H);
         const int rl[4] = { env.roi_l.x, env.roi_l.y, env.roi_l.width, env.roi_l.height }, rr[4] = { env.roi_r.x, env.roi_r.y, env.roi_r.width, env.roi_r.height };
@@ -242,6 +256,8 @@ bool rectify(Env& env, const Config& cfg, wass_ctx* ctx)                        
     WLOGI << "rectification map generated. Size: " << env.left_crop.w << "x" << env.left_crop.h;
     return true;
 }
+
+bool rectify(Env& env, const Config& cfg, wass_ctx* ctx) { return rectify_plan(env, cfg) && rectify_resample(env, ctx); }   // :447-613
 
 void show_time_stats(const Timer& t)                                                       // render.hpp:175-191
 {
@@ -276,6 +292,31 @@ void gpu_check(wass_ctx* ctx, int rc, const char* what, bool allow_overflow = fa
 {
     if (rc == WASS_OK || (allow_overflow && rc == WASS_ERR_COST_OVERFLOW)) return;
     throw GpuError(std::string(what) + ": " + wass_last_error(ctx));
+}
+
+
+// plane_refinement_inliers.xyz (:2077-2085): "x y z" per line in the stream's default format
+inline void write_inliers_xyz(const std::string& path, const double* xyz, size_t n)
+{
+    // "x y z" per line in the stream's default format (%g): fmt_g6 gives printf's characters (tests/test_hostio.py)
+    std::string text;
+    text.resize(n * 48 + 64);
+    char* q = &text[0];
+    char* const end = q + text.size();
+    for (size_t j = 0; j < n; ++j) {
+        if (end - q < 128) {                             // (never with 48 bytes per line and |numbers| that fit %g's 13 characters)
+            const size_t used = (size_t)(q - &text[0]);
+            text.resize(text.size() * 2);
+            q = &text[0] + used;
+        }
+        char* const lim = &text[0] + text.size();
+        for (int k = 0; k < 3; ++k) {
+            q = fmt_g6(q, lim - 2, xyz[3 * j + k]);
+            *q++ = k < 2 ? ' ' : '\n';
+        }
+    }
+    std::ofstream ofs(path.c_str(), std::ios::binary);
+    ofs.write(text.data(), (std::streamsize)(q - &text[0]));
 }
 
 
@@ -577,32 +618,8 @@ inline int wass_run_frame(const char* config_path, const std::string& workdir, c
                 double* sel = nullptr;
                 uint64_t nsel = 0;
                 gpu_check(ctx, wass_mesh_refinement_inliers(ctx, mesh, &rp, 10, &sel, &nsel), "wass_mesh_refinement_inliers");
-                // "x y z" per line in the stream's default format (%g, six significant digits); formatted into one buffer and
-                // written once: half a million operator<< / std::endl flushes used to cost 0.5 s per frame at 2456 x 2058
-                constexpr int NT = 12;                                // formatting is the slow part (0.3 us per number): twelve threads
-                std::string part[NT];
-                std::thread th[NT];
-                for (int t = 0; t < NT; ++t)
-                    th[t] = std::thread([&, t]() {
-                        const size_t a = (size_t)nsel * t / NT, b = (size_t)nsel * (t + 1) / NT;
-                        part[t].reserve((b - a) * 40);
-                        char line[128];
-                        for (size_t j = a; j < b; ++j) {
-                            // std::to_chars(general, 6) is specified to produce what printf("%g") prints (checked on 2 M values),
-                            // three times as fast
-                            char* q = line;
-                            for (int k = 0; k < 3; ++k) {
-                                q = std::to_chars(q, line + sizeof line - 2, sel[3 * j + k], std::chars_format::general, 6).ptr;
-                                *q++ = k < 2 ? ' ' : '\n';
-                            }
-                            part[t].append(line, (size_t)(q - line));
-                        }
-                    });
-                std::string text;
-                for (int t = 0; t < NT; ++t) { th[t].join(); text += part[t]; }
+                write_inliers_xyz(path_join(env.workdir, "plane_refinement_inliers.xyz"), sel, (size_t)nsel);
                 wass_free(sel);
-                std::ofstream ofs(path_join(env.workdir, "plane_refinement_inliers.xyz").c_str(), std::ios::binary);
-                ofs.write(text.data(), (std::streamsize)text.size());
             }
             gpu_check(ctx, wass_mesh_crop_plane(ctx, mesh, plane, cfg.get_double("PLANE_MAX_DISTANCE"), &kept), "wass_mesh_crop_plane");
             WLOG_SCOPE("crop_plane");

@@ -6,7 +6,7 @@
 // Same argv, exit codes, config format, workdir inputs/outputs, stdout progress markers and log format as the
 // reference; the per-frame work is wass_frame.hpp.  There is NO CPU implementation of the hot
 // path here: without a GPU (or without libwassgpu.so) the program fails with exit code -1.
-#include "wass_frame.hpp"
+#include "frame_pipeline.hpp"
 
 using namespace wassframe;
 
@@ -30,6 +30,36 @@ int main(int argc, char* argv[])
     if (argc != 3 && argc != 4) { std::cerr << "Invalid arguments" << std::endl; return -1; }
     if (!exists(argv[2])) { std::cerr << argv[2] << " does not exists, aborting." << std::endl; return -1; }
     wass_ctx* ctx = nullptr;
+    // Without the debug pictures (WASS_DEBUG_IMAGES=0) nothing of a frame has to come back to the host between the stages:
+    // the frame goes through the device-resident chain the sequence driver uses (frame_pipeline.hpp), one frame deep.  With
+    // them (the reference's default: it always writes them) the stage-by-stage calls run, because the pictures are made
+    // from every stage's intermediate map.  The files both ways are the same (tests/test_cli.py).
+    bool debug_images = true;
+    if (const char* e = getenv("WASS_DEBUG_IMAGES")) debug_images = atoi(e) != 0;
+    if (!debug_images && argc == 3) {
+        Config cfg;
+        register_wass_stereo_options(cfg);
+        bool ok = false;
+        { std::ifstream ifs(argv[1]); if (ifs.is_open()) { try { cfg.load(ifs); ok = pipeline_eligible(cfg); } catch (const std::runtime_error&) {} } }
+        const char* dev_env = getenv("WASS_GPU_DEVICE");
+        if (ok) {
+            FramePipeline::Options fo;
+            fo.out_slots = 1;
+            fo.live = true;
+            FramePipeline pl(dev_env ? atoi(dev_env) : 0, cfg, argv[1], fo);
+            FrameJob job;
+            job.workdir = argv[2];
+            std::vector<FrameJob*> done;
+            pl.prepare(job);
+            pl.flush_live(job);
+            pl.submit(job, done);
+            pl.flush_live(job);
+            pl.flush(done);
+            for (FrameJob* j : done) pl.finish(*j);
+            return job.rc;
+        }
+        // a configuration that does not parse or an option the chain does not cover: the stage-by-stage path handles it
+    }
     const int ret = wass_run_frame(argv[1], argv[2], argc == 4 ? argv[3] : nullptr, 0, &ctx, nullptr);
     if (ctx) wass_ctx_destroy(ctx);
     return ret;

@@ -14,6 +14,12 @@
 // exchange is Coll-1: [sum a, sum b, sum c, sum d, n_valid] over the workers' planes, all-reduced over RCCL/xGMI when
 // every worker owns a GPU of its own (wass_coll_*), and the per-frame records that the parent collects through pipes to
 // write planes.txt in FRAME order (wasscli writes it in completion order) and planes_mean.txt.
+// A worker runs its frames through the PIPELINED chain of frame_pipeline.hpp: decode threads (calibration, PNG inflation,
+// previews, the rectification's decisions) -> one submitting thread (uploads one frame ahead, every GPU stage enqueued without
+// a host synchronisation, one result record per frame read one frame late) -> writer threads (the log lines that carry
+// numbers, plane.txt, plane_refinement_inliers.xyz, mesh_cam.xyzC).  Configurations that need an intermediate map or mesh on
+// the host (pipeline_eligible), --debug-images, --threads-per-proc > 1 and --stage-by-stage use the synchronous
+// stage-by-stage calls of wass_run_frame instead; the files are the same either way.
 // --skip-existing: the workdir is the checkpoint: a frame whose plane.txt and mesh_cam.xyzC /
 // mesh_cam.xyzbin exist is not recomputed, its plane is read back from plane.txt.
 #include <dirent.h>
@@ -29,7 +35,7 @@
 #include <mutex>
 #include <thread>
 
-#include "wass_frame.hpp"
+#include "frame_pipeline.hpp"
 
 using namespace wassframe;
 
@@ -160,6 +166,159 @@ int worker(int rank, int world, int device, bool distinct_gpus, const unsigned c
     return 0;
 }
 
+// finished = the point cloud file is there and at least as long as its header (148 bytes, PovMesh.cpp:377-460; the file only
+// gets its name once it is complete) -- plane.txt is checked by the caller
+bool frame_done(const std::string& wd)
+{
+    struct stat sb;
+    const std::string a = path_join(wd, "mesh_cam.xyzC");
+    if (stat(a.c_str(), &sb) == 0) return sb.st_size >= 148;
+    return exists(path_join(wd, "mesh_cam.xyzbin"));
+}
+
+struct PipeOptions { int decode_threads = 6, writer_threads = 4; bool inliers_file = true; };
+
+// One worker process, one context, frames rank, rank + world, ... through FramePipeline.
+int worker_pipelined(int rank, int world, int device, bool distinct_gpus, const unsigned char* uid, const char* cfgpath, const Config& cfg,
+                     const std::vector<std::string>& wds, bool verbose, bool skip_existing, int fd, const PipeOptions& po)
+{
+    if (!verbose) {
+        const int nul = open("/dev/null", O_WRONLY);
+        if (nul >= 0) { dup2(nul, 1); close(nul); }
+    }
+    const char* dev_env = getenv("WASS_GPU_DEVICE");
+    std::vector<size_t> mine;
+    for (size_t i = (size_t)rank; i < wds.size(); i += (size_t)world) mine.push_back(i);
+    const size_t n = mine.size();
+    double acc[5] = { 0, 0, 0, 0, 0 };
+    int status = 0;
+    FramePipeline::Options fo;
+    fo.out_slots = po.writer_threads + 2;
+    fo.inliers_file = po.inliers_file;
+    FramePipeline pl(dev_env ? atoi(dev_env) : device, cfg, cfgpath, fo);
+    {
+        std::vector<std::unique_ptr<FrameJob>> jobs(n);
+        std::vector<double> t_begin(n, 0.0);
+        std::mutex mu;                                             // ready flags, the load window, the writer queue
+        std::condition_variable cv_ready, cv_window, cv_write;
+        std::vector<char> ready(n, 0);
+        size_t next_load = 0, submitted = 0;
+        const size_t look = (size_t)po.decode_threads + 2;         // decoded frames waiting for the GPU: 10 MB each at 5 megapixels
+        std::deque<size_t> wq;                                     // positions whose GPU work is complete
+        bool wq_closed = false;
+        std::mutex out_mu;                                         // the pipe, the plane sum, stdout
+
+        auto loader = [&]() {
+            for (;;) {
+                size_t pos;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv_window.wait(lk, [&]() { return next_load >= n || next_load < submitted + look; });
+                    if (next_load >= n) return;
+                    pos = next_load++;
+                }
+                std::unique_ptr<FrameJob> j(new FrameJob());
+                j->index = mine[pos];
+                j->workdir = wds[mine[pos]];
+                t_begin[pos] = now();
+                if (!exists(j->workdir)) j->rc = -1;
+                else if (skip_existing && frame_done(j->workdir) && read_plane_txt(j->workdir, j->summary)) j->skipped = true;
+                else pl.prepare(*j);
+                std::lock_guard<std::mutex> lk(mu);
+                jobs[pos] = std::move(j);
+                ready[pos] = 1;
+                cv_ready.notify_all();
+            }
+        };
+        auto writer = [&]() {
+            for (;;) {
+                size_t pos;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv_write.wait(lk, [&]() { return !wq.empty() || wq_closed; });
+                    if (wq.empty()) return;
+                    pos = wq.front();
+                    wq.pop_front();
+                }
+                FrameJob& j = *jobs[pos];
+                pl.finish(j);
+                Record r = {};
+                r.index = (int)j.index;
+                r.rc = j.rc;
+                r.seconds = now() - t_begin[pos];
+                r.have_plane = j.rc == 0 && j.summary.have_plane;
+                r.n_points = j.summary.n_points;
+                for (int k = 0; k < 4; ++k) r.plane[k] = r.have_plane ? j.summary.plane[k] : std::nan("");
+                {
+                    std::lock_guard<std::mutex> lk(out_mu);
+                    if (verbose && !j.skipped) { FramePipeline::write_log(std::cout, j.log); std::cout.flush(); }
+                    if (r.rc == 0) wass_planes_mean_accumulate(r.plane, 1, acc);
+                    if (!write_all(fd, &r, sizeof r)) status = 2;
+                }
+                std::lock_guard<std::mutex> lk(mu);
+                jobs[pos].reset();
+            }
+        };
+        std::vector<std::thread> loaders, writers;
+        for (int t = 0; t < po.decode_threads; ++t) loaders.emplace_back(loader);
+        for (int t = 0; t < po.writer_threads; ++t) writers.emplace_back(writer);
+
+        std::vector<FrameJob*> done;
+        auto hand_over = [&](std::vector<FrameJob*>& d) {
+            if (d.empty()) return;
+            std::lock_guard<std::mutex> lk(mu);
+            for (FrameJob* j : d) wq.push_back((j->index - (size_t)rank) / (size_t)world);
+            cv_write.notify_all();
+            d.clear();
+        };
+        for (size_t pos = 0; pos < n; ++pos) {
+            FrameJob *cur, *nxt = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_ready.wait(lk, [&]() { return ready[pos] != 0; });
+                cur = jobs[pos].get();
+                if (pos + 1 < n && ready[pos + 1]) nxt = jobs[pos + 1].get();
+            }
+            pl.stage(*cur);
+            if (nxt && nxt->rc == 0 && !nxt->skipped && pl.same_geometry(*nxt)) pl.stage(*nxt);   // its upload runs underneath this frame
+            pl.submit(*cur, done);
+            // the decoded pictures have gone to the pinned ring
+            cur->env.left = Image(); cur->env.right = Image();
+            hand_over(done);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                submitted = pos + 1;
+            }
+            cv_window.notify_all();
+        }
+        pl.flush(done);
+        hand_over(done);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            wq_closed = true;
+        }
+        cv_write.notify_all();
+        cv_window.notify_all();
+        for (auto& t : loaders) t.join();
+        for (auto& t : writers) t.join();
+    }
+    if (status) return status;
+    Tail t = {};
+    t.magic = 0x57415353;
+    if (world > 1 && distinct_gpus) {
+        // Coll-1 over RCCL: needs a context (a worker without frames to compute creates one just for the collective)
+        wass_ctx* ctx = pl.context();
+        if (!ctx) return 3;
+        if (wass_coll_init(ctx, rank, world, uid) != WASS_OK || wass_coll_allreduce_sum_f64(ctx, acc, 5) != WASS_OK) {
+            std::cerr << "worker " << rank << ": RCCL all-reduce failed: " << wass_last_error(ctx) << std::endl;
+            return 4;
+        }
+        t.used_rccl = 1;
+        wass_planes_mean_finish(acc, t.mean, &t.n_valid);
+    }
+    return write_all(fd, &t, sizeof t) ? 0 : 2;
+}
+
 }  // namespace
 
 int main(int argc, char* argv[])
@@ -167,16 +326,19 @@ int main(int argc, char* argv[])
     if (argc < 3) {
         std::cout << "Usage:\n  wass_stereo_batch <config_file> <workdir>... [--gpus G] [--procs-per-gpu P] [--out <dir>] [--verbose] [--skip-existing] [--debug-images]\n"
                      "  wass_stereo_batch <config_file> --sequence <output_dir> [--gpus G] ...\n"
-                     "  --threads-per-proc T  frames in flight per worker process, each on a thread and a context of its own (default 1)\n"
-                     "  --procs-per-gpu P   worker processes per GPU (default 1).  The host side of a worker (PNG decoding, text files) is\n"
-                     "                      the limit, not the GPU: 4 workers give about 2.5 times the frames per second of one.\n";
+                     "  --decode-threads N / --writer-threads N   host threads of a worker's pipeline (default 6 / 4)\n"
+                     "  --no-inliers-file   do not write plane_refinement_inliers.xyz (14 MB of text per 5-megapixel frame that nothing reads)\n"
+                     "  --stage-by-stage    synchronous per-stage calls instead of the pipelined chain (same files)\n"
+                     "  --threads-per-proc T  stage-by-stage only: frames in flight per worker process, each on a thread and a context of its own\n"
+                     "  --procs-per-gpu P   worker processes per GPU (default 1; RCCL needs one worker per GPU, with more the parent reduces)\n";
         return argc == 1 ? 0 : -1;
     }
     const char* cfg = argv[1];
     std::vector<std::string> wds;
     std::string outdir;
     int gpus = 1, ppg = 1, tpp = 1;
-    bool verbose = false, skip_existing = false, debug_images = false;
+    bool verbose = false, skip_existing = false, debug_images = false, stage_by_stage = false;
+    PipeOptions po;
     for (int i = 2; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "--gpus" && i + 1 < argc) gpus = atoi(argv[++i]);
@@ -186,6 +348,10 @@ int main(int argc, char* argv[])
         else if (a == "--verbose") verbose = true;
         else if (a == "--skip-existing") skip_existing = true;
         else if (a == "--debug-images") debug_images = true;       // the reference's per-frame debug pictures (render.hpp); off here
+        else if (a == "--stage-by-stage") stage_by_stage = true;   // the synchronous per-stage calls instead of the pipelined chain
+        else if (a == "--decode-threads" && i + 1 < argc) po.decode_threads = atoi(argv[++i]);
+        else if (a == "--writer-threads" && i + 1 < argc) po.writer_threads = atoi(argv[++i]);
+        else if (a == "--no-inliers-file") po.inliers_file = false;
         else if (a == "--sequence" && i + 1 < argc) {
             const std::string root = argv[++i];
             if (outdir.empty()) outdir = root;
@@ -202,8 +368,20 @@ int main(int argc, char* argv[])
         } else if (a.rfind("--", 0) == 0) { std::cerr << "unknown option " << a << std::endl; return -1; }
         else wds.push_back(a);
     }
-    if (gpus < 1 || ppg < 1 || tpp < 1 || wds.empty()) { std::cerr << "Invalid arguments" << std::endl; return -1; }
-    { std::ifstream ifs(cfg); if (!ifs.is_open()) { std::cerr << "Unable to load " << cfg << std::endl; return -1; } }
+    if (gpus < 1 || ppg < 1 || tpp < 1 || po.decode_threads < 1 || po.writer_threads < 1 || wds.empty()) { std::cerr << "Invalid arguments" << std::endl; return -1; }
+    // The configuration is read once here to choose the worker form; a file that does not parse is left to the per-frame
+    // path, which reports it in every frame's log exactly as wass_stereo does.
+    Config config;
+    register_wass_stereo_options(config);
+    bool pipelined = !stage_by_stage && !debug_images && tpp == 1;
+    {
+        std::ifstream ifs(cfg);
+        if (!ifs.is_open()) { std::cerr << "Unable to load " << cfg << std::endl; return -1; }
+        std::string why;
+        try { config.load(ifs); if (pipelined && !pipeline_eligible(config, &why)) { pipelined = false; std::cout << "stage-by-stage calls: " << why << std::endl; } }
+        catch (const std::runtime_error&) { pipelined = false; }
+    }
+    if (const char* e = getenv("WASS_DEBUG_IMAGES")) if (atoi(e) != 0) pipelined = false;
     if (outdir.empty()) outdir = ".";
     const int world = gpus * ppg;
     const bool distinct = ppg == 1;
@@ -213,7 +391,8 @@ int main(int argc, char* argv[])
         return -1;
     }
 
-    std::cout << "wass_stereo_batch: " << wds.size() << " frame(s), " << world << " worker process(es) x " << tpp << " thread(s) on " << gpus << " GPU(s)" << std::endl;
+    std::cout << "wass_stereo_batch: " << wds.size() << " frame(s), " << world << " worker process(es) x " << tpp << " thread(s) on " << gpus << " GPU(s)"
+              << (pipelined ? ", pipelined (" + std::to_string(po.decode_threads) + " decode / " + std::to_string(po.writer_threads) + " writer threads per worker)" : std::string(", stage by stage")) << std::endl;
     const double t0 = now();
     std::vector<pid_t> pids(world);
     std::vector<int> fds(world);
@@ -225,7 +404,8 @@ int main(int argc, char* argv[])
         if (pid == 0) {
             close(pfd[0]);
             for (int q = 0; q < r; ++q) close(fds[q]);
-            _exit(worker(r, world, r / ppg, distinct, uid, cfg, wds, verbose, skip_existing, debug_images, pfd[1], tpp));
+            _exit(pipelined ? worker_pipelined(r, world, r / ppg, distinct, uid, cfg, config, wds, verbose, skip_existing, pfd[1], po)
+                            : worker(r, world, r / ppg, distinct, uid, cfg, wds, verbose, skip_existing, debug_images, pfd[1], tpp));
         }
         close(pfd[1]);
         pids[r] = pid; fds[r] = pfd[0];
