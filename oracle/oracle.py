@@ -175,6 +175,16 @@ def resize_cubic_u8(img, fx, fy):
     return out
 
 
+def resize_f32(img, ow, oh, cubic=True):
+    """cv::resize(img, dst, Size(ow, oh), 0, 0, INTER_CUBIC | INTER_NEAREST) for CV_32FC1 (wass_stereo.cpp:903-904)."""
+    img = np.ascontiguousarray(img, np.float32)
+    sh, sw = img.shape
+    out = np.empty((oh, ow), np.float32)
+    fn = lib().orc_resize_cubic_f32 if cubic else lib().orc_resize_nn_f32
+    fn(_p(img, C.c_float), sw, sh, _p(out, C.c_float), ow, oh, C.c_double(sw / ow), C.c_double(sh / oh))
+    return out
+
+
 def dense_inputs(right, left, dense_scale):
     """wass_stereo.cpp:788-796 (identity at scale 1: the reference's defect there is not reproduced)."""
     if dense_scale == 1.0:

@@ -1,4 +1,6 @@
-"""The pin for rows a2-a6: oracle/sgbm_oracle.c against the REAL cv::StereoSGBM.
+"""The pins: oracle/sgbm_oracle.c against the REAL cv::StereoSGBM (rows a2-a6), and the restatements of the other OpenCV
+routines -- stereoRectify / initUndistortRectifyMap / remap / warpPerspective (f1), undistort / CLAHE (f2), resize /
+filterSpeckles / the gradient-component extraction (a9) -- against the real functions (tests/golden/opencv_other.npz).
 
 tests/golden/sgbm_opencv.npz is written by scripts/pin_with_opencv.py on a machine that has OpenCV (the build image has
 none: no cv2, no library, and the reference cannot be compiled here -- SURVEY.md 8c).  While the file is absent this test
@@ -48,4 +50,88 @@ def test_oracle_reproduces_opencv(oracle):
                 continue            # A.7: OpenCV itself is build-dependent there (scalar wraps, SIMD saturates); recorded, not compared
             if not np.array_equal(d, z[f"{name}__{key}"]):
                 bad.append((name, key, int((d != z[f"{name}__{key}"]).sum())))
+    assert not bad, f"oracle differs from OpenCV {z['opencv_version']}: {bad}"
+
+
+# ------------------------------------------------------------------------------------ rows f1, f2, a9: the other restatements
+PIN_OTHER = os.path.join(ROOT, "tests", "golden", "opencv_other.npz")
+
+
+def _other_cases():
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import pin_with_opencv
+    return pin_with_opencv.other_cases()
+
+
+def oracle_other(O, c):
+    """What oracle/*.c gives for one case of scripts/pin_with_opencv.py:other_cases(), keyed like run_other()."""
+    k = c["kind"]
+    if k == "rectify":
+        rr = O.stereo_rectify(c["K1"], c["K2"], c["w"], c["h"], c["R"], c["T"], 1.0)
+        mx1, my1 = O.init_rectify_map(c["K1"], rr["R1"], rr["P1"], c["w"], c["h"])
+        mx2, my2 = O.init_rectify_map(c["K2"], rr["R2"], rr["P2"], c["w"], c["h"])
+        return dict(R1=rr["R1"], R2=rr["R2"], P1=rr["P1"], P2=rr["P2"], roi1=np.array(rr["roi1"]), roi2=np.array(rr["roi2"]), mx1=mx1, my1=my1,
+                    mx2=mx2, my2=my2, left_rect=O.remap_cubic(c["left"], mx1, my1), right_rect=O.remap_cubic(c["right"], mx2, my2))
+    if k == "warp":
+        h, w = c["src"].shape
+        return dict(dst=O.warp_perspective(c["src"], c["H"], w, h))
+    if k == "undistort":
+        return dict(dst=O.undistort(c["src"], c["K"], list(c["dist"])))
+    if k == "clahe":
+        return dict(dst=O.clahe(c["src"], c["clip"], c["tiles"]))
+    if k == "resize_u8":
+        return dict(dst=O.resize_cubic_u8(c["src"], c["fx"], c["fy"]))
+    if k == "resize_f32":
+        return dict(nearest=O.resize_f32(c["src"], c["ow"], c["oh"], cubic=False), cubic=O.resize_f32(c["src"], c["ow"], c["oh"], cubic=True))
+    if k == "speckle":
+        return dict(dst=O.filter_speckles(c["src"], c["new_val"], c["max_size"], c["max_diff"]))
+    if k == "component":
+        return dict(dst=O.biggest_component_by_gradient(c["src"], c["threshold"])[0])
+    raise ValueError(k)
+
+
+# how close each stored array has to be: exact for everything integer; the rectification's matrices are fp64 results of a
+# few hundred operations (1e-12), the maps float32 casts of fp64 accumulations (one unit in the last place), the float
+# resize and the gradient float32 arithmetic in OpenCV's operation order (exact)
+_TOL = {"R1": 1e-12, "R2": 1e-12, "P1": 1e-9, "P2": 1e-9, "mx1": 1e-4, "my1": 1e-4, "mx2": 1e-4, "my2": 1e-4}
+
+
+def test_pin_script_other_cases_run_through_the_oracle(oracle):
+    """Every case of the second pin file goes through the restatement it will be compared with (no OpenCV needed): the
+    inputs are valid, the outputs have the shapes the real functions return, and nothing is degenerate (an all-zero result
+    would make a later comparison meaningless)."""
+    seen = set()
+    kinds = set()
+    for c in _other_cases():
+        assert c["name"] not in seen
+        seen.add(c["name"]); kinds.add(c["kind"])
+        got = oracle_other(oracle, c)
+        for key, v in got.items():
+            v = np.asarray(v)
+            assert v.size > 0 and np.isfinite(v.astype(np.float64)).all(), (c["name"], key)
+            if key in ("dst", "left_rect", "right_rect", "cubic", "nearest") and c["name"] != "clahe_flat":
+                assert len(np.unique(v)) > 4, (c["name"], key)
+        if c["kind"] == "rectify":
+            assert got["roi1"][2] > 0 and got["roi2"][3] > 0
+            assert got["left_rect"].shape == (c["h"], c["w"])
+    assert kinds == {"rectify", "warp", "undistort", "clahe", "resize_u8", "resize_f32", "speckle", "component"}
+
+
+@pytest.mark.skipif(not os.path.exists(PIN_OTHER), reason="tests/golden/opencv_other.npz not generated (scripts/pin_with_opencv.py needs cv2)")
+def test_oracle_reproduces_opencv_other(oracle):
+    z = np.load(PIN_OTHER)
+    bad = []
+    for c in _other_cases():
+        got = oracle_other(oracle, c)
+        for key, v in got.items():
+            ref = z[f"{c['name']}__{key}"]
+            v = np.asarray(v)
+            if v.shape != ref.shape:
+                bad.append((c["name"], key, "shape", v.shape, ref.shape))
+            elif key in _TOL:
+                err = float(np.abs(v.astype(np.float64) - ref.astype(np.float64)).max())
+                if err > _TOL[key]:
+                    bad.append((c["name"], key, "max abs error", err))
+            elif not np.array_equal(v, ref):
+                bad.append((c["name"], key, "differing elements", int((v != ref).sum()), "of", int(v.size)))
     assert not bad, f"oracle differs from OpenCV {z['opencv_version']}: {bad}"

@@ -136,6 +136,7 @@ SYMBOLS = {
     "wass_ctx_frame_result": (_i, [_vp, C.POINTER(FrameResult)]),
     "wass_device_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "wass_device_free": (None, [_vp, _vp]),
+    "wass_download": (_i, [_vp, _vp, _vp, _sz]),
     "wass_pinned_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "wass_pinned_free": (None, [_vp, _vp]),
     "wass_free": (None, [_vp]),

@@ -187,7 +187,11 @@ int wass_device_alloc(wass_ctx* c, size_t nbytes, void** d_out)
     WASS_HIP(c, hipSetDevice(c->device));
     *d_out = nullptr;
     if (hipMalloc(d_out, nbytes) != hipSuccess) { *d_out = nullptr; return set_err(c, WASS_ERR_NO_MEMORY, "hipMalloc(%zu) failed", nbytes); }
+    // hipMemset on device memory returns before the fill has run, and the fill is ordered on the NULL stream, which the
+    // context's non-blocking streams do not wait for: without the synchronisation it can land on top of what the caller's
+    // first kernel or upload wrote (seen: the first rectified crop of a sequence partly zeroed, differently every run)
     WASS_HIP(c, hipMemset(*d_out, 0, nbytes));
+    WASS_HIP(c, hipDeviceSynchronize());
     return WASS_OK;
 }
 void wass_device_free(wass_ctx* c, void* d_ptr)
@@ -195,6 +199,16 @@ void wass_device_free(wass_ctx* c, void* d_ptr)
     if (!c || !d_ptr) return;
     (void)hipSetDevice(c->device);
     (void)hipFree(d_ptr);
+}
+int wass_download(wass_ctx* c, void* h_dst, const void* d_src, size_t nbytes)
+{
+    if (!c || !h_dst || !d_src) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    WASS_HIP(c, hipSetDevice(c->device));
+    WASS_HIP(c, hipStreamSynchronize(c->stream));
+    WASS_HIP(c, hipStreamSynchronize(c->tail));
+    WASS_HIP(c, hipStreamSynchronize(c->copy));
+    WASS_HIP(c, hipMemcpy(h_dst, d_src, nbytes, hipMemcpyDeviceToHost));
+    return WASS_OK;
 }
 int wass_pinned_alloc(wass_ctx* c, size_t nbytes, void** h_out)
 {

@@ -285,6 +285,16 @@ public:
             mesh = nullptr;
             pending_ = &job;
             ++nsub_;
+            if (const char* dd = getenv("WASS_PIPE_DUMP")) {          // debugging aid: the frame's intermediate maps, as raw bytes
+                auto dump = [&](const char* name, const void* d, size_t nb) {
+                    std::vector<char> hbuf(nb);
+                    if (wass_download(ctx_, hbuf.data(), d, nb) == WASS_OK) { std::ofstream f(path_join(dd, name).c_str(), std::ios::binary); f.write(hbuf.data(), (std::streamsize)nb); }
+                };
+                dump("left_crop.bin", in_[k].d_cl, (size_t)rl[2] * rl[3]);
+                dump("right_crop.bin", in_[k].d_cr, (size_t)rr[2] * rr[3]);
+                dump("disp16.bin", d16, (size_t)cw * ch * 2);
+                dump("dispf.bin", d_dispf_, (size_t)cw * ch * 4);
+            }
             job.t_submitted = Timer::now();
         } catch (const std::exception& e) {
             if (mesh) wass_mesh_destroy(mesh);

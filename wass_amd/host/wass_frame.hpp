@@ -436,6 +436,13 @@ inline int wass_run_frame(const char* config_path, const std::string& workdir, c
         }
         gpu_check(ctx, wass_disparity_postprocess_ex(ctx, disp16.data(), ws, hs, &sp, dil, ero, cfg.get_int("MEDIAN_FILTER_WSIZE"), cc_threshold,
                                                      cw, ch, dispf.data()), "wass_disparity_postprocess");
+        if (const char* dd = getenv("WASS_PIPE_DUMP")) {              // debugging aid, see frame_pipeline.hpp
+            auto dump = [&](const char* name, const void* d, size_t nb) { std::ofstream f(path_join(dd, name).c_str(), std::ios::binary); f.write((const char*)d, (std::streamsize)nb); };
+            dump("left_crop.bin", env.left_crop.px.data(), env.left_crop.px.size());
+            dump("right_crop.bin", env.right_crop.px.data(), env.right_crop.px.size());
+            dump("disp16.bin", disp16.data(), disp16.size() * 2);
+            dump("dispf.bin", dispf.data(), dispf.size() * 4);
+        }
         if (debug_images && cc_threshold > 0) {                      // :958-960, 981-983
             Image lg(cw, ch), nb(cw, ch);
             gpu_check(ctx, wass_large_gradient_mask(ctx, cw, ch, lg.px.data()), "wass_large_gradient_mask");
