@@ -137,6 +137,12 @@ int wass_sgm_last_timings(wass_ctx* ctx, wass_sgm_timings* out);
  * enqueued, without waiting for frame n+1 */
 int wass_sgm_prev_timings(wass_ctx* ctx, wass_sgm_timings* out);
 
+/* Measurement hook for the roofline accounting (bench.py): re-runs the vertical block sum of the LAST call on its retained
+ * horizontal sums, once as the plain sum (plain_ms) and once in the form the call used (production_ms; in 8-path mode it
+ * also carries paths 2 / 6 and their checkpoints, in 5-path mode path 2 and S = L_2), best of three, hipEvents on the
+ * context's stream.  production_ms - plain_ms is what the column paths add to the cost stage.  Synchronises. */
+int wass_sgm_probe_vsum(wass_ctx* ctx, float* plain_ms, float* production_ms);
+
 /* Test hooks: copy intermediates of the last wass_sgm_disparity call to host.
  * C/S are [h][width1][num_disp] int16 with width1 = w + max(disp_offset,0) -
  * min_disp (C without the +P2 bias); raw is the padded-width disparity before

@@ -101,6 +101,7 @@ SYMBOLS = {
     "wass_sgm_last_timings": (_i, [_vp, C.POINTER(SgmTimings)]),
     "wass_sgm_prev_timings": (_i, [_vp, C.POINTER(SgmTimings)]),
     "wass_sgm_debug_fetch": (_i, [_vp, _vp, _vp, _vp]),
+    "wass_sgm_probe_vsum": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "wass_disparity_postprocess": (_i, [_vp, _vp, _i, _i, C.POINTER(SgmParams), _i, _i, _i, _vp]),
     "wass_disparity_postprocess_dev": (_i, [_vp, _vp, _i, _i, C.POINTER(SgmParams), _i, _i, _i, _vp]),
     "wass_triangulate": (_i, [_vp, _vp, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(Geom), _vp, _i, _i, _vp, _vp,
@@ -187,7 +188,10 @@ def load() -> C.CDLL:
     except ImportError:
         pass
     lib = C.CDLL(SO_PATH)
+    other_build = bool(os.environ.get("WASS_GPU_LIB"))
     for name, (res, args) in SYMBOLS.items():
+        if other_build and not hasattr(lib, name):
+            continue                     # an OLDER build of the library in an A/B measurement: newer entry points are simply absent
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args

@@ -351,6 +351,37 @@ int wass_sgm_prev_timings(wass_ctx* c, wass_sgm_timings* out)
     return read_timings(c, c->nsgm - 2, out);
 }
 
+int wass_sgm_probe_vsum(wass_ctx* c, float* plain_ms, float* production_ms)
+{
+    if (!c || !plain_ms || !production_ms) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    if (!c->have_last) return set_err(c, WASS_ERR_INVALID_ARG, "no completed wass_sgm_disparity call");
+    WASS_HIP(c, hipSetDevice(c->device));
+    WASS_HIP(c, hipStreamSynchronize(c->stream));
+    WASS_HIP(c, hipStreamSynchronize(c->side));
+    WASS_HIP(c, hipStreamSynchronize(c->tail));
+    hipEvent_t e[3] = { nullptr, nullptr, nullptr };
+    for (auto& x : e) if (hipEventCreate(&x) != hipSuccess) { for (auto& y : e) if (y) (void)hipEventDestroy(y); return set_err(c, WASS_ERR_DEVICE, "hipEventCreate failed"); }
+    int rc = WASS_OK;
+    float best[2] = { 1e30f, 1e30f };
+    for (int rep = 0; rep < 3 && rc == WASS_OK; ++rep) {        // the hsum volume of the last frame is still there; both forms write the same C
+        (void)hipEventRecord(e[0], c->stream);
+        rc = launch_vsum_only(c, c->last, true);
+        (void)hipEventRecord(e[1], c->stream);
+        if (rc == WASS_OK) rc = launch_vsum_only(c, c->last, false);
+        (void)hipEventRecord(e[2], c->stream);
+        if (hipStreamSynchronize(c->stream) != hipSuccess) rc = set_err(c, WASS_ERR_DEVICE, "probe failed");
+        float a = 0, b = 0;
+        if (rc == WASS_OK && hipEventElapsedTime(&a, e[0], e[1]) == hipSuccess && hipEventElapsedTime(&b, e[1], e[2]) == hipSuccess) {
+            best[0] = a < best[0] ? a : best[0];
+            best[1] = b < best[1] ? b : best[1];
+        }
+    }
+    for (auto& x : e) (void)hipEventDestroy(x);
+    if (rc != WASS_OK) return rc;
+    *plain_ms = best[0]; *production_ms = best[1];
+    return WASS_OK;
+}
+
 int wass_sgm_disparity(wass_ctx* c, const uint8_t* right, const uint8_t* left, int w, int h, size_t pitch,
                        const wass_sgm_params* p, int16_t* disp16_out)
 {

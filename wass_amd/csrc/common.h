@@ -252,6 +252,7 @@ void mesh_pool_purge(const void* owner);      // mesh.hip: parked mesh allocatio
 // stage launchers (each enqueues on c->stream)
 int launch_prefilter(wass_ctx* c, const SgmDims& d);
 int launch_cost_volume(wass_ctx* c, const SgmDims& d);
+int launch_vsum_only(wass_ctx* c, const SgmDims& d, bool plain);   // the vertical block sum alone, on the hsum volume of the last frame
 int launch_aggregate(wass_ctx* c, const SgmDims& d, int* n_launches);
 int launch_select(wass_ctx* c, const SgmDims& d);
 int launch_median_crop(wass_ctx* c, const SgmDims& d, int16_t* d_out);

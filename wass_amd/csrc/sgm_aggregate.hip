@@ -257,6 +257,9 @@ __device__ __forceinline__ void lds_ld(const uint32_t* p, us2 (&v)[NP])
 #ifndef WASS_VREC
 #define WASS_VREC 7                                // bit 0: k_pair, bit 1: k_pairx column records, bit 2: k_pairx row records
 #endif
+#ifndef WASS_REC_TIE
+#define WASS_REC_TIE 0
+#endif
 template <int N, bool VEC>
 struct Rec {
     uint32_t v[VEC ? 1 : N / 2];
@@ -272,7 +275,11 @@ struct Rec {
             v[0] = __builtin_amdgcn_raw_buffer_load_b32(mk_rsrc(p), (uint32_t)min(lane, N / 2 - 1) * 4u, 0, 0);
             // the loaded REGISTER is an operand of the fence: a bare memory clobber does not formally order a read-only
             // buffer-load intrinsic, a volatile asm that consumes its result does (it cannot be sunk past it)
+#if WASS_REC_TIE
             asm volatile("" : "+v"(v[0]) :: "memory");
+#else
+            asm volatile("" ::: "memory");
+#endif
         } else {
 #pragma unroll
             for (int i = 0; i < N / 2; ++i) v[i] = p[i];
@@ -531,10 +538,21 @@ k_pair(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t*
 // XB = 10: 2 * ceil(2455 / 10) = 492 workgroups of ten waves, two per CU (2 x 80 KiB of LDS, five waves per SIMD): all of
 // config B's columns are resident at once.  With XB = 8 there were 614 workgroups for 512 places and the kernel ran two
 // rounds, the second one a fifth full (2.85 ms).
-constexpr int XB = 10;
+// D = 257 .. 512 (NP = 3, 4; round 4): the hand-over block of XB columns x K = 8 rows x two kinds is XB * 16 vectors of 768 B /
+// 1 KiB -- 120 KiB with ten columns at NP = 3, 128 KiB with EIGHT columns at NP = 4: one workgroup per CU (2.5 / 2 waves per
+// SIMD, which is also all the plain pair kernel gets there: its hand-over slots are 16 KiB per wave), every wave with a row of
+// its own in the row phase.  The earlier attempt at D = 512 kept ten columns and halved K to fit (two barriers every FOUR
+// rows, six of ten waves idle in the row phase: 28.1 against 23.3 ms); with K = 8 the fused form is the one S pass less that
+// the byte budget of config E needed.
 #ifndef WASS_FUSE_NP
-#define WASS_FUSE_NP 2
+#define WASS_FUSE_NP 4
 #endif
+template <int NP> struct Fuse {
+    static constexpr int XB = NP <= 3 ? 10 : 8;              // columns per workgroup of k_pairx = block size of the row entry states
+    static constexpr int MINW = NP <= 2 ? 5 : 2;              // waves per SIMD the register budget is cut for
+    static constexpr int MAXW = NP <= 2 ? 5 : (NP == 3 ? 3 : 2);
+};
+inline int fuse_xb(int NP) { return NP <= 3 ? 10 : 8; }
 
 // One wave per row walks BOTH paths at once, path 0 from the left border and path 4 from the right border, the two
 // recurrences interleaved statement by statement (sgm_step_pair): the row chains are the longest in the image (2 455
@@ -547,6 +565,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))
 k_rowsweep(const uint32_t* __restrict__ C, uint32_t* __restrict__ entF, uint32_t* __restrict__ entB, uint16_t* __restrict__ MF,
            uint16_t* __restrict__ MB, int width1, int h, int P1, int P2, int nbx)
 {
+    constexpr int XB = Fuse<NP>::XB;
     const int lane = threadIdx.x & 63;
     const int y = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
     if (y >= h) return;
@@ -660,11 +679,12 @@ struct RowSide {                     // what k_rowsweep left behind
 
 // ACC: S already holds another family's sum (S += ...); otherwise this kernel writes S first.
 template <int NP, int K, bool ACC>
-__global__ void __launch_bounds__(64 * XB) __attribute__((amdgpu_waves_per_eu(5, 5)))
+__global__ void __launch_bounds__(64 * Fuse<NP>::XB) __attribute__((amdgpu_waves_per_eu(Fuse<NP>::MINW, Fuse<NP>::MAXW)))
 k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t* __restrict__ ckpt, const uint16_t* __restrict__ mins,
         const RowSide rs, int width1, int h, int P1, int P2, int maxseg, const uint32_t* __restrict__ endstate)
 {
-    static_assert(K % 2 == 0 && K <= XB, "one wave per row of a K-row segment");
+    constexpr int XB = Fuse<NP>::XB;
+    static_assert(K % 2 == 0 && K <= XB && XB % 2 == 0, "one wave per row of a K-row segment; minima records are read as dwords");
     static_assert((size_t)XB * 2 * K * 256 * NP <= 160 * 1024, "the hand-over block must fit a CU's LDS");
     constexpr int VW = 64 * NP, VB = 256 * NP;
     // hand-over slots [2][K][XB][VW]: [0] cost vectors, [1] forward path costs; slot (element of a K-row segment), column.
@@ -1006,6 +1026,7 @@ CkptLayout ckpt_layout(const SgmDims& d)
         o += ((size_t)L.nch[f] * L.mseg[f] * L.K * sizeof(uint16_t) + 255) & ~(size_t)255;
     }
     if (L.rows_fused) {              // k_rowsweep: entry states per block of XB columns and minima per pixel, both row paths
+        const int XB = fuse_xb(d.NP);
         L.nbx = (d.width1 + XB - 1) / XB;
         const size_t eb = ((size_t)d.h * L.nbx * (64 * d.NP) * sizeof(uint32_t) + 255) & ~(size_t)255;
         const size_t mb = ((size_t)d.h * L.nbx * XB * sizeof(uint16_t) + 255) & ~(size_t)255;
@@ -1043,11 +1064,13 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
     WASS_HIP(c, hipStreamWaitEvent(c->side, c->ev_cost, 0));
     char* const ckb = (char*)c->ckpt.p;
     if (lay.rows_fused) {                            // the row sweeps come first: the first kernel on the main stream needs them
-        hipLaunchKernelGGL((k_rowsweep<NP>), dim3((d.h + 3) / 4), dim3(256), 0, c->side, C, (uint32_t*)(ckb + lay.roff[0]),
-                           (uint32_t*)(ckb + lay.roff[1]), (uint16_t*)(ckb + lay.roff[2]), (uint16_t*)(ckb + lay.roff[3]), d.width1, d.h,
-                           d.P1, d.P2, lay.nbx);
-        WASS_HIP(c, hipEventRecord(c->ev_ckpt[3], c->side));
-        ++nl;
+        if constexpr (NP <= WASS_FUSE_NP) {
+            hipLaunchKernelGGL((k_rowsweep<NP>), dim3((d.h + 3) / 4), dim3(256), 0, c->side, C, (uint32_t*)(ckb + lay.roff[0]),
+                               (uint32_t*)(ckb + lay.roff[1]), (uint16_t*)(ckb + lay.roff[2]), (uint16_t*)(ckb + lay.roff[3]), d.width1, d.h,
+                               d.P1, d.P2, lay.nbx);
+            WASS_HIP(c, hipEventRecord(c->ev_ckpt[3], c->side));
+            ++nl;
+        }
     }
     for (int f = 0; f < nf; ++f) {
         if (f == 0 && lay.cols_from_cost) {         // written by k_vsum_col on the main stream already
@@ -1092,6 +1115,7 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
                 WASS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_ckpt[3], 0));
                 const RowSide rs = { (const uint32_t*)(ckb + lay.roff[0]), (const uint32_t*)(ckb + lay.roff[1]),
                                      (const uint16_t*)(ckb + lay.roff[2]), (const uint16_t*)(ckb + lay.roff[3]), lay.nbx };
+                constexpr int XB = Fuse<NP>::XB;
                 const size_t ldsx = (size_t)XB * 2 * K * (64 * NP) * sizeof(uint32_t);
                 WASS_HIP(c, hipFuncSetAttribute((const void*)k_pairx<NP, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx));
                 hipLaunchKernelGGL((k_pairx<NP, K, true>), dim3(2 * lay.nbx), dim3(64 * XB), ldsx, c->stream, C, S, ck, mn, rs, d.width1, d.h, d.P1,

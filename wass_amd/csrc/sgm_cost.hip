@@ -466,6 +466,9 @@ __global__ void __launch_bounds__(256) k_vsum_col(const uint32_t* __restrict__ h
 }
 
 template <int NP>
+static int launch_vsum_np(wass_ctx* c, const SgmDims& d, bool plain);
+
+template <int NP>
 static int launch_cost_np(wass_ctx* c, const SgmDims& d)
 {
     {
@@ -484,11 +487,19 @@ static int launch_cost_np(wass_ctx* c, const SgmDims& d)
                            XQ, off, nch, (uint32_t*)c->hsum.p);
     }
     WASS_HIP(c, hipEventRecord(c->ev[7], c->stream));                        // start of the vertical sum (wass_sgm_timings.vsum_ms)
+    return launch_vsum_np<NP>(c, d, false);
+}
+
+// The vertical block sum.  plain: the sum alone (k_vsum, row segments), whatever the schedule -- what the stage would cost
+// without the column paths riding on it; the roofline accounting times it against the production form (wass_sgm_probe_vsum).
+template <int NP>
+static int launch_vsum_np(wass_ctx* c, const SgmDims& d, bool plain)
+{
     const int YSEG = 128;
     const size_t lds2 = (size_t)4 * (2 * d.SW2 + 1) * NP * 64 * sizeof(uint32_t);
     if (lds2 > 160 * 1024) return set_err(c, WASS_ERR_UNSUPPORTED, "WINSIZE %d too large for the LDS ring", 2 * d.SW2 + 1);
     const CkptLayout lay = ckpt_layout(d);
-    if (lay.cols_from_cost || lay.path2_from_cost) {
+    if (!plain && (lay.cols_from_cost || lay.path2_from_cost)) {
         constexpr int K = ckpt_k(NP);
         int rc = ensure(c, c->ckpt, lay.total);
         if (rc) return rc;
@@ -520,6 +531,21 @@ static int launch_cost_np(wass_ctx* c, const SgmDims& d)
                        d.SW2, d.P2, YSEG, (uint32_t*)c->C.p, (uint32_t*)c->flags.p);
     WASS_HIP(c, hipGetLastError());
     return WASS_OK;
+}
+
+int launch_vsum_only(wass_ctx* c, const SgmDims& d, bool plain)
+{
+    switch (d.NP) {
+        case 1: return launch_vsum_np<1>(c, d, plain);
+        case 2: return launch_vsum_np<2>(c, d, plain);
+        case 3: return launch_vsum_np<3>(c, d, plain);
+        case 4: return launch_vsum_np<4>(c, d, plain);
+        case 5: return launch_vsum_np<5>(c, d, plain);
+        case 6: return launch_vsum_np<6>(c, d, plain);
+        case 7: return launch_vsum_np<7>(c, d, plain);
+        case 8: return launch_vsum_np<8>(c, d, plain);
+    }
+    return set_err(c, WASS_ERR_UNSUPPORTED, "MAX_DISPARITY %d not supported (max 1024)", d.D);
 }
 
 int launch_cost_volume(wass_ctx* c, const SgmDims& d)

@@ -128,27 +128,37 @@ __device__ __forceinline__ void buf_ld(rsrc_t r, uint32_t voff, uint32_t soff, u
 template <int NP>
 __device__ __forceinline__ void buf_st(rsrc_t r, uint32_t voff, uint32_t soff, const us2 (&src)[NP])
 {
-    if constexpr (NP % 4 == 0) {
-        // A 128-bit buffer store whose scalar offset is an SGPR fetches its data registers late (the ISA manual lists
-        // buffer_store_dwordx3/x4 with an SGPR offset as needing a wait state before a VALU overwrites the data; under
-        // memory back-pressure the window is far longer and an LDS read or a load landing in the same registers also
-        // corrupts the store -- measured: ~1e-4 of the pixels wrong at D = 512, run to run different, only with x4
-        // stores, never with x4 loads or x2 stores).  The offset therefore goes into the VGPR: one v_add per store.
+    // A buffer store of MORE than 64 bits whose scalar offset is an SGPR fetches its data registers late (the ISA manual
+    // lists buffer_store_dwordx3/x4 with an SGPR offset as needing a wait state before a VALU overwrites the data; under
+    // memory back-pressure the window is far longer and an LDS read or a load landing in the same registers also
+    // corrupts the store -- measured: ~1e-4 of the pixels wrong at D = 512, run to run different, only with x4 stores,
+    // never with x4 loads or x2 stores).  It does not take a 128-bit store in the SOURCE to get one: the compiler merges
+    // neighbouring dword / dwordx2 stores (NP = 3: three b32 stores became buffer_store_dwordx3 ... s8 offen, and the third
+    // dword of a handful of vectors per frame came out wrong in k_pairx<3>, round 4).  Whenever a vector is wider than
+    // one 64-bit store the offset therefore goes into the VGPR: one v_add per vector.
+    if constexpr (NP > 2) {
         const uint32_t vo = voff + soff;
+        if constexpr (NP % 4 == 0) {
 #pragma unroll
-        for (int j = 0; j < NP; j += 4) {
-            const wass_v4u v = { as_u32(src[j]), as_u32(src[j + 1]), as_u32(src[j + 2]), as_u32(src[j + 3]) };
-            __builtin_amdgcn_raw_buffer_store_b128(v, r, vo + 4 * j, 0, WASS_NT ? 2 : 0);
-        }
-    } else if constexpr (NP % 2 == 0) {
+            for (int j = 0; j < NP; j += 4) {
+                const wass_v4u v = { as_u32(src[j]), as_u32(src[j + 1]), as_u32(src[j + 2]), as_u32(src[j + 3]) };
+                __builtin_amdgcn_raw_buffer_store_b128(v, r, vo + 4 * j, 0, WASS_NT ? 2 : 0);
+            }
+        } else if constexpr (NP % 2 == 0) {
 #pragma unroll
-        for (int j = 0; j < NP; j += 2) {
-            const wass_v2u v = { as_u32(src[j]), as_u32(src[j + 1]) };
-            __builtin_amdgcn_raw_buffer_store_b64(v, r, voff + 4 * j, soff, WASS_NT ? 2 : 0);
+            for (int j = 0; j < NP; j += 2) {
+                const wass_v2u v = { as_u32(src[j]), as_u32(src[j + 1]) };
+                __builtin_amdgcn_raw_buffer_store_b64(v, r, vo + 4 * j, 0, WASS_NT ? 2 : 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) __builtin_amdgcn_raw_buffer_store_b32(as_u32(src[j]), r, vo + 4 * j, 0, WASS_NT ? 2 : 0);
         }
+    } else if constexpr (NP == 2) {
+        const wass_v2u v = { as_u32(src[0]), as_u32(src[1]) };
+        __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, WASS_NT ? 2 : 0);
     } else {
-#pragma unroll
-        for (int j = 0; j < NP; ++j) __builtin_amdgcn_raw_buffer_store_b32(as_u32(src[j]), r, voff + 4 * j, soff, WASS_NT ? 2 : 0);
+        __builtin_amdgcn_raw_buffer_store_b32(as_u32(src[0]), r, voff, soff, WASS_NT ? 2 : 0);
     }
 }
 

@@ -50,6 +50,10 @@ struct Record {            // worker -> parent, one per frame
 struct Tail {              // worker -> parent, once: what the worker's all-reduce returned
     int magic, used_rccl, n_valid;
     double mean[4];
+    // when the worker's first and last computed frames were complete (files written), and how many it computed: the rate
+    // between the two is the worker's steady state, without its start-up (HIP initialisation, first allocations)
+    double first_done, last_done;
+    int computed;
 };
 
 bool write_all(int fd, const void* p, size_t n)
@@ -176,7 +180,7 @@ bool frame_done(const std::string& wd)
     return exists(path_join(wd, "mesh_cam.xyzbin"));
 }
 
-struct PipeOptions { int decode_threads = 6, writer_threads = 4; bool inliers_file = true; };
+struct PipeOptions { int decode_threads = 8, writer_threads = 4; bool inliers_file = true; };
 
 // One worker process, one context, frames rank, rank + world, ... through FramePipeline.
 int worker_pipelined(int rank, int world, int device, bool distinct_gpus, const unsigned char* uid, const char* cfgpath, const Config& cfg,
@@ -192,6 +196,8 @@ int worker_pipelined(int rank, int world, int device, bool distinct_gpus, const 
     const size_t n = mine.size();
     double acc[5] = { 0, 0, 0, 0, 0 };
     int status = 0;
+    double first_done = 0, last_done = 0;
+    int computed = 0;
     FramePipeline::Options fo;
     fo.out_slots = po.writer_threads + 2;
     fo.inliers_file = po.inliers_file;
@@ -254,6 +260,7 @@ int worker_pipelined(int rank, int world, int device, bool distinct_gpus, const 
                     if (verbose && !j.skipped) { FramePipeline::write_log(std::cout, j.log); std::cout.flush(); }
                     if (r.rc == 0) wass_planes_mean_accumulate(r.plane, 1, acc);
                     if (!write_all(fd, &r, sizeof r)) status = 2;
+                    if (!j.skipped && r.rc == 0) { const double t = now(); if (!computed++) first_done = t; last_done = t; }
                 }
                 std::lock_guard<std::mutex> lk(mu);
                 jobs[pos].reset();
@@ -305,6 +312,7 @@ int worker_pipelined(int rank, int world, int device, bool distinct_gpus, const 
     if (status) return status;
     Tail t = {};
     t.magic = 0x57415353;
+    t.first_done = first_done; t.last_done = last_done; t.computed = computed;
     if (world > 1 && distinct_gpus) {
         // Coll-1 over RCCL: needs a context (a worker without frames to compute creates one just for the collective)
         wass_ctx* ctx = pl.context();
@@ -326,7 +334,7 @@ int main(int argc, char* argv[])
     if (argc < 3) {
         std::cout << "Usage:\n  wass_stereo_batch <config_file> <workdir>... [--gpus G] [--procs-per-gpu P] [--out <dir>] [--verbose] [--skip-existing] [--debug-images]\n"
                      "  wass_stereo_batch <config_file> --sequence <output_dir> [--gpus G] ...\n"
-                     "  --decode-threads N / --writer-threads N   host threads of a worker's pipeline (default 6 / 4)\n"
+                     "  --decode-threads N / --writer-threads N   host threads of a worker's pipeline (default 8 / 4)\n"
                      "  --no-inliers-file   do not write plane_refinement_inliers.xyz (14 MB of text per 5-megapixel frame that nothing reads)\n"
                      "  --stage-by-stage    synchronous per-stage calls instead of the pipelined chain (same files)\n"
                      "  --threads-per-proc T  stage-by-stage only: frames in flight per worker process, each on a thread and a context of its own\n"
@@ -507,5 +515,11 @@ int main(int argc, char* argv[])
     std::cout << "mean plane over " << nvalid << " frame(s): " << std::setprecision(12) << mean[0] << " " << mean[1] << " " << mean[2] << " " << mean[3]
               << (world > 1 && distinct ? "  (RCCL all-reduce)" : "") << std::endl;
     std::cout << wds.size() - nfail << "/" << wds.size() << " frame(s) ok in " << dt << " s (" << (wds.size() / dt) << " frames/s)" << std::endl;
+    {
+        double steady = 0;
+        for (int r = 0; r < world; ++r)
+            if (tails[r].computed > 1 && tails[r].last_done > tails[r].first_done) steady += (tails[r].computed - 1) / (tails[r].last_done - tails[r].first_done);
+        if (steady > 0) std::cout << "steady state (first to last finished frame of every worker, start-up excluded): " << steady << " frames/s" << std::endl;
+    }
     return ok && nfail == 0 ? 0 : -1;
 }

@@ -127,6 +127,12 @@ class Context:
         """d_mask = d_img <= 254 on the context's SGM stream (DISCARD_BURNED_AREAS, wass_stereo.cpp:1072)."""
         self._check(self._lib.wass_burned_area_mask_dev(self._h, d_img.data_ptr(), d_img.numel(), d_mask.data_ptr()))
 
+    def sgm_probe_vsum(self):
+        """(plain_ms, production_ms) of the vertical block sum on the last call's horizontal sums (wass_sgm_probe_vsum)."""
+        a, b = C.c_float(), C.c_float()
+        self._check(self._lib.wass_sgm_probe_vsum(self._h, C.byref(a), C.byref(b)))
+        return float(a.value), float(b.value)
+
     def sgm_timings(self, previous: bool = False) -> SgmTimings:
         """Stage times of the last SGM call (previous=True: of the call before it, which a pipelined driver can
         read without waiting for the frame it has just enqueued)."""
