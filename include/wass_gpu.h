@@ -137,6 +137,14 @@ int wass_sgm_last_timings(wass_ctx* ctx, wass_sgm_timings* out);
  * enqueued, without waiting for frame n+1 */
 int wass_sgm_prev_timings(wass_ctx* ctx, wass_sgm_timings* out);
 
+/* Device-side canary for the aggregation kernels: runs one synthetic w x h pair with num_disp disparities through the
+ * production schedule (checkpoint sweeps, pair kernels with recomputation, row fusion) and through one plain sweep per path,
+ * and compares the two aggregated volumes S cell by cell ON THE DEVICE -- no CPU oracle, usable in the field.  *mismatches
+ * receives the number of differing cells; returns WASS_ERR_DEVICE when it is not zero.  The two forms share the arithmetic
+ * of one path step and nothing of the scheduling around it, which is where an instance-specific miscompile and a hardware
+ * store hazard were found.  __graft_entry__.smoke() and tests/test_sgm_gpu.py run it for every NP. */
+int wass_sgm_selftest(wass_ctx* ctx, int w, int h, int num_disp, int ndirs, uint64_t* mismatches);
+
 /* Measurement hook for the roofline accounting (bench.py): re-runs the vertical block sum of the LAST call on its retained
  * horizontal sums, once as the plain sum (plain_ms) and once in the form the call used (production_ms; in 8-path mode it
  * also carries paths 2 / 6 and their checkpoints, in 5-path mode path 2 and S = L_2), best of three, hipEvents on the

@@ -120,6 +120,16 @@ def test_short_chains_every_instance(gpu_ctx, oracle, D, ndirs):
         gpu_ctx.set_debug(False)
 
 
+@pytest.mark.parametrize("ndirs", [5, 8])
+@pytest.mark.parametrize("D", [64, 256, 384, 512, 640, 768, 896, 1024])
+def test_device_selftest_passes(gpu_ctx, D, ndirs):
+    """wass_sgm_selftest: the production schedule against one plain sweep per path, compared on the device (no oracle).  It
+    must pass on a healthy build for every NP; scripts/selftest.py shows it failing on the build without the compiler fence
+    of Rec::load (profiles/r04_selftest_nofence.txt)."""
+    for (w, h) in ((D + 56, 40), (D + 40, 17)):
+        assert gpu_ctx.sgm_selftest(w, h, D, ndirs) == 0
+
+
 def test_random_noise_images(gpu_ctx, oracle):
     """Untextured/random inputs: many ties, rejected pixels and saturated S."""
     rng = np.random.default_rng(7)

@@ -3,6 +3,7 @@
 
 #include <stdarg.h>
 #include <new>
+#include <vector>
 
 namespace wass {
 
@@ -349,6 +350,56 @@ int wass_sgm_prev_timings(wass_ctx* c, wass_sgm_timings* out)
     if (!c || !out) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
     if (c->nsgm < 2) return set_err(c, WASS_ERR_INVALID_ARG, "fewer than two wass_sgm_disparity calls so far");
     return read_timings(c, c->nsgm - 2, out);
+}
+
+int wass_sgm_selftest(wass_ctx* c, int w, int h, int num_disp, int ndirs, uint64_t* mismatches)
+{
+    if (!c || !mismatches) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    if (w < 16 || h < 1 || w > 8192 || h > 8192) return set_err(c, WASS_ERR_INVALID_ARG, "bad self-test size");
+    *mismatches = ~0ull;
+    WASS_HIP(c, hipSetDevice(c->device));
+    // a textured pair with a disparity ramp, from a fixed integer hash: bit-identical wherever this runs
+    std::vector<uint8_t> R((size_t)w * h), L((size_t)w * h);
+    auto tex = [](int x, int y) {
+        uint32_t v = (uint32_t)(x >> 2) * 73856093u ^ (uint32_t)(y >> 1) * 19349663u;
+        v ^= v >> 13; v *= 0x5bd1e995u; v ^= v >> 15;
+        uint32_t n = (uint32_t)x * 2654435761u + (uint32_t)y * 40503u;
+        n ^= n >> 16; n *= 0x85ebca6bu; n ^= n >> 13;
+        return (int)(40 + (v % 150u) + (n % 24u));
+    };
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const int dsp = 2 + (num_disp * (y + 3 * x % 7)) / (3 * h + 9);      // inside (minD, D)
+            L[(size_t)y * w + x] = (uint8_t)tex(x, y);
+            R[(size_t)y * w + x] = (uint8_t)tex(x - dsp, y);
+        }
+    wass_sgm_params p;
+    p.min_disp = 1; p.num_disp = num_disp; p.win = 5; p.P1 = 2 * 25; p.P2 = 64 * 25; p.uniq_ratio = 1; p.disp12_max_diff = -1;
+    p.prefilter_cap = 60; p.speckle_win = -70; p.speckle_range = 16; p.ndirs = ndirs; p.disp_offset = 0; p.dense_scale = 1.0;
+    std::vector<int16_t> disp((size_t)w * h);
+    const bool was_debug = c->debug;
+    c->debug = true;                                          // keep the finished S volume
+    int rc = wass_sgm_disparity(c, R.data(), L.data(), w, h, (size_t)w, &p, disp.data());
+    c->debug = was_debug;
+    if (rc != WASS_OK && rc != WASS_ERR_COST_OVERFLOW) return rc;
+    const SgmDims d = c->last;
+    wass::Buf s2;
+    unsigned long long* d_count = nullptr;
+    if ((rc = ensure(c, s2, d.cells() * sizeof(uint16_t) + 256))) return rc;
+    d_count = (unsigned long long*)((char*)s2.p + d.cells() * sizeof(uint16_t));
+    d_count = (unsigned long long*)(((uintptr_t)d_count + 7) & ~(uintptr_t)7);
+    hipError_t e = hipMemsetAsync(d_count, 0, 8, c->stream);
+    if (e == hipSuccess) rc = selftest_reference(c, d, (uint32_t*)s2.p, d_count);
+    unsigned long long hc = ~0ull;
+    if (e == hipSuccess && rc == WASS_OK) e = hipMemcpyAsync(&hc, d_count, 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(s2.p);
+    if (rc != WASS_OK) return rc;
+    if (e != hipSuccess) return set_err(c, WASS_ERR_DEVICE, "self-test: %s", hipGetErrorString(e));
+    *mismatches = hc;
+    if (hc) return set_err(c, WASS_ERR_DEVICE, "self-test: the production schedule and the plain per-path sweeps disagree in %llu cells of S "
+                                              "(%dx%d, D=%d, %d paths)", hc, w, h, num_disp, ndirs);
+    return WASS_OK;
 }
 
 int wass_sgm_probe_vsum(wass_ctx* c, float* plain_ms, float* production_ms)

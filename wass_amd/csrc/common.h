@@ -254,6 +254,8 @@ int launch_prefilter(wass_ctx* c, const SgmDims& d);
 int launch_cost_volume(wass_ctx* c, const SgmDims& d);
 int launch_vsum_only(wass_ctx* c, const SgmDims& d, bool plain);   // the vertical block sum alone, on the hsum volume of the last frame
 int launch_aggregate(wass_ctx* c, const SgmDims& d, int* n_launches);
+// wass_sgm_selftest: S of the last call (kept: debug mode) against one plain sweep per path into S2; mismatching cells are added to *d_count
+int selftest_reference(wass_ctx* c, const SgmDims& d, uint32_t* S2, unsigned long long* d_count);
 int launch_select(wass_ctx* c, const SgmDims& d);
 int launch_median_crop(wass_ctx* c, const SgmDims& d, int16_t* d_out);
 int wait_uploads(wass_ctx* c, const void* p, hipStream_t s);   // order s after the pending uploads that cover p

@@ -260,6 +260,9 @@ __device__ __forceinline__ void lds_ld(const uint32_t* p, us2 (&v)[NP])
 #ifndef WASS_REC_TIE
 #define WASS_REC_TIE 0
 #endif
+#ifndef WASS_REC_FENCE
+#define WASS_REC_FENCE 1                           // 0: the build that miscompiles k_pair<2, 8, 1> -- kept selectable so that the
+#endif                                             // device self-test (wass_sgm_selftest) can be shown to catch it
 template <int N, bool VEC>
 struct Rec {
     uint32_t v[VEC ? 1 : N / 2];
@@ -277,7 +280,7 @@ struct Rec {
             // buffer-load intrinsic, a volatile asm that consumes its result does (it cannot be sunk past it)
 #if WASS_REC_TIE
             asm volatile("" : "+v"(v[0]) :: "memory");
-#else
+#elif WASS_REC_FENCE
             asm volatile("" ::: "memory");
 #endif
         } else {
@@ -1138,6 +1141,69 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
     if (n_launches) *n_launches = nl;
     WASS_HIP(c, hipGetLastError());
     return WASS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Device-side canary (wass_sgm_selftest): the aggregated volume S of the production schedule -- checkpoint sweeps, pair
+// kernels with recomputation and LDS hand-over, row fusion -- against S built the plain way, one k_sweep per path over the
+// same C.  The two share the arithmetic of one step (sgm_step) and nothing of the machinery around it, which is where a
+// miscompiled loop, a late store or a missing wait would sit.  No CPU oracle involved: runs wherever the library runs.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_count_diff(const uint32_t* __restrict__ A, const uint32_t* __restrict__ B, size_t nvec, int vecdw,
+                                                    int D, unsigned long long* __restrict__ out)
+{
+    // one thread per dword; disparities d >= D are padding (0xFFFF costs) and are not compared
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned int bad = 0;
+    if (i < nvec * (size_t)vecdw) {
+        const int dw = (int)(i % (size_t)vecdw);
+        const uint32_t a = A[i], b = B[i];
+        if (2 * dw < D && (a & 0xFFFFu) != (b & 0xFFFFu)) ++bad;
+        if (2 * dw + 1 < D && (a >> 16) != (b >> 16)) ++bad;
+    }
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_down(bad, o);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(out, (unsigned long long)bad);
+}
+
+template <int NP>
+static int selftest_reference_np(wass_ctx* c, const SgmDims& d, uint32_t* S2, unsigned long long* d_count)
+{
+    constexpr int U = ckpt_k(NP);
+    const uint32_t* C = (const uint32_t*)c->C.p;
+    // direction of travel = -r of Appendix A.4: paths 0..4 of MODE_SGBM, then 5..7 of MODE_HH
+    static const int dirs[8][2] = { { 1, 0 }, { 1, 1 }, { 0, 1 }, { -1, 1 }, { -1, 0 }, { 1, -1 }, { 0, -1 }, { -1, -1 } };
+    for (int r = 0; r < d.ndirs; ++r) {
+        const int dx = dirs[r][0], dy = dirs[r][1];
+        const int nch = dy == 0 ? d.h : (dx == 0 ? d.width1 : d.width1 + d.h - 1);
+        const dim3 grid((nch + 3) / 4), block(256);
+        if (r == 0)
+            hipLaunchKernelGGL((k_sweep<NP, 0, U>), grid, block, 0, c->stream, C, S2, d.width1, d.h, dx, dy, d.P1, d.P2, nch, d.D, d.minD, d.uniq, 1,
+                               (int16_t*)nullptr, (uint32_t*)nullptr);
+        else
+            hipLaunchKernelGGL((k_sweep<NP, 1, U>), grid, block, 0, c->stream, C, S2, d.width1, d.h, dx, dy, d.P1, d.P2, nch, d.D, d.minD, d.uniq, 1,
+                               (int16_t*)nullptr, (uint32_t*)nullptr);
+    }
+    const size_t nvec = (size_t)d.h * d.width1;
+    const size_t ndw = nvec * (size_t)(64 * NP);
+    hipLaunchKernelGGL(k_count_diff, dim3((unsigned)((ndw + 255) / 256)), dim3(256), 0, c->stream, (const uint32_t*)c->S.p, (const uint32_t*)S2, nvec,
+                       64 * NP, d.D, d_count);
+    WASS_HIP(c, hipGetLastError());
+    return WASS_OK;
+}
+
+int selftest_reference(wass_ctx* c, const SgmDims& d, uint32_t* S2, unsigned long long* d_count)
+{
+    switch (d.NP) {
+        case 1: return selftest_reference_np<1>(c, d, S2, d_count);
+        case 2: return selftest_reference_np<2>(c, d, S2, d_count);
+        case 3: return selftest_reference_np<3>(c, d, S2, d_count);
+        case 4: return selftest_reference_np<4>(c, d, S2, d_count);
+        case 5: return selftest_reference_np<5>(c, d, S2, d_count);
+        case 6: return selftest_reference_np<6>(c, d, S2, d_count);
+        case 7: return selftest_reference_np<7>(c, d, S2, d_count);
+        case 8: return selftest_reference_np<8>(c, d, S2, d_count);
+    }
+    return set_err(c, WASS_ERR_UNSUPPORTED, "MAX_DISPARITY %d not supported (max 1024)", d.D);
 }
 
 int launch_aggregate(wass_ctx* c, const SgmDims& d, int* n_launches)

@@ -136,7 +136,13 @@ __device__ __forceinline__ void buf_st(rsrc_t r, uint32_t voff, uint32_t soff, c
     // neighbouring dword / dwordx2 stores (NP = 3: three b32 stores became buffer_store_dwordx3 ... s8 offen, and the third
     // dword of a handful of vectors per frame came out wrong in k_pairx<3>, round 4).  Whenever a vector is wider than
     // one 64-bit store the offset therefore goes into the VGPR: one v_add per vector.
-    if constexpr (NP > 2) {
+#ifndef WASS_BUFST_SGPR_WIDE
+#define WASS_BUFST_SGPR_WIDE 0                     // 1: the form that runs into the trap (kept selectable: scripts/selftest.py on such
+#endif                                             // a build is the demonstration that the device self-test catches it)
+    if constexpr (NP > 2 && WASS_BUFST_SGPR_WIDE) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) __builtin_amdgcn_raw_buffer_store_b32(as_u32(src[j]), r, voff + 4 * j, soff, WASS_NT ? 2 : 0);
+    } else if constexpr (NP > 2) {
         const uint32_t vo = voff + soff;
         if constexpr (NP % 4 == 0) {
 #pragma unroll

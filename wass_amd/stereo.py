@@ -127,6 +127,15 @@ class Context:
         """d_mask = d_img <= 254 on the context's SGM stream (DISCARD_BURNED_AREAS, wass_stereo.cpp:1072)."""
         self._check(self._lib.wass_burned_area_mask_dev(self._h, d_img.data_ptr(), d_img.numel(), d_mask.data_ptr()))
 
+    def sgm_selftest(self, w: int, h: int, num_disp: int, ndirs: int = 8) -> int:
+        """Device-side canary (wass_sgm_selftest): number of cells of S in which the production schedule and the plain
+        per-path sweeps disagree (0 = fine); no oracle involved."""
+        n = C.c_uint64()
+        rc = self._lib.wass_sgm_selftest(self._h, w, h, num_disp, ndirs, C.byref(n))
+        if rc != 0 and n.value in (0, 2 ** 64 - 1):
+            self._check(rc)
+        return int(n.value)
+
     def sgm_probe_vsum(self):
         """(plain_ms, production_ms) of the vertical block sum on the last call's horizontal sums (wass_sgm_probe_vsum)."""
         a, b = C.c_float(), C.c_float()
