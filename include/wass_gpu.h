@@ -75,6 +75,9 @@ int wass_device_alloc(wass_ctx* ctx, size_t nbytes, void** d_out);
 void wass_device_free(wass_ctx* ctx, void* d_ptr);
 /* d_src -> h_dst after everything enqueued on the context so far; returns when the bytes are in host memory */
 int wass_download(wass_ctx* ctx, void* h_dst, const void* d_src, size_t nbytes);
+/* the same without waiting: the copy runs on the context's copy stream once everything enqueued on the SGM stream so far has
+ * finished; h_dst (pinned) is complete when a later wass_ctx_frame_result() or wass_ctx_synchronize() returns */
+int wass_download_async(wass_ctx* ctx, void* h_dst, const void* d_src, size_t nbytes);
 int wass_pinned_alloc(wass_ctx* ctx, size_t nbytes, void** h_out);
 void wass_pinned_free(wass_ctx* ctx, void* h_ptr);
 /* DISCARD_BURNED_AREAS (wass_stereo.cpp:1072,1086): d_mask[i] = d_img[i] <= 254, on the context's SGM stream; feeds the

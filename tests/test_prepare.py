@@ -258,3 +258,63 @@ def test_prepare_then_stereo(prepare, tmp_path):
     assert a.returncode == 0 and b.returncode == 0, a.stdout[-2000:]
     for name in ("mesh_cam.xyzC", "plane.txt", "P0cam.txt", "P1cam.txt"):
         assert open(wd / name, "rb").read() == open(os.path.join(wd0, name), "rb").read(), name
+
+
+# ------------------------------------------------------------------ GPU: the prepare-less mode of the sequence driver (row f2, fused)
+@pytest.mark.gpu
+@pytest.mark.parametrize("save_undistorted", [False, True])
+def test_raw_sequence_equals_prepare_then_stereo(prepare, tmp_path, save_undistorted):
+    """wass_stereo_batch --raw runs wass_prepare's undistortion (+ CLAHE) on the GPU INSIDE the frame chain, from the cameras'
+    raw pictures: no undistorted/*.png is written or read unless asked for.  Every file of every workdir must equal what the
+    two-executable route leaves behind (wass_prepare per frame, then the sequence driver on the prepared workdirs) -- two
+    interpolations with the reference's arithmetic, not one fused resampling."""
+    from wass_amd import build, synth
+    w, h, D = 320, 240, 32
+    rig = synth.rig_geometry(w, h)
+    calib = tmp_path / "config"; calib.mkdir()
+    _write_xml(calib / "intrinsics_00.xml", "intr", rig["K_left"])
+    _write_xml(calib / "intrinsics_01.xml", "intr", rig["K_right"])
+    _write_xml(calib / "distortion_00.xml", "dist", np.array([-0.012, 0.004, 2e-4, -1e-4, 0.0]).reshape(5, 1))
+    _write_xml(calib / "distortion_01.xml", "dist", np.array([0.009, -0.003, -1e-4, 2e-4, 1e-3]).reshape(5, 1))
+    _write_xml(calib / "ext_R.xml", "R", rig["R"])
+    _write_xml(calib / "ext_T.xml", "T", np.array(rig["T"]).reshape(3, 1) * 2.5)
+    (calib / "prepare_config.txt").write_text("CAM1_CLAHE_TILEGRIDSIZE=4\nCAM1_CLAHE_CLIPLIMIT=40.0\n")
+    cfg = tmp_path / "stereo_config.txt"
+    cfg.write_text(f"MAX_DISPARITY={D}\nRANDOM_SEED=12345\nUSE_CUSTOM_STEREORECTIFY=true\nRECTIFY_ANGLE=1e-6\nDISABLE_RECTIFY_ROI=true\n")
+    cam0 = tmp_path / "input" / "cam0"; cam1 = tmp_path / "input" / "cam1"
+    cam0.mkdir(parents=True); cam1.mkdir(parents=True)
+    nframes = 3
+    for t in range(nframes):
+        right, left = synth.make_pair(w, h, D, frame_idx=40 + t)
+        _write_png(cam0 / ("%06d_frame.png" % t), left)
+        _write_png(cam1 / ("%06d_frame.png" % t), right)
+    # route A: wass_prepare per frame (wasscli.py:222-227), then the sequence driver on the prepared workdirs
+    seq_a = tmp_path / "a"; seq_a.mkdir()
+    for t in range(nframes):
+        r = run(prepare, "--workdir", str(seq_a / ("%06d_wd" % t)), "--calibdir", str(calib), "--c0", str(cam0 / ("%06d_frame.png" % t)),
+                "--c1", str(cam1 / ("%06d_frame.png" % t)))
+        assert r.returncode == 0, r.stdout
+    a = subprocess.run([build.BATCH, str(cfg), "--sequence", str(seq_a)], capture_output=True, text=True)
+    assert a.returncode == 0 and "pipelined" in a.stdout, a.stdout + a.stderr
+    # route B: one command from the raw pictures
+    seq_b = tmp_path / "b"
+    extra = ["--save-undistorted"] if save_undistorted else []
+    b = subprocess.run([build.BATCH, str(cfg), "--raw", str(calib), "--cam0", str(cam0), "--cam1", str(cam1), "--sequence", str(seq_b), *extra],
+                       capture_output=True, text=True)
+    assert b.returncode == 0, b.stdout + b.stderr
+    names = ["mesh_cam.xyzC", "plane.txt", "plane_refinement_inliers.xyz", "P0cam.txt", "P1cam.txt", "Cam0_poseR.txt", "Cam1_poseT.txt", "K0_small.txt",
+             "K1_small.txt", "scale.txt", "00000000_s.png", "00000001_s.png", "intrinsics_00000000.xml", "intrinsics_00000001.xml", "ext_R.xml", "ext_T.xml",
+             "H0_rect.txt", "H1_rect.txt", "stereo_config.txt"]
+    if save_undistorted:
+        names += ["undistorted/00000000.png", "undistorted/00000001.png"]
+    for t in range(nframes):
+        wa, wb = seq_a / ("%06d_wd" % t), seq_b / ("%06d_wd" % t)
+        for name in names:
+            assert (wa / name).read_bytes() == (wb / name).read_bytes(), f"frame {t}: {name}"
+        if not save_undistorted:
+            assert not (wb / "undistorted").exists()                  # the PNG round trip is gone, not hidden
+        log = (wb / "wass_stereo_log.txt").read_text()
+        assert "image 0 loaded, Size: 320x240" in log and "All done." in log
+        npts = int.from_bytes((wb / "mesh_cam.xyzC").read_bytes()[:4], "little")
+        assert npts > 0.5 * w * h                                     # the distortion is mild: the surface is still recovered
+    assert (seq_a / "planes.txt").read_text() == (seq_b / "planes.txt").read_text()

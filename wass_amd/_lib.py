@@ -139,6 +139,7 @@ SYMBOLS = {
     "wass_device_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "wass_device_free": (None, [_vp, _vp]),
     "wass_download": (_i, [_vp, _vp, _vp, _sz]),
+    "wass_download_async": (_i, [_vp, _vp, _vp, _sz]),
     "wass_pinned_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "wass_pinned_free": (None, [_vp, _vp]),
     "wass_free": (None, [_vp]),

@@ -77,9 +77,10 @@ extern "C" int wass_clahe_dev(wass_ctx* c, const uint8_t* d_src, int w, int h, s
     const int tw = ew / tiles_x, th = eh / tiles_y, area = tw * th;
     int clip = 0;
     if (clip_limit > 0.0) { clip = (int)(clip_limit * area / 256); if (clip < 1) clip = 1; }
-    int rc = ensure(c, c->uf, (size_t)tiles_x * tiles_y * 256);
+    int rc = ensure(c, c->clahe_lut, (size_t)tiles_x * tiles_y * 256);
     if (rc) return rc;
-    uint8_t* lut = (uint8_t*)c->uf.p;
+    if ((rc = wait_uploads(c, d_src, c->stream))) return rc;
+    uint8_t* lut = (uint8_t*)c->clahe_lut.p;
     hipStream_t s = c->stream;
     hipLaunchKernelGGL(k_clahe_lut, dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, s, d_src, w, h, src_stride, tiles_x, tw, th, clip,
                        (float)255 / (float)area, lut);

@@ -139,6 +139,7 @@ struct wass_ctx {
     void* h_stage = nullptr;       // pinned source images of the frame tail's small H2D copies (mesh.hip host_stage)
     hipEvent_t ev_stage = nullptr;
     hipEvent_t ev_producer = nullptr; // wass_ctx_wait_for_stream
+    hipEvent_t ev_dl = nullptr;        // wass_download_async: orders the copy stream after the SGM stream
     bool stage_uv_busy = false;
     hipStream_t copy = nullptr;    // D2H of the xyzC payload
     // Everything after the SGM call (disparity clean-up, triangulation, mesh stages: post.hip, mesh.hip) is enqueued on
@@ -156,6 +157,11 @@ struct wass_ctx {
     wass::Buf rect_tab;            // fixed-point interpolation tables of the rectification resamplers (rectify.hip)
     bool rect_tab_ready = false;
     wass::Buf rect_mx, rect_my;    // staging for host-pointer map uploads
+    // cv::undistort's normalised coordinate tables depend on (K, w, h) only: kept per camera so that the per-frame call of a
+    // sequence neither recomputes nor synchronises (wass_undistort_dev)
+    struct UndCache { double K[9] = {}; int w = 0, h = 0; bool valid = false; wass::Buf xy; } und_cache[2];
+    int und_next = 0;
+    wass::Buf clahe_lut;           // per-tile look-up tables of wass_clahe_dev
     // stage events of the SGM call, two sets used alternately so that the timings of call n can be read after call
     // n+1 has been enqueued (a lagging reader never stalls the pipeline)
     hipEvent_t evs[2][8] = {};

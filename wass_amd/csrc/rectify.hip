@@ -392,29 +392,44 @@ static int undistort_dev(wass_ctx* c, const uint8_t* d_src, int w, int h, size_t
     if (w > 32767 || h > 32767) return set_err(c, WASS_ERR_UNSUPPORTED, "images larger than 32767 px are not supported");
     Dist12 D;
     for (int i = 0; i < 12; ++i) D.k[i] = i < n ? dist[i] : 0.0;
-    // normalised coordinates exactly as initUndistortRectifyMap produces them inside cv::undistort's stripes
-    std::vector<double> xy((size_t)w + h);
-    int stripe0 = std::min(std::max(1, 4096 / std::max(w, 1)), h);
-    for (int y0 = 0; y0 < h; y0 += stripe0) {
-        const int stripe = std::min(stripe0, h - y0);
-        double Ar[9], ir[9];
-        memcpy(Ar, K, sizeof Ar);
-        Ar[5] = K[5] - y0;
-        if (!inv33(Ar, ir)) return set_err(c, WASS_ERR_INVALID_ARG, "singular camera matrix");
-        if (ir[1] != 0 || ir[3] != 0 || ir[6] != 0 || ir[7] != 0 || ir[8] != 1)
-            return set_err(c, WASS_ERR_UNSUPPORTED, "camera matrix with skew is not supported");
-        if (y0 == 0) {
-            double _x = ir[2];
-            for (int j = 0; j < w; ++j, _x += ir[0]) xy[j] = _x * (1. / 1.);
-        }
-        for (int i = 0; i < stripe; ++i) xy[(size_t)w + y0 + i] = (i * ir[4] + ir[5]) * (1. / 1.);
-    }
     int rc = ensure_tables(c);
     if (rc) return rc;
-    if ((rc = ensure(c, c->rect_mx, xy.size() * sizeof(double)))) return rc;
-    WASS_HIP(c, hipMemcpyAsync(c->rect_mx.p, xy.data(), xy.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    WASS_HIP(c, hipStreamSynchronize(c->stream));          // xy is pageable and about to go out of scope
-    const double* dxy = (const double*)c->rect_mx.p;
+    if ((rc = wait_uploads(c, d_src, c->stream))) return rc;
+    // The normalised coordinates depend on (K, w, h) only: one table per camera is kept on the device, so the per-frame call
+    // of a sequence computes nothing on the host and does not synchronise.
+    wass_ctx::UndCache* hit = nullptr;
+    for (auto& e : c->und_cache)
+        if (e.valid && e.w == w && e.h == h && memcmp(e.K, K, sizeof e.K) == 0) hit = &e;
+    if (!hit) {
+        // exactly as initUndistortRectifyMap produces them inside cv::undistort's stripes
+        std::vector<double> xy((size_t)w + h);
+        int stripe0 = std::min(std::max(1, 4096 / std::max(w, 1)), h);
+        for (int y0 = 0; y0 < h; y0 += stripe0) {
+            const int stripe = std::min(stripe0, h - y0);
+            double Ar[9], ir[9];
+            memcpy(Ar, K, sizeof Ar);
+            Ar[5] = K[5] - y0;
+            if (!inv33(Ar, ir)) return set_err(c, WASS_ERR_INVALID_ARG, "singular camera matrix");
+            if (ir[1] != 0 || ir[3] != 0 || ir[6] != 0 || ir[7] != 0 || ir[8] != 1)
+                return set_err(c, WASS_ERR_UNSUPPORTED, "camera matrix with skew is not supported");
+            if (y0 == 0) {
+                double _x = ir[2];
+                for (int j = 0; j < w; ++j, _x += ir[0]) xy[j] = _x * (1. / 1.);
+            }
+            for (int i = 0; i < stripe; ++i) xy[(size_t)w + y0 + i] = (i * ir[4] + ir[5]) * (1. / 1.);
+        }
+        wass_ctx::UndCache& e = c->und_cache[c->und_next];
+        c->und_next ^= 1;
+        // the entry being replaced may still be read by a kernel in flight
+        WASS_HIP(c, hipStreamSynchronize(c->stream));
+        e.valid = false;
+        if ((rc = ensure(c, e.xy, xy.size() * sizeof(double)))) return rc;
+        WASS_HIP(c, hipMemcpyAsync(e.xy.p, xy.data(), xy.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        WASS_HIP(c, hipStreamSynchronize(c->stream));          // xy is pageable and about to go out of scope
+        memcpy(e.K, K, sizeof e.K); e.w = w; e.h = h; e.valid = true;
+        hit = &e;
+    }
+    const double* dxy = (const double*)hit->xy.p;
     hipLaunchKernelGGL(k_undistort, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, c->stream, d_src, w, h, ss, dxy, dxy + w, D,
                        K[0], K[4], K[2], K[5], d_dst, (const short*)c->rect_tab.p);
     WASS_HIP(c, hipGetLastError());

@@ -22,6 +22,7 @@
 #include <deque>
 #include <mutex>
 
+#include "prepare_common.hpp"
 #include "wass_frame.hpp"
 
 namespace wassframe {
@@ -47,6 +48,11 @@ struct FrameJob {
     int rc = 0;                      // -1: the frame failed (the log says why)
     bool skipped = false;            // --skip-existing: nothing to do, summary read back from plane.txt
     bool staged = false;
+    // prepare-less mode: the frame starts from the cameras' RAW pictures (c0, c1) and a calibration directory -- what
+    // wass_prepare would have turned into <workdir>/undistorted/*.png first
+    bool raw = false;
+    std::string c0, c1;
+    int prev_w = 0, prev_h = 0;      // size of the scaled previews, written once the undistorted pictures are back (0: none)
     unsigned int ransac_seed = 0;
     int in_slot = -1, out_slot = -1;
     long long sgm_call = -1;         // which wass_sgm_disparity_dev call of the pipeline's context produced the frame's disparity
@@ -64,6 +70,8 @@ public:
         int out_slots = 4;           // pinned output sets (file image + inlier points) that writer threads may hold at once
         bool inliers_file = true;    // plane_refinement_inliers.xyz (a debug artefact of the reference; 14 MB of text per 5-megapixel frame)
         bool live = false;           // single-frame executable: echo log and progress markers to stdout as the phases end
+        const PrepareSetup* prep = nullptr;   // prepare-less mode: the calibration directory (jobs with raw = true need it)
+        bool save_undistorted = false;        // ... and whether undistorted/0000000X.png are written all the same
     };
 
     // The context is created on `device` when the first frame needs the GPU (as wass_stereo does: a sequence whose frames
@@ -97,7 +105,7 @@ public:
         if (!ctx_) return;
         (void)wass_ctx_synchronize(ctx_);
         release_buffers();
-        for (auto& o : out_) { if (o.xyzc) wass_pinned_free(ctx_, o.xyzc); if (o.inl) wass_pinned_free(ctx_, o.inl); }
+        for (auto& o : out_) { if (o.xyzc) wass_pinned_free(ctx_, o.xyzc); if (o.inl) wass_pinned_free(ctx_, o.inl); for (auto& u : o.und) if (u) wass_pinned_free(ctx_, u); }
         wass_ctx_destroy(ctx_);
     }
     // the pipeline's context, created if need be (owner thread); nullptr when there is no usable GPU
@@ -121,6 +129,12 @@ public:
         Env& env = job.env;
         WLOG_SCOPE("wass_stereo");
         try {
+            if (job.raw) {
+                if (!opt_.prep) throw std::runtime_error("prepare-less frame without a calibration directory");
+                create_directories(env.workdir);
+                if (opt_.save_undistorted) create_directories(path_join(env.workdir, "undistorted"));
+                write_prepared_calibration(env.workdir, *opt_.prep);
+            }
             WLOGI << "Loading configuration file " << config_path_;
             if (save_configuration(cfg_, path_join(env.workdir, "stereo_config.txt")) != 0) WLOGE << "Unable to save stereo configuration file";
             job.ransac_seed = (unsigned int)time(0);
@@ -128,7 +142,15 @@ public:
             WLOGI << "Reconstructing " << env.workdir;
             env.timer.start();
             env.cam_distance = 1.0;
-            if (!load_data(env, cfg_, nullptr, nullptr)) { job.rc = -1; return; }
+            if (job.raw) {
+                // wass_prepare's part of the workdir (wass_prepare.cpp:505-533), then wass_stereo's load_data on it -- with the
+                // raw pictures in place of undistorted/*.png: the GPU undistorts them inside the frame chain (submit)
+                if (!load_calibration(env)) { job.rc = -1; return; }
+                try { env.left = read_image_gray(job.c0); env.right = read_image_gray(job.c1); }
+                catch (const std::exception& e) { WLOG_SCOPE("load_data"); WLOGE << "unable to load input images: " << e.what(); job.rc = -1; return; }
+                if (!images_loaded(env)) { job.rc = -1; return; }
+                input_scale_outputs(env, cfg_, false, nullptr, &job.prev_w, &job.prev_h);
+            } else if (!load_data(env, cfg_, nullptr, nullptr)) { job.rc = -1; return; }
             job.t_loaded = Timer::now();
             marker(job, 10);
             auto save_cams = [&]() {
@@ -172,8 +194,8 @@ public:
             const size_t n = (size_t)W_ * H_;
             memcpy(in_[k].h_l, env.left.px.data(), n);
             memcpy(in_[k].h_r, env.right.px.data(), n);
-            check(wass_upload_async(ctx_, in_[k].d_l, in_[k].h_l, n), "wass_upload_async");
-            check(wass_upload_async(ctx_, in_[k].d_r, in_[k].h_r, n), "wass_upload_async");
+            check(wass_upload_async(ctx_, job.raw ? in_[k].d_rawl : in_[k].d_l, in_[k].h_l, n), "wass_upload_async");
+            check(wass_upload_async(ctx_, job.raw ? in_[k].d_rawr : in_[k].d_r, in_[k].h_r, n), "wass_upload_async");
             job.in_slot = k;
             job.staged = true;
         } catch (const std::exception& e) {
@@ -202,6 +224,24 @@ public:
             const int k = job.in_slot;
             const int rl[4] = { env.roi_l.x, env.roi_l.y, env.roi_l.width, env.roi_l.height };
             const int rr[4] = { env.roi_r.x, env.roi_r.y, env.roi_r.width, env.roi_r.height };
+            job.out_slot = acquire_out((size_t)rr[2] * rr[3], job.raw ? (size_t)W_ * H_ : 0);
+            if (job.raw) {
+                // ---- wass_prepare's process_image (wass_prepare.cpp:257-275) on the device: optional CLAHE, cv::undistort.  The
+                // camera a picture came from decides its parameters -- rectify_plan may have swapped left and right since.
+                const PrepareSetup& ps = *opt_.prep;
+                for (int side = 0; side < 2; ++side) {
+                    const int cam = side == 0 ? env.left_index : env.right_index;
+                    const uint8_t* src = side == 0 ? in_[k].d_rawl : in_[k].d_rawr;
+                    uint8_t* dst = side == 0 ? in_[k].d_l : in_[k].d_r;
+                    if (ps.clahe_tiles[cam] > 0) {
+                        check(wass_clahe_dev(ctx_, src, W_, H_, (size_t)W_, ps.clahe_clip[cam], ps.clahe_tiles[cam], ps.clahe_tiles[cam], in_[k].d_tmp), "wass_clahe");
+                        src = in_[k].d_tmp;
+                    }
+                    check(wass_undistort_dev(ctx_, src, W_, H_, (size_t)W_, ps.intr[cam].d.data(), ps.dist[cam].d.data(), (int)ps.dist[cam].d.size(), dst), "wass_undistort");
+                    // back to the host for the scaled previews (and undistorted/*.png when asked for): lands with the frame's result
+                    check(wass_download_async(ctx_, out_[job.out_slot].und[side], dst, (size_t)W_ * H_), "wass_download_async");
+                }
+            }
             // ---- rectify(): the resampling (:515-528, 600-607), ROI crop fused, from the device-resident pictures
             WLOG_SCOPE("rectify");
             if (env.use_custom) {
@@ -275,8 +315,7 @@ public:
                 if (wass_ransac_sample_seeded(job.ransac_seed, rr[2], rr[3], rounds, uv_.data()) != WASS_OK) throw std::runtime_error("invalid PLANE_RANSAC_ROUNDS / mesh size");
                 uv_seed_ = job.ransac_seed; uv_w_ = rr[2]; uv_h_ = rr[3];
             }
-            const int slot = acquire_out((size_t)rr[2] * rr[3]);
-            job.out_slot = slot;
+            const int slot = job.out_slot;
             check(wass_mesh_finish_frame_async_ex(ctx_, mesh, cfg_.get_double("ZGAP_PERCENTILE"), uv_.data(), rounds, cfg_.get_double("PLANE_RANSAC_THRESHOLD"),
                                                   &rp_, cfg_.get_double("PLANE_MAX_DISTANCE"), out_[slot].xyzc, out_[slot].xyzc_cap,
                                                   opt_.inliers_file ? out_[slot].inl : nullptr, opt_.inliers_file ? out_[slot].inl_cap : 0, 10),
@@ -383,6 +422,20 @@ public:
                     WLOGI << "total data size: " << ((double)r.xyzc_bytes / 1E6) << " MB";
                     WLOG_SCOPE("wass_stereo");
                 }
+                if (job.raw) {
+                    // the scaled previews of load_data (:413-418) and, on request, wass_prepare's own output: from the undistorted
+                    // pictures that came back with the result (und[0] = the picture that ended up LEFT, und[1] = right)
+                    const OutSet& o = out_[job.out_slot];
+                    const size_t n = (size_t)env.left.w * env.left.h;
+                    Image cam[2] = { Image(env.left.w, env.left.h), Image(env.left.w, env.left.h) };
+                    memcpy(cam[env.left_index].px.data(), o.und[0], n);
+                    memcpy(cam[env.right_index].px.data(), o.und[1], n);
+                    if (job.prev_w > 0 && job.prev_h > 0) write_previews(env.workdir, cam[0], cam[1], job.prev_w, job.prev_h);
+                    if (opt_.save_undistorted) {
+                        write_png_gray(path_join(path_join(env.workdir, "undistorted"), "00000000.png"), cam[0]);
+                        write_png_gray(path_join(path_join(env.workdir, "undistorted"), "00000001.png"), cam[1]);
+                    }
+                }
                 marker(job, 100);
                 // the time table (render.hpp:175-191).  A pipelined frame has no per-stage wall times: its GPU stages run
                 // underneath its neighbours'.  "Dense Stereo" is the GPU time of the SGM stage (hipEvents); "GPU pipeline" the
@@ -447,8 +500,9 @@ public:
     int frames_submitted() const { return nsub_; }
 
 private:
-    struct InSet { uint8_t *h_l = nullptr, *h_r = nullptr, *d_l = nullptr, *d_r = nullptr, *d_cl = nullptr, *d_cr = nullptr, *d_ml = nullptr, *d_mr = nullptr; };
-    struct OutSet { void* xyzc = nullptr; size_t xyzc_cap = 0; double* inl = nullptr; size_t inl_cap = 0; };
+    struct InSet { uint8_t *h_l = nullptr, *h_r = nullptr, *d_l = nullptr, *d_r = nullptr, *d_cl = nullptr, *d_cr = nullptr, *d_ml = nullptr, *d_mr = nullptr,
+                           *d_rawl = nullptr, *d_rawr = nullptr, *d_tmp = nullptr; };
+    struct OutSet { void* xyzc = nullptr; size_t xyzc_cap = 0; double* inl = nullptr; size_t inl_cap = 0; uint8_t* und[2] = { nullptr, nullptr }; size_t und_cap = 0; };
 
     void check(int rc, const char* what) const { if (rc != WASS_OK) throw GpuError(std::string(what) + ": " + wass_last_error(ctx_)); }
     void marker(FrameJob& job, int pct) const
@@ -477,7 +531,7 @@ private:
     void release_buffers()
     {
         for (auto& s : in_) {
-            for (uint8_t** p : { &s.d_l, &s.d_r, &s.d_cl, &s.d_cr, &s.d_ml, &s.d_mr }) { if (*p) wass_device_free(ctx_, *p); *p = nullptr; }
+            for (uint8_t** p : { &s.d_l, &s.d_r, &s.d_cl, &s.d_cr, &s.d_ml, &s.d_mr, &s.d_rawl, &s.d_rawr, &s.d_tmp }) { if (*p) wass_device_free(ctx_, *p); *p = nullptr; }
             for (uint8_t** p : { &s.h_l, &s.h_r }) { if (*p) wass_pinned_free(ctx_, *p); *p = nullptr; }
         }
         for (auto& p : d_disp16_) { if (p) wass_device_free(ctx_, p); p = nullptr; }
@@ -500,6 +554,7 @@ private:
             s.h_l = (uint8_t*)pin(n); s.h_r = (uint8_t*)pin(n);
             s.d_l = (uint8_t*)dev(n); s.d_r = (uint8_t*)dev(n); s.d_ml = (uint8_t*)dev(n); s.d_mr = (uint8_t*)dev(n);
             s.d_cl = (uint8_t*)dev((size_t)cwl_ * chl_ + 4); s.d_cr = (uint8_t*)dev((size_t)cwr_ * chr_ + 4);
+            if (opt_.prep) { s.d_rawl = (uint8_t*)dev(n); s.d_rawr = (uint8_t*)dev(n); s.d_tmp = (uint8_t*)dev(n); }
         }
         for (auto& p : d_disp16_) p = (int16_t*)dev((size_t)cwr_ * chr_ * 2);
         d_dispf_ = (float*)dev((size_t)cwr_ * chr_ * 4);
@@ -533,7 +588,7 @@ private:
         map_valid_ = true;
     }
 
-    int acquire_out(size_t npts)
+    int acquire_out(size_t npts, size_t und_bytes)
     {
         std::unique_lock<std::mutex> lk(out_mu_);
         out_cv_.wait(lk, [&]() { for (bool f : out_free_) if (f) return true; return false; });
@@ -541,6 +596,7 @@ private:
         while (!out_free_[(size_t)slot]) ++slot;
         out_free_[(size_t)slot] = false;
         lk.unlock();
+        struct Guard { FramePipeline* p; int slot; bool armed; ~Guard() { if (armed) p->release_out(slot); } } guard{ this, slot, true };   // an allocation below may throw
         OutSet& o = out_[(size_t)slot];
         const size_t need = 148 + 6 * npts, icap = (npts + 9) / 10;
         if (o.xyzc_cap < need) {
@@ -556,6 +612,17 @@ private:
             check(wass_pinned_alloc(ctx_, icap * 24, &p), "wass_pinned_alloc");
             o.inl = (double*)p; o.inl_cap = icap;
         }
+        if (und_bytes > o.und_cap) {
+            for (auto& u : o.und) {
+                if (u) wass_pinned_free(ctx_, u);
+                u = nullptr;
+                void* p = nullptr;
+                check(wass_pinned_alloc(ctx_, und_bytes, &p), "wass_pinned_alloc");
+                u = (uint8_t*)p;
+            }
+            o.und_cap = und_bytes;
+        }
+        guard.armed = false;
         return slot;
     }
     void release_out(int slot)

@@ -110,7 +110,10 @@ inline void preload_images(const std::string& workdir, Preload& p)
     if (p.error.empty()) p.error = err1;
 }
 
-bool load_data(Env& env, const Config& cfg, Preload* pre = nullptr, BgTask* bg = nullptr)    // :337-445
+// load_data() (:337-445) in three parts, in the reference's order: calibration, pictures, the SAVE_INPUT_SCALE outputs.  The
+// pipelined driver's prepare-less mode (frame_pipeline.hpp) runs the first, decodes RAW camera frames instead of the second
+// and writes the previews of the third once the GPU has undistorted them.
+bool load_calibration(Env& env)                                                           // :340-391
 {
     WLOG_SCOPE("load_data");
     env.R = load_matrix_xml(path_join(env.workdir, "ext_R.xml"));
@@ -128,34 +131,51 @@ bool load_data(Env& env, const Config& cfg, Preload* pre = nullptr, BgTask* bg =
     if (env.K0.rows != 3 || env.K0.cols != 3 || env.K1.rows != 3 || env.K1.cols != 3) { WLOGE << "invalid intrinsics"; return false; }
     env.K_left = env.K0; env.K_right = env.K1;
     computeP(env);
-    {
-        Preload local;
-        if (!pre || pre->workdir != env.workdir) { preload_images(env.workdir, local); pre = &local; }   // the two PNGs are inflated side by side
-        if (!pre->error.empty()) { WLOGE << "unable to load input images: " << pre->error; return false; }
-        env.left = std::move(pre->left); env.right = std::move(pre->right);
-        env.left_index = 0;
-        WLOGI << "image 0 loaded, Size: " << env.left.w << "x" << env.left.h;
-        env.right_index = 1;
-        WLOGI << "image 1 loaded, Size: " << env.right.w << "x" << env.right.h;
-    }
+    return true;
+}
+
+// env.left / env.right are in place (cam0 / cam1): the lines and the check of :393-399
+bool images_loaded(Env& env)
+{
+    WLOG_SCOPE("load_data");
+    env.left_index = 0;
+    WLOGI << "image 0 loaded, Size: " << env.left.w << "x" << env.left.h;
+    env.right_index = 1;
+    WLOGI << "image 1 loaded, Size: " << env.right.w << "x" << env.right.h;
     if (env.left.w != env.right.w || env.left.h != env.right.h) { WLOGE << "left and right images differ in size"; return false; }
+    return true;
+}
+
+inline void write_previews(const std::string& wd, const Image& cam0, const Image& cam1, int nw, int nh)   // :413-418
+{
+    write_png_gray(path_join(wd, "00000000_s.png"), resize_cubic(cam0, nw, nh));
+    write_png_gray(path_join(wd, "00000001_s.png"), resize_cubic(cam1, nw, nh));
+}
+
+// :401-434.  previews = false: everything but the two scaled pictures (the caller writes them later: *nw, *nh say at which size)
+void input_scale_outputs(Env& env, const Config& cfg, bool previews, BgTask* bg, int* pnw = nullptr, int* pnh = nullptr)
+{
+    WLOG_SCOPE("load_data");
+    if (pnw) *pnw = 0;
+    if (pnh) *pnh = 0;
     const double sis = cfg.get_double("SAVE_INPUT_SCALE");
-    if (sis < 1.0) {                                                                      // :401-434
+    if (sis < 1.0) {
         const size_t nw = (size_t)(env.left.w * sis), nh = (size_t)(env.left.h * sis);
         const double scale = (double)nw / (double)env.left.w;
         WLOGI << "original size: " << env.left.w << "x" << env.left.h;
         WLOGI << "  scaled size: " << nw << "x" << nh;
         WLOGI << "        scale: " << scale;
         if (nw > 0 && nh > 0) {
-            // resize + deflate of the two previews (~20 ms) on a host thread while the frame goes to the GPU.  The task owns
-            // copies of the pictures: rectify() may swap env.left / env.right (swapLeftRight) while it runs.
-            auto l = std::make_shared<Image>(env.left), r = std::make_shared<Image>(env.right);
-            const std::string wd = env.workdir;
-            auto work = [l, r, wd, nw, nh]() {
-                write_png_gray(path_join(wd, "00000000_s.png"), resize_cubic(*l, (int)nw, (int)nh));
-                write_png_gray(path_join(wd, "00000001_s.png"), resize_cubic(*r, (int)nw, (int)nh));
-            };
-            if (bg) bg->run(work); else work();
+            if (pnw) *pnw = (int)nw;
+            if (pnh) *pnh = (int)nh;
+            if (previews) {
+                // resize + deflate of the two previews (~20 ms) on a host thread while the frame goes to the GPU.  The task owns
+                // copies of the pictures: rectify() may swap env.left / env.right (swapLeftRight) while it runs.
+                auto l = std::make_shared<Image>(env.left), r = std::make_shared<Image>(env.right);
+                const std::string wd = env.workdir;
+                auto work = [l, r, wd, nw, nh]() { write_previews(wd, *l, *r, (int)nw, (int)nh); };
+                if (bg) bg->run(work); else work();
+            }
         }
         Mat k0 = scaled(env.K_left, scale), k1 = scaled(env.K_right, scale);
         k0(2, 2) = 1; k1(2, 2) = 1;
@@ -164,6 +184,20 @@ bool load_data(Env& env, const Config& cfg, Preload* pre = nullptr, BgTask* bg =
         std::ofstream ofs(path_join(env.workdir, "scale.txt").c_str());
         ofs.precision(16); ofs << std::scientific << scale;
     }
+}
+
+bool load_data(Env& env, const Config& cfg, Preload* pre = nullptr, BgTask* bg = nullptr)    // :337-445
+{
+    WLOG_SCOPE("load_data");
+    if (!load_calibration(env)) return false;
+    {
+        Preload local;
+        if (!pre || pre->workdir != env.workdir) { preload_images(env.workdir, local); pre = &local; }   // the two PNGs are inflated side by side
+        if (!pre->error.empty()) { WLOGE << "unable to load input images: " << pre->error; return false; }
+        env.left = std::move(pre->left); env.right = std::move(pre->right);
+    }
+    if (!images_loaded(env)) return false;
+    input_scale_outputs(env, cfg, true, bg);
     return true;
 }
 

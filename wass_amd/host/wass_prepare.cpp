@@ -18,8 +18,7 @@
 #include <fstream>
 #include <iostream>
 
-#include "config.hpp"
-#include "hostio.hpp"
+#include "prepare_common.hpp"
 #include "tiff.hpp"
 #include "../../include/wass_gpu.h"
 
@@ -32,28 +31,9 @@ using namespace wasshost;
 namespace {
 
 bool exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
-bool is_dir(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode); }
-std::string join(const std::string& a, const std::string& b) { return (!a.empty() && a.back() == '/') ? a + b : a + "/" + b; }
-// boost::filesystem::create_directories: true when something was created
-bool create_directories(const std::string& p)
-{
-    if (is_dir(p)) return false;
-    bool made = false;
-    for (size_t i = 1; i <= p.size(); ++i)
-        if (i == p.size() || p[i] == '/') {
-            const std::string sub = p.substr(0, i);
-            if (!is_dir(sub) && mkdir(sub.c_str(), 0777) == 0) made = true;
-        }
-    return made && is_dir(p);
-}
-
-void register_options(Config& c)                                                              // wass_prepare.cpp:36-39
-{
-    c.add(Config::DOUBLE, "CAM0_CLAHE_CLIPLIMIT", "2.0", "CAM0 CLAHE cliplimit parameter");
-    c.add(Config::INT, "CAM0_CLAHE_TILEGRIDSIZE", "0", "CAM0 CLAHE tile grid size (set to 0 to disable CLAHE). 150 is a good value to start");
-    c.add(Config::DOUBLE, "CAM1_CLAHE_CLIPLIMIT", "2.0", "CAM1 CLAHE cliplimit parameter");
-    c.add(Config::INT, "CAM1_CLAHE_TILEGRIDSIZE", "0", "CAM1 CLAHE tile grid size (set to 0 to disable CLAHE). 150 is a good value to start");
-}
+bool is_dir(const std::string& p) { return prep_is_dir(p); }
+std::string join(const std::string& a, const std::string& b) { return prep_join(a, b); }
+void register_options(Config& c) { register_prepare_options(c); }                              // wass_prepare.cpp:36-39
 
 const char* kUsage =
     "wass_prepare arguments:\n"

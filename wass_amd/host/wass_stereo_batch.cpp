@@ -180,7 +180,15 @@ bool frame_done(const std::string& wd)
     return exists(path_join(wd, "mesh_cam.xyzbin"));
 }
 
-struct PipeOptions { int decode_threads = 8, writer_threads = 4; bool inliers_file = true; };
+struct PipeOptions {
+    int decode_threads = 8, writer_threads = 4;
+    bool inliers_file = true;
+    // prepare-less mode (--raw): frame i starts from cam0[i] / cam1[i] and the calibration directory
+    const PrepareSetup* prep = nullptr;
+    const std::vector<std::string>* cam0 = nullptr;
+    const std::vector<std::string>* cam1 = nullptr;
+    bool save_undistorted = false;
+};
 
 // One worker process, one context, frames rank, rank + world, ... through FramePipeline.
 int worker_pipelined(int rank, int world, int device, bool distinct_gpus, const unsigned char* uid, const char* cfgpath, const Config& cfg,
@@ -201,6 +209,8 @@ int worker_pipelined(int rank, int world, int device, bool distinct_gpus, const 
     FramePipeline::Options fo;
     fo.out_slots = po.writer_threads + 2;
     fo.inliers_file = po.inliers_file;
+    fo.prep = po.prep;
+    fo.save_undistorted = po.save_undistorted;
     FramePipeline pl(dev_env ? atoi(dev_env) : device, cfg, cfgpath, fo);
     {
         std::vector<std::unique_ptr<FrameJob>> jobs(n);
@@ -227,7 +237,8 @@ int worker_pipelined(int rank, int world, int device, bool distinct_gpus, const 
                 j->index = mine[pos];
                 j->workdir = wds[mine[pos]];
                 t_begin[pos] = now();
-                if (!exists(j->workdir)) j->rc = -1;
+                if (po.prep) { j->raw = true; j->c0 = (*po.cam0)[mine[pos]]; j->c1 = (*po.cam1)[mine[pos]]; }
+                if (!po.prep && !exists(j->workdir)) j->rc = -1;
                 else if (skip_existing && frame_done(j->workdir) && read_plane_txt(j->workdir, j->summary)) j->skipped = true;
                 else pl.prepare(*j);
                 std::lock_guard<std::mutex> lk(mu);
@@ -335,6 +346,9 @@ int main(int argc, char* argv[])
         std::cout << "Usage:\n  wass_stereo_batch <config_file> <workdir>... [--gpus G] [--procs-per-gpu P] [--out <dir>] [--verbose] [--skip-existing] [--debug-images]\n"
                      "  wass_stereo_batch <config_file> --sequence <output_dir> [--gpus G] ...\n"
                      "  --decode-threads N / --writer-threads N   host threads of a worker's pipeline (default 8 / 4)\n"
+                     "  --raw <calibdir> --cam0 <dir> --cam1 <dir> --sequence <output_dir> [--frames N] [--save-undistorted]\n"
+                     "                      prepare-less mode: wass_prepare's undistortion (and CLAHE) runs on the GPU inside the frame chain, from\n"
+                     "                      the cameras' raw pictures; undistorted/*.png are only written with --save-undistorted\n"
                      "  --no-inliers-file   do not write plane_refinement_inliers.xyz (14 MB of text per 5-megapixel frame that nothing reads)\n"
                      "  --stage-by-stage    synchronous per-stage calls instead of the pipelined chain (same files)\n"
                      "  --threads-per-proc T  stage-by-stage only: frames in flight per worker process, each on a thread and a context of its own\n"
@@ -347,6 +361,8 @@ int main(int argc, char* argv[])
     int gpus = 1, ppg = 1, tpp = 1;
     bool verbose = false, skip_existing = false, debug_images = false, stage_by_stage = false;
     PipeOptions po;
+    std::string raw_calibdir, cam0_dir, cam1_dir, raw_out;
+    long max_frames = -1;
     for (int i = 2; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "--gpus" && i + 1 < argc) gpus = atoi(argv[++i]);
@@ -360,6 +376,15 @@ int main(int argc, char* argv[])
         else if (a == "--decode-threads" && i + 1 < argc) po.decode_threads = atoi(argv[++i]);
         else if (a == "--writer-threads" && i + 1 < argc) po.writer_threads = atoi(argv[++i]);
         else if (a == "--no-inliers-file") po.inliers_file = false;
+        else if (a == "--raw" && i + 1 < argc) raw_calibdir = argv[++i];
+        else if (a == "--cam0" && i + 1 < argc) cam0_dir = argv[++i];
+        else if (a == "--cam1" && i + 1 < argc) cam1_dir = argv[++i];
+        else if (a == "--frames" && i + 1 < argc) max_frames = atol(argv[++i]);
+        else if (a == "--save-undistorted") po.save_undistorted = true;
+        else if (a == "--sequence" && i + 1 < argc && !raw_calibdir.empty()) {
+            raw_out = argv[++i];                                  // prepare-less mode: the workdirs are created below
+            if (outdir.empty()) outdir = raw_out;
+        }
         else if (a == "--sequence" && i + 1 < argc) {
             const std::string root = argv[++i];
             if (outdir.empty()) outdir = root;
@@ -376,6 +401,30 @@ int main(int argc, char* argv[])
         } else if (a.rfind("--", 0) == 0) { std::cerr << "unknown option " << a << std::endl; return -1; }
         else wds.push_back(a);
     }
+    // prepare-less mode: wass_prepare's work (undistortion, optional CLAHE) is done on the GPU inside the frame chain, from the
+    // cameras' raw pictures; frame t -> <output_dir>/%06d_wd as wasscli numbers them (wasscli.py:222-227)
+    PrepareSetup prep;
+    std::vector<std::string> cam0_files, cam1_files;
+    if (!raw_calibdir.empty()) {
+        if (raw_out.empty() || cam0_dir.empty() || cam1_dir.empty() || !wds.empty()) {
+            std::cerr << "--raw <calibdir> needs --cam0 <dir> --cam1 <dir> and, AFTER it, --sequence <output_dir> (no workdir arguments)" << std::endl;
+            return -1;
+        }
+        std::string err;
+        if (!load_prepare_setup(raw_calibdir, prep, &err)) { std::cerr << err << std::endl; return -1; }
+        if (!prep.have_ext) { std::cerr << "Extrinsic calibration not found in " << raw_calibdir << " (ext_R.xml, ext_T.xml): wass_stereo cannot run on such workdirs" << std::endl; return -1; }
+        cam0_files = list_image_files(cam0_dir);
+        cam1_files = list_image_files(cam1_dir);
+        if (cam0_files.empty() || cam0_files.size() != cam1_files.size()) {
+            std::cerr << "cam0 and cam1 directories are empty or contain a different set of images" << std::endl;
+            return -1;
+        }
+        size_t n = cam0_files.size();
+        if (max_frames >= 0 && (size_t)max_frames < n) n = (size_t)max_frames;
+        create_directories(raw_out);
+        for (size_t t = 0; t < n; ++t) { char nm[32]; snprintf(nm, sizeof nm, "%06zu_wd", t); wds.push_back(path_join(raw_out, nm)); }
+        po.prep = &prep; po.cam0 = &cam0_files; po.cam1 = &cam1_files;
+    }
     if (gpus < 1 || ppg < 1 || tpp < 1 || po.decode_threads < 1 || po.writer_threads < 1 || wds.empty()) { std::cerr << "Invalid arguments" << std::endl; return -1; }
     // The configuration is read once here to choose the worker form; a file that does not parse is left to the per-frame
     // path, which reports it in every frame's log exactly as wass_stereo does.
@@ -390,6 +439,7 @@ int main(int argc, char* argv[])
         catch (const std::runtime_error&) { pipelined = false; }
     }
     if (const char* e = getenv("WASS_DEBUG_IMAGES")) if (atoi(e) != 0) pipelined = false;
+    if (po.prep && !pipelined) { std::cerr << "--raw needs the pipelined chain (no --stage-by-stage / --debug-images / --threads-per-proc, an eligible configuration)" << std::endl; return -1; }
     if (outdir.empty()) outdir = ".";
     const int world = gpus * ppg;
     const bool distinct = ppg == 1;
