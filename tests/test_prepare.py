@@ -262,12 +262,14 @@ def test_prepare_then_stereo(prepare, tmp_path):
 
 # ------------------------------------------------------------------ GPU: the prepare-less mode of the sequence driver (row f2, fused)
 @pytest.mark.gpu
-@pytest.mark.parametrize("save_undistorted", [False, True])
-def test_raw_sequence_equals_prepare_then_stereo(prepare, tmp_path, save_undistorted):
+@pytest.mark.parametrize("save_undistorted,swapped", [(False, False), (True, False), (True, True)])
+def test_raw_sequence_equals_prepare_then_stereo(prepare, tmp_path, save_undistorted, swapped):
     """wass_stereo_batch --raw runs wass_prepare's undistortion (+ CLAHE) on the GPU INSIDE the frame chain, from the cameras'
     raw pictures: no undistorted/*.png is written or read unless asked for.  Every file of every workdir must equal what the
     two-executable route leaves behind (wass_prepare per frame, then the sequence driver on the prepared workdirs) -- two
-    interpolations with the reference's arithmetic, not one fused resampling."""
+    interpolations with the reference's arithmetic, not one fused resampling.  swapped: cam0 is the RIGHT camera (T.x < 0), so
+    wass_stereo exchanges the pictures (wass_stereo.cpp:486) -- each must still be undistorted with its own camera's
+    coefficients and contrast settings."""
     from wass_amd import build, synth
     w, h, D = 320, 240, 32
     rig = synth.rig_geometry(w, h)
@@ -277,7 +279,7 @@ def test_raw_sequence_equals_prepare_then_stereo(prepare, tmp_path, save_undisto
     _write_xml(calib / "distortion_00.xml", "dist", np.array([-0.012, 0.004, 2e-4, -1e-4, 0.0]).reshape(5, 1))
     _write_xml(calib / "distortion_01.xml", "dist", np.array([0.009, -0.003, -1e-4, 2e-4, 1e-3]).reshape(5, 1))
     _write_xml(calib / "ext_R.xml", "R", rig["R"])
-    _write_xml(calib / "ext_T.xml", "T", np.array(rig["T"]).reshape(3, 1) * 2.5)
+    _write_xml(calib / "ext_T.xml", "T", np.array(rig["T"]).reshape(3, 1) * (-2.5 if swapped else 2.5))
     (calib / "prepare_config.txt").write_text("CAM1_CLAHE_TILEGRIDSIZE=4\nCAM1_CLAHE_CLIPLIMIT=40.0\n")
     cfg = tmp_path / "stereo_config.txt"
     cfg.write_text(f"MAX_DISPARITY={D}\nRANDOM_SEED=12345\nUSE_CUSTOM_STEREORECTIFY=true\nRECTIFY_ANGLE=1e-6\nDISABLE_RECTIFY_ROI=true\n")
@@ -286,8 +288,8 @@ def test_raw_sequence_equals_prepare_then_stereo(prepare, tmp_path, save_undisto
     nframes = 3
     for t in range(nframes):
         right, left = synth.make_pair(w, h, D, frame_idx=40 + t)
-        _write_png(cam0 / ("%06d_frame.png" % t), left)
-        _write_png(cam1 / ("%06d_frame.png" % t), right)
+        _write_png(cam0 / ("%06d_frame.png" % t), right if swapped else left)
+        _write_png(cam1 / ("%06d_frame.png" % t), left if swapped else right)
     # route A: wass_prepare per frame (wasscli.py:222-227), then the sequence driver on the prepared workdirs
     seq_a = tmp_path / "a"; seq_a.mkdir()
     for t in range(nframes):
@@ -315,6 +317,7 @@ def test_raw_sequence_equals_prepare_then_stereo(prepare, tmp_path, save_undisto
             assert not (wb / "undistorted").exists()                  # the PNG round trip is gone, not hidden
         log = (wb / "wass_stereo_log.txt").read_text()
         assert "image 0 loaded, Size: 320x240" in log and "All done." in log
+        assert ("auto-swapping left-right images" in log) == swapped
         npts = int.from_bytes((wb / "mesh_cam.xyzC").read_bytes()[:4], "little")
         assert npts > 0.5 * w * h                                     # the distortion is mild: the surface is still recovered
     assert (seq_a / "planes.txt").read_text() == (seq_b / "planes.txt").read_text()

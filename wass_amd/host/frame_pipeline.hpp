@@ -53,6 +53,7 @@ struct FrameJob {
     bool raw = false;
     std::string c0, c1;
     int prev_w = 0, prev_h = 0;      // size of the scaled previews, written once the undistorted pictures are back (0: none)
+    int img_w = 0, img_h = 0;        // size of the cameras' pictures (the driver drops the decoded pictures once they are staged)
     unsigned int ransac_seed = 0;
     int in_slot = -1, out_slot = -1;
     long long sgm_call = -1;         // which wass_sgm_disparity_dev call of the pipeline's context produced the frame's disparity
@@ -149,6 +150,7 @@ public:
                 try { env.left = read_image_gray(job.c0); env.right = read_image_gray(job.c1); }
                 catch (const std::exception& e) { WLOG_SCOPE("load_data"); WLOGE << "unable to load input images: " << e.what(); job.rc = -1; return; }
                 if (!images_loaded(env)) { job.rc = -1; return; }
+                job.img_w = env.left.w; job.img_h = env.left.h;
                 input_scale_outputs(env, cfg_, false, nullptr, &job.prev_w, &job.prev_h);
             } else if (!load_data(env, cfg_, nullptr, nullptr)) { job.rc = -1; return; }
             job.t_loaded = Timer::now();
@@ -426,8 +428,8 @@ public:
                     // the scaled previews of load_data (:413-418) and, on request, wass_prepare's own output: from the undistorted
                     // pictures that came back with the result (und[0] = the picture that ended up LEFT, und[1] = right)
                     const OutSet& o = out_[job.out_slot];
-                    const size_t n = (size_t)env.left.w * env.left.h;
-                    Image cam[2] = { Image(env.left.w, env.left.h), Image(env.left.w, env.left.h) };
+                    const size_t n = (size_t)job.img_w * job.img_h;
+                    Image cam[2] = { Image(job.img_w, job.img_h), Image(job.img_w, job.img_h) };
                     memcpy(cam[env.left_index].px.data(), o.und[0], n);
                     memcpy(cam[env.right_index].px.data(), o.und[1], n);
                     if (job.prev_w > 0 && job.prev_h > 0) write_previews(env.workdir, cam[0], cam[1], job.prev_w, job.prev_h);
