@@ -337,14 +337,17 @@ def cxx_driver_record(ndirs: int, frames: int = 8, replicate: int = 24, decode_t
         wall = time.perf_counter() - t0
         if r.returncode != 0:
             return {"error": (r.stdout[-600:] + r.stderr[-600:]).strip(), "returncode": r.returncode}
-        steady = None
+        steady = cpu_ms = cores = None
         for line in r.stdout.splitlines():
             if line.startswith("steady state"):
                 steady = float(line.split(":")[1].split()[0])
+            if line.startswith("host CPU of the workers"):
+                cores = float(line.split("(")[1].split()[0])
+                cpu_ms = float(line.split(",")[1].split()[0])
         sizes = [os.path.getsize(os.path.join(seq, "%06d_wd" % (n - 1), f)) for f in ("mesh_cam.xyzC", "plane_refinement_inliers.xyz")]
         return {"pairs_per_sec": round(steady, 2) if steady else None, "pairs_per_sec_incl_startup": round(n / wall, 2), "seconds": round(wall, 2),
                 "frames": n, "distinct_frames": frames, "workers": 1, "decode_threads": decode_threads, "writer_threads": writer_threads,
-                "ndirs": ndirs, "pipelined": "pipelined" in r.stdout,
+                "ndirs": ndirs, "pipelined": "pipelined" in r.stdout, "host_cpu_ms_per_frame": cpu_ms, "host_cores_busy": cores,
                 "outputs": "all files wass_stereo writes without its debug pictures, per workdir: mesh_cam.xyzC "
                            f"({sizes[0] / 1e6:.1f} MB), plane.txt, plane_refinement_inliers.xyz ({sizes[1] / 1e6:.1f} MB), camera / pose files, "
                            "scaled previews, stereo_config.txt, wass_stereo_log.txt; planes.txt + planes_mean.txt for the sequence",

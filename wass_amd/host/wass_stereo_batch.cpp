@@ -24,6 +24,7 @@
 // mesh_cam.xyzbin exist is not recomputed, its plane is read back from plane.txt.
 #include <dirent.h>
 #include <fcntl.h>
+#include <sys/resource.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <poll.h>
@@ -570,6 +571,12 @@ int main(int argc, char* argv[])
         for (int r = 0; r < world; ++r)
             if (tails[r].computed > 1 && tails[r].last_done > tails[r].first_done) steady += (tails[r].computed - 1) / (tails[r].last_done - tails[r].first_done);
         if (steady > 0) std::cout << "steady state (first to last finished frame of every worker, start-up excluded): " << steady << " frames/s" << std::endl;
+        rusage ru;                                           // the workers have been waited for: their CPU time is the host's share of a frame
+        if (getrusage(RUSAGE_CHILDREN, &ru) == 0) {
+            const double cpu = (double)ru.ru_utime.tv_sec + ru.ru_utime.tv_usec / 1e6 + (double)ru.ru_stime.tv_sec + ru.ru_stime.tv_usec / 1e6;
+            std::cout << "host CPU of the workers: " << cpu << " s (" << (cpu / dt) << " cores busy on average, " << (1e3 * cpu / std::max<size_t>(wds.size(), 1))
+                      << " ms per frame)" << std::endl;
+        }
     }
     return ok && nfail == 0 ? 0 : -1;
 }
