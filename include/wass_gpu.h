@@ -83,6 +83,10 @@ void wass_pinned_free(wass_ctx* ctx, void* h_ptr);
 /* DISCARD_BURNED_AREAS (wass_stereo.cpp:1072,1086): d_mask[i] = d_img[i] <= 254, on the context's SGM stream; feeds the
  * left_mask / right_mask arguments of wass_triangulate_dev.  Both pointers 4-byte aligned. */
 int wass_burned_area_mask_dev(wass_ctx* ctx, const uint8_t* d_img, size_t n, uint8_t* d_mask);
+/* The camera masks of triangulate() in general (wass_stereo.cpp:1057-1093): d_mask[i] = (d_file_mask ? d_file_mask[i] != 0 : 1)
+ * && (d_img ? d_img[i] <= 254 : 1) -- LEFT_MASK_IMAGE / RIGHT_MASK_IMAGE thresholded by the caller (0/1 bytes), combined with
+ * DISCARD_BURNED_AREAS on the device.  Either input may be NULL.  On the context's SGM stream; waits for pending uploads. */
+int wass_camera_mask_dev(wass_ctx* ctx, const uint8_t* d_img, const uint8_t* d_file_mask, size_t n, uint8_t* d_mask);
 
 /* ------------------------------------------------------------------------
  * cv::StereoSGBM parameters as sgbm_dense_stereo sets them

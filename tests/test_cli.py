@@ -208,7 +208,8 @@ def test_no_gpu_is_a_loud_failure_in_the_pipelined_chain_too(cli, tmp_path):
 
 # ------------------------------------------------------------------ GPU: BASELINE config A through the CLI
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", ["", "USE_CUSTOM_STEREORECTIFY=false\n", "DENSE_PATHS=8\nMEDIAN_FILTER_WSIZE=3\nDISCARD_BURNED_AREAS=false\n"])
+@pytest.mark.parametrize("extra", ["", "USE_CUSTOM_STEREORECTIFY=false\n", "DENSE_PATHS=8\nMEDIAN_FILTER_WSIZE=3\nDISCARD_BURNED_AREAS=false\n",
+                                   "LEFT_MASK_IMAGE=lmask.png\nRIGHT_MASK_IMAGE=rmask.png\n", "RIGHT_MASK_IMAGE=missing.png\nDISCARD_BURNED_AREAS=false\n"])
 def test_pipelined_chain_writes_the_files_of_the_stage_by_stage_calls(cli, tmp_path, extra):
     """wass_stereo runs a frame through the host-sync-free device chain when the debug pictures are off and through the
     synchronous per-stage calls when they are on: every file a tool reads must come out the same, byte for byte, and the
@@ -216,6 +217,11 @@ def test_pipelined_chain_writes_the_files_of_the_stage_by_stage_calls(cli, tmp_p
     import shutil
     w, h, D = 400, 300, 64
     wd, cfg, *_ = make_workdir(str(tmp_path), w, h, D, extra_cfg=extra)
+    if "lmask.png" in extra:                                   # camera masks (wass_stereo.cpp:1059-1087): a ship's bow and a pole
+        lm = np.full((h, w), 255, np.uint8); lm[h - 60:, :120] = 0
+        rm = np.full((h, w), 255, np.uint8); rm[:, 300:310] = 0; rm[20:40, 50:90] = 0
+        _write_png(os.path.join(wd, "lmask.png"), lm)
+        _write_png(os.path.join(wd, "rmask.png"), rm)
     wd2 = os.path.join(str(tmp_path), "pipelined_wd")
     shutil.copytree(wd, wd2)
     a = subprocess.run([cli, cfg, wd], capture_output=True, text=True, env=dict(os.environ, WASS_DEBUG_IMAGES="1"))
@@ -234,6 +240,9 @@ def test_pipelined_chain_writes_the_files_of_the_stage_by_stage_calls(cli, tmp_p
                 "estimated plane coeffs", "number of points after plane cropping", "total data size", "rectification map generated")
         return [l for l in out.splitlines() if any(k in l for k in keep)]
     assert numbers(a.stdout) == numbers(b.stdout) and len(numbers(a.stdout)) == 9
+    masks = [l for l in a.stdout.splitlines() if "camera mask" in l or "not found or invalid image" in l]
+    assert masks == [l for l in b.stdout.splitlines() if "camera mask" in l or "not found or invalid image" in l]
+    assert len(masks) == (2 if "MASK_IMAGE" in extra else 0)
     log = open(os.path.join(wd2, "wass_stereo_log.txt")).read()
     assert "[P|" not in log and log.count("Reconstructing") == 1 and "All done." in log
 

@@ -153,6 +153,7 @@ SYMBOLS = {
     "wass_biggest_component_by_gradient_dev": (_i, [_vp, _vp, _i, _i, _i]),
     "wass_upload_async": (_i, [_vp, _vp, _vp, _sz]),
     "wass_burned_area_mask_dev": (_i, [_vp, _vp, _sz, _vp]),
+    "wass_camera_mask_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "wass_clahe": (_i, [_vp, _vp, _i, _i, _sz, C.c_double, _i, _i, _vp]),
     "wass_clahe_dev": (_i, [_vp, _vp, _i, _i, _sz, C.c_double, _i, _i, _vp]),
     "wass_coll_unique_id": (_i, [_vp]),

@@ -41,6 +41,18 @@ __global__ void __launch_bounds__(256) k_burned_mask(const uint8_t* __restrict__
     }
 }
 
+// the camera masks of triangulate() (wass_stereo.cpp:1057-1093): the thresholded mask picture of the configuration (file:
+// 0/1 bytes, may be null) AND, with DISCARD_BURNED_AREAS, "the undistorted picture is not saturated" (img, may be null)
+__global__ void __launch_bounds__(256) k_camera_mask(const uint8_t* __restrict__ img, const uint8_t* __restrict__ file, size_t n,
+                                                     uint8_t* __restrict__ mask)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint8_t m = file ? (file[i] ? 1 : 0) : 1;
+    if (img && img[i] > 254) m = 0;
+    mask[i] = m;
+}
+
 __global__ void __launch_bounds__(256) k_dilate_zero(const float* __restrict__ src, float* __restrict__ out, int w, int h)
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
@@ -351,6 +363,18 @@ extern "C" int wass_burned_area_mask_dev(wass_ctx* c, const uint8_t* d_img, size
     WASS_HIP(c, hipSetDevice(c->device));
     if (int rc = wass::wait_uploads(c, d_img, c->stream)) return rc;
     hipLaunchKernelGGL(wass::k_burned_mask, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, c->stream, d_img, n, d_mask);
+    WASS_HIP(c, hipGetLastError());
+    return WASS_OK;
+}
+
+extern "C" int wass_camera_mask_dev(wass_ctx* c, const uint8_t* d_img, const uint8_t* d_file_mask, size_t n, uint8_t* d_mask)
+{
+    if (!c || !d_mask || n == 0) return wass::set_err(c, WASS_ERR_INVALID_ARG, "bad argument");
+    WASS_HIP(c, hipSetDevice(c->device));
+    int rc;
+    if (d_img && (rc = wass::wait_uploads(c, d_img, c->stream))) return rc;
+    if (d_file_mask && (rc = wass::wait_uploads(c, d_file_mask, c->stream))) return rc;
+    hipLaunchKernelGGL(wass::k_camera_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_img, d_file_mask, n, d_mask);
     WASS_HIP(c, hipGetLastError());
     return WASS_OK;
 }

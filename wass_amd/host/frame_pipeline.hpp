@@ -34,7 +34,6 @@ inline bool pipeline_eligible(const Config& cfg, std::string* why = nullptr)
     if (cfg.get_bool("SAVE_FULL_MESH")) return no("SAVE_FULL_MESH (the mesh before the plane stages goes to the host)");
     if (cfg.get_bool("SAVE_AS_PLY")) return no("SAVE_AS_PLY (the whole mesh goes to the host)");
     if (!cfg.get_bool("SAVE_COMPRESSED")) return no("SAVE_COMPRESSED=false (the whole mesh goes to the host)");
-    if (cfg.get_string("LEFT_MASK_IMAGE") != "none" || cfg.get_string("RIGHT_MASK_IMAGE") != "none") return no("mask images");
     const int rounds = cfg.get_int("PLANE_RANSAC_ROUNDS");
     if (rounds <= 0 || rounds > 1800) return no("PLANE_RANSAC_ROUNDS outside 1..1800");
     return true;
@@ -54,6 +53,10 @@ struct FrameJob {
     std::string c0, c1;
     int prev_w = 0, prev_h = 0;      // size of the scaled previews, written once the undistorted pictures are back (0: none)
     int img_w = 0, img_h = 0;        // size of the cameras' pictures (the driver drops the decoded pictures once they are staged)
+    // LEFT_MASK_IMAGE / RIGHT_MASK_IMAGE (wass_stereo.cpp:1059-1087): thresholded to 0/1 on the decode thread (empty: none);
+    // mask_log: the lines triangulate() would have logged while loading them, replayed at their place
+    std::vector<uint8_t> fmask[2];
+    std::string mask_log;
     unsigned int ransac_seed = 0;
     int in_slot = -1, out_slot = -1;
     long long sgm_call = -1;         // which wass_sgm_disparity_dev call of the pipeline's context produced the frame's disparity
@@ -166,6 +169,21 @@ public:
             save_cams();
             if (!rectify_plan(env, cfg_)) { job.rc = -1; return; }
             save_cams();
+            for (int side = 0; side < 2; ++side) {              // the masks belong to the pictures that are left / right NOW (after a swap)
+                const std::string name = cfg_.get_string(side == 0 ? "LEFT_MASK_IMAGE" : "RIGHT_MASK_IMAGE");
+                if (name == "none") continue;
+                const std::string fn = path_join(env.workdir, name);
+                LogSinkScope ms(&job.mask_log);
+                WLOG_SCOPE("triangulate");
+                WLOGI << "Loading " << fn << " as " << (side == 0 ? "left" : "right") << " camera mask";
+                try {
+                    const Image aux = read_image_gray(fn);
+                    if (aux.w == env.left.w && aux.h == env.left.h) {
+                        job.fmask[side].resize(aux.px.size());
+                        for (size_t i = 0; i < aux.px.size(); ++i) job.fmask[side][i] = aux.px[i] > 0 ? 1 : 0;    // threshold(0.5)
+                    } else WLOGE << "not found or invalid image.";
+                } catch (const std::exception&) { WLOGE << "not found or invalid image."; }
+            }
             job.t_planned = Timer::now();
         } catch (const std::exception& e) {
             WLOG_SCOPE("wass_stereo");
@@ -198,6 +216,15 @@ public:
             memcpy(in_[k].h_r, env.right.px.data(), n);
             check(wass_upload_async(ctx_, job.raw ? in_[k].d_rawl : in_[k].d_l, in_[k].h_l, n), "wass_upload_async");
             check(wass_upload_async(ctx_, job.raw ? in_[k].d_rawr : in_[k].d_r, in_[k].h_r, n), "wass_upload_async");
+            for (int side = 0; side < 2; ++side)
+                if (!job.fmask[side].empty()) {
+                    uint8_t*& hp = side == 0 ? in_[k].h_fl : in_[k].h_fr;
+                    uint8_t*& dp = side == 0 ? in_[k].d_fl : in_[k].d_fr;
+                    if (!hp) { void* p = nullptr; check(wass_pinned_alloc(ctx_, n + 4, &p), "wass_pinned_alloc"); hp = (uint8_t*)p; }
+                    if (!dp) { void* p = nullptr; check(wass_device_alloc(ctx_, n + 4, &p), "wass_device_alloc"); dp = (uint8_t*)p; }
+                    memcpy(hp, job.fmask[side].data(), n);
+                    check(wass_upload_async(ctx_, dp, hp, n), "wass_upload_async");
+                }
             job.in_slot = k;
             job.staged = true;
         } catch (const std::exception& e) {
@@ -257,10 +284,11 @@ public:
             WLOGI << "rectification map generated. Size: " << rl[2] << "x" << rl[3];
             marker(job, 20);
             const bool burned = cfg_.get_bool("DISCARD_BURNED_AREAS");
-            if (burned) {                                   // :1072,1086 -- the masks of the ORIGINAL pictures
+            const bool mask_l = burned || !job.fmask[0].empty(), mask_r = burned || !job.fmask[1].empty();
+            {                                               // :1057-1093 -- the masks of the ORIGINAL (undistorted) pictures
                 const size_t n = (size_t)W_ * H_;
-                check(wass_burned_area_mask_dev(ctx_, in_[k].d_l, n, in_[k].d_ml), "wass_burned_area_mask");
-                check(wass_burned_area_mask_dev(ctx_, in_[k].d_r, n, in_[k].d_mr), "wass_burned_area_mask");
+                if (mask_l) check(wass_camera_mask_dev(ctx_, burned ? in_[k].d_l : nullptr, job.fmask[0].empty() ? nullptr : in_[k].d_fl, n, in_[k].d_ml), "wass_camera_mask");
+                if (mask_r) check(wass_camera_mask_dev(ctx_, burned ? in_[k].d_r : nullptr, job.fmask[1].empty() ? nullptr : in_[k].d_fr, n, in_[k].d_mr), "wass_camera_mask");
             }
             // ---- sgbm_dense_stereo (:764-1020)
             WLOG_SCOPE("sgbm_dense_stereo");
@@ -304,9 +332,10 @@ public:
                 tp.bbox[2] = cfg_.get_double("TRIANG_BBOX_RIGHT"); tp.bbox[3] = cfg_.get_double("TRIANG_BBOX_BOTTOM");
             }
             tp.cam_distance = env.cam_distance;
+            job.log += job.mask_log;                        // "Loading ... as left camera mask" (:1062,1079), where triangulate() logs it
             WLOGI << "triangulating disparity map";
-            check(wass_triangulate_dev(ctx_, d_dispf_, W_, H_, rl, rr, &g, in_[k].d_r, W_, H_, burned ? in_[k].d_ml : nullptr,
-                                       burned ? in_[k].d_mr : nullptr, &tp, &mesh, nullptr), "wass_triangulate");
+            check(wass_triangulate_dev(ctx_, d_dispf_, W_, H_, rl, rr, &g, in_[k].d_r, W_, H_, mask_l ? in_[k].d_ml : nullptr,
+                                       mask_r ? in_[k].d_mr : nullptr, &tp, &mesh, nullptr), "wass_triangulate");
             WLOGI << "... 100%";
             // ---- the previous frame: its record and file image have arrived while this one was being enqueued
             if (FrameJob* p = collect()) done.push_back(p);
@@ -503,7 +532,7 @@ public:
 
 private:
     struct InSet { uint8_t *h_l = nullptr, *h_r = nullptr, *d_l = nullptr, *d_r = nullptr, *d_cl = nullptr, *d_cr = nullptr, *d_ml = nullptr, *d_mr = nullptr,
-                           *d_rawl = nullptr, *d_rawr = nullptr, *d_tmp = nullptr; };
+                           *d_rawl = nullptr, *d_rawr = nullptr, *d_tmp = nullptr, *h_fl = nullptr, *h_fr = nullptr, *d_fl = nullptr, *d_fr = nullptr; };
     struct OutSet { void* xyzc = nullptr; size_t xyzc_cap = 0; double* inl = nullptr; size_t inl_cap = 0; uint8_t* und[2] = { nullptr, nullptr }; size_t und_cap = 0; };
 
     void check(int rc, const char* what) const { if (rc != WASS_OK) throw GpuError(std::string(what) + ": " + wass_last_error(ctx_)); }
@@ -533,8 +562,8 @@ private:
     void release_buffers()
     {
         for (auto& s : in_) {
-            for (uint8_t** p : { &s.d_l, &s.d_r, &s.d_cl, &s.d_cr, &s.d_ml, &s.d_mr, &s.d_rawl, &s.d_rawr, &s.d_tmp }) { if (*p) wass_device_free(ctx_, *p); *p = nullptr; }
-            for (uint8_t** p : { &s.h_l, &s.h_r }) { if (*p) wass_pinned_free(ctx_, *p); *p = nullptr; }
+            for (uint8_t** p : { &s.d_l, &s.d_r, &s.d_cl, &s.d_cr, &s.d_ml, &s.d_mr, &s.d_rawl, &s.d_rawr, &s.d_tmp, &s.d_fl, &s.d_fr }) { if (*p) wass_device_free(ctx_, *p); *p = nullptr; }
+            for (uint8_t** p : { &s.h_l, &s.h_r, &s.h_fl, &s.h_fr }) { if (*p) wass_pinned_free(ctx_, *p); *p = nullptr; }
         }
         for (auto& p : d_disp16_) { if (p) wass_device_free(ctx_, p); p = nullptr; }
         if (d_dispf_) wass_device_free(ctx_, d_dispf_);
