@@ -388,6 +388,12 @@ typedef struct {
     int    width, height;           /* XX.shape[1], XX.shape[0]                         */
 } wass_grid_setup;
 int wass_mesh_grid_idw(wass_ctx* ctx, const wass_mesh* m, const wass_grid_setup* gs, float* grid_out, uint8_t* mask_out);
+/* The same with the cell statistic chosen: WASS_GRID_CELL_MEAN (what wass_mesh_grid_idw computes) or WASS_GRID_CELL_MEDIAN, the
+ * exact median of the points of a cell -- deterministic, independent of the point order, and robust against a few outliers
+ * in a cell like the reference's nanmedian of random sub-samples (:330-345), whose expected value it is. */
+enum { WASS_GRID_CELL_MEAN = 0, WASS_GRID_CELL_MEDIAN = 1 };
+int wass_mesh_grid_idw_ex(wass_ctx* ctx, const wass_mesh* m, const wass_grid_setup* gs, int cell_statistic, float* grid_out,
+                          uint8_t* mask_out);
 
 /* Coll-1: NaN-aware mean of per-frame planes (np.nanmean of planes.txt,
  * gridding/wassgridsurface/wassgridsurface.py:672-678).  Reduces

@@ -11,6 +11,8 @@ Cell statistic.  The reference fills a cell with the nanmedian of ten random sub
   cell="mean"              the mean of the cell's points in plain float64 (np.add.at) -- what grid.hip computes up to its
                            fixed-point accumulation; nothing here mirrors the GPU's arithmetic, the test tolerance follows
                            from the GPU's 2^-24 quantisation and its float32 output;
+  cell="median"            the exact median of the cell's points (np.median per cell), the deterministic statistic grid.hip offers
+                           beside the mean (wass_mesh_grid_idw_ex);
   cell="subsample_median"  the reference's statistic restated line by line (np.random.seed(seed) first), so that the GPU
                            grid can also be compared with what the reference would have produced for one seed."""
 import numpy as np
@@ -34,6 +36,16 @@ def cell_values(px, py, pz, width, height, cell="mean", seed=0, subsample_percen
         np.add.at(ssum, (py, px), pz)
         with np.errstate(invalid="ignore", divide="ignore"):
             return np.where(cnt > 0, ssum / cnt, np.nan)
+    if cell == "median":                                 # exact per-cell median (numpy's: mean of the two middle values for even counts)
+        out = np.full((height, width), np.nan)
+        key = py * width + px
+        order = np.argsort(key, kind="stable")
+        ks, zs = key[order], pz[order]
+        starts = np.flatnonzero(np.r_[True, ks[1:] != ks[:-1]])
+        ends = np.r_[starts[1:], ks.size]
+        for a, b in zip(starts, ends):
+            out.flat[ks[a]] = np.median(zs[a:b])
+        return out
     if cell == "subsample_median":                       # wassgridsurface.py:319,330-345, verbatim order of the random draws
         np.random.seed(seed)
         perm = np.random.permutation(px.shape[0])        # :319 (the permutation of the aligned mesh, here of its in-grid points)

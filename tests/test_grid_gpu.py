@@ -55,6 +55,41 @@ def test_grid_matches_oracle_on_a_random_cloud(gpu_ctx):
     np.testing.assert_array_equal(grid, grid2)
 
 
+def test_grid_median_cells_match_oracle_and_resist_outliers(gpu_ctx):
+    """wass_mesh_grid_idw_ex(WASS_GRID_CELL_MEDIAN): every cell holds the exact median of its points (np.median in the oracle),
+    the grid does not depend on the point order, and a few gross outliers per cell move it far less than they move the mean --
+    the property the reference's nanmedian of random sub-samples (wassgridsurface.py:330-345) has and a mean has not."""
+    from oracle import grid_oracle as G
+    rng = np.random.default_rng(11)
+    w, h = 200, 150
+    plane = np.array([0.02, 0.81, 0.586, -11.0]); plane[:3] /= np.linalg.norm(plane[:3])
+    X = rng.uniform(-6, 6, (h, w)); Y = rng.uniform(-3, 3, (h, w))
+    Z = (-plane[3] - plane[0] * X - plane[1] * Y) / plane[2] + 0.05 * np.sin(X * 2.0)
+    out = rng.random((h, w)) < 0.02                              # 2 % spikes, 3 baselines off the surface
+    Z = Z + out * 3.0
+    valid = (rng.random((h, w)) < 0.8).astype(np.uint8)
+    p3d = np.stack([X, Y, Z], axis=-1)
+    mesh = gpu_ctx.mesh_upload(valid, p3d)
+    args = dict(baseline=2.5, xmin=-12.0, xmax=12.0, ymin=-30.0, ymax=-5.0, width=48, height=40)     # coarse grid: many points per cell
+    grid, mask = mesh.grid_idw(plane, cell="median", **args)
+    pts = p3d[valid.astype(bool)].T.copy()
+    ref, rmask = G.grid_idw(pts, plane, cell="median", **args)
+    np.testing.assert_array_equal(mask, rmask)
+    # float32 output of float64 medians (|z| <= 10 m: 1e-6), the inverse-distance fill a convex combination of them
+    np.testing.assert_allclose(grid[mask == 1], ref[rmask == 1], rtol=0, atol=2e-6)
+    # order independence, bit for bit
+    perm = rng.permutation(w * h)
+    mesh2 = gpu_ctx.mesh_upload(valid.ravel()[perm].reshape(h, w), p3d.reshape(-1, 3)[perm].reshape(h, w, 3))
+    grid2, _ = mesh2.grid_idw(plane, cell="median", **args)
+    np.testing.assert_array_equal(grid, grid2)
+    # robustness: against the clean surface (no spikes) the median grid is several times closer than the mean grid
+    clean = np.stack([X, Y, Z - out * 3.0], axis=-1)
+    truth, _ = G.grid_idw(clean[valid.astype(bool)].T.copy(), plane, cell="median", **args)
+    mean_grid, _ = mesh.grid_idw(plane, cell="mean", **args)
+    e_med = np.abs(grid[mask == 1] - truth[mask == 1]).mean(); e_mean = np.abs(mean_grid[mask == 1] - truth[mask == 1]).mean()
+    assert e_med < 0.25 * e_mean, (e_med, e_mean)
+
+
 def test_grid_of_the_synthetic_sea_plane_is_flat(gpu_ctx):
     """Whole path: SGM -> clean-up -> triangulation -> plane fit -> grid.  Aligned on its own plane the synthetic surface
     (an exact plane plus a +-0.6 px disparity ripple) is flat to a few centimetres at a 2.5 m baseline."""

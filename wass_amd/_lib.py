@@ -144,6 +144,7 @@ SYMBOLS = {
     "wass_pinned_free": (None, [_vp, _vp]),
     "wass_free": (None, [_vp]),
     "wass_mesh_grid_idw": (_i, [_vp, _vp, C.POINTER(GridSetup), _vp, _vp]),
+    "wass_mesh_grid_idw_ex": (_i, [_vp, _vp, C.POINTER(GridSetup), _i, _vp, _vp]),
     "wass_planes_mean_accumulate": (None, [C.POINTER(C.c_double), _i, C.POINTER(C.c_double)]),
     "wass_planes_mean_finish": (None, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
     "wass_ctx_wait_for_stream": (_i, [_vp, _vp]),

@@ -401,14 +401,16 @@ class Mesh:
                                                          gray.ctypes.data))
         return valid, p3d, gray
 
-    def grid_idw(self, plane, baseline: float, xmin: float, xmax: float, ymin: float, ymax: float, width: int, height: int):
-        """Surface grid of this cloud aligned on `plane` (wassgridsurface.py:316-365, IDW): (float32 grid, uint8 mask)."""
+    def grid_idw(self, plane, baseline: float, xmin: float, xmax: float, ymin: float, ymax: float, width: int, height: int, cell: str = "mean"):
+        """Surface grid of this cloud aligned on `plane` (wassgridsurface.py:316-365, IDW): (float32 grid, uint8 mask).
+        cell: "mean" or "median" -- the statistic a cell takes of its points."""
         gs = _lib.GridSetup()
         R, T, _, _ = RT_from_plane(plane)
         gs.R[:] = np.asarray(R, float).ravel().tolist(); gs.T[:] = np.asarray(T, float).ravel().tolist()
         gs.baseline, gs.xmin, gs.xmax, gs.ymin, gs.ymax, gs.width, gs.height = baseline, xmin, xmax, ymin, ymax, width, height
         grid = np.empty((height, width), np.float32); mask = np.empty((height, width), np.uint8)
-        self.ctx._check(self.ctx._lib.wass_mesh_grid_idw(self.ctx._h, self._h, C.byref(gs), grid.ctypes.data, mask.ctypes.data))
+        self.ctx._check(self.ctx._lib.wass_mesh_grid_idw_ex(self.ctx._h, self._h, C.byref(gs), {"mean": 0, "median": 1}[cell], grid.ctypes.data,
+                                                            mask.ctypes.data))
         return grid, mask
 
     def zgap_percentile(self, pct: float):
