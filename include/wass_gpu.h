@@ -342,6 +342,12 @@ typedef struct {
     uint64_t n_triangulated;
     /* points written to inliers_dst by wass_mesh_finish_frame_async_ex (0 for the plain form or when RANSAC failed) */
     uint64_t n_inliers_out;
+    /* GPU time (hipEvents on the context's tail stream, milliseconds) of the reference's timer rows after "Dense Stereo"
+     * (wass_stereo.cpp:1982,2047,2049,2065,2089): [0] Triangulation, [1] Z-gap stats, [2] Outlier removal, [3] Plane fitting,
+     * [4] Plane refinement (crop, refinement, crop, mesh_cam.xyzC image).  Zero when the mesh did not come from a
+     * wass_triangulate[_dev] call of this context.  Under tail overlap the tail shares the GPU with the next frame's SGM stage. */
+    float stage_ms[5];
+    int reserved;
 } wass_frame_result;
 int wass_mesh_finish_frame_async(wass_ctx* ctx, wass_mesh* m, double percentile, const int32_t* uv_triplets, int rounds,
                                  double ransac_thr, const wass_refine_params* rp, double max_distance, void* dst,
@@ -349,10 +355,13 @@ int wass_mesh_finish_frame_async(wass_ctx* ctx, wass_mesh* m, double percentile,
 /* The same, and additionally what main() writes to plane_refinement_inliers.xyz (wass_stereo.cpp:2077-2085): every
  * `inliers_every`-th refinement inlier (PovMesh.cpp:590-606) in raster order, selected on the device between the
  * refinement and the final crop and downloaded next to the file image -- inliers_dst: pinned host memory for
- * inliers_capacity points of 3 doubles (ceil(width*height / inliers_every) is always enough); NULL: not wanted. */
+ * inliers_capacity points of 3 doubles (ceil(width*height / inliers_every) is always enough); NULL: not wanted.
+ * component_mask_dst: pinned host memory for width*height bytes, the validity mask as cluster_biggest_connected_component leaves
+ * it (PovMesh.cpp:929-987) -- before the plane stages crop it further; what graph_components.jpg is drawn from; NULL: not wanted. */
 int wass_mesh_finish_frame_async_ex(wass_ctx* ctx, wass_mesh* m, double percentile, const int32_t* uv_triplets, int rounds,
                                     double ransac_thr, const wass_refine_params* rp, double max_distance, void* dst,
-                                    size_t capacity, double* inliers_dst, size_t inliers_capacity, int inliers_every);
+                                    size_t capacity, double* inliers_dst, size_t inliers_capacity, int inliers_every,
+                                    uint8_t* component_mask_dst);
 int wass_ctx_frame_result(wass_ctx* ctx, wass_frame_result* out);
 
 /* RT_from_plane (:1044-1069); pure host math */

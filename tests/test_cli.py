@@ -211,9 +211,10 @@ def test_no_gpu_is_a_loud_failure_in_the_pipelined_chain_too(cli, tmp_path):
 @pytest.mark.parametrize("extra", ["", "USE_CUSTOM_STEREORECTIFY=false\n", "DENSE_PATHS=8\nMEDIAN_FILTER_WSIZE=3\nDISCARD_BURNED_AREAS=false\n",
                                    "LEFT_MASK_IMAGE=lmask.png\nRIGHT_MASK_IMAGE=rmask.png\n", "RIGHT_MASK_IMAGE=missing.png\nDISCARD_BURNED_AREAS=false\n"])
 def test_pipelined_chain_writes_the_files_of_the_stage_by_stage_calls(cli, tmp_path, extra):
-    """wass_stereo runs a frame through the host-sync-free device chain when the debug pictures are off and through the
-    synchronous per-stage calls when they are on: every file a tool reads must come out the same, byte for byte, and the
-    log must carry the same numbers."""
+    """wass_stereo runs a frame through the host-sync-free device chain (frame_pipeline.hpp) -- the debug pictures are drawn
+    from maps fetched afterwards -- or, on request (WASS_STAGE_BY_STAGE=1) and for a few options, through the synchronous
+    per-stage calls: every file must come out the same, byte for byte, the debug pictures included, and the log must carry the
+    same numbers."""
     import shutil
     w, h, D = 400, 300, 64
     wd, cfg, *_ = make_workdir(str(tmp_path), w, h, D, extra_cfg=extra)
@@ -224,10 +225,23 @@ def test_pipelined_chain_writes_the_files_of_the_stage_by_stage_calls(cli, tmp_p
         _write_png(os.path.join(wd, "rmask.png"), rm)
     wd2 = os.path.join(str(tmp_path), "pipelined_wd")
     shutil.copytree(wd, wd2)
-    a = subprocess.run([cli, cfg, wd], capture_output=True, text=True, env=dict(os.environ, WASS_DEBUG_IMAGES="1"))
-    b = subprocess.run([cli, cfg, wd2], capture_output=True, text=True, env=dict(os.environ, WASS_DEBUG_IMAGES="0"))
-    assert a.returncode == 0 and b.returncode == 0, a.stdout[-2000:] + b.stdout[-2000:]
-    assert "GPU pipeline" in b.stdout and "GPU pipeline" not in a.stdout          # which path ran is visible in the time table
+    wd3 = os.path.join(str(tmp_path), "pipelined_nodebug_wd")
+    shutil.copytree(wd, wd3)
+    a = subprocess.run([cli, cfg, wd], capture_output=True, text=True, env=dict(os.environ, WASS_STAGE_BY_STAGE="1"))
+    b = subprocess.run([cli, cfg, wd2], capture_output=True, text=True)
+    c = subprocess.run([cli, cfg, wd3], capture_output=True, text=True, env=dict(os.environ, WASS_DEBUG_IMAGES="0"))
+    assert a.returncode == 0 and b.returncode == 0 and c.returncode == 0, a.stdout[-2000:] + b.stdout[-2000:] + c.stdout[-1000:]
+    assert "pipelined chain:" in b.stdout and "pipelined chain:" in c.stdout and "pipelined chain:" not in a.stdout   # which path ran
+    for stage in ("Data load", "Rectification", "Dense Stereo", "Triangulation", "Z-gap stats", "Outlier removal", "Plane fitting",
+                  "Plane refinement", "TOTAL"):
+        assert stage in b.stdout, stage                           # the reference's time-table rows, GPU times
+    pics = ["stereo.jpg", "stereo_input.jpg", "disparity_stereo_ouput.jpg", "disparity_final_scaled.jpg", "disparity_coverage.jpg", "graph_components.jpg",
+            "undistorted/R0.jpg", "undistorted/R1.jpg"]
+    for name in pics:
+        assert open(os.path.join(wd, name), "rb").read() == open(os.path.join(wd2, name), "rb").read(), name
+        assert not os.path.exists(os.path.join(wd3, name)), name
+    for name in ("mesh_cam.xyzC", "plane.txt", "plane_refinement_inliers.xyz"):
+        assert open(os.path.join(wd, name), "rb").read() == open(os.path.join(wd3, name), "rb").read(), name
     for name in ("mesh_cam.xyzC", "plane.txt", "plane_refinement_inliers.xyz", "P0cam.txt", "P1cam.txt", "Cam0_poseR.txt", "Cam1_poseT.txt",
                  "K0_small.txt", "K1_small.txt", "scale.txt", "00000000_s.png", "00000001_s.png", "stereo_config.txt") + \
             (() if "USE_CUSTOM_STEREORECTIFY=false" in extra else ("H0_rect.txt", "H1_rect.txt")):

@@ -126,7 +126,7 @@ void wass_ctx_destroy(wass_ctx* c)
     mesh_pool_ctx_alive(c, false);
     mesh_pool_purge(c);
     for (Buf* b : { &c->img1, &c->img2, &c->bt1, &c->bt2, &c->hsum, &c->C, &c->S, &c->ckpt, &c->sel_d16, &c->sel_key, &c->raw,
-                    &c->flags, &c->tmp_in0, &c->tmp_in1, &c->tmp_out, &c->tmp_mask, &c->fA, &c->fB, &c->fC, &c->fD, &c->fE, &c->uf, &c->rs_r, &c->rs_l, &c->raw2, &c->grid, &c->scratch, &c->counters, &c->tri_cnt, &c->inl, &c->clahe_lut, &c->und_cache[0].xy, &c->und_cache[1].xy, &c->dstate, &c->rect_tab, &c->rect_mx, &c->rect_my, &c->xyzc, &c->limits })
+                    &c->flags, &c->tmp_in0, &c->tmp_in1, &c->tmp_out, &c->tmp_mask, &c->fA, &c->fB, &c->fC, &c->fD, &c->fE, &c->uf, &c->rs_r, &c->rs_l, &c->raw2, &c->grid, &c->scratch, &c->counters, &c->tri_cnt, &c->inl, &c->clahe_lut, &c->ccmask, &c->und_cache[0].xy, &c->und_cache[1].xy, &c->dstate, &c->rect_tab, &c->rect_mx, &c->rect_my, &c->xyzc, &c->limits })
         release(*b);
     for (auto& set : c->evs) for (auto& e : set) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_ckpt) if (e) (void)hipEventDestroy(e);
@@ -141,6 +141,7 @@ void wass_ctx_destroy(wass_ctx* c)
     if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
     if (c->ev_producer) (void)hipEventDestroy(c->ev_producer);
     if (c->ev_dl) (void)hipEventDestroy(c->ev_dl);
+    for (auto& e : c->ev_tail) if (e) (void)hipEventDestroy(e);
     if (c->ev_pack) (void)hipEventDestroy(c->ev_pack);
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     for (auto& u : c->uploads) if (u.ev) (void)hipEventDestroy(u.ev);

@@ -150,6 +150,11 @@ struct wass_ctx {
     bool tail_overlap = false;
     hipStream_t ts() const { return tail_overlap ? tail : stream; }
     hipEvent_t ev_pack = nullptr, ev_copy = nullptr;
+    // stage times of the frame tail (wass_frame_result.stage_ms): [0] before k_triangulate, [1] entry of the mesh tail, [2] z-gap
+    // percentile found, [3] biggest component kept, [4] RANSAC plane picked, [5] file image packed.  Created on first use.
+    hipEvent_t ev_tail[6] = {};
+    bool tail_timed = false;
+    wass::Buf ccmask;              // valid mask after the outlier removal, kept for graph_components.jpg when asked for
     // wass_upload_async: uploads in flight on the copy stream, by destination; consumers wait for the matching event
     struct UploadSlot { const char* dst = nullptr; size_t n = 0; hipEvent_t ev = nullptr; bool pending = false, consumed = false; };
     UploadSlot uploads[8];

@@ -1213,6 +1213,11 @@ int wass_triangulate_dev(wass_ctx* c, const float* d_disp, int W, int H, const i
     cnt = (unsigned long long*)c->tri_cnt.p;
     if (hipMemsetAsync(cnt, 0, (size_t)NSLOT * 8, c->ts()) != hipSuccess) { wass_mesh_destroy(m); return set_err(c, WASS_ERR_DEVICE, "memset failed"); }
     dim3 grid((m->w + 255) / 256, std::min(m->h, 512));
+    if (!c->ev_tail[0])
+        for (auto& e : c->ev_tail)
+            if (hipEventCreate(&e) != hipSuccess) { e = nullptr; wass_mesh_destroy(m); return set_err(c, WASS_ERR_DEVICE, "hipEventCreate failed"); }
+    (void)hipEventRecord(c->ev_tail[0], c->ts());
+    c->tail_timed = false;
     hipLaunchKernelGGL(k_triangulate, grid, dim3(256), 0, c->ts(), d_disp, W, H, roi_l[0], roi_r[0], roi_r[1], m->w, m->h,
                        gd, d_right_img, img_w, img_h, d_lmask, d_rmask, tp->min_angle_deg, tp->bbox[0], tp->bbox[1],
                        tp->bbox[2], tp->bbox[3], tp->cam_distance, m->valid, m->x, m->y, m->z, m->gray, m->codes, cnt);
@@ -1570,7 +1575,9 @@ static int enqueue_remove_outliers(wass_ctx* c, wass_mesh* m, double percentile,
                            (const DevState*)ds, hist);
         hipLaunchKernelGGL(k_radix_pick, dim3(1), dim3(256), 0, c->ts(), hist, pass, shift, nbits, percentile, ds);
     }
+    if (c->ev_tail[2]) (void)hipEventRecord(c->ev_tail[2], c->ts());
     if ((rc = enqueue_ccl(c, m, ds))) return rc;
+    if (c->ev_tail[3]) (void)hipEventRecord(c->ev_tail[3], c->ts());
     *dsp = ds;
     return WASS_OK;
 }
@@ -1849,6 +1856,7 @@ static int enqueue_fit_plane(wass_ctx* c, wass_mesh* m, const int32_t* uv, int r
     hipLaunchKernelGGL(k_ransac_score<PTS>, dim3((m->w + 255) / 256, (m->h + PTS - 1) / PTS), dim3(256), lds, s, m->valid, m->x,
                        m->y, m->z, m->w, m->h, (const PlaneCand*)cand, rounds, ransac_thr, counts);
     hipLaunchKernelGGL(k_ransac_pick, dim3(1), dim3(64), 0, s, (const PlaneCand*)cand, (const unsigned long long*)counts, rounds, n, ds);
+    if (c->ev_tail[4]) (void)hipEventRecord(c->ev_tail[4], s);
     RefineDev rd;
     rd.xmin = rp->xmin; rd.xmax = rp->xmax; rd.ymin = rp->ymin; rd.ymax = rp->ymax; rd.maxd = rp->max_distance;
     rd.weighted = rp->weight_by_distance;
@@ -1902,12 +1910,12 @@ int wass_mesh_fit_plane(wass_ctx* c, wass_mesh* m, const int32_t* uv, int rounds
 int wass_mesh_finish_frame_async(wass_ctx* c, wass_mesh* m, double percentile, const int32_t* uv, int rounds, double ransac_thr,
                                  const wass_refine_params* rp, double max_distance, void* dst, size_t capacity)
 {
-    return wass_mesh_finish_frame_async_ex(c, m, percentile, uv, rounds, ransac_thr, rp, max_distance, dst, capacity, nullptr, 0, 0);
+    return wass_mesh_finish_frame_async_ex(c, m, percentile, uv, rounds, ransac_thr, rp, max_distance, dst, capacity, nullptr, 0, 0, nullptr);
 }
 
 int wass_mesh_finish_frame_async_ex(wass_ctx* c, wass_mesh* m, double percentile, const int32_t* uv, int rounds, double ransac_thr,
                                     const wass_refine_params* rp, double max_distance, void* dst, size_t capacity,
-                                    double* inliers_dst, size_t inliers_capacity, int inliers_every)
+                                    double* inliers_dst, size_t inliers_capacity, int inliers_every, uint8_t* component_mask_dst)
 {
     if (!c || !m || !dst) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
     if (inliers_dst && (inliers_every <= 0 || inliers_capacity == 0)) return set_err(c, WASS_ERR_INVALID_ARG, "bad inlier selection");
@@ -1920,7 +1928,14 @@ int wass_mesh_finish_frame_async_ex(wass_ctx* c, wass_mesh* m, double percentile
     DevState* ds = nullptr;
     unsigned long long* kept1 = nullptr;
     int rc;
+    const bool timed = c->ev_tail[0] != nullptr;          // a wass_triangulate[_dev] call of this context has created (and recorded) them
+    if (timed) (void)hipEventRecord(c->ev_tail[1], c->ts());
     if ((rc = enqueue_remove_outliers(c, m, percentile, &ds))) return rc;
+    if (component_mask_dst) {                              // what cluster_biggest_connected_component left valid (graph_components.jpg)
+        if ((rc = ensure(c, c->ccmask, n))) return rc;
+        WASS_HIP(c, hipStreamWaitEvent(c->ts(), c->ev_copy, 0));
+        WASS_HIP(c, hipMemcpyAsync(c->ccmask.p, m->valid, n, hipMemcpyDeviceToDevice, c->ts()));
+    }
     if ((rc = enqueue_fit_plane(c, m, uv, rounds, ransac_thr, rp, max_distance, &ds, &kept1, false))) return rc;
     const unsigned nb = nblk(n);
     if ((rc = ensure(c, c->xyzc, 148 + n * 6 + 16))) return rc;
@@ -1971,11 +1986,13 @@ int wass_mesh_finish_frame_async_ex(wass_ctx* c, wass_mesh* m, double percentile
     hipLaunchKernelGGL(k_xyzc_pack_dev, dim3(nb), dim3(256), 0, s, m->valid, m->x, m->y, m->z, n, (const DevState*)ds,
                        (const unsigned int*)bcnt, (uint16_t*)(img + 148));
     WASS_HIP(c, hipGetLastError());
+    if (timed) { (void)hipEventRecord(c->ev_tail[5], s); c->tail_timed = true; }
     WASS_HIP(c, hipEventRecord(c->ev_pack, s));
     WASS_HIP(c, hipStreamWaitEvent(c->copy, c->ev_pack, 0));
     WASS_HIP(c, hipMemcpyAsync(c->h_frame, ds, sizeof(DevState), hipMemcpyDeviceToHost, c->copy));
     WASS_HIP(c, hipMemcpyAsync(dst, img, 148 + n * 6, hipMemcpyDeviceToHost, c->copy));
     if (inl_copy) WASS_HIP(c, hipMemcpyAsync(inliers_dst, (const char*)c->inl.p + 256, inl_copy, hipMemcpyDeviceToHost, c->copy));
+    if (component_mask_dst) WASS_HIP(c, hipMemcpyAsync(component_mask_dst, c->ccmask.p, n, hipMemcpyDeviceToHost, c->copy));
     WASS_HIP(c, hipEventRecord(c->ev_copy, c->copy));
     c->frame_inl_every = inliers_dst ? inliers_every : 0;
     c->frame_pending = true;
@@ -1998,6 +2015,10 @@ int wass_ctx_frame_result(wass_ctx* c, wass_frame_result* out)
     out->n_points = h.npts;
     out->xyzc_bytes = 148 + (uint64_t)h.npts * 6;
     out->n_triangulated = h.ntri;
+    if (c->tail_timed) {                                     // all six events lie before the download this function has waited for
+        for (int k = 0; k < 5; ++k)
+            if (hipEventElapsedTime(&out->stage_ms[k], c->ev_tail[k], c->ev_tail[k + 1]) != hipSuccess) out->stage_ms[k] = 0.0f;
+    }
     out->n_inliers_out = c->frame_inl_every > 0 ? ((uint64_t)h.ninl_sel + (uint64_t)c->frame_inl_every - 1) / (uint64_t)c->frame_inl_every : 0;
     if (c->frame_sgm_call > 0 && c->nsgm - c->frame_sgm_call < 2) {
         // status word of the frame's SGM call: copied to pinned memory in stream order long before the download this

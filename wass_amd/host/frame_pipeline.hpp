@@ -57,6 +57,11 @@ struct FrameJob {
     // mask_log: the lines triangulate() would have logged while loading them, replayed at their place
     std::vector<uint8_t> fmask[2];
     std::string mask_log;
+    // debug pictures: the mesh is kept until its rejection codes have been fetched; the maps the pictures are drawn from
+    wass_mesh* mesh = nullptr;
+    int disp_slot = 0;
+    DebugMaps dbg;
+    bool have_dbg = false;
     unsigned int ransac_seed = 0;
     int in_slot = -1, out_slot = -1;
     long long sgm_call = -1;         // which wass_sgm_disparity_dev call of the pipeline's context produced the frame's disparity
@@ -74,6 +79,8 @@ public:
         int out_slots = 4;           // pinned output sets (file image + inlier points) that writer threads may hold at once
         bool inliers_file = true;    // plane_refinement_inliers.xyz (a debug artefact of the reference; 14 MB of text per 5-megapixel frame)
         bool live = false;           // single-frame executable: echo log and progress markers to stdout as the phases end
+        bool debug_pictures = false; // the reference's debug pictures (stereo.jpg ... graph_components.jpg): every frame's intermediate
+                                     // maps come back to the host once it is complete, which takes the pipeline down to one frame
         const PrepareSetup* prep = nullptr;   // prepare-less mode: the calibration directory (jobs with raw = true need it)
         bool save_undistorted = false;        // ... and whether undistorted/0000000X.png are written all the same
     };
@@ -109,7 +116,7 @@ public:
         if (!ctx_) return;
         (void)wass_ctx_synchronize(ctx_);
         release_buffers();
-        for (auto& o : out_) { if (o.xyzc) wass_pinned_free(ctx_, o.xyzc); if (o.inl) wass_pinned_free(ctx_, o.inl); for (auto& u : o.und) if (u) wass_pinned_free(ctx_, u); }
+        for (auto& o : out_) { if (o.xyzc) wass_pinned_free(ctx_, o.xyzc); if (o.inl) wass_pinned_free(ctx_, o.inl); for (auto& u : o.und) if (u) wass_pinned_free(ctx_, u); if (o.ccmask) wass_pinned_free(ctx_, o.ccmask); }
         wass_ctx_destroy(ctx_);
     }
     // the pipeline's context, created if need be (owner thread); nullptr when there is no usable GPU
@@ -245,6 +252,8 @@ public:
         }
         stage(job);
         if (job.rc != 0) { if (FrameJob* p = collect()) done.push_back(p); done.push_back(&job); return; }
+        // debug pictures: the previous frame's maps are fetched from buffers this frame is about to overwrite
+        if (opt_.debug_pictures) if (FrameJob* p = collect()) done.push_back(p);
         LogSinkScope sink(&job.log);
         job.t_submit0 = Timer::now();
         Env& env = job.env;
@@ -253,7 +262,7 @@ public:
             const int k = job.in_slot;
             const int rl[4] = { env.roi_l.x, env.roi_l.y, env.roi_l.width, env.roi_l.height };
             const int rr[4] = { env.roi_r.x, env.roi_r.y, env.roi_r.width, env.roi_r.height };
-            job.out_slot = acquire_out((size_t)rr[2] * rr[3], job.raw ? (size_t)W_ * H_ : 0);
+            job.out_slot = acquire_out((size_t)rr[2] * rr[3], job.raw ? (size_t)W_ * H_ : 0, opt_.debug_pictures);
             if (job.raw) {
                 // ---- wass_prepare's process_image (wass_prepare.cpp:257-275) on the device: optional CLAHE, cv::undistort.  The
                 // camera a picture came from decides its parameters -- rectify_plan may have swapped left and right since.
@@ -298,7 +307,8 @@ public:
             env.disparity_compensation = sp_.disp_offset > 0 ? 0 : -sp_.disp_offset;
             WLOGI << "Dense-stereo input resize: [" << cw << " x " << ch << "] -> [" << cw << " x " << ch << "]";
             WLOGI << "computing dense disparity map... (may take a while)";
-            int16_t* d16 = d_disp16_[nsub_ & 1];
+            job.disp_slot = nsub_ & 1;
+            int16_t* d16 = d_disp16_[job.disp_slot];
             check(wass_sgm_disparity_dev(ctx_, in_[k].d_cr, in_[k].d_cl, cw, ch, (size_t)cw, &sp_, d16), "wass_sgm_disparity");
             job.sgm_call = ++sgm_calls_;
             const int dil = cfg_.get_int("DISP_DILATE_STEPS"), ero = cfg_.get_int("DISP_EROSION_STEPS"), med = cfg_.get_int("MEDIAN_FILTER_WSIZE");
@@ -349,9 +359,11 @@ public:
             const int slot = job.out_slot;
             check(wass_mesh_finish_frame_async_ex(ctx_, mesh, cfg_.get_double("ZGAP_PERCENTILE"), uv_.data(), rounds, cfg_.get_double("PLANE_RANSAC_THRESHOLD"),
                                                   &rp_, cfg_.get_double("PLANE_MAX_DISTANCE"), out_[slot].xyzc, out_[slot].xyzc_cap,
-                                                  opt_.inliers_file ? out_[slot].inl : nullptr, opt_.inliers_file ? out_[slot].inl_cap : 0, 10),
+                                                  opt_.inliers_file ? out_[slot].inl : nullptr, opt_.inliers_file ? out_[slot].inl_cap : 0, 10,
+                                                  opt_.debug_pictures ? out_[slot].ccmask : nullptr),
                   "wass_mesh_finish_frame_async");
-            wass_mesh_destroy(mesh);                        // back to the context's pool; the kernels enqueued on it run in stream order
+            if (opt_.debug_pictures) job.mesh = mesh;       // its rejection codes are fetched when the frame is collected
+            else wass_mesh_destroy(mesh);                   // back to the context's pool; the kernels enqueued on it run in stream order
             mesh = nullptr;
             pending_ = &job;
             ++nsub_;
@@ -390,6 +402,11 @@ public:
         if (job.rc == 0 && !job.skipped) {
             try {
                 const wass_frame_result& r = job.res;
+                if (job.have_dbg) {                          // :1910-1925, 833-1017, 1381-1382
+                    debug_stereo_picture(env);
+                    debug_dense_pictures(env, sp_, cfg_.get_int("DENSE_DISPARITY_BIGGEST_COMPONENT_THRESHOLD"), job.dbg);
+                    debug_triangulation_pictures(env, env.disparity_compensation, sp_.dense_scale, job.dbg);
+                }
                 WLOG_SCOPE("triangulate");
                 WLOGI << r.n_triangulated << " valid points found";
                 job.summary.n_points = r.n_triangulated;
@@ -397,6 +414,7 @@ public:
                 WLOG_SCOPE("wass_stereo");
                 if (r.sgm_cost_overflow == 1) WLOGE << "matching costs exceeded the int16 range; the disparity is outside the reference's defined behaviour";
                 if ((long long)r.n_triangulated < cfg_.get_int("MIN_TRIANGULATED_POINTS")) { WLOGE << "Too few points triangulated, aborting"; throw GpuError("too few points"); }
+                if (job.have_dbg) debug_components_picture(env, job.dbg);
                 WLOG_SCOPE("cluster");
                 WLOGI << "biggest component size: " << r.component_size << " (px)";
                 marker(job, 80);
@@ -468,19 +486,20 @@ public:
                     }
                 }
                 marker(job, 100);
-                // the time table (render.hpp:175-191).  A pipelined frame has no per-stage wall times: its GPU stages run
-                // underneath its neighbours'.  "Dense Stereo" is the GPU time of the SGM stage (hipEvents); "GPU pipeline" the
-                // wall time from submission to the arrival of the result record, queueing behind the previous frame included.
+                // the time table (render.hpp:175-191) with the reference's rows.  A pipelined frame has no per-stage WALL times (its
+                // GPU stages run underneath its neighbours'): the two host rows are wall times, the others GPU times from hipEvents
+                // (wass_sgm_timings.total_ms, wass_frame_result.stage_ms); the line after the table says what the frame took end to end.
                 Timer t;
-                t.events.emplace_back(job.t_loaded - job.t_prepare0, "Data load");
-                t.events.emplace_back(job.t_planned - job.t_prepare0, "Rectification");
-                double at = job.t_planned - job.t_prepare0;
-                t.events.emplace_back(at += job.t_submitted - job.t_submit0, "Submission");
-                if (job.have_sgm) t.events.emplace_back(at += job.sgm.total_ms / 1e3, "Dense Stereo (GPU)");
-                t.events.emplace_back(at += job.t_result - job.t_submitted, "GPU pipeline");
-                t.events.emplace_back(at += Timer::now() - t0, "Output");
+                double at = 0;
+                t.events.emplace_back(at += job.t_loaded - job.t_prepare0, "Data load");
+                t.events.emplace_back(at += (job.t_planned - job.t_loaded) + (job.t_submitted - job.t_submit0), "Rectification");
+                t.events.emplace_back(at += (job.have_sgm ? job.sgm.total_ms : 0.0f) / 1e3, "Dense Stereo");
+                static const char* rows[5] = { "Triangulation", "Z-gap stats", "Outlier removal", "Plane fitting", "Plane refinement" };
+                for (int k = 0; k < 5; ++k)
+                    if (k < 3 || r.found) t.events.emplace_back(at += r.stage_ms[k] / 1e3, rows[k]);
                 t.t0 = 0; t.tend = at;
                 show_time_stats(t);
+                WLOGI << "pipelined chain: GPU stage times above; submission to result " << (job.t_result - job.t_submit0) << " s, output " << (Timer::now() - t0) << " s";
                 WLOGI << "All done.";
             } catch (const GpuError& e) {
                 WLOG_SCOPE("wass_stereo");
@@ -533,7 +552,8 @@ public:
 private:
     struct InSet { uint8_t *h_l = nullptr, *h_r = nullptr, *d_l = nullptr, *d_r = nullptr, *d_cl = nullptr, *d_cr = nullptr, *d_ml = nullptr, *d_mr = nullptr,
                            *d_rawl = nullptr, *d_rawr = nullptr, *d_tmp = nullptr, *h_fl = nullptr, *h_fr = nullptr, *d_fl = nullptr, *d_fr = nullptr; };
-    struct OutSet { void* xyzc = nullptr; size_t xyzc_cap = 0; double* inl = nullptr; size_t inl_cap = 0; uint8_t* und[2] = { nullptr, nullptr }; size_t und_cap = 0; };
+    struct OutSet { void* xyzc = nullptr; size_t xyzc_cap = 0; double* inl = nullptr; size_t inl_cap = 0; uint8_t* und[2] = { nullptr, nullptr }; size_t und_cap = 0;
+                    uint8_t* ccmask = nullptr; size_t cc_cap = 0; };
 
     void check(int rc, const char* what) const { if (rc != WASS_OK) throw GpuError(std::string(what) + ": " + wass_last_error(ctx_)); }
     void marker(FrameJob& job, int pct) const
@@ -556,6 +576,32 @@ private:
         // stage times of the frame's SGM call: the last call, or the last but one if another frame has been enqueued since
         const long long behind = sgm_calls_ - j->sgm_call;
         j->have_sgm = behind == 0 ? wass_sgm_last_timings(ctx_, &j->sgm) == WASS_OK : (behind == 1 && wass_sgm_prev_timings(ctx_, &j->sgm) == WASS_OK);
+        if (opt_.debug_pictures && j->mesh) {
+            // the maps the debug pictures are drawn from (nothing else has been enqueued since this frame: see submit)
+            try {
+                Env& env = j->env;
+                const int k = j->in_slot, cw = env.roi_r.width, ch = env.roi_r.height;
+                DebugMaps& dm = j->dbg;
+                env.left_crop = Image(env.roi_l.width, env.roi_l.height); env.right_crop = Image(cw, ch);
+                check(wass_download(ctx_, env.left_crop.px.data(), in_[k].d_cl, env.left_crop.px.size()), "wass_download");
+                check(wass_download(ctx_, env.right_crop.px.data(), in_[k].d_cr, env.right_crop.px.size()), "wass_download");
+                dm.ws = cw; dm.hs = ch;
+                dm.disp16.resize((size_t)cw * ch); dm.dispf.resize((size_t)cw * ch); dm.codes.resize((size_t)cw * ch);
+                check(wass_download(ctx_, dm.disp16.data(), d_disp16_[j->disp_slot], dm.disp16.size() * 2), "wass_download");
+                check(wass_download(ctx_, dm.dispf.data(), d_dispf_, dm.dispf.size() * 4), "wass_download");
+                if (cfg_.get_int("DENSE_DISPARITY_BIGGEST_COMPONENT_THRESHOLD") > 0) {
+                    dm.large_gradient.resize((size_t)cw * ch);
+                    check(wass_large_gradient_mask(ctx_, cw, ch, dm.large_gradient.data()), "wass_large_gradient_mask");
+                }
+                check(wass_mesh_reject_codes(ctx_, j->mesh, dm.codes.data()), "wass_mesh_reject_codes");
+                dm.valid_before.resize(dm.codes.size());
+                for (size_t i = 0; i < dm.codes.size(); ++i) dm.valid_before[i] = dm.codes[i] == (WASS_CODE_GREY | (WASS_CODE_GREY << 4));   // triangulated
+                dm.valid_after.assign(out_[j->out_slot].ccmask, out_[j->out_slot].ccmask + dm.codes.size());
+                j->have_dbg = true;
+            } catch (const std::exception& e) { WLOGE << e.what(); }
+            wass_mesh_destroy(j->mesh);
+            j->mesh = nullptr;
+        }
         return j;
     }
 
@@ -619,7 +665,7 @@ private:
         map_valid_ = true;
     }
 
-    int acquire_out(size_t npts, size_t und_bytes)
+    int acquire_out(size_t npts, size_t und_bytes, bool ccmask)
     {
         std::unique_lock<std::mutex> lk(out_mu_);
         out_cv_.wait(lk, [&]() { for (bool f : out_free_) if (f) return true; return false; });
@@ -652,6 +698,13 @@ private:
                 u = (uint8_t*)p;
             }
             o.und_cap = und_bytes;
+        }
+        if (ccmask && o.cc_cap < npts) {
+            if (o.ccmask) wass_pinned_free(ctx_, o.ccmask);
+            o.ccmask = nullptr; o.cc_cap = 0;
+            void* p = nullptr;
+            check(wass_pinned_alloc(ctx_, npts, &p), "wass_pinned_alloc");
+            o.ccmask = (uint8_t*)p; o.cc_cap = npts;
         }
         guard.armed = false;
         return slot;

@@ -329,6 +329,110 @@ void gpu_check(wass_ctx* ctx, int rc, const char* what, bool allow_overflow = fa
 }
 
 
+
+// ---------------------------------------------------------------- the reference's debug pictures
+// Drawn from host copies of a frame's intermediate maps.  The stage-by-stage path has them anyway; the pipelined chain
+// downloads them once the frame is complete (frame_pipeline.hpp) -- same functions, same pictures.
+struct DebugMaps {
+    std::vector<int16_t> disp16;            // ws x hs: the SGBM map (:837-839)
+    int ws = 0, hs = 0;
+    std::vector<float> dispf;               // cw x ch: after clean_and_convert / dilate / erode / resize / mask / median / component (:853-986)
+    std::vector<uint8_t> large_gradient;    // cw x ch, non-zero where the squared Sobel magnitude exceeded the threshold (cc_threshold > 0 only)
+    std::vector<uint8_t> codes;             // roi_r: why triangulate kept or rejected each pixel (wass_mesh_reject_codes)
+    std::vector<uint8_t> valid_before, valid_after;   // roi_r: the mesh before / after cluster_biggest_connected_component
+};
+
+inline void debug_stereo_picture(const Env& env)                                          // stereo.jpg (:1910-1925)
+{
+    const int W0 = env.left.w, H0 = env.left.h;
+    ImageRGB l = gray_to_rgb(paste(env.left_crop, env.roi_l.x, env.roi_l.y, W0, H0)), r = gray_to_rgb(paste(env.right_crop, env.roi_r.x, env.roi_r.y, W0, H0));
+    rectangle_red(l, env.roi_l.x, env.roi_l.y, env.roi_l.width, env.roi_l.height);
+    rectangle_red(r, env.roi_r.x, env.roi_r.y, env.roi_r.width, env.roi_r.height);
+    ImageRGB st(2 * W0, H0);
+    for (int y = 0; y < H0; ++y) {
+        memcpy(&st.px[(size_t)y * st.w * 3], &l.px[(size_t)y * W0 * 3], (size_t)W0 * 3);
+        memcpy(&st.px[((size_t)y * st.w + W0) * 3], &r.px[(size_t)y * W0 * 3], (size_t)W0 * 3);
+        if (y % 20 == 0) for (int x = 0; x < st.w; ++x) st.set(y, x, 255, 0, 0);
+    }
+    write_debug_rgb(path_join(env.workdir, "stereo"), st);
+}
+
+inline void debug_dense_pictures(const Env& env, const wass_sgm_params& sp, int cc_threshold, const DebugMaps& dm)
+{
+    const int cw = env.right_crop.w, ch = env.right_crop.h;
+    if (cc_threshold > 0 && !dm.large_gradient.empty()) {        // :958-960, 981-983
+        Image lg(cw, ch), nb(cw, ch);
+        for (size_t i = 0; i < lg.px.size(); ++i) {
+            lg.px[i] = dm.large_gradient[i] ? 255 : 0;
+            nb.px[i] = dm.dispf[i] == 0.0f ? 255 : 0;               // 255 outside the biggest component: the map is non-zero exactly on it
+        }
+        write_debug_gray(path_join(env.workdir, "disparity_large_gradient"), lg);
+        write_debug_gray(path_join(env.workdir, "disparity_biggest_component"), nb);
+    }
+    const int D = sp.num_disp, offp = sp.disp_offset > 0 ? sp.disp_offset : 0, comp = sp.disp_offset > 0 ? 0 : -sp.disp_offset;
+    const int Wp = cw + D + offp;
+    Image in2(Wp, 2 * ch);                                       // stereo_input.jpg (:820-833): padded left above padded right
+    for (int y = 0; y < ch; ++y) {
+        memcpy(&in2.px[(size_t)y * Wp + (D + offp - comp)], &env.left_crop.px[(size_t)y * cw], cw);
+        memcpy(&in2.px[(size_t)(ch + y) * Wp + D], &env.right_crop.px[(size_t)y * cw], cw);
+    }
+    if (sp.dense_scale == 1.0) write_debug_gray(path_join(env.workdir, "stereo_input"), in2);   // (the resized inputs stay on the GPU)
+    std::vector<float> conv((size_t)dm.ws * dm.hs);              // clean_and_convert_disparity (:714-733) of the raw map
+    const double scl = 1.0 / sp.dense_scale;
+    for (size_t i = 0; i < conv.size(); ++i) {
+        float dval = ((float)dm.disp16[i]) / 16.0f;
+        conv[i] = (dval <= (float)sp.min_disp || dval > (float)sp.num_disp) ? 0.0f : (float)((double)(dval + (float)sp.disp_offset) * scl);
+    }
+    write_debug_gray(path_join(env.workdir, "disparity_stereo_ouput"), render_disparity_float(conv.data(), dm.ws, dm.hs));
+    write_debug_gray(path_join(env.workdir, "disparity_final_scaled"), render_disparity_float(dm.dispf.data(), cw, ch));
+    const int W0 = env.right.w, H0 = env.right.h;               // disparity_coverage.jpg (:1002-1017)
+    ImageRGB cov = gray_to_rgb(paste(env.right_crop, env.roi_r.x, env.roi_r.y, W0, H0));
+    for (int y = 0; y < ch; ++y)
+        for (int x = 0; x < cw; ++x)
+            if (dm.dispf[(size_t)y * cw + x] > 1.0f && env.roi_r.y + y < H0 && env.roi_r.x + x < W0)
+                cov.px[((size_t)(env.roi_r.y + y) * W0 + env.roi_r.x + x) * 3 + 1] = 100;
+    rectangle_red(cov, env.roi_r.x, env.roi_r.y, env.roi_r.width, env.roi_r.height);
+    write_debug_rgb(path_join(env.workdir, "disparity_coverage"), half_size(cov));
+}
+
+// undistorted/R0.jpg, R1.jpg (:1111-1119, 1216-1338, 1381-1382): per processed pixel of the right ROI the rectified grey value,
+// overpainted with the colour of the test that rejected it (the codes come from the triangulation kernel); R1's grey is the
+// LEFT rectified image at the match
+inline void debug_triangulation_pictures(const Env& env, double disparity_compensation, double dense_scale, const DebugMaps& dm)
+{
+    const int roi_l[4] = { env.roi_l.x, env.roi_l.y, env.roi_l.width, env.roi_l.height };
+    const int roi_r[4] = { env.roi_r.x, env.roi_r.y, env.roi_r.width, env.roi_r.height };
+    const int gw = roi_r[2], gh = roi_r[3], W0 = env.left.w, H0 = env.left.h;
+    ImageRGB R0(W0, H0), R1(W0, H0);
+    static const uint8_t rgb[7][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 255, 255 }, { 255, 255, 0 }, { 0, 255, 0 }, { 0, 0, 255 }, { 255, 0, 0 } };
+    const float comp = (float)(disparity_compensation / dense_scale);
+    for (int v = 0; v < gh; ++v)
+        for (int u = 0; u < gw; ++u) {
+            const uint8_t cd = dm.codes[(size_t)v * gw + u];
+            const int c0 = cd & 15, c1 = cd >> 4, xr = roi_r[0] + u, yr = roi_r[1] + v;
+            if (xr < 0 || xr >= W0 || yr < 0 || yr >= H0) continue;
+            if (c0 == WASS_CODE_GREY) { const uint8_t gv = env.right_crop.at(v, u); R0.set(yr, xr, gv, gv, gv); }
+            else if (c0 != WASS_CODE_NONE) R0.set(yr, xr, rgb[c0][0], rgb[c0][1], rgb[c0][2]);
+            if (c1 == WASS_CODE_GREY) {
+                const float xl = (float)((float)(u + roi_l[0]) - dm.dispf[(size_t)v * gw + u] + comp);
+                const int lx = (int)std::floor(xl + 0.5f) - roi_l[0], ly = yr - roi_l[1];
+                const uint8_t gv = (lx >= 0 && lx < env.left_crop.w && ly >= 0 && ly < env.left_crop.h) ? env.left_crop.at(ly, lx) : 0;
+                R1.set(yr, xr, gv, gv, gv);
+            } else if (c1 != WASS_CODE_NONE) R1.set(yr, xr, rgb[c1][0], rgb[c1][1], rgb[c1][2]);
+        }
+    write_debug_rgb(path_join(path_join(env.workdir, "undistorted"), "R0"), R0);
+    write_debug_rgb(path_join(path_join(env.workdir, "undistorted"), "R1"), R1);
+}
+
+inline void debug_components_picture(const Env& env, const DebugMaps& dm)                  // graph_components.jpg (PovMesh.cpp:222-250, 982-984)
+{
+    ImageRGB gc(env.roi_r.width, env.roi_r.height);
+    for (size_t i = 0; i < dm.valid_after.size(); ++i)
+        if (dm.valid_after[i]) { gc.px[3 * i + 1] = 255; }                  // biggest component: palette.back() = (0,255,0)
+        else if (dm.valid_before[i]) { gc.px[3 * i + 2] = 255; }           // every other component: palette[0] = BGR (255,0,0)
+    write_debug_rgb(path_join(env.workdir, "graph_components"), half_size(gc));
+}
+
 // plane_refinement_inliers.xyz (:2077-2085): "x y z" per line in the stream's default format
 inline void write_inliers_xyz(const std::string& path, const double* xyz, size_t n)
 {
@@ -414,19 +518,7 @@ inline int wass_run_frame(const char* config_path, const std::string& workdir, c
         env.timer << "Rectification";
         std::cout << "[P|20|100]" << std::endl;
         save_cams();
-        if (debug_images) {                                          // stereo.jpg (:1910-1925)
-            const int W0 = env.left.w, H0 = env.left.h;
-            ImageRGB l = gray_to_rgb(paste(env.left_crop, env.roi_l.x, env.roi_l.y, W0, H0)), r = gray_to_rgb(paste(env.right_crop, env.roi_r.x, env.roi_r.y, W0, H0));
-            rectangle_red(l, env.roi_l.x, env.roi_l.y, env.roi_l.width, env.roi_l.height);
-            rectangle_red(r, env.roi_r.x, env.roi_r.y, env.roi_r.width, env.roi_r.height);
-            ImageRGB st(2 * W0, H0);
-            for (int y = 0; y < H0; ++y) {
-                memcpy(&st.px[(size_t)y * st.w * 3], &l.px[(size_t)y * W0 * 3], (size_t)W0 * 3);
-                memcpy(&st.px[((size_t)y * st.w + W0) * 3], &r.px[(size_t)y * W0 * 3], (size_t)W0 * 3);
-                if (y % 20 == 0) for (int x = 0; x < st.w; ++x) st.set(y, x, 255, 0, 0);
-            }
-            write_debug_rgb(path_join(env.workdir, "stereo"), st);
-        }
+        if (debug_images) debug_stereo_picture(env);                 // stereo.jpg (:1910-1925)
         WLOG_SCOPE("wass_stereo");
         if (mode && std::string("--rectify-only") == mode) { WLOGI << "All done."; return 0; }
         if (mode && std::string("--measure") == mode) { WLOGE << "--measure needs the interactive GUI, which this build does not have"; return -1; }
@@ -477,41 +569,14 @@ inline int wass_run_frame(const char* config_path, const std::string& workdir, c
             dump("disp16.bin", disp16.data(), disp16.size() * 2);
             dump("dispf.bin", dispf.data(), dispf.size() * 4);
         }
-        if (debug_images && cc_threshold > 0) {                      // :958-960, 981-983
-            Image lg(cw, ch), nb(cw, ch);
-            gpu_check(ctx, wass_large_gradient_mask(ctx, cw, ch, lg.px.data()), "wass_large_gradient_mask");
-            for (size_t i = 0; i < lg.px.size(); ++i) {
-                lg.px[i] = lg.px[i] ? 255 : 0;
-                nb.px[i] = dispf[i] == 0.0f ? 255 : 0;               // 255 outside the biggest component: the map is non-zero exactly on it
-            }
-            write_debug_gray(path_join(env.workdir, "disparity_large_gradient"), lg);
-            write_debug_gray(path_join(env.workdir, "disparity_biggest_component"), nb);
-        }
+        DebugMaps dm;
         if (debug_images) {
-            const int D = sp.num_disp, offp = sp.disp_offset > 0 ? sp.disp_offset : 0, comp = sp.disp_offset > 0 ? 0 : -sp.disp_offset;
-            const int Wp = cw + D + offp;
-            Image in2(Wp, 2 * ch);                                   // stereo_input.jpg (:820-833): padded left above padded right
-            for (int y = 0; y < ch; ++y) {
-                memcpy(&in2.px[(size_t)y * Wp + (D + offp - comp)], &env.left_crop.px[(size_t)y * cw], cw);
-                memcpy(&in2.px[(size_t)(ch + y) * Wp + D], &env.right_crop.px[(size_t)y * cw], cw);
+            if (cc_threshold > 0) {                                  // :958-960, 981-983
+                dm.large_gradient.resize((size_t)cw * ch);
+                gpu_check(ctx, wass_large_gradient_mask(ctx, cw, ch, dm.large_gradient.data()), "wass_large_gradient_mask");
             }
-            if (sp.dense_scale == 1.0) write_debug_gray(path_join(env.workdir, "stereo_input"), in2);   // (the resized inputs stay on the GPU)
-            std::vector<float> conv((size_t)ws * hs);                // clean_and_convert_disparity (:714-733) of the raw map
-            const double scl = 1.0 / sp.dense_scale;
-            for (size_t i = 0; i < conv.size(); ++i) {
-                float dval = ((float)disp16[i]) / 16.0f;
-                conv[i] = (dval <= (float)sp.min_disp || dval > (float)sp.num_disp) ? 0.0f : (float)((double)(dval + (float)sp.disp_offset) * scl);
-            }
-            write_debug_gray(path_join(env.workdir, "disparity_stereo_ouput"), render_disparity_float(conv.data(), ws, hs));
-            write_debug_gray(path_join(env.workdir, "disparity_final_scaled"), render_disparity_float(dispf.data(), cw, ch));
-            const int W0 = env.right.w, H0 = env.right.h;           // disparity_coverage.jpg (:1002-1017)
-            ImageRGB cov = gray_to_rgb(paste(env.right_crop, env.roi_r.x, env.roi_r.y, W0, H0));
-            for (int y = 0; y < ch; ++y)
-                for (int x = 0; x < cw; ++x)
-                    if (dispf[(size_t)y * cw + x] > 1.0f && env.roi_r.y + y < H0 && env.roi_r.x + x < W0)
-                        cov.px[((size_t)(env.roi_r.y + y) * W0 + env.roi_r.x + x) * 3 + 1] = 100;
-            rectangle_red(cov, env.roi_r.x, env.roi_r.y, env.roi_r.width, env.roi_r.height);
-            write_debug_rgb(path_join(env.workdir, "disparity_coverage"), half_size(cov));
+            dm.disp16 = disp16; dm.ws = ws; dm.hs = hs; dm.dispf = dispf;
+            debug_dense_pictures(env, sp, cc_threshold, dm);
         }
         WLOGI << "dense stereo completed successfully";
         env.timer << "Dense Stereo";
@@ -563,30 +628,9 @@ inline int wass_run_frame(const char* config_path, const std::string& workdir, c
         WLOGI << "... 100%";
         WLOGI << n_pts << " valid points found";
         if (debug_images) {                                          // undistorted/R0.jpg, R1.jpg (:1111-1119, 1216-1338, 1381-1382)
-            // per processed pixel of the right ROI: the rectified grey value, overpainted with the colour of the test that
-            // rejected it (the codes come from the triangulation kernel); R1's grey is the LEFT rectified image at the match
-            const int gw = roi_r[2], gh = roi_r[3], W0 = env.left.w, H0 = env.left.h;
-            std::vector<uint8_t> codes((size_t)gw * gh);
-            gpu_check(ctx, wass_mesh_reject_codes(ctx, mesh, codes.data()), "wass_mesh_reject_codes");
-            ImageRGB R0(W0, H0), R1(W0, H0);
-            static const uint8_t rgb[7][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 255, 255 }, { 255, 255, 0 }, { 0, 255, 0 }, { 0, 0, 255 }, { 255, 0, 0 } };
-            const float comp = (float)(g.disparity_compensation / g.dense_scale);
-            for (int v = 0; v < gh; ++v)
-                for (int u = 0; u < gw; ++u) {
-                    const uint8_t cd = codes[(size_t)v * gw + u];
-                    const int c0 = cd & 15, c1 = cd >> 4, xr = roi_r[0] + u, yr = roi_r[1] + v;
-                    if (xr < 0 || xr >= W0 || yr < 0 || yr >= H0) continue;
-                    if (c0 == WASS_CODE_GREY) { const uint8_t gv = env.right_crop.at(v, u); R0.set(yr, xr, gv, gv, gv); }
-                    else if (c0 != WASS_CODE_NONE) R0.set(yr, xr, rgb[c0][0], rgb[c0][1], rgb[c0][2]);
-                    if (c1 == WASS_CODE_GREY) {
-                        const float xl = (float)((float)(u + roi_l[0]) - dispf[(size_t)v * gw + u] + comp);
-                        const int lx = (int)std::floor(xl + 0.5f) - roi_l[0], ly = yr - roi_l[1];
-                        const uint8_t gv = (lx >= 0 && lx < env.left_crop.w && ly >= 0 && ly < env.left_crop.h) ? env.left_crop.at(ly, lx) : 0;
-                        R1.set(yr, xr, gv, gv, gv);
-                    } else if (c1 != WASS_CODE_NONE) R1.set(yr, xr, rgb[c1][0], rgb[c1][1], rgb[c1][2]);
-                }
-            write_debug_rgb(path_join(path_join(env.workdir, "undistorted"), "R0"), R0);
-            write_debug_rgb(path_join(path_join(env.workdir, "undistorted"), "R1"), R1);
+            dm.codes.resize((size_t)roi_r[2] * roi_r[3]);
+            gpu_check(ctx, wass_mesh_reject_codes(ctx, mesh, dm.codes.data()), "wass_mesh_reject_codes");
+            debug_triangulation_pictures(env, g.disparity_compensation, g.dense_scale, dm);
         }
         if (summary) summary->n_points = n_pts;
         env.timer << "Triangulation";
@@ -598,17 +642,12 @@ inline int wass_run_frame(const char* config_path, const std::string& workdir, c
         double pct = 0; uint64_t ngaps = 0, csize = 0;
         gpu_check(ctx, wass_mesh_zgap_percentile(ctx, mesh, cfg.get_double("ZGAP_PERCENTILE"), &pct, &ngaps), "wass_mesh_zgap_percentile");
         env.timer << "Z-gap stats";
-        std::vector<uint8_t> valid_before;
-        if (debug_images) { valid_before.resize((size_t)roi_r[2] * roi_r[3]); gpu_check(ctx, wass_mesh_download(ctx, mesh, valid_before.data(), nullptr, nullptr), "wass_mesh_download"); }
+        if (debug_images) { dm.valid_before.resize((size_t)roi_r[2] * roi_r[3]); gpu_check(ctx, wass_mesh_download(ctx, mesh, dm.valid_before.data(), nullptr, nullptr), "wass_mesh_download"); }
         gpu_check(ctx, wass_mesh_keep_biggest_component(ctx, mesh, pct, &csize), "wass_mesh_keep_biggest_component");
         if (debug_images) {                                          // graph_components.jpg (PovMesh.cpp:222-250, 982-984)
-            std::vector<uint8_t> valid_after(valid_before.size());
-            gpu_check(ctx, wass_mesh_download(ctx, mesh, valid_after.data(), nullptr, nullptr), "wass_mesh_download");
-            ImageRGB gc(roi_r[2], roi_r[3]);
-            for (size_t i = 0; i < valid_after.size(); ++i)
-                if (valid_after[i]) { gc.px[3 * i + 1] = 255; }                     // biggest component: palette.back() = (0,255,0)
-                else if (valid_before[i]) { gc.px[3 * i + 2] = 255; }              // every other component: palette[0] = BGR (255,0,0)
-            write_debug_rgb(path_join(env.workdir, "graph_components"), half_size(gc));
+            dm.valid_after.resize(dm.valid_before.size());
+            gpu_check(ctx, wass_mesh_download(ctx, mesh, dm.valid_after.data(), nullptr, nullptr), "wass_mesh_download");
+            debug_components_picture(env, dm);
         }
         WLOG_SCOPE("cluster");
         WLOGI << "biggest component size: " << csize << " (px)";

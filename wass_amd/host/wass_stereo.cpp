@@ -30,13 +30,15 @@ int main(int argc, char* argv[])
     if (argc != 3 && argc != 4) { std::cerr << "Invalid arguments" << std::endl; return -1; }
     if (!exists(argv[2])) { std::cerr << argv[2] << " does not exists, aborting." << std::endl; return -1; }
     wass_ctx* ctx = nullptr;
-    // Without the debug pictures (WASS_DEBUG_IMAGES=0) nothing of a frame has to come back to the host between the stages:
-    // the frame goes through the device-resident chain the sequence driver uses (frame_pipeline.hpp), one frame deep.  With
-    // them (the reference's default: it always writes them) the stage-by-stage calls run, because the pictures are made
-    // from every stage's intermediate map.  The files both ways are the same (tests/test_cli.py).
-    bool debug_images = true;
+    // A whole frame goes through the device-resident chain the sequence driver uses (frame_pipeline.hpp), one frame deep: nothing
+    // comes back to the host between the stages; the debug pictures (on by default, like the reference: WASS_DEBUG_IMAGES=0
+    // switches them off) are drawn from maps fetched after the frame is complete.  The synchronous stage-by-stage calls of
+    // wass_frame.hpp remain for --rectify-only, for the options that need an intermediate mesh on the host
+    // (pipeline_eligible) and on request (WASS_STAGE_BY_STAGE=1); the files both ways are the same (tests/test_cli.py).
+    bool debug_images = true, stage_by_stage = false;
     if (const char* e = getenv("WASS_DEBUG_IMAGES")) debug_images = atoi(e) != 0;
-    if (!debug_images && argc == 3) {
+    if (const char* e = getenv("WASS_STAGE_BY_STAGE")) stage_by_stage = atoi(e) != 0;
+    if (!stage_by_stage && argc == 3) {
         Config cfg;
         register_wass_stereo_options(cfg);
         bool ok = false;
@@ -46,6 +48,7 @@ int main(int argc, char* argv[])
             FramePipeline::Options fo;
             fo.out_slots = 1;
             fo.live = true;
+            fo.debug_pictures = debug_images;
             FramePipeline pl(dev_env ? atoi(dev_env) : 0, cfg, argv[1], fo);
             FrameJob job;
             job.workdir = argv[2];

@@ -184,6 +184,7 @@ bool frame_done(const std::string& wd)
 struct PipeOptions {
     int decode_threads = 8, writer_threads = 4;
     bool inliers_file = true;
+    bool debug_pictures = false;
     // prepare-less mode (--raw): frame i starts from cam0[i] / cam1[i] and the calibration directory
     const PrepareSetup* prep = nullptr;
     const std::vector<std::string>* cam0 = nullptr;
@@ -212,6 +213,7 @@ int worker_pipelined(int rank, int world, int device, bool distinct_gpus, const 
     fo.inliers_file = po.inliers_file;
     fo.prep = po.prep;
     fo.save_undistorted = po.save_undistorted;
+    fo.debug_pictures = po.debug_pictures;
     FramePipeline pl(dev_env ? atoi(dev_env) : device, cfg, cfgpath, fo);
     {
         std::vector<std::unique_ptr<FrameJob>> jobs(n);
@@ -301,8 +303,8 @@ int worker_pipelined(int rank, int world, int device, bool distinct_gpus, const 
             pl.stage(*cur);
             if (nxt && nxt->rc == 0 && !nxt->skipped && pl.same_geometry(*nxt)) pl.stage(*nxt);   // its upload runs underneath this frame
             pl.submit(*cur, done);
-            // the decoded pictures have gone to the pinned ring
-            cur->env.left = Image(); cur->env.right = Image();
+            // the decoded pictures have gone to the pinned ring (the debug pictures still want their size)
+            if (!po.debug_pictures) { cur->env.left = Image(); cur->env.right = Image(); }
             hand_over(done);
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -431,7 +433,9 @@ int main(int argc, char* argv[])
     // path, which reports it in every frame's log exactly as wass_stereo does.
     Config config;
     register_wass_stereo_options(config);
-    bool pipelined = !stage_by_stage && !debug_images && tpp == 1;
+    if (const char* e = getenv("WASS_DEBUG_IMAGES")) debug_images = atoi(e) != 0;
+    bool pipelined = !stage_by_stage && tpp == 1;
+    po.debug_pictures = debug_images;
     {
         std::ifstream ifs(cfg);
         if (!ifs.is_open()) { std::cerr << "Unable to load " << cfg << std::endl; return -1; }
@@ -439,8 +443,7 @@ int main(int argc, char* argv[])
         try { config.load(ifs); if (pipelined && !pipeline_eligible(config, &why)) { pipelined = false; std::cout << "stage-by-stage calls: " << why << std::endl; } }
         catch (const std::runtime_error&) { pipelined = false; }
     }
-    if (const char* e = getenv("WASS_DEBUG_IMAGES")) if (atoi(e) != 0) pipelined = false;
-    if (po.prep && !pipelined) { std::cerr << "--raw needs the pipelined chain (no --stage-by-stage / --debug-images / --threads-per-proc, an eligible configuration)" << std::endl; return -1; }
+    if (po.prep && !pipelined) { std::cerr << "--raw needs the pipelined chain (no --stage-by-stage / --threads-per-proc, an eligible configuration)" << std::endl; return -1; }
     if (outdir.empty()) outdir = ".";
     const int world = gpus * ppg;
     const bool distinct = ppg == 1;
