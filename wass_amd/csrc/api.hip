@@ -101,7 +101,7 @@ int wass_ctx_create(int device_id, wass_ctx** out)
     if (hipStreamCreateWithFlags(&c->tail, hipStreamNonBlocking) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
     if (hipEventCreateWithFlags(&c->ev_post, hipEventDisableTiming) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
     if (hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
-    if (hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
+    if (hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming | (getenv("WASS_SPIN_WAIT") ? 0 : hipEventBlockingSync)) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
     for (auto& set : c->evs)
         for (auto& e : set)
             if (hipEventCreate(&e) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
