@@ -163,3 +163,43 @@ def test_bench_runs_two_ranks_or_fails_loudly():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["ranks"]["world_size_from_process_group"] == 2
     assert len(line["ranks"]["pairs_per_sec_per_rank"]) == 2 and line["planes_averaged"] == 4
+
+
+def test_raw_mode_prepares_workdirs_and_fails_loudly_without_a_gpu(exes, tmp_path):
+    """--raw (prepare-less mode) on a machine without a GPU: the host side still does wass_prepare's part of every workdir
+    (calibration copies, wasscli's numbering of the pairs), every frame fails loudly in its own log, and nothing pretends to
+    have been computed."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from test_cli import _write_png, _write_xml
+    from wass_amd import synth
+    w, h = 96, 64
+    rig = synth.rig_geometry(w, h)
+    calib = tmp_path / "config"; calib.mkdir()
+    _write_xml(calib / "intrinsics_00.xml", "intr", rig["K_left"]); _write_xml(calib / "intrinsics_01.xml", "intr", rig["K_right"])
+    _write_xml(calib / "ext_R.xml", "R", rig["R"]); _write_xml(calib / "ext_T.xml", "T", np.array(rig["T"]).reshape(3, 1))
+    cam0 = tmp_path / "cam0"; cam1 = tmp_path / "cam1"; cam0.mkdir(); cam1.mkdir()
+    rng = np.random.default_rng(3)
+    for t in range(3):
+        _write_png(cam0 / ("b_%03d.png" % t), rng.integers(0, 255, (h, w), dtype=np.uint8))
+        _write_png(cam1 / ("a_%03d.png" % t), rng.integers(0, 255, (h, w), dtype=np.uint8))
+    (cam0 / "notes.txt").write_text("not a picture")
+    cfg = tmp_path / "cfg.txt"; cfg.write_text("MAX_DISPARITY=16\n")
+    out = tmp_path / "output"
+    r = subprocess.run([exes[1], str(cfg), "--raw", str(calib), "--cam0", str(cam0), "--cam1", str(cam1), "--sequence", str(out), "--frames", "2"],
+                       capture_output=True, text=True)
+    assert r.returncode == 255 and "2 frame(s)" in r.stdout and "pipelined" in r.stdout, r.stdout + r.stderr
+    for t in range(2):
+        wd = out / ("%06d_wd" % t)
+        assert "rc=-1" in r.stdout and (wd / "intrinsics_00000000.xml").exists() and (wd / "ext_T.xml").exists() and (wd / "stereo_config.txt").exists()
+        log = (wd / "wass_stereo_log.txt").read_text()
+        assert "no usable MI355X GPU" in log and f"image 0 loaded, Size: {w}x{h}" in log
+        assert not (wd / "mesh_cam.xyzC").exists() and not (wd / "undistorted").exists()
+    assert not (out / "000002_wd").exists()
+    # argument checking: --raw needs both camera directories and extrinsics in the calibration directory
+    r = subprocess.run([exes[1], str(cfg), "--raw", str(calib), "--cam0", str(cam0), "--sequence", str(out)], capture_output=True, text=True)
+    assert r.returncode == 255 and "--cam0 <dir> --cam1 <dir>" in r.stderr
+    (calib / "ext_R.xml").unlink()
+    r = subprocess.run([exes[1], str(cfg), "--raw", str(calib), "--cam0", str(cam0), "--cam1", str(cam1), "--sequence", str(out)], capture_output=True, text=True)
+    assert r.returncode == 255 and "Extrinsic calibration not found" in r.stderr
