@@ -20,6 +20,12 @@ pictures are 8-bit renderings at a third of the resolution (one grey level = 2.5
 padding, crop, sign, scale, the clean-up and the SHAPE of the rejected regions on the real program's output; it cannot show
 bit-exactness.
 
+  stereo_input100.jpg, stereo_input-100.jpg (documentation/stereo.html.md:67-68) -- the same frame's `stereo_input.jpg` with
+                                                       DISPARITY_OFFSET = 100 / -100: what row a1's padding rule
+                                                       (wass_stereo.cpp:801-831) does to the two pictures.  Only a band of
+                                                       32 rows of each half is kept (rows 800..831, stored losslessly as
+                                                       stereo_input{+100,-100}_band.png: the left band on top of the right).
+
 Run in the build container only:  python tests/golden/refdoc/make_refdoc.py
 """
 import hashlib
@@ -32,3 +38,13 @@ for name in ("stereo_input0.jpg", "disparity_stereo_output.png", "disparity_fina
     shutil.copyfile(os.path.join(SRC, name), os.path.join(HERE, name))
     os.chmod(os.path.join(HERE, name), 0o644)
     print(name, hashlib.sha256(open(os.path.join(HERE, name), "rb").read()).hexdigest())
+
+import numpy as np  # noqa: E402
+from PIL import Image  # noqa: E402
+
+for src, dst in (("stereo_input100.jpg", "stereo_input+100_band.png"), ("stereo_input-100.jpg", "stereo_input-100_band.png")):
+    im = np.array(Image.open(os.path.join(SRC, src)))
+    h = im.shape[0] // 2
+    band = np.concatenate([im[800:832], im[h + 800:h + 832]], 0)
+    Image.fromarray(band).save(os.path.join(HERE, dst), optimize=True)
+    print(dst, band.shape, os.path.getsize(os.path.join(HERE, dst)))

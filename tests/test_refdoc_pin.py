@@ -142,6 +142,46 @@ def test_wrong_readings_fit_worse(oracle, doc_pair, oracle_d16):
     assert hh["valid_agree"] < same["valid_agree"] - 0.005
 
 
+def measured_layout(name, L0, R0):
+    """Where the reference put the two pictures in `stereo_input.jpg` for a DISPARITY_OFFSET (a band of 32 rows of the
+    published picture): column of the left picture, column of the right picture, total width."""
+    from PIL import Image
+    band = np.array(Image.open(os.path.join(DOC, name))).astype(np.float64)
+    top, bot = band[:32], band[32:]
+    w = L0.shape[1]
+
+    def best(img, pic):
+        errs = {c: np.abs(img[:, c:c + w] - pic).mean() for c in range(D - 160, D + 161, 4) if c + w <= img.shape[1]}
+        c0 = min(errs, key=errs.get)
+        errs = {c: np.abs(img[:, c:c + w] - pic).mean() for c in range(c0 - 4, c0 + 5) if c >= 0 and c + w <= img.shape[1]}
+        c1 = min(errs, key=errs.get)
+        assert errs[c1] < 2.0, (name, errs[c1])               # two JPEG copies of the same pixels
+        return c1
+    return best(top, L0), best(bot, R0), band.shape[1]
+
+
+@pytest.mark.parametrize("offset,name", [(100, "stereo_input+100_band.png"), (-100, "stereo_input-100_band.png")])
+def test_padding_rule_of_disparity_offset_matches_the_published_inputs(oracle, doc_pair, offset, name):
+    """Row a1 (wass_stereo.cpp:801-831) against the reference's own pictures of its padded inputs for DISPARITY_OFFSET =
+    +100 / -100 (documentation/stereo.html.md:67-68): which picture moves, which way, and how wide the result is.  The
+    oracle called with that offset must equal SGBM on pictures laid out as the reference's were."""
+    right, left = doc_pair
+    rows = slice(800, 832)
+    L0, R0 = left[rows].astype(np.float64), right[rows].astype(np.float64)
+    cl, cr, width = measured_layout(name, L0, R0)
+    w = L0.shape[1]
+    assert cr == D                                                          # the right picture never moves
+    assert cl == D + offset                                                 # the left one moves by the offset, either way
+    assert width == w + D + max(offset, 0)                                  # only a positive offset widens the pictures
+    Lp = np.zeros((32, width), np.uint8); Rp = np.zeros((32, width), np.uint8)
+    Lp[:, cl:cl + w] = left[rows]; Rp[:, cr:cr + w] = right[rows]
+    p = oracle.wass_params(D, mode=5)
+    want = oracle.sgbm_compute(Rp, Lp, p)
+    want = want[0] if isinstance(want, tuple) else want
+    got, _ = oracle.dense_disparity16(right[rows], left[rows], p, disparity_offset=offset)
+    assert np.array_equal(got, np.asarray(want)[:, D:D + w])                # the crop of :839 as well
+
+
 @pytest.mark.gpu
 def test_gpu_equals_oracle_on_the_reference_frame_and_fits_the_published_maps(gpu_ctx, oracle, doc_pair, oracle_d16):
     """The HIP path on the real frame (2197 x 1753, D = 640: the NP = 5 instances, real sea texture with its ties and
