@@ -510,11 +510,11 @@ def main():
             step(i)
         barrier()
         planes.clear(); npts_hist.clear(); nbytes_hist.clear(); overflows.clear()
-        tm = {"agg": [], "cost": [], "sel": [], "sgm": [], "vsum": []}
+        tm = {"agg": [], "cost": [], "sel": [], "sgm": [], "vsum": [], "pre": [], "med": []}
 
         def take(t):
             tm["agg"].append(t.aggregate_ms); tm["cost"].append(t.cost_ms); tm["sel"].append(t.select_ms); tm["sgm"].append(t.total_ms)
-            tm["vsum"].append(t.vsum_ms)
+            tm["vsum"].append(t.vsum_ms); tm["pre"].append(t.prefilter_ms); tm["med"].append(t.median_ms)
 
         # Stage timings come from hipEvents recorded on the context's own stream; frame n's are read after frame n+1 has been
         # enqueued (two event sets), so the reader never drains the pipeline
@@ -639,9 +639,13 @@ def main():
             "roofline_cost_volume": {"bound": "valu", "kernel": "k_prefilter + k_hsum_q + k_vsum_col", "achieved": round(cost_tops, 2),
                                      "peak": round(VALU_PK16_PEAK_TOPS, 1), "unit": "Tops/s (u16)", "frac": round(cost_tops / VALU_PK16_PEAK_TOPS, 4),
                                      "ops_per_cell": COST_OPS_PER_CELL, "ms": round(t_cost * 1e3, 3),
-                                     "peak_source": "measured issue rate, scripts/micro/valu2.hip: 4.5 cycles per wave instruction per SIMD"},
-            "stage_ms": {"cost_volume": round(float(np.mean(cost_ms)), 3), "vertical_sum_and_path2": round(t_vs * 1e3, 3), "aggregate": round(t_agg * 1e3, 3),
-                         "select": round(float(np.mean(sel_ms)), 3), "sgm_total": round(float(np.mean(sgm_ms)), 3)},
+                                     "peak_source": "measured issue rate, scripts/micro/valu2.hip: 4.5 cycles per wave instruction per SIMD",
+                                     # the stage AS BUILT is two kernels with the horizontal sums handed over through HBM (DESIGN.md 5,
+                                     # "The hsum round trip"): 2 B/cell written + 2 read for hsum, 2 written for C -- against the same 8 TB/s
+                                     "as_built": {"bound": "hbm", "bytes": cells * 6, "achieved": round(cells * 6 / t_cost / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                                  "unit": "GB/s", "frac": round(cells * 6 / t_cost / 1e9 / HBM_PEAK_GBS, 4)}},
+            "stage_ms": {"prefilter": round(float(np.mean(main_pass["tm"]["pre"])), 3), "cost_volume": round(float(np.mean(cost_ms)), 3), "vertical_sum_and_path2": round(t_vs * 1e3, 3), "aggregate": round(t_agg * 1e3, 3),
+                         "select": round(float(np.mean(sel_ms)), 3), "lr_check_median_crop": round(float(np.mean(main_pass["tm"]["med"])), 3), "sgm_total": round(float(np.mean(sgm_ms)), 3)},
             "mean_plane": [None if x != x else round(float(x), 9) for x in mean_plane], "planes_averaged": n_planes,
             "plane_allreduce": coll_info,
             "points_per_frame": int(np.mean(npts_hist)) if npts_hist else None,

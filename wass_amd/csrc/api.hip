@@ -125,7 +125,7 @@ void wass_ctx_destroy(wass_ctx* c)
     coll_release(c);
     mesh_pool_ctx_alive(c, false);
     mesh_pool_purge(c);
-    for (Buf* b : { &c->img1, &c->img2, &c->bt1, &c->bt2, &c->hsum, &c->C, &c->S, &c->ckpt, &c->sel_d16, &c->sel_key, &c->raw,
+    for (Buf* b : { &c->bt1, &c->bt2, &c->hsum, &c->C, &c->S, &c->ckpt, &c->sel_d16, &c->sel_key, &c->raw,
                     &c->flags, &c->tmp_in0, &c->tmp_in1, &c->tmp_out, &c->tmp_mask, &c->fA, &c->fB, &c->fC, &c->fD, &c->fE, &c->uf, &c->rs_r, &c->rs_l, &c->raw2, &c->grid, &c->scratch, &c->counters, &c->tri_cnt, &c->inl, &c->clahe_lut, &c->ccmask, &c->und_cache[0].xy, &c->und_cache[1].xy, &c->dstate, &c->rect_tab, &c->rect_mx, &c->rect_my, &c->xyzc, &c->limits })
         release(*b);
     for (auto& set : c->evs) for (auto& e : set) if (e) (void)hipEventDestroy(e);
@@ -275,8 +275,7 @@ int wass_sgm_disparity_dev(wass_ctx* c, const uint8_t* d_right, const uint8_t* d
 
     const size_t npad = (size_t)d.Wp * d.h;
     const size_t vol = d.cells() * sizeof(uint16_t);
-    if ((rc = ensure(c, c->img1, npad)) || (rc = ensure(c, c->img2, npad)) ||
-        (rc = ensure(c, c->bt1, npad * 8)) || (rc = ensure(c, c->bt2, (size_t)d.h * 6 * bt2_pitch(d.Wp) * 2 + 8192)) ||
+    if ((rc = ensure(c, c->bt1, npad * 8)) || (rc = ensure(c, c->bt2, (size_t)d.h * 6 * bt2_pitch(d.Wp) * 2 + 8192)) ||
         (rc = ensure(c, c->hsum, vol)) || (rc = ensure(c, c->C, vol)) ||
         (rc = ensure(c, c->S, vol)) ||
         (rc = ensure(c, c->sel_d16, (size_t)d.width1 * d.h * 2)) ||
@@ -288,14 +287,9 @@ int wass_sgm_disparity_dev(wass_ctx* c, const uint8_t* d_right, const uint8_t* d
     const int set = (int)(c->nsgm & 1);
     c->ev = c->evs[set];
     WASS_HIP(c, hipEventRecord(c->ev[0], s));
-    // wass_stereo.cpp:820-831: zero images, left at column D+off-comp, right at column D
-    WASS_HIP(c, hipMemsetAsync(c->img1.p, 0, npad, s));
-    WASS_HIP(c, hipMemsetAsync(c->img2.p, 0, npad, s));
-    WASS_HIP(c, hipMemsetAsync(c->flags.p, 0, 64, s));
-    WASS_HIP(c, hipMemcpy2DAsync((uint8_t*)c->img1.p + d.D, d.Wp, d_right, pitch, w, h, hipMemcpyDeviceToDevice, s));
-    WASS_HIP(c, hipMemcpy2DAsync((uint8_t*)c->img2.p + (d.D + d.off_pos - d.comp), d.Wp, d_left, pitch, w, h,
-                                 hipMemcpyDeviceToDevice, s));
-    if ((rc = launch_prefilter(c, d))) return rc;
+    // wass_stereo.cpp:820-831: zero images, left at column D+off-comp, right at column D -- the padded pictures are not
+    // materialised: the pre-filter reads the crops through the padding rule (and clears the frame's status words)
+    if ((rc = launch_prefilter(c, d, d_right, d_left, pitch))) return rc;
     WASS_HIP(c, hipEventRecord(c->ev[1], s));
     if ((rc = launch_cost_volume(c, d))) return rc;
     WASS_HIP(c, hipEventRecord(c->ev[2], s));

@@ -109,7 +109,6 @@ struct wass_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     // scratch HBM (grown on demand, never shrunk)
-    wass::Buf img1, img2;          // padded u8 images (right / left)
     wass::Buf bt1, bt2;            // BT interval records: bt1 8 B/pixel; bt2 six mirrored u16 planes per row
     wass::Buf hsum, C, S;          // u16 volumes [h][width1][Dp]
     wass::Buf ckpt;                // forward-path checkpoints of k_pair (1/K of a volume)
@@ -261,7 +260,7 @@ void mesh_pool_ctx_alive(const void* ctx, bool alive);   // mesh.hip: only live 
 void mesh_pool_purge(const void* owner);      // mesh.hip: parked mesh allocations of a context that is going away
 
 // stage launchers (each enqueues on c->stream)
-int launch_prefilter(wass_ctx* c, const SgmDims& d);
+int launch_prefilter(wass_ctx* c, const SgmDims& d, const uint8_t* d_img1, const uint8_t* d_img2, size_t pitch);
 int launch_cost_volume(wass_ctx* c, const SgmDims& d);
 int launch_vsum_only(wass_ctx* c, const SgmDims& d, bool plain);   // the vertical block sum alone, on the hsum volume of the last frame
 int launch_aggregate(wass_ctx* c, const SgmDims& d, int* n_launches);

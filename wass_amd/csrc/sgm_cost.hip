@@ -22,36 +22,48 @@ namespace wass {
 // K1: per pixel {v, lo, hi} for the clipped x-Sobel channel and the raw channel
 // (lo/hi = min/max over the value and its two half-pixel neighbours).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int sobel_at(const uint8_t* img, int Wp, int h, int X, int y, int ftzero)
+// The padded pictures of wass_stereo.cpp:820-831 (zero images of width Wp, the crop copied in at column xo) are never
+// materialised: PadImg answers pixel reads of the padded picture from the caller's crop.
+struct PadImg {
+    const uint8_t* src; size_t pitch; int w, xo;
+    __device__ __forceinline__ int at(int X, int y) const
+    {
+        const int x = X - xo;
+        return (unsigned)x < (unsigned)w ? src[(size_t)y * pitch + x] : 0;
+    }
+};
+
+__device__ __forceinline__ int sobel_at(const PadImg& img, int Wp, int h, int X, int y, int ftzero)
 {
     if (X <= 0 || X >= Wp - 1) return ftzero;                 // tab[0]
     const int yn = y > 0 ? y - 1 : 0, ys = y < h - 1 ? y + 1 : y;
-    const uint8_t* r = img + (size_t)y * Wp;
-    const uint8_t* rn = img + (size_t)yn * Wp;
-    const uint8_t* rs = img + (size_t)ys * Wp;
-    int v = (r[X + 1] - r[X - 1]) * 2 + (rn[X + 1] - rn[X - 1]) + (rs[X + 1] - rs[X - 1]);
+    int v = (img.at(X + 1, y) - img.at(X - 1, y)) * 2 + (img.at(X + 1, yn) - img.at(X - 1, yn)) + (img.at(X + 1, ys) - img.at(X - 1, ys));
     v = v < -ftzero ? -ftzero : (v > ftzero ? ftzero : v);
     return v + ftzero;
 }
-__device__ __forceinline__ int raw_at(const uint8_t* img, int Wp, int X, int y, int ftzero)
+__device__ __forceinline__ int raw_at(const PadImg& img, int Wp, int X, int y, int ftzero)
 {
     if (X <= 0 || X >= Wp - 1) return ftzero;                 // tab[0] on the border columns too
-    return img[(size_t)y * Wp + X];
+    return img.at(X, y);
 }
 
-// MIRROR = false: image 1 (the reference image of the match): one 8-byte record per pixel
+// blockIdx.z = 0: image 1 (the reference image of the match): one 8-byte record per pixel
 //   {sobel v, lo, hi, raw v, lo, hi} -- read wave-uniformly by k_hsum_q.
-// MIRROR = true: image 2: six u16 planes per row, [y][plane][Wp + pad], stored MIRRORED in x
+// blockIdx.z = 1: image 2: six u16 planes per row, [y][plane][Wp + pad], stored MIRRORED in x
 //   (index Wp-1-X), so that the values a lane needs for consecutive disparities d, d+1, ... at
 //   column X (image-2 columns X-d, X-d-1, ...) are consecutive, ascending u16 in memory and arrive
 //   as ready-made packed pairs (the same trick OpenCV's calcPixelCostBT uses for its SIMD loop).
-template <bool MIRROR>
-__global__ void __launch_bounds__(256) k_prefilter(const uint8_t* __restrict__ img, int Wp, int h, int ftzero,
-                                                   uint2* __restrict__ out1, unsigned short* __restrict__ out2, int pitch2)
+// One launch for both pictures; it also clears the frame's status words (flags), which the cost stage ORs into.
+__global__ void __launch_bounds__(256) k_prefilter(PadImg img1, PadImg img2, int Wp, int h, int ftzero,
+                                                   uint2* __restrict__ out1, unsigned short* __restrict__ out2, int pitch2,
+                                                   uint32_t* __restrict__ flags)
 {
     const int X = blockIdx.x * 256 + threadIdx.x;
     const int y = blockIdx.y;
+    const bool MIRROR = blockIdx.z != 0;
+    if (blockIdx.x == 0 && y == 0 && !MIRROR && threadIdx.x < 16) flags[threadIdx.x] = 0;
     if (X >= Wp) return;
+    const PadImg& img = MIRROR ? img2 : img1;
     int s0 = sobel_at(img, Wp, h, X, y, ftzero);
     int r0 = raw_at(img, Wp, X, y, ftzero);
     int sl = X > 0 ? (s0 + sobel_at(img, Wp, h, X - 1, y, ftzero)) / 2 : s0;
@@ -74,16 +86,17 @@ __global__ void __launch_bounds__(256) k_prefilter(const uint8_t* __restrict__ i
 }
 
 
-int launch_prefilter(wass_ctx* c, const SgmDims& d)
+// img1 = the picture SGBM takes as its first argument (wass_stereo's right crop, at column D), img2 the other one
+// (left crop, at column D + off - comp); w, pitch: the crops'.
+int launch_prefilter(wass_ctx* c, const SgmDims& d, const uint8_t* d_img1, const uint8_t* d_img2, size_t pitch)
 {
-    dim3 grid((d.Wp + 255) / 256, d.h);
+    dim3 grid((d.Wp + 255) / 256, d.h, 2);
     const int pitch2 = bt2_pitch(d.Wp);
-    // the slack columns are never written; clear them once per (re)allocation is not enough because sizes change,
-    // but their content only ever feeds padded disparity slots, which k_vsum overwrites with 0xFFFF.
-    hipLaunchKernelGGL(k_prefilter<false>, grid, dim3(256), 0, c->stream, (const uint8_t*)c->img1.p, d.Wp, d.h,
-                       d.ftzero, (uint2*)c->bt1.p, (unsigned short*)nullptr, 0);
-    hipLaunchKernelGGL(k_prefilter<true>, grid, dim3(256), 0, c->stream, (const uint8_t*)c->img2.p, d.Wp, d.h,
-                       d.ftzero, (uint2*)nullptr, (unsigned short*)c->bt2.p + BT2_FRONT, pitch2);
+    // the slack columns of bt2 are never written; their content only ever feeds padded disparity slots, which k_vsum
+    // overwrites with 0xFFFF.
+    const PadImg i1 = { d_img1, pitch, d.w, d.D }, i2 = { d_img2, pitch, d.w, d.D + d.off_pos - d.comp };
+    hipLaunchKernelGGL(k_prefilter, grid, dim3(256), 0, c->stream, i1, i2, d.Wp, d.h, d.ftzero, (uint2*)c->bt1.p,
+                       (unsigned short*)c->bt2.p + BT2_FRONT, pitch2, (uint32_t*)c->flags.p);
     WASS_HIP(c, hipGetLastError());
     return WASS_OK;
 }
