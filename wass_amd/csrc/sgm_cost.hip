@@ -58,20 +58,29 @@ __global__ void __launch_bounds__(256) k_prefilter(PadImg img1, PadImg img2, int
                                                    uint2* __restrict__ out1, unsigned short* __restrict__ out2, int pitch2,
                                                    uint32_t* __restrict__ flags)
 {
-    const int X = blockIdx.x * 256 + threadIdx.x;
+    __shared__ uint16_t sv[260];                              // (sobel | raw << 8) of columns base-1 .. base+256
+    const int base = blockIdx.x * 256;
     const int y = blockIdx.y;
     const bool MIRROR = blockIdx.z != 0;
     if (blockIdx.x == 0 && y == 0 && !MIRROR && threadIdx.x < 16) flags[threadIdx.x] = 0;
-    if (X >= Wp) return;
     const PadImg& img = MIRROR ? img2 : img1;
-    int s0 = sobel_at(img, Wp, h, X, y, ftzero);
-    int r0 = raw_at(img, Wp, X, y, ftzero);
-    int sl = X > 0 ? (s0 + sobel_at(img, Wp, h, X - 1, y, ftzero)) / 2 : s0;
-    int sr = X < Wp - 1 ? (s0 + sobel_at(img, Wp, h, X + 1, y, ftzero)) / 2 : s0;
-    int rl = X > 0 ? (r0 + raw_at(img, Wp, X - 1, y, ftzero)) / 2 : r0;
-    int rr = X < Wp - 1 ? (r0 + raw_at(img, Wp, X + 1, y, ftzero)) / 2 : r0;
-    int slo = min(min(sl, sr), s0), shi = max(max(sl, sr), s0);
-    int rlo = min(min(rl, rr), r0), rhi = max(max(rl, rr), r0);
+    for (int t = threadIdx.x; t < 258; t += 256) {
+        const int X = base - 1 + t;
+        int s = ftzero, r = ftzero;
+        if (X >= 0 && X < Wp) { s = sobel_at(img, Wp, h, X, y, ftzero); r = raw_at(img, Wp, X, y, ftzero); }
+        sv[t] = (uint16_t)(s | (r << 8));
+    }
+    __syncthreads();
+    const int X = base + threadIdx.x;
+    if (X >= Wp) return;
+    const int c = sv[threadIdx.x + 1], l = sv[threadIdx.x], g = sv[threadIdx.x + 2];
+    const int s0 = c & 0xff, r0 = c >> 8;
+    const int sl = X > 0 ? (s0 + (l & 0xff)) / 2 : s0;
+    const int sr = X < Wp - 1 ? (s0 + (g & 0xff)) / 2 : s0;
+    const int rl = X > 0 ? (r0 + (l >> 8)) / 2 : r0;
+    const int rr = X < Wp - 1 ? (r0 + (g >> 8)) / 2 : r0;
+    const int slo = min(min(sl, sr), s0), shi = max(max(sl, sr), s0);
+    const int rlo = min(min(rl, rr), r0), rhi = max(max(rl, rr), r0);
     if (!MIRROR) {
         uint2 o;
         o.x = (uint32_t)s0 | ((uint32_t)slo << 8) | ((uint32_t)shi << 16) | ((uint32_t)r0 << 24);
