@@ -11,7 +11,7 @@ from wass_amd import synth, default_sgm_params
 w, h, D = 2456, 2058, 256
 dev = torch.device("cuda", 0)
 r, l = synth.make_pair_torch(w, h, D, frame_idx=1, device=dev)
-p = default_sgm_params(D, ndirs=8)
+p = default_sgm_params(D, ndirs=int(os.environ.get("AB_NDIRS", "8")))
 out = torch.empty((h, w), dtype=torch.int16, device=dev)
 with wass_amd.Context(0) as ctx:
     pre, cost, vs, agg, tot = [], [], [], [], []
