@@ -554,21 +554,36 @@ def main():
             from wass_amd import _lib
             lib = _lib.load()
             uid_t = torch.zeros(128, dtype=torch.uint8, device=coll_dev)
+            # A failure of this leg is REPORTED in the line (plane_allreduce.error), it does not take the throughput
+            # measurement down with it: the timed region is over, and the mean then comes from the torch all-reduce.
+            ok_t = torch.ones(1, dtype=torch.int32, device=coll_dev)
             if rank == 0:
                 uid = (C.c_ubyte * 128)()
                 if lib.wass_coll_unique_id(uid) != 0:
-                    sys.exit("bench.py: wass_coll_unique_id failed (librccl not loadable)")
-                uid_t = torch.tensor(list(uid), dtype=torch.uint8, device=coll_dev)
-            dist.broadcast(uid_t, 0)
-            uid = (C.c_ubyte * 128)(*uid_t.cpu().tolist())
-            a5 = (C.c_double * 5)(*acc.tolist())
-            t0c = time.perf_counter()
-            if lib.wass_coll_init(ctx._h, rank, world, uid) != 0 or lib.wass_coll_allreduce_sum_f64(ctx._h, a5, 5) != 0:
-                sys.exit(f"bench.py: rank {rank}: wass_coll all-reduce failed: " + lib.wass_last_error(ctx._h).decode())
-            coll_ms = (time.perf_counter() - t0c) * 1e3
-            acc = np.array(a5[:])
-            coll_info = {"path": "wass_coll_allreduce_sum_f64 (RCCL via the C ABI)", "ranks": world, "ms_incl_comm_init": round(coll_ms, 2),
-                         "matches_torch_distributed": bool(np.array_equal(acc, acc_torch))}
+                    ok_t.zero_()
+                else:
+                    uid_t = torch.tensor(list(uid), dtype=torch.uint8, device=coll_dev)
+            dist.broadcast(ok_t, 0)
+            coll_err = None if int(ok_t.item()) else "wass_coll_unique_id failed on rank 0 (librccl not loadable)"
+            if coll_err is None:
+                dist.broadcast(uid_t, 0)
+                uid = (C.c_ubyte * 128)(*uid_t.cpu().tolist())
+                a5 = (C.c_double * 5)(*acc.tolist())
+                t0c = time.perf_counter()
+                bad = lib.wass_coll_init(ctx._h, rank, world, uid) != 0 or lib.wass_coll_allreduce_sum_f64(ctx._h, a5, 5) != 0
+                coll_ms = (time.perf_counter() - t0c) * 1e3
+                bad_t = torch.tensor([1 if bad else 0], dtype=torch.int32, device=coll_dev)
+                dist.all_reduce(bad_t, op=dist.ReduceOp.MAX)
+                if int(bad_t.item()):
+                    coll_err = ("rank %d: " % rank + lib.wass_last_error(ctx._h).decode()) if bad else "wass_coll failed on another rank"
+            if coll_err is None:
+                acc = np.array(a5[:])
+                coll_info = {"path": "wass_coll_allreduce_sum_f64 (RCCL via the C ABI)", "ranks": world, "ms_incl_comm_init": round(coll_ms, 2),
+                             "matches_torch_distributed": bool(np.array_equal(acc, acc_torch))}
+            else:
+                print(f"bench.py: rank {rank}: wass_coll all-reduce FAILED: {coll_err}", file=sys.stderr, flush=True)
+                acc = acc_torch
+                coll_info = {"path": "torch.distributed all-reduce (the library's own RCCL path FAILED)", "ranks": world, "error": coll_err}
         else:
             acc = acc_torch
             coll_info = {"path": "torch.distributed gloo (shared-GPU functional test: RCCL refuses two ranks on one device)", "ranks": world}
