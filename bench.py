@@ -227,7 +227,8 @@ def measured_traffic(config: str, ndirs: int):
         try:
             j = json.load(open(f))
             if j.get("config") == config and j.get("ndirs") == ndirs:
-                best = (j["aggregation_hbm_bytes_per_frame"], os.path.relpath(f, ROOT))
+                cost = j.get("cost_stage_read_bytes_per_frame", 0) + j.get("cost_stage_write_bytes_per_frame", 0)
+                best = (j["aggregation_hbm_bytes_per_frame"], os.path.relpath(f, ROOT), cost or None)
         except Exception:
             pass
     return best
@@ -658,7 +659,8 @@ def main():
                                      # the stage AS BUILT is two kernels with the horizontal sums handed over through HBM (DESIGN.md 5,
                                      # "The hsum round trip"): 2 B/cell written + 2 read for hsum, 2 written for C -- against the same 8 TB/s
                                      "as_built": {"bound": "hbm", "bytes": cells * 6, "achieved": round(cells * 6 / t_cost / 1e9, 1), "peak": HBM_PEAK_GBS,
-                                                  "unit": "GB/s", "frac": round(cells * 6 / t_cost / 1e9 / HBM_PEAK_GBS, 4)}},
+                                                  "unit": "GB/s", "frac": round(cells * 6 / t_cost / 1e9 / HBM_PEAK_GBS, 4),
+                                                  "traffic": int(traffic[2]) if traffic and traffic[2] else None}},
             "stage_ms": {"prefilter": round(float(np.mean(main_pass["tm"]["pre"])), 3), "cost_volume": round(float(np.mean(cost_ms)), 3), "vertical_sum_and_path2": round(t_vs * 1e3, 3), "aggregate": round(t_agg * 1e3, 3),
                          "select": round(float(np.mean(sel_ms)), 3), "lr_check_median_crop": round(float(np.mean(main_pass["tm"]["med"])), 3), "sgm_total": round(float(np.mean(sgm_ms)), 3)},
             "mean_plane": [None if x != x else round(float(x), 9) for x in mean_plane], "planes_averaged": n_planes,

@@ -43,7 +43,18 @@ frames = fetch[hs[0]][0] if hs else 1
 for k, v in rows.items():
     tot_r += v["read_bytes_per_launch"] * v["launches"] / frames
     tot_w += v["write_bytes_per_launch"] * v["launches"] / frames
+# the cost stage (not part of the aggregation figure): the production launches only -- k_vsum_col runs 10 times in 7 frames
+# because wass_sgm_probe_vsum re-runs it three times after the timed region, with the same bytes per launch
+cost = {}
+cr = cw = 0.0
+for k in sorted(set(fetch) | set(write)):
+    if k.startswith(("k_prefilter", "k_hsum_q", "k_vsum_col")):
+        n = fetch[k][0]
+        cost[k] = {"launches": n, "read_bytes_per_launch": 2 * fetch[k][1] / n * 1024, "write_bytes_per_launch": write[k][1] / max(write[k][0], 1) * 1024}
+        cr += cost[k]["read_bytes_per_launch"]
+        cw += cost[k]["write_bytes_per_launch"]
 print(json.dumps({"config": config, "ndirs": ndirs, "frames_profiled": frames, "aggregation_read_bytes_per_frame": tot_r,
+                  "cost_stage_read_bytes_per_frame": cr, "cost_stage_write_bytes_per_frame": cw, "cost_stage_kernels": cost,
                   "aggregation_write_bytes_per_frame": tot_w, "aggregation_hbm_bytes_per_frame": tot_r + tot_w,
                   "fetch_size_correction": 2.0, "kernels": rows,
                   "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, scripts/profile.sh"}, indent=1))
