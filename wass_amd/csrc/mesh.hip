@@ -102,7 +102,15 @@ __device__ __forceinline__ void triangulate_point(const double* p, const double*
 }
 
 // triangulate(StereoMatchEnv&) (wass_stereo.cpp:1173-1365): one thread per ROI pixel
-__global__ void __launch_bounds__(256) k_triangulate(const float* __restrict__ disp, int W, int H, int rlx, int rrx, int rry,
+// At most WASS_TRI_WAVES waves per SIMD: in a sequence this kernel -- fp64 divisions and an acos per pixel -- is the first big
+// kernel of a frame's tail and runs underneath the NEXT frame's k_hsum_q, which is issue-bound.  At full occupancy it took
+// the horizontal sum from 0.59 ms (alone) to 0.83 ms; held to one wave per SIMD it takes three times as long itself, which
+// nobody waits for, and the cost stage of the next frame 1.79 instead of 2.05 ms (frame period -1.7 .. 3 %, alternating
+// builds on one box).  Holding ALL tail kernels down makes the tail the bottleneck (10.3 ms per frame at one wave, 8.8 at two).
+#ifndef WASS_TRI_WAVES
+#define WASS_TRI_WAVES 1
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, WASS_TRI_WAVES))) k_triangulate(const float* __restrict__ disp, int W, int H, int rlx, int rrx, int rry,
                                                      int mw, int mh, GeomDev g, const uint8_t* __restrict__ right_img,
                                                      int img_w, int img_h, const uint8_t* __restrict__ lmask,
                                                      const uint8_t* __restrict__ rmask, double min_angle, double bx0,
