@@ -16,6 +16,9 @@
 
 #include <algorithm>
 
+#ifndef WASS_HSUM_XQ
+#define WASS_HSUM_XQ 116
+#endif
 namespace wass {
 
 // ---------------------------------------------------------------------------
@@ -496,7 +499,9 @@ static int launch_cost_np(wass_ctx* c, const SgmDims& d)
     {
         constexpr int G = 2 * NP;
         const int WIN = 2 * d.SW2 + 1;
-        const int XQ = 116 / G * G;                                          // columns per chunk, a multiple of G
+        // columns per chunk, a multiple of G: 232 where that still leaves >= 16 waves per SIMD-slot round (5 % instead of 10 % of
+        // window warm-up: 0.570 against 0.597 ms at config B; 348 is slower again, 60 no faster), 116 on small pictures
+        const int XQ = ((size_t)d.h * ((d.width1 + 231) / 232) >= 16384 ? 232 : WASS_HSUM_XQ) / G * G;
         // chunk starts are shifted left by -off in [0, G) so that (t0 + minX1) == (Wp + minD) (mod G)
         const int m = (((d.Wp + d.minD - d.minX1 + d.SW2) % G) + G) % G;
         const int off = m == 0 ? 0 : m - G;
