@@ -387,6 +387,8 @@ def main():
     ap.add_argument("--no-cxx-driver", action="store_true", help="skip the C++ sequence driver's own throughput (cxx_driver)")
     ap.add_argument("--stage", default="full", choices=("full", "sgm"),
                     help="full = a1-a20 (SGBM, clean-up, triangulation, plane fit, xyzC); sgm = a1-a6 only")
+    ap.add_argument("--rccl-single-rank", action="store_true",
+                    help="functional test: run the multi-rank epilogue (RCCL through the C ABI included) with a process group of one rank")
     ap.add_argument("--allow-shared-gpu", action="store_true",
                     help="let several ranks share one GPU (rank r uses device r %% device_count): only for exercising the "
                          "multi-rank path on a single-GPU box; throughput numbers are then meaningless")
@@ -423,6 +425,17 @@ def main():
                  f"(--allow-shared-gpu runs the ranks on shared devices, for functional tests only)")
     dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
+    if world == 1 and args.rccl_single_rank:
+        # functional test of everything a multi-rank run does after the timed region -- process-group collectives, the library's
+        # own RCCL all-reduce (wass_coll_*), the gathered per-rank rates -- with a process group of ONE rank on one GPU
+        import socket
+        import torch.distributed as dist
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(port))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", dev_index))
     if world > 1:
         import torch.distributed as dist
         # RCCL refuses two ranks on one device; the functional single-GPU test of the multi-rank path uses gloo

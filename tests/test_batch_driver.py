@@ -165,6 +165,23 @@ def test_bench_runs_two_ranks_or_fails_loudly():
     assert len(line["ranks"]["pairs_per_sec_per_rank"]) == 2 and line["planes_averaged"] == 4
 
 
+@pytest.mark.gpu
+def test_bench_multi_rank_epilogue_with_the_librarys_rccl_leg():
+    """Everything `bench.py --gpus N` does after the timed region on RCCL -- the process-group collectives, the sequence mean
+    plane through wass_coll_init / wass_coll_allreduce_sum_f64 (the product's own path, cross-checked against torch), the
+    gathered per-rank rates -- run with a process group of ONE rank: the code the 8-GPU run executes, on the one GPU there is."""
+    import json
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rccl-single-rank", "--steps", "4", "--warmup", "1", "--config", "A",
+                        "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    pa = line["plane_allreduce"]
+    assert pa is not None and "error" not in pa, pa
+    assert pa["path"].startswith("wass_coll_allreduce_sum_f64") and pa["matches_torch_distributed"] is True
+    assert line["ranks"]["backend"] == "nccl" and line["planes_averaged"] == 4
+
+
 def test_raw_mode_prepares_workdirs_and_fails_loudly_without_a_gpu(exes, tmp_path):
     """--raw (prepare-less mode) on a machine without a GPU: the host side still does wass_prepare's part of every workdir
     (calibration copies, wasscli's numbering of the pairs), every frame fails loudly in its own log, and nothing pretends to
