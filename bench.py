@@ -234,14 +234,15 @@ def measured_traffic(config: str, ndirs: int):
     return best
 
 
-def config_e_record(dev_index: int, ndirs: int, steps: int = 5, warmup: int = 2):
+def config_e_record(dev_index: int, ndirs: int, steps: int = 5, warmup: int = 2, config: str = "E"):
     """BASELINE.json configs[4] (3840x2160, D=512; the HBM-bound stress case) inside the default run: a few frames through the
     SGM stage a1-a6 with resident inputs, the same hipEvent brackets as the headline, so that the driver's BENCH record carries
-    config E's aggregation time and roofline fraction next to config B's."""
+    config E's aggregation time and roofline fraction next to config B's.  With config = "B": the headline configuration's SGM
+    stage on its own, i.e. the aggregation kernels WITHOUT the previous frame's tail running underneath them."""
     import torch
     import wass_amd
     from wass_amd import synth
-    w, h, D = CONFIGS["E"]
+    w, h, D = CONFIGS[config]
     dev = torch.device("cuda", dev_index)
     params = wass_amd.default_sgm_params(D, ndirs=ndirs)
     frames = [synth.make_pair_torch(w, h, D, frame_idx=900000 + k, device=dev) for k in range(2)]
@@ -263,8 +264,8 @@ def config_e_record(dev_index: int, ndirs: int, steps: int = 5, warmup: int = 2)
     cells = w * h * D
     alg = cells * (2 * ndirs + 4)
     t_agg = float(np.mean(agg)) * 1e-3
-    traffic = measured_traffic("E", ndirs)
-    return {"workload": f"config E: {w}x{h}, D={D}, {ndirs}-path, SGM stage a1-a6, resident inputs, {steps} frames after {warmup}",
+    traffic = measured_traffic(config, ndirs)
+    return {"workload": f"config {config}: {w}x{h}, D={D}, {ndirs}-path, SGM stage a1-a6, resident inputs, {steps} frames after {warmup}",
             "aggregate_ms": round(t_agg * 1e3, 3), "sgm_total_ms": round(float(np.mean(tot)), 3), "cost_volume_ms": round(float(np.mean(cost)), 3),
             "pairs_per_sec_sgm_stage": round(1e3 / float(np.mean(tot)), 2),
             "roofline": {"bound": "hbm", "achieved": round(alg / t_agg / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -694,6 +695,11 @@ def main():
             ctx.close()
             ctx = None
             line["config_E"] = config_e_record(dev_index, args.ndirs)
+            # the headline configuration's aggregation without the frame pipelining: in the timed region the previous frame's
+            # tail (clean-up, triangulation, plane fit, encoder: 1 ms of small kernels) runs underneath these kernels and costs
+            # them 0.1-0.3 ms; this is the kernel family on its own, same brackets
+            line["roofline"]["sgm_stage_alone"] = {k: v for k, v in config_e_record(dev_index, args.ndirs, steps=8, config="B").items()
+                                                   if k in ("workload", "aggregate_ms", "cost_volume_ms", "sgm_total_ms", "roofline")}
         if world == 1 and args.config == "B" and args.stage == "full" and not args.no_cxx_driver:
             if ctx is not None:
                 ctx.close()
