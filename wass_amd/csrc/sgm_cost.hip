@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #ifndef WASS_HSUM_XQ
 #define WASS_HSUM_XQ 116
@@ -179,7 +180,8 @@ __global__ void __launch_bounds__(256) k_hsum_q(const uint2* __restrict__ bt1, c
     int slot = 0;
     uint32_t* o = hsum + ((size_t)y * width1 + max(xs, 0)) * (64 * NP) + lane * NP;
     // one finished pixel-cost vector: slide the window, write the column whose window is complete now
-    auto emit = [&](const us2 (&pix)[NP], int i, int t) {
+    // always: the caller knows (wave-uniformly, once per group) that the column's window is complete and inside the chunk
+    auto emit = [&](const us2 (&pix)[NP], int i, int t, auto always) {
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             uint32_t* rs = ring + (slot * NP + j) * 64;
@@ -188,7 +190,7 @@ __global__ void __launch_bounds__(256) k_hsum_q(const uint2* __restrict__ bt1, c
         }
         slot = slot + 1 == WIN ? 0 : slot + 1;
         const int xo = t - SW2;
-        if (i >= 2 * SW2 && xo >= 0 && xo < xe) {
+        if (decltype(always)::value || (i >= 2 * SW2 && xo >= 0 && xo < xe)) {
             st_stream_vec<NP>(o, acc);
             o += 64 * NP;
         }
@@ -200,29 +202,34 @@ __global__ void __launch_bounds__(256) k_hsum_q(const uint2* __restrict__ bt1, c
         for (int p = 0; p < 6; ++p) nx[p] = *(const AVec<NP>*)(row2 + (size_t)p * pitch2 + (b - G));
         const int tg = t0 + g0;
         if (tg >= 0 && tg + G - 1 <= width1 - 1) {                     // wave-uniform: the whole group is inside the row
-            uint2 a1[G];
+            auto fast_group = [&](auto always) {
+                uint2 a1[G];
 #pragma unroll
-            for (int s = 0; s < G; ++s) a1[s] = row1[tg + s];          // uniform addresses: one scalar load each
+                for (int s = 0; s < G; ++s) a1[s] = row1[tg + s];          // uniform addresses: one scalar load each
 #pragma unroll
-            for (int s = 0; s < G; ++s) {
-                const int oo = G - 1 - s;                             // window offset inside [lo | hi], in elements
-                us2 v[6][NP], pix[NP];
+                for (int s = 0; s < G; ++s) {
+                    const int oo = G - 1 - s;                             // window offset inside [lo | hi], in elements
+                    us2 v[6][NP], pix[NP];
 #pragma unroll
-                for (int p = 0; p < 6; ++p)
+                    for (int p = 0; p < 6; ++p)
 #pragma unroll
-                    for (int j = 0; j < NP; ++j) {
-                        const int q = oo / 2 + j;                     // dword index into the 2*NP-dword concatenation
-                        const uint32_t d0 = q < NP ? lo[p].v[q] : hi[p].v[q - NP];
-                        if (oo & 1) {
-                            const uint32_t d1 = q + 1 < NP ? lo[p].v[q + 1] : hi[p].v[q + 1 - NP];
-                            v[p][j] = as_us2(__builtin_amdgcn_alignbit(d1, d0, 16));
-                        } else {
-                            v[p][j] = as_us2(d0);
+                        for (int j = 0; j < NP; ++j) {
+                            const int q = oo / 2 + j;                     // dword index into the 2*NP-dword concatenation
+                            const uint32_t d0 = q < NP ? lo[p].v[q] : hi[p].v[q - NP];
+                            if (oo & 1) {
+                                const uint32_t d1 = q + 1 < NP ? lo[p].v[q + 1] : hi[p].v[q + 1 - NP];
+                                v[p][j] = as_us2(__builtin_amdgcn_alignbit(d1, d0, 16));
+                            } else {
+                                v[p][j] = as_us2(d0);
+                            }
                         }
-                    }
-                bt_eval<NP>(a1[s], v, pix);
-                emit(pix, g0 + s, tg + s);
-            }
+                    bt_eval<NP>(a1[s], v, pix);
+                    emit(pix, g0 + s, tg + s, always);
+                }
+            };
+            // steady state (every column of the group is written): no per-column tests, no branches around the stores
+            if (g0 >= 2 * SW2 && tg - SW2 >= 0 && tg + G - 1 - SW2 < xe) fast_group(std::true_type{});
+            else fast_group(std::false_type{});
         } else {                                                       // a replicated border column: per-column loads
             for (int s = 0; s < G; ++s) {
                 const int t = tg + s;
@@ -237,7 +244,7 @@ __global__ void __launch_bounds__(256) k_hsum_q(const uint2* __restrict__ bt1, c
                     for (int j = 0; j < NP; ++j) v[p][j] = as_us2(u.v[j]);
                 }
                 bt_eval<NP>(row1[tc], v, pix);
-                emit(pix, g0 + s, t);
+                emit(pix, g0 + s, t, std::false_type{});
             }
         }
 #pragma unroll
