@@ -488,6 +488,96 @@ __device__ __forceinline__ int div_small(int num, int den)
 // is a single dependent chain full of DPP and readlane wait states).  Branch-free; lane u collects the result of
 // cell u (res_d: fixed-point disparity, res_k: (minS << 16) | d or ~0 for a rejected pixel), so that a batch is
 // written with one store per output array.
+#ifndef WASS_WTA_VECTOR_TAIL
+#define WASS_WTA_VECTOR_TAIL 1
+#endif
+#if WASS_WTA_VECTOR_TAIL
+// Round 4: the per-cell tail -- neighbours of the winner, uniqueness decision, sub-pixel division, output words -- used to
+// run cell by cell on the scalar unit (88 scalar + 34 vector instructions per cell; the last aggregation kernel carries 99
+// scalar instructions per pixel, which is a CU's whole scalar issue for 0.8 of its 1.2 ms).  Now only what NEEDS the
+// scalar unit stays there (the reduced key, the ballots of the uniqueness count, the lane index of the two neighbours); the
+// per-cell values are gathered into lane u and the tail runs ONCE per batch, K cells side by side in K lanes.  Same integer
+// arithmetic, same results.
+template <int NP, int K>
+__device__ __forceinline__ void wta_batch_eval(const us2 (&Sv)[K][NP], int lane, int D, int minD, int uniq, int& res_d,
+                                               uint32_t& res_k)
+{
+    constexpr int V = 2 * NP;
+    constexpr int ABSENT = 1 << 22;                             // a neighbour that does not exist never passes a test
+    const int dlane = lane * V;
+    // padded slots (d >= D) always hold the saturated 0x7FFF and a larger d than every real slot, so they can
+    // only win the key minimum when every real slot is 0x7FFF too -- and then the smallest (real) d wins anyway
+    uint32_t key[K];
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+        key[u] = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const uint32_t w = as_u32(Sv[u][j]);
+            key[u] = min(key[u], min((w << 16) | (uint32_t)(dlane + 2 * j), (w & 0xFFFF0000u) | (uint32_t)(dlane + 2 * j + 1)));
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < K; ++u) key[u] = wave_min_u32(key[u]);
+    const int q = 100 - uniq;
+    // lanes whose slot j is a real disparity (d = lane*V + j < D), as ballot masks
+    unsigned long long inr[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const int nl = (D - j + V - 1) / V;
+        inr[j] = nl >= 64 ? ~0ull : ((1ull << (nl < 0 ? 0 : nl)) - 1ull);
+    }
+    // cell u's values, gathered into lane u
+    uint32_t g_key = 0xFFFFFFFFu, g_aw[NP], g_cw[NP];
+    int g_cnt = 0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) g_aw[j] = g_cw[j] = 0;
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+        const int minS = (int)(key[u] >> 16);
+        const int best = minS >= 32767 ? -1 : (int)(key[u] & 0xFFFF);
+        // uniqueness: the slots with S[d]*(100-uniq) < minS*100 over the whole vector (ballots, scalar popcounts)
+        const int T = minS * 100;
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const uint32_t sv = (j & 1) ? Sv[u][j >> 1].y : Sv[u][j >> 1].x;
+            cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64((int)__umul24(sv, (uint32_t)q) < T) & inr[j]);
+        }
+        const int lna = max(best - 1, 0) / V, lnc = min(best + 1, D - 1) / V;        // wave-uniform lane indices
+        const bool mine = lane == u;
+        g_key = mine ? key[u] : g_key;
+        g_cnt = mine ? cnt : g_cnt;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const uint32_t aw = (uint32_t)__builtin_amdgcn_readlane((int)as_u32(Sv[u][j]), lna);
+            const uint32_t cw = (uint32_t)__builtin_amdgcn_readlane((int)as_u32(Sv[u][j]), lnc);
+            g_aw[j] = mine ? aw : g_aw[j];
+            g_cw[j] = mine ? cw : g_cw[j];
+        }
+    }
+    // ---- the tail, once, cell u in lane u
+    const int minS = (int)(g_key >> 16);
+    // "if (Sval < minS)" with minS initialised to MAX_COST never fires when every S is MAX_COST
+    const int best = minS >= 32767 ? -1 : (int)(g_key & 0xFFFF);
+    const int T = minS * 100;
+    auto half_at = [&](const uint32_t (&w)[NP], int d) {
+        const int slot = d % V;
+        uint32_t pv = 0;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) pv = (slot >> 1) == j ? w[j] : pv;
+        return (int)((slot & 1) ? (pv >> 16) : (pv & 0xFFFF));
+    };
+    const int am = half_at(g_aw, max(best - 1, 0)), cp = half_at(g_cw, min(best + 1, D - 1));
+    const int a = best >= 1 ? am : ABSENT, cc = best + 1 < D ? cp : ABSENT;
+    const int near = (a * q < T) + (cc * q < T) + (best >= 0 && minS * q < T);
+    const bool ok = g_cnt <= near, sub = 0 < best && best < D - 1;
+    const int denom2 = max(a + cc - 2 * minS, 1);
+    const int frac = div_small((a - cc) * 16 + denom2, denom2 * 2);
+    res_d = ok ? (best * 16 + (sub ? frac : 0) + minD * 16) : (minD - 1) * 16;
+    res_k = ok ? (((uint32_t)minS << 16) | (uint32_t)(best & 0xFFFF)) : 0xFFFFFFFFu;
+}
+#else
 template <int NP, int K>
 __device__ __forceinline__ void wta_batch_eval(const us2 (&Sv)[K][NP], int lane, int D, int minD, int uniq, int& res_d,
                                                uint32_t& res_k)
@@ -547,6 +637,8 @@ __device__ __forceinline__ void wta_batch_eval(const us2 (&Sv)[K][NP], int lane,
         res_k = lane == u ? k : res_k;
     }
 }
+
+#endif
 
 // ... for cells that lie on an arithmetic progression of pixels (one chain segment)
 template <int NP, int K>
