@@ -252,6 +252,37 @@ __global__ void __launch_bounds__(256) k_hsum_q(const uint2* __restrict__ bt1, c
     }
 }
 
+// Range check and padding of one finished cost vector without branches: padm has 0xFFFF in the half-words of the padded
+// disparity slots (d >= D) of this lane, which become the 0xFFFF sentinel; the running maximum of the REAL slots is kept in
+// mx and compared with the int16 limit once, at the end of the walk (the per-half-word tests with their exec-mask
+// bookkeeping were 40 of the 110 vector instructions per row of k_vsum_col).
+template <int NP>
+struct RangeCheck {
+    uint32_t padm[NP];
+    us2 mx[NP];
+    __device__ __forceinline__ void init(int dlane, int D)
+    {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int d = dlane + 2 * j;
+            padm[j] = (d < D ? 0u : 0xFFFFu) | (d + 1 < D ? 0u : 0xFFFF0000u);
+            mx[j] = pk_splat(0);
+        }
+    }
+    __device__ __forceinline__ us2 apply(us2 acc, int j)
+    {
+        mx[j] = pk_max(mx[j], as_us2(as_u32(acc) & ~padm[j]));
+        return as_us2(as_u32(acc) | padm[j]);
+    }
+    __device__ __forceinline__ bool over(us2 lim) const
+    {
+        bool o = false;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) o |= (mx[j].x > lim.x) | (mx[j].y > lim.y);
+        return o;
+    }
+};
+
 // ---------------------------------------------------------------------------
 // K2b: C[y][x][d] = sum_{j=-SH2..SH2} hsum[clamp(y+j, 0, h-1)][x][d]   (no +P2
 // bias is stored; it cancels in the path recurrence and only matters for the
@@ -291,7 +322,8 @@ __global__ void __launch_bounds__(256) k_vsum(const uint32_t* __restrict__ hsum,
             acc[j] += as_us2(v);
         }
     }
-    bool over = false;
+    RangeCheck<NP> rng;
+    rng.init(dlane, D);
     int slot = 0;                                                     // slot of row clamp(y - SH2): the one leaving next
     us2 nxt[NP];
     {
@@ -302,10 +334,7 @@ __global__ void __launch_bounds__(256) k_vsum(const uint32_t* __restrict__ hsum,
     for (int y = y0; y < y1; ++y) {
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-            us2 v = acc[j];
-            const int d = dlane + 2 * j;
-            if (d < D) over |= (v.x > lim.x); else v.x = 0xFFFF;
-            if (d + 1 < D) over |= (v.y > lim.y); else v.y = 0xFFFF;
+            const us2 v = rng.apply(acc[j], j);
             cp[(size_t)y * rowstride + j] = as_u32(v);
         }
         // slide: row min(y+SH2+1, h-1) enters (already in flight), row clamp(y-SH2) leaves
@@ -324,7 +353,7 @@ __global__ void __launch_bounds__(256) k_vsum(const uint32_t* __restrict__ hsum,
         }
         slot = slot + 1 == WIN ? 0 : slot + 1;
     }
-    if (__any(over) && lane == 0) atomicOr(flags, 1u);
+    if (__any(rng.over(lim)) && lane == 0) atomicOr(flags, 1u);
 }
 
 // ---------------------------------------------------------------------------
@@ -388,7 +417,8 @@ __global__ void __launch_bounds__(256) k_vsum_col(const uint32_t* __restrict__ h
             acc[j] += as_us2(v);
         }
     }
-    bool over = false;
+    RangeCheck<NP> rng;
+    rng.init(dlane, D);
     int slot = 0;                                                     // slot of logical row t - SH2: the one leaving next
     PathState<NP> st;
     st.reset();
@@ -406,10 +436,7 @@ __global__ void __launch_bounds__(256) k_vsum_col(const uint32_t* __restrict__ h
         us2 cv[NP], L[NP];
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-            us2 v = acc[j];
-            const int d = dlane + 2 * j;
-            if (d < D) over |= (v.x > lim.x); else v.x = 0xFFFF;
-            if (d + 1 < D) over |= (v.y > lim.y); else v.y = 0xFFFF;
+            const us2 v = rng.apply(acc[j], j);
             cv[j] = v;
             cp[(size_t)y * rowstride + j] = as_u32(v);
         }
@@ -447,10 +474,7 @@ __global__ void __launch_bounds__(256) k_vsum_col(const uint32_t* __restrict__ h
             sl = sl >= WIN ? sl - WIN : sl;
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
-                us2 v = acc[j];
-                const int d = dlane + 2 * j;
-                if (d < D) over |= (v.x > lim.x); else v.x = 0xFFFF;
-                if (d + 1 < D) over |= (v.y > lim.y); else v.y = 0xFFFF;
+                const us2 v = rng.apply(acc[j], j);
                 cv[u][j] = v;
                 acc[j] = acc[j] + in[u][j] - old[u][j];
                 ring[(sl * NP + j) * 64] = as_u32(in[u][j]);
@@ -494,7 +518,7 @@ __global__ void __launch_bounds__(256) k_vsum_col(const uint32_t* __restrict__ h
     for (int u = 0; u < K; ++u)
         if (u < r) row(F * K + u, nb[u], u);
     if (SPLIT) st.store_normalised(endstate + (size_t)c2 * vec + lane * NP);
-    if (__any(over) && lane == 0) atomicOr(flags, 1u);
+    if (__any(rng.over(lim)) && lane == 0) atomicOr(flags, 1u);
 }
 
 template <int NP>
