@@ -5,9 +5,11 @@
 
 One "step" = one synthetic rectified stereo pair pushed through the whole GPU hot path a1-a20 (SGBM, disparity
 clean-up, triangulation, outlier removal, RANSAC plane + refinement, mesh_cam.xyzC image in host memory).  The timed region
-cycles through up to 64 distinct frames per rank that are RESIDENT IN HBM when the clock starts (`value`); a second, shorter
-pass uploads both pictures of every frame from pinned host memory inside the step, one frame ahead, and is reported as
-`pcie_inclusive` (the boundary of the C++ driver hands over host buffers: decoded PNGs).  With N > 1
+cycles through up to 64 distinct frames per rank.  `value` is the rate of the pass that uploads both pictures of every frame
+from pinned host memory inside the step, one frame ahead ("H2D of 2 x 5 MB images + all kernels + D2H of the
+xyzC"; the boundary of the C++ driver hands over host buffers: decoded PNGs); the same steps with the inputs RESIDENT IN HBM
+when the clock starts are timed in the same run.  Both passes are always reported under the stable names `pcie_inclusive` and
+`resident_inputs` (rounds 1-3 and 5: value = pcie_inclusive; round 4: value = resident_inputs; `value_is` says which).  With N > 1
 (one rank per GPU under torch.distributed.run; `--gpus N` without a launcher starts one) every rank processes its own
 frames -- stereo frames are independent, there is no data-path collective -- and the reported value is the whole-job
 rate (weak scaling); the only exchange is the 40-byte plane all-reduce after the timed region.
@@ -16,8 +18,10 @@ Prints ONE JSON line (rank 0) with BASELINE.json's metric plus
   roofline              -- path aggregation kernel family vs the 8 TB/s HBM roofline ((2R+4) B/cell)
   roofline_cost_volume  -- the cost-volume stage vs the packed-int16 VALU issue peak (it is not HBM-bound)
   cpu_baseline          -- the CPU oracle (5-path, whole path) timed on this box's host cores (rank 0, N = 1)
-  cxx_driver            -- the shipped C++ sequence driver (wass_stereo_batch, one worker process) on a config-B sequence of
-                           workdirs with every consumed output written: the product's own pairs/s, same run
+  cxx_driver            -- the shipped C++ sequence driver (wass_stereo_batch, one worker process per GPU) on a config-B sequence
+                           of workdirs with every consumed output written: the product's own pairs/s, same run
+  mode_5path            -- config B in the mode the reference runs (MODE_SGBM, wass_stereo.cpp:775-777): pairs/s of the whole
+                           chain, aggregation ms against its own (2*5+4) B/cell roofline
 """
 from __future__ import annotations
 
@@ -274,12 +278,15 @@ def config_e_record(dev_index: int, ndirs: int, steps: int = 5, warmup: int = 2,
             "cost_overflow": int(overflow)}
 
 
-def cxx_driver_record(ndirs: int, frames: int = 8, replicate: int = 24, decode_threads: int = 8, writer_threads: int = 4):
+def cxx_driver_record(ndirs: int, frames: int = 8, replicate: int = 24, decode_threads: int = 8, writer_threads: int = 4,
+                      gpus: int = 1, procs_per_gpu: int = 1):
     """What drops into wasscli: the C++ sequence driver (wass_amd/host/wass_stereo_batch.cpp, frame_pipeline.hpp -- decode threads
     -> device-resident frame chain -> writer threads) on a sequence of config-B workdirs as wass_prepare / wass_autocalibrate
     leave them (PNG + XML), one worker process on this GPU, every output a tool reads written (mesh_cam.xyzC, plane.txt, the
     camera files, the previews, the log; plane_refinement_inliers.xyz too).  `frames` distinct pairs, each workdir replicated
-    `replicate` times with symlinked inputs.  The sequence lives in /dev/shm (memory-backed: 43 MB of output per frame)."""
+    `replicate` times with symlinked inputs.  The sequence lives in /dev/shm (memory-backed: 43 MB of output per frame).
+    gpus > 1 (bench.py --gpus N, rank 0 after every rank has released its GPU): one worker process per GPU, `replicate` workdir
+    copies PER GPU (fewer when the scratch directory cannot hold them) -- the product's own scaling point beside the harness's."""
     import shutil
     import struct
     import subprocess
@@ -306,15 +313,21 @@ def cxx_driver_record(ndirs: int, frames: int = 8, replicate: int = 24, decode_t
                     f'  <cols>{m.shape[1]}</cols>\n  <dt>d</dt>\n  <data>\n    {data}</data></{node}>\n</opencv_storage>\n')
 
     build.build_host()
-    need = frames * replicate * 45e6 + frames * 12e6 + 1e9        # outputs (43 MB per frame) + inputs + slack
+    nworkers = max(1, gpus) * max(1, procs_per_gpu)
     base = None
-    for cand in ("/dev/shm", tempfile.gettempdir()):
-        try:
-            if os.path.isdir(cand) and os.access(cand, os.W_OK) and shutil.disk_usage(cand).free > need:
-                base = cand
-                break
-        except OSError:
-            pass
+    want = replicate * nworkers
+    for rep in (want, max(replicate, want // 2), max(replicate // 2, want // 4), max(4, replicate // 2)):
+        need = frames * rep * 45e6 + frames * 12e6 + 1e9          # outputs (43 MB per frame) + inputs + slack
+        for cand in ("/dev/shm", tempfile.gettempdir()):
+            try:
+                if os.path.isdir(cand) and os.access(cand, os.W_OK) and shutil.disk_usage(cand).free > need:
+                    base = cand
+                    break
+            except OSError:
+                pass
+        if base is not None:
+            replicate = rep
+            break
     if base is None:
         return {"error": f"no directory with {need / 1e9:.0f} GB free for the sequence (/dev/shm, {tempfile.gettempdir()})"}
     tmp = tempfile.mkdtemp(prefix="wass_bench_seq_", dir=base)
@@ -344,8 +357,9 @@ def cxx_driver_record(ndirs: int, frames: int = 8, replicate: int = 24, decode_t
                     os.symlink(os.path.join(seq, "%06d_wd" % i, f), os.path.join(dst, f))
                 n += 1
         t0 = time.perf_counter()
-        r = subprocess.run([build.BATCH, cfg, "--sequence", seq, "--gpus", "1", "--decode-threads", str(decode_threads),
-                            "--writer-threads", str(writer_threads)], capture_output=True, text=True)
+        r = subprocess.run([build.BATCH, cfg, "--sequence", seq, "--gpus", str(max(1, gpus)), "--decode-threads", str(decode_threads),
+                            "--writer-threads", str(writer_threads)] + (["--procs-per-gpu", str(procs_per_gpu)] if procs_per_gpu > 1 else []),
+                           capture_output=True, text=True)
         wall = time.perf_counter() - t0
         if r.returncode != 0:
             return {"error": (r.stdout[-600:] + r.stderr[-600:]).strip(), "returncode": r.returncode}
@@ -358,7 +372,8 @@ def cxx_driver_record(ndirs: int, frames: int = 8, replicate: int = 24, decode_t
                 cpu_ms = float(line.split(",")[1].split()[0])
         sizes = [os.path.getsize(os.path.join(seq, "%06d_wd" % (n - 1), f)) for f in ("mesh_cam.xyzC", "plane_refinement_inliers.xyz")]
         return {"pairs_per_sec": round(steady, 2) if steady else None, "pairs_per_sec_incl_startup": round(n / wall, 2), "seconds": round(wall, 2),
-                "frames": n, "distinct_frames": frames, "workers": 1, "decode_threads": decode_threads, "writer_threads": writer_threads,
+                "frames": n, "distinct_frames": frames, "workers": nworkers, "gpus": max(1, gpus), "decode_threads": decode_threads,
+                "writer_threads": writer_threads,
                 "ndirs": ndirs, "pipelined": "pipelined" in r.stdout, "host_cpu_ms_per_frame": cpu_ms, "host_cores_busy": cores,
                 "outputs": "all files wass_stereo writes without its debug pictures, per workdir: mesh_cam.xyzC "
                            f"({sizes[0] / 1e6:.1f} MB), plane.txt, plane_refinement_inliers.xyz ({sizes[1] / 1e6:.1f} MB), camera / pose files, "
@@ -382,9 +397,12 @@ def main():
     ap.add_argument("--no-config-e", action="store_true", help="skip the short config E (3840x2160, D=512) sub-record of the default run")
     ap.add_argument("--no-tail-overlap", action="store_true",
                     help="run the post-SGM stages on the SGM stream instead of the context's tail stream")
-    ap.add_argument("--uploads", action="store_true",
-                    help="make the PCIe-inclusive pass (pinned host pictures uploaded inside every step) the main timed region")
-    ap.add_argument("--no-pcie-pass", action="store_true", help="skip the second, PCIe-inclusive pass")
+    ap.add_argument("--uploads", action="store_true", help="(default since round 5; kept for old command lines)")
+    ap.add_argument("--resident-inputs", action="store_true",
+                    help="make the resident-input pass the main timed region (`value`); kernel-path number, not the contract's metric")
+    ap.add_argument("--no-pcie-pass", "--no-second-pass", dest="no_pcie_pass", action="store_true",
+                    help="skip the second pass (the one that is not `value`)")
+    ap.add_argument("--no-5path", action="store_true", help="skip the 5-path (MODE_SGBM) sub-record of the default run")
     ap.add_argument("--no-cxx-driver", action="store_true", help="skip the C++ sequence driver's own throughput (cxx_driver)")
     ap.add_argument("--stage", default="full", choices=("full", "sgm"),
                     help="full = a1-a20 (SGBM, clean-up, triangulation, plane fit, xyzC); sgm = a1-a6 only")
@@ -484,7 +502,7 @@ def main():
     pipe = FramePipeline(ctx, w, h, params, geom, tail_overlap=tail_overlap) if args.stage == "full" else None
     sgm_out = torch.empty((h, w), dtype=torch.int16, device=dev)
 
-    def run_pass(resident: bool, steps: int, warmup: int):
+    def run_pass(resident: bool, steps: int, warmup: int, pipe=pipe, params=params):
         """W untimed steps, then exactly `steps` timed ones between two barriers; returns what the JSON line needs."""
         planes, npts_hist, nbytes_hist, overflows = [], [], [], []
 
@@ -542,14 +560,23 @@ def main():
         barrier()
         return {"elapsed": time.perf_counter() - t0, "planes": planes, "npts": npts_hist, "nbytes": nbytes_hist, "overflows": overflows, "tm": tm}
 
-    resident_main = not args.uploads
+    # the metric's pass includes the H2D of both pictures.  (Round 4 had the resident pass as `value`; the two
+    # differ by a fraction of a percent -- the 10 MB upload hides under the previous frame -- and both are always reported.)
+    resident_main = bool(args.resident_inputs)
     main_pass = run_pass(resident_main, args.steps, args.warmup)
     elapsed = main_pass["elapsed"]
     planes, npts_hist, nbytes_hist, overflows = main_pass["planes"], main_pass["npts"], main_pass["nbytes"], main_pass["overflows"]
     agg_ms, cost_ms, sel_ms, sgm_ms, vsum_ms = (main_pass["tm"][k] for k in ("agg", "cost", "sel", "sgm", "vsum"))
     other_pass = None
     if world == 1 and not args.no_pcie_pass:
-        other_pass = run_pass(not resident_main, min(args.steps, 40), min(args.warmup, 5))
+        other_pass = run_pass(not resident_main, args.steps, min(args.warmup, 5))
+    # The mode the reference actually runs: StereoSGBM::create leaves MODE_SGBM, five paths (wass_stereo.cpp:775-777).  Same
+    # frames, same chain, same brackets, inputs uploaded inside the step like the headline pass.
+    pass5 = None
+    if world == 1 and args.config == "B" and args.stage == "full" and args.ndirs == 8 and not args.no_5path:
+        params5 = wass_amd.default_sgm_params(D, ndirs=5)
+        pipe5 = FramePipeline(ctx, w, h, params5, geom, tail_overlap=tail_overlap)
+        pass5 = run_pass(False, min(args.steps, 64), min(args.warmup, 5), pipe=pipe5, params=params5)
     # what the column paths add to the cost stage's vertical sum, measured on the last frame's horizontal sums (plain sum vs
     # the production kernel, best of three each, outside the timed region)
     vsum_probe = ctx.sgm_probe_vsum()
@@ -649,6 +676,7 @@ def main():
                        "distinct_frames_per_rank": nf, "stage": args.stage, "tail_overlap": tail_overlap,
                        "inputs": "resident in HBM when the timed region starts" if resident_main else
                                  "pinned host memory, uploaded inside the timed region, one frame ahead (2 images per step)"},
+            "value_is": "resident_inputs" if resident_main else "pcie_inclusive",
             "roofline": {"bound": "hbm", "kernel": "path aggregation family (k_rowsweep + k_ckpt + k_pairx + k_pair [+ k_sweep]), all launches "
                                                    "of one frame, side stream included",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -684,13 +712,33 @@ def main():
             "cost_overflow": int(overflow),
             "repeat_check": repeat_check(planes, npts_hist, args.warmup, nf),
         }
+        def pass_record(ps, steps, resident):
+            return {"pairs_per_sec": round(world * steps / ps["elapsed"], 4), "ms_per_step": round(ps["elapsed"] / steps * 1e3, 3), "steps": steps,
+                    "inputs": ("resident in HBM when the clock starts" if resident else
+                               "both pictures of every frame uploaded from pinned host memory inside the step, one frame ahead (wass_upload_async)"),
+                    "aggregate_ms": round(float(np.mean(ps["tm"]["agg"])), 3)}
+        # both definitions under stable names, whichever one is `value` (the main pass's elapsed is the max over ranks)
+        line["resident_inputs" if resident_main else "pcie_inclusive"] = pass_record({**main_pass, "elapsed": elapsed}, args.steps, resident_main)
         if other_pass is not None:
-            o_steps = min(args.steps, 40)
-            line["pcie_inclusive" if resident_main else "resident_inputs"] = {
-                "pairs_per_sec": round(o_steps / other_pass["elapsed"], 4), "ms_per_step": round(other_pass["elapsed"] / o_steps * 1e3, 3), "steps": o_steps,
-                "inputs": ("both pictures of every frame uploaded from pinned host memory inside the step, one frame ahead (wass_upload_async)"
-                           if resident_main else "resident in HBM"),
-                "aggregate_ms": round(float(np.mean(other_pass["tm"]["agg"])), 3)}
+            line["pcie_inclusive" if resident_main else "resident_inputs"] = pass_record(other_pass, args.steps, not resident_main)
+        if pass5 is not None:
+            s5 = min(args.steps, 64)
+            alg5 = cells * (2 * 5 + 4)
+            t5 = float(np.mean(pass5["tm"]["agg"])) * 1e-3
+            tr5 = measured_traffic(args.config, 5)
+            line["mode_5path"] = {
+                "workload": f"config {args.config}: {w}x{h}, D={D}, 5-path MODE_SGBM (what wass_stereo.cpp:775-777 runs), whole chain a1-a20, "
+                            f"pictures uploaded inside the step, {s5} frames",
+                "pairs_per_sec": round(s5 / pass5["elapsed"], 4), "ms_per_step": round(pass5["elapsed"] / s5 * 1e3, 3), "steps": s5,
+                "aggregate_ms": round(t5 * 1e3, 3),
+                "stage_ms": {"cost_volume": round(float(np.mean(pass5["tm"]["cost"])), 3), "aggregate": round(t5 * 1e3, 3),
+                             "sgm_total": round(float(np.mean(pass5["tm"]["sgm"])), 3)},
+                "roofline": {"bound": "hbm", "kernel": "k_sweep (paths 1, 3) + k_ckpt + k_pair (rows); path 2 rides in k_vsum_col",
+                             "achieved": round(alg5 / t5 / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(alg5 / t5 / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": alg5,
+                             "traffic": int(tr5[0]) if tr5 else None, "traffic_source": tr5[1] if tr5 else None},
+                "repeat_check": repeat_check(pass5["planes"], pass5["npts"], min(args.warmup, 5), nf),
+                "cost_overflow": int(max(pass5["overflows"])) if pass5["overflows"] else 0}
         if world == 1 and args.config == "B" and args.stage == "full" and not args.no_config_e:
             ctx.close()
             ctx = None
@@ -710,6 +758,33 @@ def main():
                 line["cxx_driver"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.config)
+    # N > 1: the PRODUCT's scaling point beside the harness's -- the shipped sequence driver with one worker per GPU, run by rank 0
+    # once every rank has let go of its GPU (contexts closed, caches emptied; the ranks wait at the barrier below meanwhile)
+    multi_cxx = world > 1 and args.config == "B" and args.stage == "full" and not args.no_cxx_driver
+    if multi_cxx:
+        ctx.close()
+        ctx = None
+        del pipe, dres, dring
+        torch.cuda.empty_cache()
+        dist.barrier()
+        if rank == 0:
+            shared = bool(args.allow_shared_gpu and world > ndev)
+            try:
+                line["cxx_driver"] = cxx_driver_record(args.ndirs, gpus=(ndev if shared else world),
+                                                       procs_per_gpu=((world + ndev - 1) // ndev if shared else 1))
+            except Exception as e:
+                line["cxx_driver"] = {"error": f"{type(e).__name__}: {e}"}
+        # the other ranks wait on the HOST (a key of the rendezvous store): an RCCL barrier would spin on their GPUs underneath
+        # the driver's workers
+        try:
+            store = dist.distributed_c10d._get_default_store()
+            if rank == 0:
+                store.set("wass_cxx_driver_done", "1")
+            else:
+                store.wait(["wass_cxx_driver_done"])
+        except Exception:
+            pass
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -75,8 +75,9 @@ int wass_device_alloc(wass_ctx* ctx, size_t nbytes, void** d_out);
 void wass_device_free(wass_ctx* ctx, void* d_ptr);
 /* d_src -> h_dst after everything enqueued on the context so far; returns when the bytes are in host memory */
 int wass_download(wass_ctx* ctx, void* h_dst, const void* d_src, size_t nbytes);
-/* the same without waiting: the copy runs on the context's copy stream once everything enqueued on the SGM stream so far has
- * finished; h_dst (pinned) is complete when a later wass_ctx_frame_result() or wass_ctx_synchronize() returns */
+/* the same without waiting: the copy runs on the context's copy stream once everything enqueued so far on the SGM stream AND on
+ * the tail stream (clean-up, triangulation, mesh stages under tail overlap) has finished; h_dst (pinned) is complete when a
+ * later wass_ctx_frame_result() or wass_ctx_synchronize() returns */
 int wass_download_async(wass_ctx* ctx, void* h_dst, const void* d_src, size_t nbytes);
 int wass_pinned_alloc(wass_ctx* ctx, size_t nbytes, void** h_out);
 void wass_pinned_free(wass_ctx* ctx, void* h_ptr);
@@ -143,6 +144,9 @@ int wass_sgm_last_timings(wass_ctx* ctx, wass_sgm_timings* out);
 /* the call before the last one: lets a pipelined driver read frame n's stage times after frame n+1 has been
  * enqueued, without waiting for frame n+1 */
 int wass_sgm_prev_timings(wass_ctx* ctx, wass_sgm_timings* out);
+/* number of wass_sgm_disparity[_dev] calls of this context that were enqueued completely (a failed call does not count): a
+ * pipelined driver remembers the value after its frame's call and later picks last / prev timings by the difference */
+int wass_sgm_call_count(wass_ctx* ctx, uint64_t* n_calls);
 
 /* Device-side canary for the aggregation kernels: runs one synthetic w x h pair with num_disp disparities through the
  * production schedule (checkpoint sweeps, pair kernels with recomputation, row fusion) and through one plain sweep per path,

@@ -134,6 +134,31 @@ def test_batch_equals_one_process_per_frame(exes, tmp_path, layout):
 
 
 @pytest.mark.gpu
+def test_every_frame_of_a_pipelined_sequence_has_its_gpu_stage_times(exes, tmp_path):
+    """The time table of every frame's log carries GPU event times for the tail stages -- also for the frames that are NOT the last of
+    the sequence: the driver enqueues frame n+1's triangulation before it reads frame n's record, so the tail's timing events are two
+    sets (round 4 had one, and every frame but the last showed 0 s for Triangulation .. Plane refinement)."""
+    import re
+    cli, batch = exes
+    w, h, D = 320, 240, 64
+    seq = tmp_path / "seq"
+    cfg = None
+    nframes = 4
+    for i in range(nframes):
+        t = tmp_path / f"mk{i}"
+        t.mkdir()
+        wd, cfg, *_ = make_workdir(str(t), w, h, D, frame=i)
+        shutil.copytree(wd, seq / ("%06d_wd" % i))
+    r = subprocess.run([batch, cfg, "--sequence", str(seq), "--gpus", "1"], capture_output=True, text=True)
+    assert r.returncode == 0 and "pipelined" in r.stdout, r.stdout + r.stderr
+    for i in range(nframes):
+        log = (seq / ("%06d_wd" % i) / "wass_stereo_log.txt").read_text()
+        rows = dict((m.group(1).strip(), float(m.group(2))) for m in re.finditer(r"\|\s+([A-Za-z][A-Za-z \-]+?)\s+\|\s+([0-9.eE+\-]+) \|", log))
+        for stage in ("Dense Stereo", "Triangulation", "Z-gap stats", "Outlier removal", "Plane fitting", "Plane refinement"):
+            assert rows.get(stage, 0.0) > 0.0, f"frame {i}: row {stage!r} of the time table is {rows.get(stage)} ({sorted(rows)})"
+
+
+@pytest.mark.gpu
 def test_rccl_allreduce_through_the_c_abi(gpu_ctx):
     """Coll-1 over RCCL on one rank (the multi-rank case needs one GPU per rank): unique id, communicator, all-reduce."""
     import ctypes as C

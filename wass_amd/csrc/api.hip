@@ -141,7 +141,8 @@ void wass_ctx_destroy(wass_ctx* c)
     if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
     if (c->ev_producer) (void)hipEventDestroy(c->ev_producer);
     if (c->ev_dl) (void)hipEventDestroy(c->ev_dl);
-    for (auto& e : c->ev_tail) if (e) (void)hipEventDestroy(e);
+    if (c->ev_dl_tail) (void)hipEventDestroy(c->ev_dl_tail);
+    for (auto& set : c->ev_tail_sets) for (auto& e : set) if (e) (void)hipEventDestroy(e);
     if (c->ev_pack) (void)hipEventDestroy(c->ev_pack);
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     for (auto& u : c->uploads) if (u.ev) (void)hipEventDestroy(u.ev);
@@ -220,6 +221,13 @@ int wass_download_async(wass_ctx* c, void* h_dst, const void* d_src, size_t nbyt
     if (!c->ev_dl) WASS_HIP(c, hipEventCreateWithFlags(&c->ev_dl, hipEventDisableTiming));
     WASS_HIP(c, hipEventRecord(c->ev_dl, c->stream));                 // after what the SGM stream has been given so far
     WASS_HIP(c, hipStreamWaitEvent(c->copy, c->ev_dl, 0));
+    if (c->tail_overlap && c->tail) {                                 // ... and the tail stream: the source may be a map it wrote
+        if (!c->ev_dl_tail) WASS_HIP(c, hipEventCreateWithFlags(&c->ev_dl_tail, hipEventDisableTiming));
+        if (hipStreamQuery(c->tail) != hipSuccess) {                  // an idle stream has nothing to order (and an event recorded on
+            WASS_HIP(c, hipEventRecord(c->ev_dl_tail, c->tail));      // one can land behind another stream's work: DESIGN.md 4.3)
+            WASS_HIP(c, hipStreamWaitEvent(c->copy, c->ev_dl_tail, 0));
+        }
+    }
     WASS_HIP(c, hipMemcpyAsync(h_dst, d_src, nbytes, hipMemcpyDeviceToHost, c->copy));
     return WASS_OK;
 }
@@ -349,6 +357,13 @@ int wass_sgm_last_timings(wass_ctx* c, wass_sgm_timings* out)
     if (!c || !out) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
     if (!c->timings_valid || c->nsgm == 0) return set_err(c, WASS_ERR_INVALID_ARG, "no completed wass_sgm_disparity call");
     return read_timings(c, c->nsgm - 1, out);
+}
+
+int wass_sgm_call_count(wass_ctx* c, uint64_t* n_calls)
+{
+    if (!c || !n_calls) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    *n_calls = c->nsgm;
+    return WASS_OK;
 }
 
 int wass_sgm_prev_timings(wass_ctx* c, wass_sgm_timings* out)

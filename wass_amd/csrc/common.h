@@ -139,6 +139,7 @@ struct wass_ctx {
     hipEvent_t ev_stage = nullptr;
     hipEvent_t ev_producer = nullptr; // wass_ctx_wait_for_stream
     hipEvent_t ev_dl = nullptr;        // wass_download_async: orders the copy stream after the SGM stream
+    hipEvent_t ev_dl_tail = nullptr;   // ... and after the tail stream
     bool stage_uv_busy = false;
     hipStream_t copy = nullptr;    // D2H of the xyzC payload
     // Everything after the SGM call (disparity clean-up, triangulation, mesh stages: post.hip, mesh.hip) is enqueued on
@@ -151,8 +152,13 @@ struct wass_ctx {
     hipEvent_t ev_pack = nullptr, ev_copy = nullptr;
     // stage times of the frame tail (wass_frame_result.stage_ms): [0] before k_triangulate, [1] entry of the mesh tail, [2] z-gap
     // percentile found, [3] biggest component kept, [4] RANSAC plane picked, [5] file image packed.  Created on first use.
-    hipEvent_t ev_tail[6] = {};
-    bool tail_timed = false;
+    // Two sets, alternated by wass_triangulate[_dev]: a pipelined driver enqueues frame n+1's triangulation BEFORE it reads frame
+    // n's record, so one set would be re-recorded under the reader (every frame but the last of a sequence had all-zero rows).
+    hipEvent_t ev_tail_sets[2][6] = {};
+    hipEvent_t* ev_tail = ev_tail_sets[0];  // set of the last triangulation
+    int tail_set = 0;
+    bool tail_timed[2] = {};
+    int frame_tail_set = 0;        // the set the pending frame's tail was recorded into
     wass::Buf ccmask;              // valid mask after the outlier removal, kept for graph_components.jpg when asked for
     // wass_upload_async: uploads in flight on the copy stream, by destination; consumers wait for the matching event
     struct UploadSlot { const char* dst = nullptr; size_t n = 0; hipEvent_t ev = nullptr; bool pending = false, consumed = false; };

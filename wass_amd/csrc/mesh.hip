@@ -1221,11 +1221,14 @@ int wass_triangulate_dev(wass_ctx* c, const float* d_disp, int W, int H, const i
     cnt = (unsigned long long*)c->tri_cnt.p;
     if (hipMemsetAsync(cnt, 0, (size_t)NSLOT * 8, c->ts()) != hipSuccess) { wass_mesh_destroy(m); return set_err(c, WASS_ERR_DEVICE, "memset failed"); }
     dim3 grid((m->w + 255) / 256, std::min(m->h, 512));
-    if (!c->ev_tail[0])
-        for (auto& e : c->ev_tail)
-            if (hipEventCreate(&e) != hipSuccess) { e = nullptr; wass_mesh_destroy(m); return set_err(c, WASS_ERR_DEVICE, "hipEventCreate failed"); }
+    if (!c->ev_tail_sets[0][0])
+        for (auto& set : c->ev_tail_sets)
+            for (auto& e : set)
+                if (hipEventCreate(&e) != hipSuccess) { e = nullptr; wass_mesh_destroy(m); return set_err(c, WASS_ERR_DEVICE, "hipEventCreate failed"); }
+    c->tail_set ^= 1;                            // the previous frame's set stays readable until the triangulation after this one
+    c->ev_tail = c->ev_tail_sets[c->tail_set];
     (void)hipEventRecord(c->ev_tail[0], c->ts());
-    c->tail_timed = false;
+    c->tail_timed[c->tail_set] = false;
     hipLaunchKernelGGL(k_triangulate, grid, dim3(256), 0, c->ts(), d_disp, W, H, roi_l[0], roi_r[0], roi_r[1], m->w, m->h,
                        gd, d_right_img, img_w, img_h, d_lmask, d_rmask, tp->min_angle_deg, tp->bbox[0], tp->bbox[1],
                        tp->bbox[2], tp->bbox[3], tp->cam_distance, m->valid, m->x, m->y, m->z, m->gray, m->codes, cnt);
@@ -1994,7 +1997,8 @@ int wass_mesh_finish_frame_async_ex(wass_ctx* c, wass_mesh* m, double percentile
     hipLaunchKernelGGL(k_xyzc_pack_dev, dim3(nb), dim3(256), 0, s, m->valid, m->x, m->y, m->z, n, (const DevState*)ds,
                        (const unsigned int*)bcnt, (uint16_t*)(img + 148));
     WASS_HIP(c, hipGetLastError());
-    if (timed) { (void)hipEventRecord(c->ev_tail[5], s); c->tail_timed = true; }
+    if (timed) { (void)hipEventRecord(c->ev_tail[5], s); c->tail_timed[c->tail_set] = true; }
+    c->frame_tail_set = c->tail_set;
     WASS_HIP(c, hipEventRecord(c->ev_pack, s));
     WASS_HIP(c, hipStreamWaitEvent(c->copy, c->ev_pack, 0));
     WASS_HIP(c, hipMemcpyAsync(c->h_frame, ds, sizeof(DevState), hipMemcpyDeviceToHost, c->copy));
@@ -2023,9 +2027,10 @@ int wass_ctx_frame_result(wass_ctx* c, wass_frame_result* out)
     out->n_points = h.npts;
     out->xyzc_bytes = 148 + (uint64_t)h.npts * 6;
     out->n_triangulated = h.ntri;
-    if (c->tail_timed) {                                     // all six events lie before the download this function has waited for
+    if (c->tail_timed[c->frame_tail_set]) {                  // all six events lie before the download this function has waited for
+        hipEvent_t* const ev = c->ev_tail_sets[c->frame_tail_set];   // the PENDING frame's set: the next frame may have been triangulated already
         for (int k = 0; k < 5; ++k)
-            if (hipEventElapsedTime(&out->stage_ms[k], c->ev_tail[k], c->ev_tail[k + 1]) != hipSuccess) out->stage_ms[k] = 0.0f;
+            if (hipEventElapsedTime(&out->stage_ms[k], ev[k], ev[k + 1]) != hipSuccess) out->stage_ms[k] = 0.0f;
     }
     out->n_inliers_out = c->frame_inl_every > 0 ? ((uint64_t)h.ninl_sel + (uint64_t)c->frame_inl_every - 1) / (uint64_t)c->frame_inl_every : 0;
     if (c->frame_sgm_call > 0 && c->nsgm - c->frame_sgm_call < 2) {

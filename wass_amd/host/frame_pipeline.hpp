@@ -245,6 +245,7 @@ public:
     // previous frame, and `job` itself if it cannot run), in submission order.  They go to finish().
     void submit(FrameJob& job, std::vector<FrameJob*>& done)
     {
+        struct Early { FramePipeline* p; std::vector<FrameJob*>& d; size_t at; ~Early() { d.insert(d.begin() + (long)at, p->early_.begin(), p->early_.end()); p->early_.clear(); } } early{ this, done, done.size() };
         if (job.rc != 0 || job.skipped) {                 // nothing to enqueue: keep the order
             if (FrameJob* p = collect()) done.push_back(p);
             done.push_back(&job);
@@ -310,7 +311,7 @@ public:
             job.disp_slot = nsub_ & 1;
             int16_t* d16 = d_disp16_[job.disp_slot];
             check(wass_sgm_disparity_dev(ctx_, in_[k].d_cr, in_[k].d_cl, cw, ch, (size_t)cw, &sp_, d16), "wass_sgm_disparity");
-            job.sgm_call = ++sgm_calls_;
+            job.sgm_call = (long long)sgm_calls();         // the library's own count: no shadow counter to fall out of step after a failed frame
             const int dil = cfg_.get_int("DISP_DILATE_STEPS"), ero = cfg_.get_int("DISP_EROSION_STEPS"), med = cfg_.get_int("MEDIAN_FILTER_WSIZE");
             if (dil > 0) WLOGI << "applying dilate filter (" << dil << " steps)"; else WLOGI << "dilate filter skipped.";
             if (ero > 0) WLOGI << "applying erode filter (" << ero << " steps)"; else WLOGI << "erode filter skipped.";
@@ -390,7 +391,12 @@ public:
     }
 
     // the last submitted frame (waits for it)
-    void flush(std::vector<FrameJob*>& done) { if (FrameJob* p = collect()) done.push_back(p); }
+    void flush(std::vector<FrameJob*>& done)
+    {
+        done.insert(done.end(), early_.begin(), early_.end());
+        early_.clear();
+        if (FrameJob* p = collect()) done.push_back(p);
+    }
 
     // ---- phase 3 (any thread): everything that is written from the result record (:1374, 1993, 2046-2139)
     void finish(FrameJob& job)
@@ -556,6 +562,7 @@ private:
                     uint8_t* ccmask = nullptr; size_t cc_cap = 0; };
 
     void check(int rc, const char* what) const { if (rc != WASS_OK) throw GpuError(std::string(what) + ": " + wass_last_error(ctx_)); }
+    uint64_t sgm_calls() const { uint64_t n = 0; (void)wass_sgm_call_count(ctx_, &n); return n; }
     void marker(FrameJob& job, int pct) const
     {
         if (!opt_.live) return;
@@ -574,7 +581,7 @@ private:
         if (wass_ctx_frame_result(ctx_, &j->res) != WASS_OK) { WLOGE << "wass_ctx_frame_result: " << wass_last_error(ctx_); j->rc = -1; }
         j->t_result = Timer::now();
         // stage times of the frame's SGM call: the last call, or the last but one if another frame has been enqueued since
-        const long long behind = sgm_calls_ - j->sgm_call;
+        const long long behind = (long long)sgm_calls() - j->sgm_call;
         j->have_sgm = behind == 0 ? wass_sgm_last_timings(ctx_, &j->sgm) == WASS_OK : (behind == 1 && wass_sgm_prev_timings(ctx_, &j->sgm) == WASS_OK);
         if (opt_.debug_pictures && j->mesh) {
             // the maps the debug pictures are drawn from (nothing else has been enqueued since this frame: see submit)
@@ -622,6 +629,8 @@ private:
     {
         if (W == W_ && H == H_ && roi_l.width == cwl_ && roi_l.height == chl_ && roi_r.width == cwr_ && roi_r.height == chr_) return;
         check(wass_ctx_synchronize(ctx_), "wass_ctx_synchronize");
+        // debug pictures: the pending frame's maps are fetched from these buffers when it is collected -- do that first
+        if (opt_.debug_pictures) if (FrameJob* p = collect()) early_.push_back(p);
         release_buffers();
         W_ = W; H_ = H; cwl_ = roi_l.width; chl_ = roi_l.height; cwr_ = roi_r.width; chr_ = roi_r.height;
         const size_t n = (size_t)W * H + 4;
@@ -646,21 +655,21 @@ private:
         if (map_valid_ && key == map_key_) return;
         check(wass_ctx_synchronize(ctx_), "wass_ctx_synchronize");          // a frame in flight may still read the old maps
         const size_t n = (size_t)W_ * H_;
-        std::vector<float> mx(n), my(n);
         void* h = nullptr;
         check(wass_pinned_alloc(ctx_, n * 4 * 4, &h), "wass_pinned_alloc");
+        // freed on every way out; a throw inside the upload loop first waits for the copies that may still read it
+        struct Staging { wass_ctx* c; void* h; ~Staging() { (void)wass_ctx_synchronize(c); wass_pinned_free(c, h); } } staging{ ctx_, h };
         float* hp = (float*)h;
         for (int cam = 0; cam < 2; ++cam) {
             const int rc = cam == 0 ? wass_init_rectify_map(env.K_left.d.data(), env.rec_R1, env.rec_P1, W_, H_, hp, hp + n)
                                     : wass_init_rectify_map(env.K_right.d.data(), env.rec_R2, env.rec_P2, W_, H_, hp + 2 * n, hp + 3 * n);
-            if (rc != WASS_OK) { wass_pinned_free(ctx_, h); throw std::runtime_error("singular rectification"); }
+            if (rc != WASS_OK) throw std::runtime_error("singular rectification");
         }
         for (int i = 0; i < 4; ++i) {
             if (!d_map_[i]) { void* p = nullptr; check(wass_device_alloc(ctx_, n * 4, &p), "wass_device_alloc"); d_map_[i] = (float*)p; }
             check(wass_upload_async(ctx_, d_map_[i], hp + (size_t)i * n, n * 4), "wass_upload_async");
         }
-        check(wass_ctx_synchronize(ctx_), "wass_ctx_synchronize");          // the staging buffer goes away
-        wass_pinned_free(ctx_, h);
+        check(wass_ctx_synchronize(ctx_), "wass_ctx_synchronize");          // the staging buffer goes away (Staging)
         map_key_ = key;
         map_valid_ = true;
     }
@@ -740,7 +749,7 @@ private:
     std::condition_variable out_cv_;
     FrameJob* pending_ = nullptr;
     int nsub_ = 0;
-    long long sgm_calls_ = 0;
+    std::vector<FrameJob*> early_;   // frames collected before their turn (ensure_buffers); handed out by the next submit / flush
     size_t live_pos_ = 0;
 };
 
