@@ -73,6 +73,7 @@ static int make_dims(wass_ctx* c, int w, int h, const wass_sgm_params* p, SgmDim
     d.ftzero = (p->prefilter_cap > 15 ? p->prefilter_cap : 15) | 1;
     if (d.ftzero > 127) return set_err(c, WASS_ERR_UNSUPPORTED, "DENSE_PREFILTER_CAP %d > 126", p->prefilter_cap);
     d.ndirs = p->ndirs;
+    d.diag_fuse = c->diag_fuse ? 1 : 0;
     if (d.width1 <= d.SW2) return set_err(c, WASS_ERR_INVALID_ARG, "image too narrow for the matching window");
     return WASS_OK;
 }
@@ -111,6 +112,7 @@ int wass_ctx_create(int device_id, wass_ctx** out)
     if (ensure(c, c->flags, 64) != WASS_OK) { wass_ctx_destroy(c); return WASS_ERR_NO_MEMORY; }
     if (hipHostMalloc((void**)&c->h_flags, 64, hipHostMallocDefault) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_NO_MEMORY; }
     c->h_flags[0] = c->h_flags[4] = 0;
+    if (const char* e = getenv("WASS_DIAG_FUSE")) c->diag_fuse = atoi(e) != 0;   // 0: the four-family schedule of round 4 (A/B runs on one box)
     mesh_pool_ctx_alive(c, true);
     *out = c;
     return WASS_OK;

@@ -90,6 +90,7 @@ struct SgmDims {
     int ndirs;
     int off_pos, comp;   // max(off,0), max(-off,0)
     int speckle_win = 0, speckle_range = 0;   // cv::filterSpeckles inside compute() when speckle_win > 0
+    int diag_fuse = 0;   // 8 paths, D <= 512: the diagonal family rides on k_pairx too (round 5; wass_ctx::diag_fuse)
     size_t cells() const { return (size_t)h * width1 * Dp; }
 };
 
@@ -186,6 +187,7 @@ struct wass_ctx {
     wass::SgmDims last = {};
     bool have_last = false;
     bool debug = false;            // keep the finished S volume for wass_sgm_debug_fetch
+    bool diag_fuse = true;         // 8 paths, D <= 512: fold the diagonal family into k_pairx (WASS_DIAG_FUSE=0 in the environment: round 4's schedule)
     wass_sgm_timings timings = {};
     bool timings_valid = false;
 };
@@ -252,6 +254,9 @@ struct CkptLayout {
     int nbx = 0;                     // ... blocks of 8 columns per row
     size_t roff[4] = {};             // ... byte offsets into c->ckpt: entry states of paths 0 / 4, minima of paths 0 / 4
     bool path2_from_cost = false;    // 5-path mode: k_vsum_col has already written S = L_2 (path 2 has no partner)
+    bool diag_fused = false;         // round 5: the diagonal family is folded into k_pairx as well (k_diagsweep); families: columns, anti-diagonals
+    int nyb = 0, pm = 0;             // ... blocks of K rows in image order; u16 per chain in the minima records
+    size_t doff[6] = {};             // ... byte offsets into c->ckpt: ET1, EL1, EB7, ER7 (entry states), M1, M7 (minima)
 };
 CkptLayout ckpt_layout(const SgmDims& d);
 
