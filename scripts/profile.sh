@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-config-e --no-cxx-driver --no-pcie-pass $*"
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-config-e --no-cxx-driver --no-pcie-pass --no-5path $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python "$ROOT/bench.py" $ARGS > "$OUT/stats.log" 2>&1
 # counters in their own passes (no trace domains besides --kernel-trace)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o run -- python "$ROOT/bench.py" $ARGS > "$OUT/pmc_fetch.log" 2>&1

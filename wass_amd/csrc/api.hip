@@ -112,7 +112,7 @@ int wass_ctx_create(int device_id, wass_ctx** out)
     if (ensure(c, c->flags, 64) != WASS_OK) { wass_ctx_destroy(c); return WASS_ERR_NO_MEMORY; }
     if (hipHostMalloc((void**)&c->h_flags, 64, hipHostMallocDefault) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_NO_MEMORY; }
     c->h_flags[0] = c->h_flags[4] = 0;
-    if (const char* e = getenv("WASS_DIAG_FUSE")) c->diag_fuse = atoi(e) != 0;   // 0: the four-family schedule of round 4 (A/B runs on one box)
+    if (const char* e = getenv("WASS_DIAG_FUSE")) c->diag_fuse = atoi(e) != 0;   // 1: the three-guest schedule of round 5 (A/B runs on one box)
     mesh_pool_ctx_alive(c, true);
     *out = c;
     return WASS_OK;

@@ -187,7 +187,9 @@ struct wass_ctx {
     wass::SgmDims last = {};
     bool have_last = false;
     bool debug = false;            // keep the finished S volume for wass_sgm_debug_fetch
-    bool diag_fuse = true;         // 8 paths, D <= 512: fold the diagonal family into k_pairx (WASS_DIAG_FUSE=0 in the environment: round 4's schedule)
+    // 8 paths, D <= 512: fold the diagonal family into k_pairx as well (round 5; WASS_DIAG_FUSE=1 in the environment when the context is
+    // created).  Bit-exact, 28.1 instead of 31.6 GB per config-B frame -- and slower (7.25 against 6.36 ms, NOTES/aggregation.md): OFF.
+    bool diag_fuse = false;
     wass_sgm_timings timings = {};
     bool timings_valid = false;
 };

@@ -700,7 +700,7 @@ __host__ __device__ __forceinline__ void yblock(int y, int h, int K, int& yb, bo
     if (y < mid) { yb = y / K; top = (y % K) == 0; bot = (y % K) == K - 1 || y == mid - 1; }
     else { const int z = h - 1 - y; yb = nb0 + nb1 - 1 - z / K; bot = (z % K) == 0; top = (z % K) == K - 1 || y == mid; }
 }
-inline int yblock_count(int h, int K) { const int mid = h / 2; return (mid + K - 1) / K + (h - mid + K - 1) / K; }
+__host__ __device__ inline int yblock_count(int h, int K) { const int mid = h / 2; return (mid + K - 1) / K + (h - mid + K - 1) / K; }
 
 template <int NP>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4)))
@@ -728,23 +728,40 @@ k_diagsweep(const uint32_t* __restrict__ C, uint32_t* __restrict__ ET1, uint32_t
     PathState<NP> sf, sb;
     sf.reset();
     sb.reset();
-    // the state with which a path ENTERS the pixel it is about to step on, where that pixel lies on a block edge
-    auto enter = [&](int t) {
-        if (t == 0) return;                                 // the image border: the all-zero state, never read
-        int yb;
-        bool top, bot;
-        const int y1 = y0 + t, y7 = y0 + n - 1 - t;
-        yblock(y1, h, K, yb, top, bot);
-        if (top) sf.store_normalised(ET1 + ((size_t)yb * width1 + (x0 + t)) * vec + lane * NP);
-        else if (cx1 == 0) sf.store_normalised(EL1 + ((size_t)y1 * nbx + bx1) * vec + lane * NP);
-        yblock(y7, h, K, yb, top, bot);
-        if (bot) sb.store_normalised(EB7 + ((size_t)yb * width1 + (x0 + n - 1 - t)) * vec + lane * NP);
-        else if (cx7 == XB - 1) sb.store_normalised(ER7 + ((size_t)y7 * nbx + bx7) * vec + lane * NP);
+    // The state with which a path ENTERS the pixel it is about to step on is kept where that pixel lies on a block edge.  Which of
+    // the U = K steps of a group those are is worked out once per group as bit masks (wave-uniform scalar arithmetic; a first form
+    // that decided per step cost 170 scalar instructions per step, and one with bool& outputs went through scratch memory):
+    //   block-top rows (path 1):    y = 0 mod K below the middle row, the middle row itself, y = h mod K above it
+    //   block-bottom rows (path 7): y = K-1 mod K below the middle row, the row above the middle, y = h-1 mod K from the middle on
+    //   block-left / -right columns: x = 0 / XB-1 mod XB -- at most one per group (U <= XB)
+    // The chain's own first pixels (t = 0) get their all-zero entry state stored like any other; nobody reads it.
+    static_assert(K == U && U <= XB, "one block-top row of each kind and one block-left column per group of U steps");
+    const int mid = h / 2, nyb = yblock_count(h, K);
+    auto st_entry = [&](uint32_t* base, uint32_t off, const PathState<NP>& st) {
+        const us2 mv = pk_splat(st.m);
+        us2 nrm[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) nrm[j] = st.L[j] - mv;
+        buf_st<NP>(mk_rsrc(base), voff, off, nrm);
     };
-    auto advance = [&]() {
-        if (++cx1 == XB) { cx1 = 0; ++bx1; }
-        if (--cx7 < 0) { cx7 = XB - 1; --bx7; }
-    };
+    auto yb_of = [&](int y) { return y < mid ? y / K : nyb - 1 - (h - 1 - y) / K; };
+#define WASS_DIAG_MASKS(t0_)                                                                                                         \
+        const int y1a = y0 + (t0_), y7a = y0 + n - 1 - (t0_);   /* rows of the group: path 1 y1a .. y1a+U-1, path 7 y7a .. y7a-(U-1) */ \
+        uint32_t mt, mb;                                                                                                             \
+        {                                                                                                                            \
+            const int ua = (-y1a) & (K - 1), um = mid - y1a, uc = (h - y1a) & (K - 1);                                               \
+            mt = (y1a + ua < mid ? 1u << ua : 0u) | ((unsigned)um < (unsigned)U ? 1u << um : 0u) | (y1a + uc > mid ? 1u << uc : 0u);  \
+            const int va = (y7a + 1) & (K - 1), vm = y7a - (mid - 1), vc = (y7a + 1 - h) & (K - 1);                                  \
+            mb = (y7a - va < mid ? 1u << va : 0u) | ((unsigned)vm < (unsigned)U ? 1u << vm : 0u) | (y7a - vc >= mid ? 1u << vc : 0u); \
+        }                                                                                                                            \
+        const int ul = cx1 == 0 ? 0 : XB - cx1, ur = cx7 == XB - 1 ? 0 : cx7 + 1;                                                    \
+        const uint32_t o_l = ((uint32_t)(y1a + ul) * (uint32_t)nbx + (uint32_t)(bx1 + (cx1 == 0 ? 0 : 1))) * VB;                     \
+        const uint32_t o_r = ((uint32_t)(y7a - ur) * (uint32_t)nbx + (uint32_t)(bx7 - (cx7 == XB - 1 ? 0 : 1))) * VB;
+#define WASS_DIAG_ENTRIES(t0_, u_)                                                                                                   \
+            if (mt & (1u << (u_))) st_entry(ET1, ((uint32_t)yb_of(y1a + (u_)) * (uint32_t)width1 + (uint32_t)(x0 + (t0_) + (u_))) * VB, sf);         \
+            else if ((u_) == ul) st_entry(EL1, o_l, sf);                                                                             \
+            if (mb & (1u << (u_))) st_entry(EB7, ((uint32_t)yb_of(y7a - (u_)) * (uint32_t)width1 + (uint32_t)(x0 + n - 1 - (t0_) - (u_))) * VB, sb); \
+            else if ((u_) == ur) st_entry(ER7, o_r, sb);
     us2 rf[U][NP], rb[U][NP];
     const int G = n / U, rem = n - G * U;                   // G groups of U steps, then rem steps
     if (G > 0) {
@@ -764,9 +781,10 @@ k_diagsweep(const uint32_t* __restrict__ C, uint32_t* __restrict__ ET1, uint32_t
         const rsrc_t rnf = af.run<NP>(C, nxt, cnn), rnb = ab.run<NP>(C, nxt, cnn);
         const uint32_t bnb = ab.bias(cnn);
         uint32_t msf[U], msb[U];
+        WASS_DIAG_MASKS(t0)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            enter(t0 + u);
+            WASS_DIAG_ENTRIES(t0, u)
             us2 Lf[NP], Lb[NP];
             sgm_step_pair<NP>(sf, rf[u], Lf, sb, rb[u], Lb, P1v, P2);
             msf[u] = sf.m;
@@ -774,8 +792,9 @@ k_diagsweep(const uint32_t* __restrict__ C, uint32_t* __restrict__ ET1, uint32_t
             const int uc = min(u, cnn - 1);
             buf_ld<NP>(rnf, voff, uc * af.sstep, rf[u]);
             buf_ld<NP>(rnb, voff, bnb + uc * ab.sstep, rb[u]);
-            advance();
         }
+        cx1 += U; if (cx1 >= XB) { cx1 -= XB; ++bx1; }
+        cx7 -= U; if (cx7 < 0) { cx7 += XB; --bx7; }
         store_minima<U>(m1row + (size_t)g * (U / 2), msf, lane);
         {                                                   // path 7's minima cover positions n-t0-U .. n-1-t0: not aligned
             uint32_t v = msb[0];
@@ -799,16 +818,16 @@ k_diagsweep(const uint32_t* __restrict__ C, uint32_t* __restrict__ ET1, uint32_t
         uint32_t msf[U], msb[U];
 #pragma unroll
         for (int i = 0; i < U; ++i) msf[i] = msb[i] = 0;
+        WASS_DIAG_MASKS(t0)
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (u < rem) {
-                enter(t0 + u);
+                WASS_DIAG_ENTRIES(t0, u)
                 us2 Lf[NP], Lb[NP];
                 sgm_step_pair<NP>(sf, rf[u], Lf, sb, rb[u], Lb, P1v, P2);
                 msf[u] = sf.m;
 #pragma unroll
                 for (int i = 0; i < U; ++i) msb[i] = i == rem - 1 - u ? sb.m : msb[i];     // position rem-1-u
-                advance();
             }
         {                                                   // positions t0 .. t0+rem-1 (t0 is even: whole dwords, the pad is never read)
             uint32_t v = msf[0] | (msf[1] << 16);
@@ -824,6 +843,8 @@ k_diagsweep(const uint32_t* __restrict__ C, uint32_t* __restrict__ ET1, uint32_t
         }
     }
 }
+#undef WASS_DIAG_MASKS
+#undef WASS_DIAG_ENTRIES
 
 struct DiagSide {                    // what k_diagsweep left behind
     const uint32_t* ET1; const uint32_t* EL1; const uint32_t* EB7; const uint32_t* ER7;
