@@ -352,6 +352,11 @@ typedef struct {
      * wass_triangulate[_dev] call of this context.  Under tail overlap the tail shares the GPU with the next frame's SGM stage. */
     float stage_ms[5];
     int reserved;
+    /* wass_mesh_finish_frame_async_ex2: bytes of plane_refinement_inliers.xyz text in inliers_text_dst, and how many of its numbers
+     * the device formatter could not write (inf, nan, |v| >= 1e6 or < 1e-22; never a triangulated coordinate): when that is not
+     * zero the text is NOT the file -- format inliers_dst on the host instead */
+    uint64_t inliers_text_bytes;
+    uint32_t inliers_text_unsupported, reserved2;
 } wass_frame_result;
 int wass_mesh_finish_frame_async(wass_ctx* ctx, wass_mesh* m, double percentile, const int32_t* uv_triplets, int rounds,
                                  double ransac_thr, const wass_refine_params* rp, double max_distance, void* dst,
@@ -366,6 +371,19 @@ int wass_mesh_finish_frame_async_ex(wass_ctx* ctx, wass_mesh* m, double percenti
                                     double ransac_thr, const wass_refine_params* rp, double max_distance, void* dst,
                                     size_t capacity, double* inliers_dst, size_t inliers_capacity, int inliers_every,
                                     uint8_t* component_mask_dst);
+/* The same, and the file's TEXT as well: "x y z\n" per selected inlier, every number as a default-constructed std::ofstream
+ * prints a double (precision 6, %g -- wass_stereo.cpp:2077-2085), formatted ON THE DEVICE (csrc/fmt_g6.h: correctly rounded in
+ * 128-bit integer arithmetic, the characters of printf("%g")).  1.4 million numbers per 5-megapixel frame are a third of a
+ * worker's host time when the host formats them.  inliers_text_dst: pinned host memory for 40 * ceil(width*height /
+ * inliers_every) bytes (a line is at most 39 bytes); the valid length comes back in wass_frame_result.inliers_text_bytes.
+ * inliers_dst is still filled (and required): the host's fallback should inliers_text_unsupported be non-zero. */
+int wass_mesh_finish_frame_async_ex2(wass_ctx* ctx, wass_mesh* m, double percentile, const int32_t* uv_triplets, int rounds,
+                                     double ransac_thr, const wass_refine_params* rp, double max_distance, void* dst,
+                                     size_t capacity, double* inliers_dst, size_t inliers_capacity, int inliers_every,
+                                     uint8_t* component_mask_dst, char* inliers_text_dst, size_t inliers_text_capacity);
+/* one number as the device writes it (the same code built for the host): the characters of printf("%g", v) in out[0 .. return),
+ * or -1 outside the formatter's domain.  out must hold 16 bytes.  Pure host function: no context, no GPU. */
+int wass_format_g6(double v, char* out);
 int wass_ctx_frame_result(wass_ctx* ctx, wass_frame_result* out);
 
 /* RT_from_plane (:1044-1069); pure host math */

@@ -43,7 +43,8 @@ class FrameResult(C.Structure):
                 ("plane", C.c_double * 4), ("refine_inliers", C.c_uint64), ("kept_after_ransac_crop", C.c_uint64),
                 ("kept_final", C.c_uint64), ("n_points", C.c_uint64), ("xyzc_bytes", C.c_uint64),
                 ("sgm_cost_overflow", C.c_int), ("sgm_timeout", C.c_int), ("n_triangulated", C.c_uint64),
-                ("n_inliers_out", C.c_uint64), ("stage_ms", C.c_float * 5), ("reserved", C.c_int)]
+                ("n_inliers_out", C.c_uint64), ("stage_ms", C.c_float * 5), ("reserved", C.c_int),
+                ("inliers_text_bytes", C.c_uint64), ("inliers_text_unsupported", C.c_uint32), ("reserved2", C.c_uint32)]
 
 
 class GridSetup(C.Structure):
@@ -136,6 +137,9 @@ SYMBOLS = {
     "wass_mesh_finish_frame_async": (_i, [_vp, _vp, C.c_double, _vp, _i, C.c_double, C.POINTER(RefineParams), C.c_double, _vp, _sz]),
     "wass_mesh_finish_frame_async_ex": (_i, [_vp, _vp, C.c_double, _vp, _i, C.c_double, C.POINTER(RefineParams), C.c_double, _vp, _sz,
                                              _vp, _sz, _i, _vp]),
+    "wass_mesh_finish_frame_async_ex2": (_i, [_vp, _vp, C.c_double, _vp, _i, C.c_double, C.POINTER(RefineParams), C.c_double, _vp, _sz,
+                                              _vp, _sz, _i, _vp, _vp, _sz]),
+    "wass_format_g6": (_i, [C.c_double, _vp]),
     "wass_ctx_frame_result": (_i, [_vp, C.POINTER(FrameResult)]),
     "wass_device_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "wass_device_free": (None, [_vp, _vp]),

@@ -8,6 +8,7 @@
 // operations in the same order as the reference's plain x86-64 build, so the
 // inlier counts of RANSAC / crop_plane are reproduced exactly.
 #include "common.h"
+#include "fmt_g6.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -400,7 +401,8 @@ struct DevState {
     unsigned int npts, have_plane;
     unsigned long long kept1, kept2;
     unsigned long long ntri;                              // valid points the triangulation produced
-    unsigned int ninl_sel, pad2;                          // refinement inliers seen by the selection for plane_refinement_inliers.xyz
+    unsigned int ninl_sel, inl_text_bad;                  // refinement inliers seen by the selection for plane_refinement_inliers.xyz;
+    unsigned long long inl_text_bytes;                    // ... bytes of that file's text when the device formatted it, numbers it could not format
 };
 
 // z gaps computed on the fly (no gap array): histogram of one 11-bit digit of the fp64 bit patterns that match the
@@ -840,6 +842,59 @@ __global__ void __launch_bounds__(256) k_inlier_pack(const uint8_t* __restrict__
         double* o = out + (size_t)(k / every) * 3;
         o[0] = px; o[1] = py; o[2] = pz;
     }
+}
+
+// ---- plane_refinement_inliers.xyz as TEXT, on the device (round 5).  The reference writes "x y z\n" per selected inlier through a
+// default ofstream (wass_stereo.cpp:2077-2085): six significant digits, %g.  fmt_g6.h produces exactly those characters; a line
+// is at most 3 x 12 + 3 = 39 bytes.  Two passes over the selected points (their number is only known on the device): line
+// lengths per block of 256 points -> k_scan_blocks -> the lines written at their offsets.  A number outside the formatter's
+// domain (inf, nan, |v| >= 1e6 or < 1e-22: never a triangulated coordinate) is counted in *bad and the host formats the file
+// from the doubles instead, as before.
+constexpr int INL_LINE_MAX = 40;
+__device__ __forceinline__ int inl_line(const double* __restrict__ p, char* buf, unsigned int& bad)
+{
+    int n = 0;
+#pragma unroll 1
+    for (int k = 0; k < 3; ++k) {
+        int l = fmt_g6(p[k], buf + n);
+        if (l < 0) { ++bad; buf[n] = '?'; l = 1; }
+        n += l;
+        buf[n++] = k < 2 ? ' ' : '\n';
+    }
+    return n;
+}
+__global__ void __launch_bounds__(256) k_inl_text_count(const double* __restrict__ pts, const unsigned int* __restrict__ total, unsigned int every,
+                                                        unsigned int* __restrict__ blockbytes, unsigned int* __restrict__ bad_out)
+{
+    __shared__ unsigned int wsum[4];
+    const unsigned int nsel = (*total + every - 1) / every;
+    const unsigned int j = blockIdx.x * 256 + threadIdx.x;
+    unsigned int len = 0, bad = 0;
+    if (j < nsel) { char buf[INL_LINE_MAX + 8]; len = (unsigned)inl_line(pts + (size_t)j * 3, buf, bad); }
+    unsigned int sum = len;
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) blockbytes[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (bad) atomicAdd(bad_out, bad);
+}
+__global__ void __launch_bounds__(256) k_inl_text_write(const double* __restrict__ pts, const unsigned int* __restrict__ total, unsigned int every,
+                                                        const unsigned int* __restrict__ blockoff, char* __restrict__ out)
+{
+    __shared__ unsigned int wsum[4];
+    const unsigned int nsel = (*total + every - 1) / every;
+    const unsigned int j = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    char buf[INL_LINE_MAX + 8];
+    unsigned int len = 0, bad = 0;
+    if (j < nsel) len = (unsigned)inl_line(pts + (size_t)j * 3, buf, bad);
+    unsigned int incl = len;                               // inclusive scan over the wave, then over the block's four waves
+    for (int o = 1; o < 64; o <<= 1) { const unsigned int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    unsigned int off = blockoff[blockIdx.x] + incl - len;
+    for (int q = 0; q < wv; ++q) off += wsum[q];
+    for (unsigned int i = 0; i < len; ++i) out[off + i] = buf[i];
 }
 
 // smallest-eigenvalue eigenvector of a symmetric 3x3 (cyclic Jacobi); stands in for row 2 of cv::SVD's vt
@@ -1434,9 +1489,15 @@ __global__ void __launch_bounds__(256) k_crop_limits_counts_dev(uint8_t* __restr
 // frame tail: limits -> scale factors, and the 148-byte header of the file image (PovMesh.cpp:417-436)
 __global__ void k_frame_header(DevState* __restrict__ ds, const unsigned long long* __restrict__ lim, const unsigned int* __restrict__ total,
                                const unsigned long long* __restrict__ kept /* [2][NSLOT] */, unsigned char* __restrict__ img,
-                               const unsigned long long* __restrict__ tri /* [NSLOT] or null */, const unsigned int* __restrict__ inl_total /* or null */)
+                               const unsigned long long* __restrict__ tri /* [NSLOT] or null */, const unsigned int* __restrict__ inl_total /* or null */,
+                               const unsigned int* __restrict__ text_total /* [0] bytes, [1] numbers not formatted; or null */)
 {
     if (blockIdx.x) return;
+    if (threadIdx.x == 0) {
+        const bool have = text_total && inl_total && ds->ransac_found;
+        ds->inl_text_bytes = have ? text_total[0] : 0ull;
+        ds->inl_text_bad = have ? text_total[1] : 0u;
+    }
     {
         unsigned long long k1 = 0, k2 = 0, k3 = 0;
         for (int i = threadIdx.x; i < NSLOT; i += 64) { k1 += kept[i]; k2 += kept[NSLOT + i]; k3 += tri ? tri[i] : 0ull; }
@@ -1928,8 +1989,18 @@ int wass_mesh_finish_frame_async_ex(wass_ctx* c, wass_mesh* m, double percentile
                                     const wass_refine_params* rp, double max_distance, void* dst, size_t capacity,
                                     double* inliers_dst, size_t inliers_capacity, int inliers_every, uint8_t* component_mask_dst)
 {
+    return wass_mesh_finish_frame_async_ex2(c, m, percentile, uv, rounds, ransac_thr, rp, max_distance, dst, capacity, inliers_dst, inliers_capacity,
+                                            inliers_every, component_mask_dst, nullptr, 0);
+}
+
+int wass_mesh_finish_frame_async_ex2(wass_ctx* c, wass_mesh* m, double percentile, const int32_t* uv, int rounds, double ransac_thr,
+                                     const wass_refine_params* rp, double max_distance, void* dst, size_t capacity,
+                                     double* inliers_dst, size_t inliers_capacity, int inliers_every, uint8_t* component_mask_dst,
+                                     char* inliers_text_dst, size_t inliers_text_capacity)
+{
     if (!c || !m || !dst) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
     if (inliers_dst && (inliers_every <= 0 || inliers_capacity == 0)) return set_err(c, WASS_ERR_INVALID_ARG, "bad inlier selection");
+    if (inliers_text_dst && !inliers_dst) return set_err(c, WASS_ERR_INVALID_ARG, "the inlier text comes with the inlier points (the host's fallback)");
     WASS_HIP(c, hipSetDevice(c->device));
     const size_t n = m->n();
     if (capacity < 148 + n * 6)
@@ -1956,7 +2027,8 @@ int wass_mesh_finish_frame_async_ex(wass_ctx* c, wass_mesh* m, double percentile
     hipStream_t s = c->ts();
     // plane_refinement_inliers.xyz: the refinement inliers are the points that survived the crop by the RANSAC plane, which
     // enqueue_fit_plane has just applied; the final crop (below) has not run yet -- the point main() collects them at
-    size_t inl_copy = 0;
+    size_t inl_copy = 0, text_copy = 0;
+    const char* text_src = nullptr;
     unsigned int* inl_total = nullptr;
     if (inliers_dst) {
         RefineDev rd;
@@ -1968,8 +2040,12 @@ int wass_mesh_finish_frame_async_ex(wass_ctx* c, wass_mesh* m, double percentile
         rd.vmax = rp->central_third_only ? m->h * 2 / 3 : m->h - 1;
         const size_t cap = (n + (size_t)inliers_every - 1) / (size_t)inliers_every;
         if (inliers_capacity < cap) return set_err(c, WASS_ERR_INVALID_ARG, "inliers_dst must hold %zu points", cap);
-        if ((rc = ensure(c, c->inl, cap * 24 + 256))) return rc;
-        inl_total = (unsigned int*)c->inl.p;                       // [0]: number of refinement inliers; points from byte 256
+        const unsigned nb2 = nblk(cap);
+        const size_t text_off = (256 + cap * 24 + (size_t)nb2 * 4 + 255) & ~(size_t)255;
+        if (inliers_text_dst && inliers_text_capacity < cap * INL_LINE_MAX)
+            return set_err(c, WASS_ERR_INVALID_ARG, "inliers_text_dst must hold %zu bytes", cap * (size_t)INL_LINE_MAX);
+        if ((rc = ensure(c, c->inl, text_off + (inliers_text_dst ? cap * INL_LINE_MAX : 0)))) return rc;
+        inl_total = (unsigned int*)c->inl.p;                       // [0]: number of refinement inliers, [2]: bytes of text, [3]: numbers not formatted; points from byte 256
         unsigned int* bc = (unsigned int*)((char*)c->scratch.p + 64);
         double* dout = (double*)((char*)c->inl.p + 256);
         WASS_HIP(c, hipStreamWaitEvent(s, c->ev_copy, 0));        // the previous frame's download of this buffer
@@ -1978,6 +2054,17 @@ int wass_mesh_finish_frame_async_ex(wass_ctx* c, wass_mesh* m, double percentile
         hipLaunchKernelGGL(k_inlier_pack, dim3(nb), dim3(256), 0, s, m->valid, m->x, m->y, m->z, m->w, n, rd, (const unsigned int*)bc,
                            (unsigned)inliers_every, dout);
         inl_copy = cap * 24;
+        if (inliers_text_dst) {                                   // the file's text, formatted here (fmt_g6.h)
+            unsigned int* bb = (unsigned int*)((char*)c->inl.p + 256 + cap * 24);
+            WASS_HIP(c, hipMemsetAsync(inl_total + 2, 0, 8, s));
+            hipLaunchKernelGGL(k_inl_text_count, dim3(nb2), dim3(256), 0, s, (const double*)dout, (const unsigned int*)inl_total, (unsigned)inliers_every, bb,
+                               inl_total + 3);
+            hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, bb, (int)nb2, inl_total + 2);
+            hipLaunchKernelGGL(k_inl_text_write, dim3(nb2), dim3(256), 0, s, (const double*)dout, (const unsigned int*)inl_total, (unsigned)inliers_every,
+                               (const unsigned int*)bb, (char*)c->inl.p + text_off);
+            text_copy = cap * INL_LINE_MAX;
+            text_src = (const char*)c->inl.p + text_off;
+        }
     }
     hipLaunchKernelGGL(k_frame_rt, dim3(1), dim3(64), 0, s, ds);
     unsigned char* stage = nullptr;
@@ -1993,7 +2080,8 @@ int wass_mesh_finish_frame_async_ex(wass_ctx* c, wass_mesh* m, double percentile
                        (const DevState*)ds, max_distance, kept1 + NSLOT, lim, bcnt, nb);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, bcnt, (int)nb, total);
     hipLaunchKernelGGL(k_frame_header, dim3(1), dim3(64), 0, s, ds, (const unsigned long long*)lim, (const unsigned int*)total,
-                       (const unsigned long long*)kept1, img, (const unsigned long long*)c->tri_cnt.p, (const unsigned int*)inl_total);
+                       (const unsigned long long*)kept1, img, (const unsigned long long*)c->tri_cnt.p, (const unsigned int*)inl_total,
+                       text_copy ? (const unsigned int*)(inl_total + 2) : (const unsigned int*)nullptr);
     hipLaunchKernelGGL(k_xyzc_pack_dev, dim3(nb), dim3(256), 0, s, m->valid, m->x, m->y, m->z, n, (const DevState*)ds,
                        (const unsigned int*)bcnt, (uint16_t*)(img + 148));
     WASS_HIP(c, hipGetLastError());
@@ -2004,6 +2092,8 @@ int wass_mesh_finish_frame_async_ex(wass_ctx* c, wass_mesh* m, double percentile
     WASS_HIP(c, hipMemcpyAsync(c->h_frame, ds, sizeof(DevState), hipMemcpyDeviceToHost, c->copy));
     WASS_HIP(c, hipMemcpyAsync(dst, img, 148 + n * 6, hipMemcpyDeviceToHost, c->copy));
     if (inl_copy) WASS_HIP(c, hipMemcpyAsync(inliers_dst, (const char*)c->inl.p + 256, inl_copy, hipMemcpyDeviceToHost, c->copy));
+    // (the text's length is only known on the device: the copy takes what a frame of this size can need at most -- 0.1 ms per MB)
+    if (text_copy) WASS_HIP(c, hipMemcpyAsync(inliers_text_dst, text_src, text_copy, hipMemcpyDeviceToHost, c->copy));
     if (component_mask_dst) WASS_HIP(c, hipMemcpyAsync(component_mask_dst, c->ccmask.p, n, hipMemcpyDeviceToHost, c->copy));
     WASS_HIP(c, hipEventRecord(c->ev_copy, c->copy));
     c->frame_inl_every = inliers_dst ? inliers_every : 0;
@@ -2011,6 +2101,8 @@ int wass_mesh_finish_frame_async_ex(wass_ctx* c, wass_mesh* m, double percentile
     c->frame_sgm_call = c->nsgm;              // the SGM call that fed this frame is the last one enqueued (0: none)
     return WASS_OK;
 }
+
+int wass_format_g6(double v, char* out) { return out ? wass::fmt_g6(v, out) : -1; }
 
 int wass_ctx_frame_result(wass_ctx* c, wass_frame_result* out)
 {
@@ -2033,6 +2125,8 @@ int wass_ctx_frame_result(wass_ctx* c, wass_frame_result* out)
             if (hipEventElapsedTime(&out->stage_ms[k], ev[k], ev[k + 1]) != hipSuccess) out->stage_ms[k] = 0.0f;
     }
     out->n_inliers_out = c->frame_inl_every > 0 ? ((uint64_t)h.ninl_sel + (uint64_t)c->frame_inl_every - 1) / (uint64_t)c->frame_inl_every : 0;
+    out->inliers_text_bytes = c->frame_inl_every > 0 ? h.inl_text_bytes : 0;
+    out->inliers_text_unsupported = c->frame_inl_every > 0 ? h.inl_text_bad : 0;
     if (c->frame_sgm_call > 0 && c->nsgm - c->frame_sgm_call < 2) {
         // status word of the frame's SGM call: copied to pinned memory in stream order long before the download this
         // function has just waited for; the slot is reused two calls later

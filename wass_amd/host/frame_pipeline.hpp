@@ -116,7 +116,7 @@ public:
         if (!ctx_) return;
         (void)wass_ctx_synchronize(ctx_);
         release_buffers();
-        for (auto& o : out_) { if (o.xyzc) wass_pinned_free(ctx_, o.xyzc); if (o.inl) wass_pinned_free(ctx_, o.inl); for (auto& u : o.und) if (u) wass_pinned_free(ctx_, u); if (o.ccmask) wass_pinned_free(ctx_, o.ccmask); }
+        for (auto& o : out_) { if (o.xyzc) wass_pinned_free(ctx_, o.xyzc); if (o.inl) wass_pinned_free(ctx_, o.inl); if (o.inl_text) wass_pinned_free(ctx_, o.inl_text); for (auto& u : o.und) if (u) wass_pinned_free(ctx_, u); if (o.ccmask) wass_pinned_free(ctx_, o.ccmask); }
         wass_ctx_destroy(ctx_);
     }
     // the pipeline's context, created if need be (owner thread); nullptr when there is no usable GPU
@@ -358,10 +358,13 @@ public:
                 uv_seed_ = job.ransac_seed; uv_w_ = rr[2]; uv_h_ = rr[3];
             }
             const int slot = job.out_slot;
-            check(wass_mesh_finish_frame_async_ex(ctx_, mesh, cfg_.get_double("ZGAP_PERCENTILE"), uv_.data(), rounds, cfg_.get_double("PLANE_RANSAC_THRESHOLD"),
-                                                  &rp_, cfg_.get_double("PLANE_MAX_DISTANCE"), out_[slot].xyzc, out_[slot].xyzc_cap,
-                                                  opt_.inliers_file ? out_[slot].inl : nullptr, opt_.inliers_file ? out_[slot].inl_cap : 0, 10,
-                                                  opt_.debug_pictures ? out_[slot].ccmask : nullptr),
+            // plane_refinement_inliers.xyz comes back as TEXT, formatted on the device (csrc/fmt_g6.h); the points come along for the
+            // one case in which the host still has to format them (a number outside the device formatter's domain)
+            check(wass_mesh_finish_frame_async_ex2(ctx_, mesh, cfg_.get_double("ZGAP_PERCENTILE"), uv_.data(), rounds, cfg_.get_double("PLANE_RANSAC_THRESHOLD"),
+                                                   &rp_, cfg_.get_double("PLANE_MAX_DISTANCE"), out_[slot].xyzc, out_[slot].xyzc_cap,
+                                                   opt_.inliers_file ? out_[slot].inl : nullptr, opt_.inliers_file ? out_[slot].inl_cap : 0, 10,
+                                                   opt_.debug_pictures ? out_[slot].ccmask : nullptr,
+                                                   opt_.inliers_file && device_text_ ? out_[slot].inl_text : nullptr, opt_.inliers_file && device_text_ ? out_[slot].inl_text_cap : 0),
                   "wass_mesh_finish_frame_async");
             if (opt_.debug_pictures) job.mesh = mesh;       // its rejection codes are fetched when the frame is collected
             else wass_mesh_destroy(mesh);                   // back to the context's pool; the kernels enqueued on it run in stream order
@@ -444,7 +447,13 @@ public:
                     WLOGI << "refinement inliers (after cropping): " << r.refine_inliers;
                     WLOGI << "estimated plane coeffs: " << r.plane[0] << " " << r.plane[1] << " " << r.plane[2] << " " << r.plane[3];
                     WLOG_SCOPE("wass_stereo");
-                    if (opt_.inliers_file) write_inliers_xyz(path_join(env.workdir, "plane_refinement_inliers.xyz"), out_[job.out_slot].inl, (size_t)r.n_inliers_out);
+                    if (opt_.inliers_file) {
+                        const std::string ip = path_join(env.workdir, "plane_refinement_inliers.xyz");
+                        if (device_text_ && r.inliers_text_unsupported == 0 && (r.inliers_text_bytes > 0 || r.n_inliers_out == 0)) {
+                            std::ofstream ofs(ip.c_str(), std::ios::binary);
+                            ofs.write(out_[job.out_slot].inl_text, (std::streamsize)r.inliers_text_bytes);
+                        } else write_inliers_xyz(ip, out_[job.out_slot].inl, (size_t)r.n_inliers_out);      // the host's formatter (hostio.hpp fmt_g6)
+                    }
                     WLOG_SCOPE("crop_plane");
                     WLOGI << "number of points after plane cropping: " << r.kept_final;
                     WLOG_SCOPE("wass_stereo");
@@ -559,7 +568,7 @@ private:
     struct InSet { uint8_t *h_l = nullptr, *h_r = nullptr, *d_l = nullptr, *d_r = nullptr, *d_cl = nullptr, *d_cr = nullptr, *d_ml = nullptr, *d_mr = nullptr,
                            *d_rawl = nullptr, *d_rawr = nullptr, *d_tmp = nullptr, *h_fl = nullptr, *h_fr = nullptr, *d_fl = nullptr, *d_fr = nullptr; };
     struct OutSet { void* xyzc = nullptr; size_t xyzc_cap = 0; double* inl = nullptr; size_t inl_cap = 0; uint8_t* und[2] = { nullptr, nullptr }; size_t und_cap = 0;
-                    uint8_t* ccmask = nullptr; size_t cc_cap = 0; };
+                    uint8_t* ccmask = nullptr; size_t cc_cap = 0; char* inl_text = nullptr; size_t inl_text_cap = 0; };
 
     void check(int rc, const char* what) const { if (rc != WASS_OK) throw GpuError(std::string(what) + ": " + wass_last_error(ctx_)); }
     uint64_t sgm_calls() const { uint64_t n = 0; (void)wass_sgm_call_count(ctx_, &n); return n; }
@@ -698,6 +707,13 @@ private:
             check(wass_pinned_alloc(ctx_, icap * 24, &p), "wass_pinned_alloc");
             o.inl = (double*)p; o.inl_cap = icap;
         }
+        if (opt_.inliers_file && device_text_ && o.inl_text_cap < icap * 40) {
+            if (o.inl_text) wass_pinned_free(ctx_, o.inl_text);
+            o.inl_text = nullptr; o.inl_text_cap = 0;
+            void* p = nullptr;
+            check(wass_pinned_alloc(ctx_, icap * 40, &p), "wass_pinned_alloc");
+            o.inl_text = (char*)p; o.inl_text_cap = icap * 40;
+        }
         if (und_bytes > o.und_cap) {
             for (auto& u : o.und) {
                 if (u) wass_pinned_free(ctx_, u);
@@ -751,6 +767,8 @@ private:
     int nsub_ = 0;
     std::vector<FrameJob*> early_;   // frames collected before their turn (ensure_buffers); handed out by the next submit / flush
     size_t live_pos_ = 0;
+    // WASS_HOST_INLIER_TEXT=1: the round-4 form (the host formats the inlier file from the downloaded points); same bytes either way
+    bool device_text_ = !(getenv("WASS_HOST_INLIER_TEXT") && atoi(getenv("WASS_HOST_INLIER_TEXT")) != 0);
 };
 
 }  // namespace wassframe

@@ -6,6 +6,7 @@
 //   PLY / xyzbin      src/wass_stereo/PovMesh.cpp:346-375,463-517 (App. B.2, B.6)
 #pragma once
 
+#include <dlfcn.h>
 #include <zlib.h>
 
 #include <charconv>
@@ -149,6 +150,86 @@ inline bool save_matrix_txt(const std::string& filename, const Mat& m)
     return true;
 }
 
+// ------------------------------------------------------------------ zlib streams, fast
+// A frame's host time is mostly zlib: two 5-megapixel PNGs inflated (2 x 25 ms with libz), two previews deflated.  libdeflate
+// does the same streams 2-3 times faster; the image ships its runtime (libdeflate.so.0) but no header, so the handful of entry
+// points used here are declared locally and resolved with dlopen -- and libz remains the fallback when the library is not
+// there (WASS_NO_LIBDEFLATE=1 forces it).  Same bytes out of inflate either way; deflate output differs between the two
+// (any valid stream is a valid PNG), which is why only files whose PIXELS matter are written through it.
+struct FastZ {
+    void* (*alloc_d)() = nullptr;
+    int (*zlib_d)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
+    void (*free_d)(void*) = nullptr;
+    void* (*alloc_c)(int) = nullptr;
+    size_t (*zlib_c)(void*, const void*, size_t, void*, size_t) = nullptr;
+    size_t (*bound_c)(void*, size_t) = nullptr;
+    void (*free_c)(void*) = nullptr;
+    bool ok = false;
+    FastZ()
+    {
+        const char* off = getenv("WASS_NO_LIBDEFLATE");
+        if (off && atoi(off) != 0) return;
+        void* h = nullptr;
+        for (const char* n : { "libdeflate.so.0", "libdeflate.so" }) if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!h) return;
+        alloc_d = (void* (*)())dlsym(h, "libdeflate_alloc_decompressor");
+        zlib_d = (int (*)(void*, const void*, size_t, void*, size_t, size_t*))dlsym(h, "libdeflate_zlib_decompress");
+        free_d = (void (*)(void*))dlsym(h, "libdeflate_free_decompressor");
+        alloc_c = (void* (*)(int))dlsym(h, "libdeflate_alloc_compressor");
+        zlib_c = (size_t (*)(void*, const void*, size_t, void*, size_t))dlsym(h, "libdeflate_zlib_compress");
+        bound_c = (size_t (*)(void*, size_t))dlsym(h, "libdeflate_zlib_compress_bound");
+        free_c = (void (*)(void*))dlsym(h, "libdeflate_free_compressor");
+        ok = alloc_d && zlib_d && free_d && alloc_c && zlib_c && bound_c && free_c;
+    }
+    static const FastZ& get() { static const FastZ z; return z; }
+};
+// a whole zlib stream -> exactly outn bytes
+inline bool zlib_inflate_exact(const uint8_t* in, size_t n, uint8_t* out, size_t outn)
+{
+    const FastZ& z = FastZ::get();
+    if (z.ok) {
+        struct D { const FastZ& z; void* d; ~D() { if (d) z.free_d(d); } };
+        static thread_local D dec{ z, nullptr };                   // a decompressor is not thread-safe; one per thread, reused
+        if (!dec.d) dec.d = z.alloc_d();
+        if (dec.d) {
+            size_t got = 0;
+            if (z.zlib_d(dec.d, in, n, out, outn, &got) == 0 && got == outn) return true;
+            // (a stream libdeflate refuses -- e.g. one with a preset dictionary -- gets its second chance below)
+        }
+    }
+    uLongf len = (uLongf)outn;
+    return uncompress(out, &len, in, (uLong)n) == Z_OK && len == outn;
+}
+// bytes -> a zlib stream; level 1 .. 9.  NOT byte-stable across the two libraries: for files whose pixels matter, not their bytes.
+inline bool zlib_deflate_fast(const uint8_t* in, size_t n, int level, std::vector<uint8_t>& out)
+{
+    const FastZ& z = FastZ::get();
+    if (z.ok) {
+        if (void* c = z.alloc_c(level)) {
+            out.resize(z.bound_c(c, n));
+            const size_t got = z.zlib_c(c, in, n, out.data(), out.size());
+            z.free_c(c);
+            if (got) { out.resize(got); return true; }
+        }
+    }
+    uLongf clen = compressBound((uLong)n);
+    out.resize(clen);
+    if (compress2(out.data(), &clen, in, (uLong)n, level) != Z_OK) return false;
+    out.resize(clen);
+    return true;
+}
+inline bool read_whole_file(const std::string& filename, std::vector<uint8_t>& f)
+{
+    FILE* fp = fopen(filename.c_str(), "rb");
+    if (!fp) return false;
+    bool ok = fseek(fp, 0, SEEK_END) == 0;
+    const long n = ok ? ftell(fp) : -1;
+    ok = ok && n >= 0 && fseek(fp, 0, SEEK_SET) == 0;
+    if (ok) { f.resize((size_t)n); ok = n == 0 || fread(f.data(), 1, (size_t)n, fp) == (size_t)n; }
+    fclose(fp);
+    return ok;
+}
+
 // ------------------------------------------------------------------ images
 struct Image {
     int w = 0, h = 0;
@@ -166,19 +247,22 @@ inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint3
 // like cv::imread(IMREAD_GRAYSCALE) (BT.601 fixed point); anything else is rejected with a clear message.
 inline Image read_png_gray(const std::string& filename)
 {
-    std::ifstream ifs(filename.c_str(), std::ios::binary);
-    if (!ifs.is_open()) throw std::runtime_error("unable to open " + filename);
-    std::vector<uint8_t> f((std::istreambuf_iterator<char>(ifs)), std::istreambuf_iterator<char>());
+    std::vector<uint8_t> f;
+    if (!read_whole_file(filename, f)) throw std::runtime_error("unable to open " + filename);
     static const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a };
     if (f.size() < 33 || memcmp(f.data(), sig, 8) != 0) throw std::runtime_error(filename + " is not a PNG file");
     int w = 0, h = 0, depth = 0, ctype = 0, interlace = 0;
-    std::vector<uint8_t> idat;
+    // the IDAT payloads, moved together in place (the zlib stream may be cut into chunks anywhere): no second buffer
+    size_t zpos = 0, zlen = 0;
     for (size_t p = 8; p + 12 <= f.size();) {
         const uint32_t len = be32(&f[p]);
         const char* type = (const char*)&f[p + 4];
         if (p + 12 + len > f.size()) throw std::runtime_error(filename + ": truncated PNG chunk");
-        if (!memcmp(type, "IHDR", 4)) { w = (int)be32(&f[p + 8]); h = (int)be32(&f[p + 12]); depth = f[p + 16]; ctype = f[p + 17]; interlace = f[p + 20]; }
-        else if (!memcmp(type, "IDAT", 4)) idat.insert(idat.end(), f.begin() + p + 8, f.begin() + p + 8 + len);
+        if (!memcmp(type, "IHDR", 4)) { if (len < 13) throw std::runtime_error(filename + ": bad IHDR"); w = (int)be32(&f[p + 8]); h = (int)be32(&f[p + 12]); depth = f[p + 16]; ctype = f[p + 17]; interlace = f[p + 20]; }
+        else if (!memcmp(type, "IDAT", 4)) {
+            if (zlen == 0) zpos = p + 8; else memmove(&f[zpos + zlen], &f[p + 8], len);     // always towards lower addresses
+            zlen += len;
+        }
         else if (!memcmp(type, "IEND", 4)) break;
         p += 12 + len;
     }
@@ -188,14 +272,22 @@ inline Image read_png_gray(const std::string& filename)
     const int ch = ctype == 0 ? 1 : (ctype == 4 ? 2 : (ctype == 2 ? 3 : 4));
     const size_t stride = (size_t)w * ch;
     std::vector<uint8_t> raw((stride + 1) * h);
-    uLongf rawlen = (uLongf)raw.size();
-    if (uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size())
+    if (!zlib_inflate_exact(f.data() + zpos, zlen, raw.data(), raw.size()))
         throw std::runtime_error(filename + ": zlib inflate failed");
     std::vector<uint8_t> cur(stride), prev(stride, 0);
     Image img(w, h);
     for (int y = 0; y < h; ++y) {
         const uint8_t ft = raw[(stride + 1) * y];
         const uint8_t* in = &raw[(stride + 1) * y + 1];
+        if (ch == 1 && ft <= 2) {
+            // grey rows with the filters None / Sub / Up (what fast encoders write): straight into the picture
+            uint8_t* o = &img.px[(size_t)y * w];
+            if (ft == 0) memcpy(o, in, stride);
+            else if (ft == 1) { uint8_t a = 0; for (size_t i = 0; i < stride; ++i) { a = (uint8_t)(in[i] + a); o[i] = a; } }
+            else { const uint8_t* up = y > 0 ? o - w : prev.data(); for (size_t i = 0; i < stride; ++i) o[i] = (uint8_t)(in[i] + up[i]); }
+            memcpy(prev.data(), o, stride);                  // a later row may use a filter of the general form
+            continue;
+        }
         for (size_t i = 0; i < stride; ++i) {
             const int a = i >= (size_t)ch ? cur[i - ch] : 0, b = prev[i], c = i >= (size_t)ch ? prev[i - ch] : 0;
             int v = in[i];
@@ -290,9 +382,10 @@ inline bool write_png_gray(const std::string& filename, const Image& img)
 {
     std::vector<uint8_t> raw((size_t)(img.w + 1) * img.h);
     for (int y = 0; y < img.h; ++y) { raw[(size_t)(img.w + 1) * y] = 0; memcpy(&raw[(size_t)(img.w + 1) * y + 1], &img.px[(size_t)y * img.w], img.w); }
-    uLongf clen = compressBound((uLong)raw.size());
-    std::vector<uint8_t> comp(clen);
-    if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 3) != Z_OK) return false;
+    // level 1, like cv::imwrite's default (Z_BEST_SPEED): a valid PNG with these pixels is the contract, not its bytes
+    std::vector<uint8_t> comp;
+    if (!zlib_deflate_fast(raw.data(), raw.size(), 1, comp)) return false;
+    const size_t clen = comp.size();
     std::ofstream ofs(filename.c_str(), std::ios::binary);
     if (ofs.fail()) return false;
     auto chunk = [&](const char* type, const uint8_t* data, uint32_t len) {
