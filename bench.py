@@ -278,21 +278,12 @@ def config_e_record(dev_index: int, ndirs: int, steps: int = 5, warmup: int = 2,
             "cost_overflow": int(overflow)}
 
 
-def cxx_driver_record(ndirs: int, frames: int = 8, replicate: int = 24, decode_threads: int = 8, writer_threads: int = 4,
-                      gpus: int = 1, procs_per_gpu: int = 1):
-    """What drops into wasscli: the C++ sequence driver (wass_amd/host/wass_stereo_batch.cpp, frame_pipeline.hpp -- decode threads
-    -> device-resident frame chain -> writer threads) on a sequence of config-B workdirs as wass_prepare / wass_autocalibrate
-    leave them (PNG + XML), one worker process on this GPU, every output a tool reads written (mesh_cam.xyzC, plane.txt, the
-    camera files, the previews, the log; plane_refinement_inliers.xyz too).  `frames` distinct pairs, each workdir replicated
-    `replicate` times with symlinked inputs.  The sequence lives in /dev/shm (memory-backed: 43 MB of output per frame).
-    gpus > 1 (bench.py --gpus N, rank 0 after every rank has released its GPU): one worker process per GPU, `replicate` workdir
-    copies PER GPU (fewer when the scratch directory cannot hold them) -- the product's own scaling point beside the harness's."""
-    import shutil
+def make_sequence(tmp: str, frames: int, replicate: int, ndirs: int):
+    """A config-B sequence of workdirs as wass_prepare / wass_autocalibrate leave them (PNG + XML) under tmp/output: `frames` distinct
+    synthetic pairs, each workdir replicated `replicate` times with symlinked inputs.  Returns (sequence dir, config file, workdirs)."""
     import struct
-    import subprocess
-    import tempfile
     import zlib
-    from wass_amd import build, synth
+    from wass_amd import synth
     w, h, D = CONFIGS["B"]
 
     def write_png(path, img):                    # zlib level 1: valid PNG files, quickly (the decoder's work is the same)
@@ -311,6 +302,50 @@ def cxx_driver_record(ndirs: int, frames: int = 8, replicate: int = 24, decode_t
         with open(path, "w") as f:
             f.write(f'<?xml version="1.0"?>\n<opencv_storage>\n<{node} type_id="opencv-matrix">\n  <rows>{m.shape[0]}</rows>\n'
                     f'  <cols>{m.shape[1]}</cols>\n  <dt>d</dt>\n  <data>\n    {data}</data></{node}>\n</opencv_storage>\n')
+
+    seq = os.path.join(tmp, "output")
+    rig = synth.rig_geometry(w, h)
+    cfg = os.path.join(tmp, "stereo_config.txt")
+    open(cfg, "w").write(f"MAX_DISPARITY={D}\nRANDOM_SEED=12345\nUSE_CUSTOM_STEREORECTIFY=true\nRECTIFY_ANGLE=1e-6\nDISABLE_RECTIFY_ROI=true\n"
+                         f"DENSE_PATHS={ndirs}\n")
+    inputs = ("undistorted/00000000.png", "undistorted/00000001.png", "intrinsics_00000000.xml", "intrinsics_00000001.xml", "ext_R.xml", "ext_T.xml")
+    for i in range(frames):
+        wd = os.path.join(seq, "%06d_wd" % i)
+        os.makedirs(os.path.join(wd, "undistorted"))
+        right, left = [t.cpu().numpy() for t in synth.make_pair_torch(w, h, D, frame_idx=700000 + i)]
+        write_png(os.path.join(wd, "undistorted", "00000000.png"), left)
+        write_png(os.path.join(wd, "undistorted", "00000001.png"), right)
+        write_xml(os.path.join(wd, "intrinsics_00000000.xml"), "intr", rig["K_left"])
+        write_xml(os.path.join(wd, "intrinsics_00000001.xml"), "intr", rig["K_right"])
+        write_xml(os.path.join(wd, "ext_R.xml"), "R", rig["R"])
+        write_xml(os.path.join(wd, "ext_T.xml"), "T", np.array(rig["T"]).reshape(3, 1) * 2.5)
+    n = frames
+    for _ in range(1, replicate):
+        for i in range(frames):
+            dst = os.path.join(seq, "%06d_wd" % n)
+            os.makedirs(os.path.join(dst, "undistorted"))
+            for f in inputs:
+                os.symlink(os.path.join(seq, "%06d_wd" % i, f), os.path.join(dst, f))
+            n += 1
+    return seq, cfg, n
+
+
+def cxx_driver_record(ndirs: int, frames: int = 8, replicate: int = 24, decode_threads: int = 8, writer_threads: int = 4,
+                      gpus: int = 1, procs_per_gpu: int = 1):
+    """What drops into wasscli: the C++ sequence driver (wass_amd/host/wass_stereo_batch.cpp, frame_pipeline.hpp -- decode threads
+    -> device-resident frame chain -> writer threads) on a sequence of config-B workdirs as wass_prepare / wass_autocalibrate
+    leave them (PNG + XML), one worker process on this GPU, every output a tool reads written (mesh_cam.xyzC, plane.txt, the
+    camera files, the previews, the log; plane_refinement_inliers.xyz too).  `frames` distinct pairs, each workdir replicated
+    `replicate` times with symlinked inputs.  The sequence lives in /dev/shm (memory-backed: 43 MB of output per frame).
+    gpus > 1 (bench.py --gpus N, rank 0 after every rank has released its GPU): one worker process per GPU, `replicate` workdir
+    copies PER GPU (fewer when the scratch directory cannot hold them) -- the product's own scaling point beside the harness's."""
+    import shutil
+    import struct
+    import subprocess
+    import tempfile
+    import zlib
+    from wass_amd import build, synth
+    w, h, D = CONFIGS["B"]
 
     build.build_host()
     nworkers = max(1, gpus) * max(1, procs_per_gpu)
@@ -332,30 +367,7 @@ def cxx_driver_record(ndirs: int, frames: int = 8, replicate: int = 24, decode_t
         return {"error": f"no directory with {need / 1e9:.0f} GB free for the sequence (/dev/shm, {tempfile.gettempdir()})"}
     tmp = tempfile.mkdtemp(prefix="wass_bench_seq_", dir=base)
     try:
-        seq = os.path.join(tmp, "output")
-        rig = synth.rig_geometry(w, h)
-        cfg = os.path.join(tmp, "stereo_config.txt")
-        open(cfg, "w").write(f"MAX_DISPARITY={D}\nRANDOM_SEED=12345\nUSE_CUSTOM_STEREORECTIFY=true\nRECTIFY_ANGLE=1e-6\nDISABLE_RECTIFY_ROI=true\n"
-                             f"DENSE_PATHS={ndirs}\n")
-        inputs = ("undistorted/00000000.png", "undistorted/00000001.png", "intrinsics_00000000.xml", "intrinsics_00000001.xml", "ext_R.xml", "ext_T.xml")
-        for i in range(frames):
-            wd = os.path.join(seq, "%06d_wd" % i)
-            os.makedirs(os.path.join(wd, "undistorted"))
-            right, left = [t.cpu().numpy() for t in synth.make_pair_torch(w, h, D, frame_idx=700000 + i)]
-            write_png(os.path.join(wd, "undistorted", "00000000.png"), left)
-            write_png(os.path.join(wd, "undistorted", "00000001.png"), right)
-            write_xml(os.path.join(wd, "intrinsics_00000000.xml"), "intr", rig["K_left"])
-            write_xml(os.path.join(wd, "intrinsics_00000001.xml"), "intr", rig["K_right"])
-            write_xml(os.path.join(wd, "ext_R.xml"), "R", rig["R"])
-            write_xml(os.path.join(wd, "ext_T.xml"), "T", np.array(rig["T"]).reshape(3, 1) * 2.5)
-        n = frames
-        for _ in range(1, replicate):
-            for i in range(frames):
-                dst = os.path.join(seq, "%06d_wd" % n)
-                os.makedirs(os.path.join(dst, "undistorted"))
-                for f in inputs:
-                    os.symlink(os.path.join(seq, "%06d_wd" % i, f), os.path.join(dst, f))
-                n += 1
+        seq, cfg, n = make_sequence(tmp, frames, replicate, ndirs)
         t0 = time.perf_counter()
         r = subprocess.run([build.BATCH, cfg, "--sequence", seq, "--gpus", str(max(1, gpus)), "--decode-threads", str(decode_threads),
                             "--writer-threads", str(writer_threads)] + (["--procs-per-gpu", str(procs_per_gpu)] if procs_per_gpu > 1 else []),
@@ -403,6 +415,9 @@ def main():
     ap.add_argument("--no-pcie-pass", "--no-second-pass", dest="no_pcie_pass", action="store_true",
                     help="skip the second pass (the one that is not `value`)")
     ap.add_argument("--no-5path", action="store_true", help="skip the 5-path (MODE_SGBM) sub-record of the default run")
+    ap.add_argument("--inlier-text", action="store_true",
+                    help="also produce plane_refinement_inliers.xyz (every 10th refinement inlier, text formatted on the device) per frame, like "
+                         "the C++ driver does; not part of the metric's pass")
     ap.add_argument("--no-cxx-driver", action="store_true", help="skip the C++ sequence driver's own throughput (cxx_driver)")
     ap.add_argument("--stage", default="full", choices=("full", "sgm"),
                     help="full = a1-a20 (SGBM, clean-up, triangulation, plane fit, xyzC); sgm = a1-a6 only")
@@ -499,7 +514,7 @@ def main():
     # refine -> crop -> mesh_cam.xyzC (defaults of SURVEY.md Appendix C, RANDOM_SEED=12345), as wass_amd.batch.FramePipeline
     # enqueues it: no host synchronisation inside a frame, the previous frame's output is collected while this one runs
     from wass_amd.batch import FramePipeline
-    pipe = FramePipeline(ctx, w, h, params, geom, tail_overlap=tail_overlap) if args.stage == "full" else None
+    pipe = FramePipeline(ctx, w, h, params, geom, tail_overlap=tail_overlap, inliers_text=args.inlier_text) if args.stage == "full" else None
     sgm_out = torch.empty((h, w), dtype=torch.int16, device=dev)
 
     def run_pass(resident: bool, steps: int, warmup: int, pipe=pipe, params=params):

@@ -75,6 +75,10 @@ int wass_device_alloc(wass_ctx* ctx, size_t nbytes, void** d_out);
 void wass_device_free(wass_ctx* ctx, void* d_ptr);
 /* d_src -> h_dst after everything enqueued on the context so far; returns when the bytes are in host memory */
 int wass_download(wass_ctx* ctx, void* h_dst, const void* d_src, size_t nbytes);
+/* cv::resize(src, dst, Size(dw, dh), 0, 0, INTER_CUBIC) of an 8-bit picture resident in HBM (the 0000000X_s.png previews of
+ * load_data, wass_stereo.cpp:401-417): 11-bit fixed-point weights, the arithmetic of the DENSE_SCALE resampler.  On the context's
+ * SGM stream; waits for pending uploads of d_src.  d_dst: dw * dh bytes, dense. */
+int wass_resize_cubic_u8_dev(wass_ctx* ctx, const uint8_t* d_src, int sw, int sh, size_t src_stride, uint8_t* d_dst, int dw, int dh);
 /* the same without waiting: the copy runs on the context's copy stream once everything enqueued so far on the SGM stream AND on
  * the tail stream (clean-up, triangulation, mesh stages under tail overlap) has finished; h_dst (pinned) is complete when a
  * later wass_ctx_frame_result() or wass_ctx_synchronize() returns */
@@ -375,8 +379,10 @@ int wass_mesh_finish_frame_async_ex(wass_ctx* ctx, wass_mesh* m, double percenti
  * prints a double (precision 6, %g -- wass_stereo.cpp:2077-2085), formatted ON THE DEVICE (csrc/fmt_g6.h: correctly rounded in
  * 128-bit integer arithmetic, the characters of printf("%g")).  1.4 million numbers per 5-megapixel frame are a third of a
  * worker's host time when the host formats them.  inliers_text_dst: pinned host memory for 40 * ceil(width*height /
- * inliers_every) bytes (a line is at most 39 bytes); the valid length comes back in wass_frame_result.inliers_text_bytes.
- * inliers_dst is still filled (and required): the host's fallback should inliers_text_unsupported be non-zero. */
+ * inliers_every) bytes (a line is at most 39 bytes); the valid length comes back in wass_frame_result.inliers_text_bytes.  When
+ * the buffer is pinned host memory (wass_pinned_alloc, hipHostMalloc) the kernel writes the text straight into it and exactly the
+ * file's bytes cross PCIe.  inliers_dst may be NULL then (the points are not downloaded); should inliers_text_unsupported come
+ * back non-zero, wass_ctx_frame_inliers() fetches them for the host's formatter -- before the next frame's tail is enqueued. */
 int wass_mesh_finish_frame_async_ex2(wass_ctx* ctx, wass_mesh* m, double percentile, const int32_t* uv_triplets, int rounds,
                                      double ransac_thr, const wass_refine_params* rp, double max_distance, void* dst,
                                      size_t capacity, double* inliers_dst, size_t inliers_capacity, int inliers_every,
@@ -384,6 +390,9 @@ int wass_mesh_finish_frame_async_ex2(wass_ctx* ctx, wass_mesh* m, double percent
 /* one number as the device writes it (the same code built for the host): the characters of printf("%g", v) in out[0 .. return),
  * or -1 outside the formatter's domain.  out must hold 16 bytes.  Pure host function: no context, no GPU. */
 int wass_format_g6(double v, char* out);
+/* the selected inlier points of the frame whose wass_ctx_frame_result() was read last (n_inliers_out of them), copied on demand and
+ * synchronously; valid until the next wass_mesh_finish_frame_async* call of the context */
+int wass_ctx_frame_inliers(wass_ctx* ctx, double* dst, size_t capacity_points, uint64_t* n_out);
 int wass_ctx_frame_result(wass_ctx* ctx, wass_frame_result* out);
 
 /* RT_from_plane (:1044-1069); pure host math */

@@ -121,7 +121,9 @@ def test_batch_equals_one_process_per_frame(exes, tmp_path, layout):
     for i in range(nframes):
         log = (seq_b / ("%06d_wd" % i) / "wass_stereo_log.txt").read_text()
         assert log.count("Reconstructing") == 1 and ("%06d_wd" % i) in log and "estimated plane coeffs" in log
-        for name in ("mesh_cam.xyzC", "plane.txt", "P0cam.txt", "Cam1_poseT.txt", "plane_refinement_inliers.xyz"):
+        # (the previews: resized by load_data on the host in wass_stereo, on the GPU in the driver's pipelined chain)
+        for name in ("mesh_cam.xyzC", "plane.txt", "P0cam.txt", "Cam1_poseT.txt", "plane_refinement_inliers.xyz", "00000000_s.png", "00000001_s.png",
+                     "K0_small.txt", "scale.txt"):
             a = (seq_a / ("%06d_wd" % i) / name).read_bytes()
             assert a == (seq_b / ("%06d_wd" % i) / name).read_bytes(), f"frame {i}: {name} differs"
         expect += " ".join((seq_a / ("%06d_wd" % i) / "plane.txt").read_text().split("\n")).strip() + "\n"

@@ -550,3 +550,31 @@ def test_frame_pipeline_matches_stage_by_stage(gpu_ctx, oracle):
     for (_, pl, by), (rpl, rby) in zip(outs, ref):
         np.testing.assert_array_equal(pl, rpl)
         assert by == rby
+
+
+@pytest.mark.gpu
+def test_inlier_text_from_the_device_equals_printf(gpu_ctx):
+    """wass_mesh_finish_frame_async_ex2: the text of plane_refinement_inliers.xyz as the device formats it (csrc/fmt_g6.h) is, byte for
+    byte, what printf("%g %g %g\\n") makes of the selected points -- the reference's default-ofstream output (wass_stereo.cpp:2077-2085)."""
+    import torch
+    import wass_amd
+    from wass_amd import synth
+    from wass_amd.batch import FramePipeline
+    w, h, D = 640, 480, 64
+    dev = torch.device("cuda", 0)
+    params = wass_amd.default_sgm_params(D, ndirs=5)
+    geom = wass_amd.make_geom(synth.rig_geometry(w, h))
+    pipe = FramePipeline(gpu_ctx, w, h, params, geom, inliers_text=True, keep_inlier_points=True)
+    outs = []
+    for k in range(3):
+        r, l = synth.make_pair_torch(w, h, D, frame_idx=40 + k, device=dev)
+        mask = (r <= 254).to(torch.uint8)
+        o = pipe.submit(r, l, d_right_image=r, d_right_mask=mask)
+        if o is not None:
+            outs.append((o.inliers_xyz.copy(), bytes(o.inliers_text)))
+    o = pipe.flush()
+    outs.append((o.inliers_xyz.copy(), bytes(o.inliers_text)))
+    assert len(outs) == 3
+    for xyz, text in outs:
+        assert len(xyz) > 1000
+        assert text == "".join("%g %g %g\n" % tuple(p) for p in xyz).encode()

@@ -140,11 +140,13 @@ SYMBOLS = {
     "wass_mesh_finish_frame_async_ex2": (_i, [_vp, _vp, C.c_double, _vp, _i, C.c_double, C.POINTER(RefineParams), C.c_double, _vp, _sz,
                                               _vp, _sz, _i, _vp, _vp, _sz]),
     "wass_format_g6": (_i, [C.c_double, _vp]),
+    "wass_ctx_frame_inliers": (_i, [_vp, _vp, _sz, C.POINTER(C.c_uint64)]),
     "wass_ctx_frame_result": (_i, [_vp, C.POINTER(FrameResult)]),
     "wass_device_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "wass_device_free": (None, [_vp, _vp]),
     "wass_download": (_i, [_vp, _vp, _vp, _sz]),
     "wass_download_async": (_i, [_vp, _vp, _vp, _sz]),
+    "wass_resize_cubic_u8_dev": (_i, [_vp, _vp, _i, _i, _sz, _vp, _i, _i]),
     "wass_pinned_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "wass_pinned_free": (None, [_vp, _vp]),
     "wass_free": (None, [_vp]),

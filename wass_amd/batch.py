@@ -49,7 +49,7 @@ class FramePipeline:
     def __init__(self, ctx: "stereo.Context", width: int, height: int, params, geom, roi_l=None, roi_r=None,
                  dilate_steps=1, erode_steps=2, median_wsize=0, min_angle_deg=20.0, zgap_percentile=99.0,
                  ransac_rounds=400, random_seed=12345, ransac_thr=1.0, plane_max_distance=1.5, refine=None,
-                 tail_overlap=True):
+                 tail_overlap=True, inliers_text=False, keep_inlier_points=False):
         import torch
         if params.dense_scale != 1.0:
             # the pipelined chain keeps every map at the crop size; DENSE_SCALE != 1 goes through the stage-by-stage calls
@@ -71,6 +71,14 @@ class FramePipeline:
         # wass_stereo seeds rand() once per process = once per frame (wass_stereo.cpp:1864-1872), so every frame of a
         # sequence draws the same RANSAC triplets for a given grid size: draw them once
         self._uv = stereo.ransac_sample(mw, mh, ransac_rounds, random_seed)
+        # plane_refinement_inliers.xyz (wass_stereo.cpp:2077-2085) as the C++ driver produces it: every 10th refinement inlier, and
+        # the file's text formatted on the device; off by default (the reference's debug artefact is not part of the metric's pass)
+        self._inl_text = None
+        self._keep_points = keep_inlier_points
+        if inliers_text:
+            cap = (mw * mh + 9) // 10
+            self._inl_text = [torch.empty(cap * 40, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+            self._inl_cap = cap
         self._n = 0
         self._pending = None
         ctx.set_tail_overlap(tail_overlap)
@@ -90,20 +98,31 @@ class FramePipeline:
                                       d_right_mask, self.min_angle, None, 1.0, count=False)
         prev = self._collect()
         host = self._host[k]
+        extra = {}
+        if self._inl_text is not None:
+            extra = dict(inliers_capacity=self._inl_cap, inliers_every=10,
+                         inliers_text_ptr=self._inl_text[k].data_ptr(), inliers_text_capacity=self._inl_text[k].numel())
         mesh.finish_frame_async(self._uv, host.data_ptr(), host.numel(), self.pct, self.ransac_thr, self.max_distance,
-                                **self.refine)
+                                **self.refine, **extra)
         mesh.close()
-        self._pending = (self._n, host)
+        self._pending = (self._n, host, k)
         self._n += 1
         return prev
 
     def _collect(self):
         if self._pending is None:
             return None
-        idx, host = self._pending
+        idx, host, k = self._pending
         fr = self.ctx.frame_result()
         self._pending = None
-        return FrameOutput(idx, fr, host[:int(fr.xyzc_bytes)].numpy())
+        out = FrameOutput(idx, fr, host[:int(fr.xyzc_bytes)].numpy())
+        if self._inl_text is not None:
+            # the bytes of plane_refinement_inliers.xyz (valid like xyzc: until two more frames have been submitted); None: a number
+            # was outside the device formatter's domain and the caller has to format inliers_xyz itself.  The points stay on the
+            # device unless they are needed for that (or asked for): fetched here, before the next frame's tail reuses the buffer
+            out.inliers_text = None if fr.inliers_text_unsupported else self._inl_text[k][:int(fr.inliers_text_bytes)].numpy()
+            out.inliers_xyz = self.ctx.frame_inliers(fr.n_inliers_out) if (fr.inliers_text_unsupported or self._keep_points) else None
+        return out
 
     def flush(self):
         """Wait for the last submitted frame."""

@@ -135,6 +135,9 @@ struct wass_ctx {
     void* h_frame = nullptr;       // pinned: device state record of the last wass_mesh_finish_frame_async
     bool frame_pending = false;
     int frame_inl_every = 0;       // > 0: the pending frame also selected every n-th refinement inlier
+    bool frame_collected = false;  // wass_ctx_frame_result has been read for the last wass_mesh_finish_frame_async* call
+    bool frame_inl_text = false;   // ... and formatted plane_refinement_inliers.xyz on the device
+    size_t frame_inl_cap = 0;      // ... capacity (points) of the selection in c->inl
     unsigned long long frame_sgm_call = 0;   // 1-based index of the SGM call whose disparity the pending frame was built from
     void* h_stage = nullptr;       // pinned source images of the frame tail's small H2D copies (mesh.hip host_stage)
     hipEvent_t ev_stage = nullptr;

@@ -28,8 +28,13 @@ typedef unsigned __int128 u128_t;
 
 WASS_HD inline uint64_t pow5_u64(int k)          // 5^k, 0 <= k <= 27
 {
-    uint64_t r = 1;
-    for (int i = 0; i < k; ++i) r *= 5u;
+    // 5^13 = 1220703125 < 2^31: two table look-ups of small powers and one multiplication instead of a loop
+    constexpr uint64_t P[14] = { 1ull, 5ull, 25ull, 125ull, 625ull, 3125ull, 15625ull, 78125ull, 390625ull, 1953125ull, 9765625ull, 48828125ull,
+                                 244140625ull, 1220703125ull };
+    const int a = k > 13 ? 13 : k;
+    uint64_t r = P[a];
+    const int b = k - a;                            // 0 .. 14
+    if (b > 0) r *= b > 13 ? P[13] * 5ull : P[b];
     return r;
 }
 

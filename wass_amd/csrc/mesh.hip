@@ -851,50 +851,52 @@ __global__ void __launch_bounds__(256) k_inlier_pack(const uint8_t* __restrict__
 // domain (inf, nan, |v| >= 1e6 or < 1e-22: never a triangulated coordinate) is counted in *bad and the host formats the file
 // from the doubles instead, as before.
 constexpr int INL_LINE_MAX = 40;
-__device__ __forceinline__ int inl_line(const double* __restrict__ p, char* buf, unsigned int& bad)
+// pass 1: a block formats 256 lines into LDS (a thread's line is a string of single bytes: in HBM that is 40 partial cache-line
+// writes per thread, 64 different lines per instruction), packs them back to back and writes them to the block's staging area
+// with coalesced stores; blockbytes[b] = their length.  pass 2 (after the scan): the blocks' chunks copied to their final offsets.
+__global__ void __launch_bounds__(256) k_inl_text_format(const double* __restrict__ pts, const unsigned int* __restrict__ total, unsigned int every,
+                                                         char* __restrict__ staging, unsigned int* __restrict__ blockbytes, unsigned int* __restrict__ bad_out)
 {
-    int n = 0;
-#pragma unroll 1
-    for (int k = 0; k < 3; ++k) {
-        int l = fmt_g6(p[k], buf + n);
-        if (l < 0) { ++bad; buf[n] = '?'; l = 1; }
-        n += l;
-        buf[n++] = k < 2 ? ' ' : '\n';
-    }
-    return n;
-}
-__global__ void __launch_bounds__(256) k_inl_text_count(const double* __restrict__ pts, const unsigned int* __restrict__ total, unsigned int every,
-                                                        unsigned int* __restrict__ blockbytes, unsigned int* __restrict__ bad_out)
-{
-    __shared__ unsigned int wsum[4];
-    const unsigned int nsel = (*total + every - 1) / every;
-    const unsigned int j = blockIdx.x * 256 + threadIdx.x;
-    unsigned int len = 0, bad = 0;
-    if (j < nsel) { char buf[INL_LINE_MAX + 8]; len = (unsigned)inl_line(pts + (size_t)j * 3, buf, bad); }
-    unsigned int sum = len;
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) blockbytes[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    if (bad) atomicAdd(bad_out, bad);
-}
-__global__ void __launch_bounds__(256) k_inl_text_write(const double* __restrict__ pts, const unsigned int* __restrict__ total, unsigned int every,
-                                                        const unsigned int* __restrict__ blockoff, char* __restrict__ out)
-{
+    __shared__ char lines[256][INL_LINE_MAX];
     __shared__ unsigned int wsum[4];
     const unsigned int nsel = (*total + every - 1) / every;
     const unsigned int j = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    char buf[INL_LINE_MAX + 8];
     unsigned int len = 0, bad = 0;
-    if (j < nsel) len = (unsigned)inl_line(pts + (size_t)j * 3, buf, bad);
+    if (j < nsel) {
+        char* const buf = lines[threadIdx.x];
+        const double* p = pts + (size_t)j * 3;
+        int n = 0;
+#pragma unroll 1
+        for (int k = 0; k < 3; ++k) {
+            int l = fmt_g6(p[k], buf + n);
+            if (l < 0) { ++bad; buf[n] = '?'; l = 1; }
+            n += l;
+            buf[n++] = k < 2 ? ' ' : '\n';
+        }
+        len = (unsigned)n;
+    }
     unsigned int incl = len;                               // inclusive scan over the wave, then over the block's four waves
     for (int o = 1; o < 64; o <<= 1) { const unsigned int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
     if (lane == 63) wsum[wv] = incl;
     __syncthreads();
-    unsigned int off = blockoff[blockIdx.x] + incl - len;
+    unsigned int off = incl - len;
     for (int q = 0; q < wv; ++q) off += wsum[q];
-    for (unsigned int i = 0; i < len; ++i) out[off + i] = buf[i];
+    char* const dst = staging + (size_t)blockIdx.x * (256 * INL_LINE_MAX);
+    for (int i = 0; i < 64; ++i) {                         // the wave's 64 lines, one after the other, lane l taking byte l
+        const unsigned int li = (unsigned)__shfl((int)len, i), oi = (unsigned)__shfl((int)off, i);
+        if ((unsigned)lane < li) dst[oi + lane] = lines[wv * 64 + i][lane];
+    }
+    if (threadIdx.x == 0) blockbytes[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (bad) atomicAdd(bad_out, bad);
+}
+__global__ void __launch_bounds__(256) k_inl_text_pack(const char* __restrict__ staging, const unsigned int* __restrict__ blockoff,
+                                                       const unsigned int* __restrict__ text_total, unsigned int nblocks, char* __restrict__ out)
+{
+    const unsigned int b = blockIdx.x;
+    const unsigned int o0 = blockoff[b], o1 = b + 1 < nblocks ? blockoff[b + 1] : *text_total;
+    const char* src = staging + (size_t)b * (256 * INL_LINE_MAX);
+    for (unsigned int i = threadIdx.x; i < o1 - o0; i += 256) out[o0 + i] = src[i];
 }
 
 // smallest-eigenvalue eigenvector of a symmetric 3x3 (cyclic Jacobi); stands in for row 2 of cv::SVD's vt
@@ -2000,7 +2002,7 @@ int wass_mesh_finish_frame_async_ex2(wass_ctx* c, wass_mesh* m, double percentil
 {
     if (!c || !m || !dst) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
     if (inliers_dst && (inliers_every <= 0 || inliers_capacity == 0)) return set_err(c, WASS_ERR_INVALID_ARG, "bad inlier selection");
-    if (inliers_text_dst && !inliers_dst) return set_err(c, WASS_ERR_INVALID_ARG, "the inlier text comes with the inlier points (the host's fallback)");
+    if (inliers_text_dst && inliers_every <= 0) return set_err(c, WASS_ERR_INVALID_ARG, "bad inlier selection");
     WASS_HIP(c, hipSetDevice(c->device));
     const size_t n = m->n();
     if (capacity < 148 + n * 6)
@@ -2030,7 +2032,7 @@ int wass_mesh_finish_frame_async_ex2(wass_ctx* c, wass_mesh* m, double percentil
     size_t inl_copy = 0, text_copy = 0;
     const char* text_src = nullptr;
     unsigned int* inl_total = nullptr;
-    if (inliers_dst) {
+    if (inliers_dst || inliers_text_dst) {
         RefineDev rd;
         rd.xmin = rp->xmin; rd.xmax = rp->xmax; rd.ymin = rp->ymin; rd.ymax = rp->ymax; rd.maxd = rp->max_distance;
         rd.weighted = rp->weight_by_distance;
@@ -2039,12 +2041,12 @@ int wass_mesh_finish_frame_async_ex2(wass_ctx* c, wass_mesh* m, double percentil
         rd.vmin = rp->central_third_only ? m->h / 4 : 0;
         rd.vmax = rp->central_third_only ? m->h * 2 / 3 : m->h - 1;
         const size_t cap = (n + (size_t)inliers_every - 1) / (size_t)inliers_every;
-        if (inliers_capacity < cap) return set_err(c, WASS_ERR_INVALID_ARG, "inliers_dst must hold %zu points", cap);
+        if (inliers_dst && inliers_capacity < cap) return set_err(c, WASS_ERR_INVALID_ARG, "inliers_dst must hold %zu points", cap);
         const unsigned nb2 = nblk(cap);
         const size_t text_off = (256 + cap * 24 + (size_t)nb2 * 4 + 255) & ~(size_t)255;
         if (inliers_text_dst && inliers_text_capacity < cap * INL_LINE_MAX)
             return set_err(c, WASS_ERR_INVALID_ARG, "inliers_text_dst must hold %zu bytes", cap * (size_t)INL_LINE_MAX);
-        if ((rc = ensure(c, c->inl, text_off + (inliers_text_dst ? cap * INL_LINE_MAX : 0)))) return rc;
+        if ((rc = ensure(c, c->inl, text_off + (inliers_text_dst ? cap * INL_LINE_MAX + (size_t)nb2 * 256 * INL_LINE_MAX + 256 : 0)))) return rc;   // text, staging
         inl_total = (unsigned int*)c->inl.p;                       // [0]: number of refinement inliers, [2]: bytes of text, [3]: numbers not formatted; points from byte 256
         unsigned int* bc = (unsigned int*)((char*)c->scratch.p + 64);
         double* dout = (double*)((char*)c->inl.p + 256);
@@ -2053,18 +2055,31 @@ int wass_mesh_finish_frame_async_ex2(wass_ctx* c, wass_mesh* m, double percentil
         hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, bc, (int)nb, inl_total);
         hipLaunchKernelGGL(k_inlier_pack, dim3(nb), dim3(256), 0, s, m->valid, m->x, m->y, m->z, m->w, n, rd, (const unsigned int*)bc,
                            (unsigned)inliers_every, dout);
-        inl_copy = cap * 24;
+        inl_copy = inliers_dst ? cap * 24 : 0;                    // (text only: the points stay on the device, wass_ctx_frame_inliers fetches them on demand)
         if (inliers_text_dst) {                                   // the file's text, formatted here (fmt_g6.h)
             unsigned int* bb = (unsigned int*)((char*)c->inl.p + 256 + cap * 24);
+            char* staging = (char*)c->inl.p + text_off + cap * INL_LINE_MAX;
             WASS_HIP(c, hipMemsetAsync(inl_total + 2, 0, 8, s));
-            hipLaunchKernelGGL(k_inl_text_count, dim3(nb2), dim3(256), 0, s, (const double*)dout, (const unsigned int*)inl_total, (unsigned)inliers_every, bb,
-                               inl_total + 3);
+            hipLaunchKernelGGL(k_inl_text_format, dim3(nb2), dim3(256), 0, s, (const double*)dout, (const unsigned int*)inl_total, (unsigned)inliers_every, staging,
+                               bb, inl_total + 3);
             hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, bb, (int)nb2, inl_total + 2);
-            hipLaunchKernelGGL(k_inl_text_write, dim3(nb2), dim3(256), 0, s, (const double*)dout, (const unsigned int*)inl_total, (unsigned)inliers_every,
-                               (const unsigned int*)bb, (char*)c->inl.p + text_off);
+            // Pinned host memory is mapped into the device's address space: the packing kernel then writes the text straight into the
+            // caller's buffer -- exactly the file's bytes cross PCIe, where a copy would have to move the 40-bytes-per-point worst
+            // case (the length is only known on the device), as one more blit kernel on the copy stream in front of the next upload.
+            char* direct = nullptr;
+            {
+                hipPointerAttribute_t at;
+                if (hipPointerGetAttributes(&at, inliers_text_dst) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) direct = (char*)at.devicePointer;
+                else (void)hipGetLastError();
+            }
+            hipLaunchKernelGGL(k_inl_text_pack, dim3(nb2), dim3(256), 0, s, (const char*)staging, (const unsigned int*)bb, (const unsigned int*)(inl_total + 2), nb2,
+                               direct ? direct : (char*)c->inl.p + text_off);
+            if (direct) { c->frame_inl_cap = cap; goto text_done; }
             text_copy = cap * INL_LINE_MAX;
             text_src = (const char*)c->inl.p + text_off;
+        text_done:;
         }
+        c->frame_inl_cap = cap;
     }
     hipLaunchKernelGGL(k_frame_rt, dim3(1), dim3(64), 0, s, ds);
     unsigned char* stage = nullptr;
@@ -2081,7 +2096,7 @@ int wass_mesh_finish_frame_async_ex2(wass_ctx* c, wass_mesh* m, double percentil
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, bcnt, (int)nb, total);
     hipLaunchKernelGGL(k_frame_header, dim3(1), dim3(64), 0, s, ds, (const unsigned long long*)lim, (const unsigned int*)total,
                        (const unsigned long long*)kept1, img, (const unsigned long long*)c->tri_cnt.p, (const unsigned int*)inl_total,
-                       text_copy ? (const unsigned int*)(inl_total + 2) : (const unsigned int*)nullptr);
+                       inliers_text_dst ? (const unsigned int*)(inl_total + 2) : (const unsigned int*)nullptr);
     hipLaunchKernelGGL(k_xyzc_pack_dev, dim3(nb), dim3(256), 0, s, m->valid, m->x, m->y, m->z, n, (const DevState*)ds,
                        (const unsigned int*)bcnt, (uint16_t*)(img + 148));
     WASS_HIP(c, hipGetLastError());
@@ -2096,19 +2111,38 @@ int wass_mesh_finish_frame_async_ex2(wass_ctx* c, wass_mesh* m, double percentil
     if (text_copy) WASS_HIP(c, hipMemcpyAsync(inliers_text_dst, text_src, text_copy, hipMemcpyDeviceToHost, c->copy));
     if (component_mask_dst) WASS_HIP(c, hipMemcpyAsync(component_mask_dst, c->ccmask.p, n, hipMemcpyDeviceToHost, c->copy));
     WASS_HIP(c, hipEventRecord(c->ev_copy, c->copy));
-    c->frame_inl_every = inliers_dst ? inliers_every : 0;
+    c->frame_inl_every = (inliers_dst || inliers_text_dst) ? inliers_every : 0;
+    c->frame_inl_text = inliers_text_dst != nullptr;
     c->frame_pending = true;
+    c->frame_collected = false;
     c->frame_sgm_call = c->nsgm;              // the SGM call that fed this frame is the last one enqueued (0: none)
     return WASS_OK;
 }
 
 int wass_format_g6(double v, char* out) { return out ? wass::fmt_g6(v, out) : -1; }
 
+// the selected inlier points of the frame whose result was read last, fetched on demand (the text-only form of
+// wass_mesh_finish_frame_async_ex2 leaves them on the device)
+int wass_ctx_frame_inliers(wass_ctx* c, double* dst, size_t capacity_points, uint64_t* n_out)
+{
+    if (!c || !dst) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    if (!c->frame_collected || c->frame_inl_every <= 0 || !c->inl.p) return set_err(c, WASS_ERR_INVALID_ARG, "no collected frame with an inlier selection");
+    WASS_HIP(c, hipSetDevice(c->device));
+    const DevState& h = *(const DevState*)c->h_frame;
+    const uint64_t n = ((uint64_t)h.ninl_sel + (uint64_t)c->frame_inl_every - 1) / (uint64_t)c->frame_inl_every;
+    if (n > capacity_points || n > c->frame_inl_cap) return set_err(c, WASS_ERR_INVALID_ARG, "dst must hold %llu points", (unsigned long long)n);
+    WASS_HIP(c, hipStreamSynchronize(c->ts()));
+    WASS_HIP(c, hipMemcpy(dst, (const char*)c->inl.p + 256, (size_t)n * 24, hipMemcpyDeviceToHost));
+    if (n_out) *n_out = n;
+    return WASS_OK;
+}
+
 int wass_ctx_frame_result(wass_ctx* c, wass_frame_result* out)
 {
     if (!c || !out) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
     if (!c->frame_pending) return set_err(c, WASS_ERR_INVALID_ARG, "no wass_mesh_finish_frame_async call to wait for");
     WASS_HIP(c, hipEventSynchronize(c->ev_copy));
+    c->frame_collected = true;
     const DevState& h = *(const DevState*)c->h_frame;
     memset(out, 0, sizeof *out);
     out->zgap = h.zgap; out->n_gaps = h.sel_total; out->component_size = h.ccl_best >> 32;
@@ -2125,8 +2159,8 @@ int wass_ctx_frame_result(wass_ctx* c, wass_frame_result* out)
             if (hipEventElapsedTime(&out->stage_ms[k], ev[k], ev[k + 1]) != hipSuccess) out->stage_ms[k] = 0.0f;
     }
     out->n_inliers_out = c->frame_inl_every > 0 ? ((uint64_t)h.ninl_sel + (uint64_t)c->frame_inl_every - 1) / (uint64_t)c->frame_inl_every : 0;
-    out->inliers_text_bytes = c->frame_inl_every > 0 ? h.inl_text_bytes : 0;
-    out->inliers_text_unsupported = c->frame_inl_every > 0 ? h.inl_text_bad : 0;
+    out->inliers_text_bytes = c->frame_inl_text ? h.inl_text_bytes : 0;
+    out->inliers_text_unsupported = c->frame_inl_text ? h.inl_text_bad : 0;
     if (c->frame_sgm_call > 0 && c->nsgm - c->frame_sgm_call < 2) {
         // status word of the frame's SGM call: copied to pinned memory in stream order long before the download this
         // function has just waited for; the slot is reused two calls later

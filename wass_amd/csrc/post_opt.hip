@@ -264,6 +264,19 @@ extern "C" int wass_dense_input_size(int w, int h, double dense_scale, int* ws, 
     return (*ws > 0 && *hs > 0) ? WASS_OK : WASS_ERR_INVALID_ARG;
 }
 
+extern "C" int wass_resize_cubic_u8_dev(wass_ctx* c, const uint8_t* d_src, int sw, int sh, size_t src_stride, uint8_t* d_dst, int dw, int dh)
+{
+    if (!c || !d_src || !d_dst || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || src_stride < (size_t)sw) return set_err(c, WASS_ERR_INVALID_ARG, "bad argument");
+    WASS_HIP(c, hipSetDevice(c->device));
+    int rc = wait_uploads(c, d_src, c->stream);
+    if (rc) return rc;
+    // explicit destination size: the scale factors are the size ratios (cv::resize with fx = fy = 0)
+    hipLaunchKernelGGL(k_resize_cubic_u8, dim3((dw + 255) / 256, dh), dim3(256), 0, c->stream, d_src, sw, sh, src_stride, d_dst, dw, dh, (double)sw / dw,
+                       (double)sh / dh);
+    WASS_HIP(c, hipGetLastError());
+    return WASS_OK;
+}
+
 extern "C" int wass_biggest_component_by_gradient_dev(wass_ctx* c, float* d_disp, int w, int h, int threshold)
 {
     if (!c || !d_disp || w <= 0 || h <= 0 || threshold <= 0) return set_err(c, WASS_ERR_INVALID_ARG, "bad argument");

@@ -74,13 +74,20 @@ struct FrameJob {
 
 class FramePipeline {
 public:
-    static constexpr int NIN = 3;    // input sets: frame n+1 is uploaded while frame n runs and frame n-1's tail still reads its picture
+    // input sets: frames n+1 and n+2 may be staged (uploaded) while frame n runs and frame n-1's tail still reads its picture.  Two
+    // frames ahead, not one: the copy stream carries uploads AND the results' downloads in the order they were enqueued, so the
+    // upload staged right before frame n is submitted queues behind frame n-1's downloads, which wait for frame n-1's tail -- and
+    // that tail ends late in frame n.  One frame ahead that was the upload frame n+1 was waiting for (a 0.5 ms stall per frame once
+    // the downloads grew by the inlier text); two ahead it is frame n+2's, with a whole frame of slack.
+    static constexpr int NIN = 4;
     struct Options {
         int out_slots = 4;           // pinned output sets (file image + inlier points) that writer threads may hold at once
         bool inliers_file = true;    // plane_refinement_inliers.xyz (a debug artefact of the reference; 14 MB of text per 5-megapixel frame)
         bool live = false;           // single-frame executable: echo log and progress markers to stdout as the phases end
         bool debug_pictures = false; // the reference's debug pictures (stereo.jpg ... graph_components.jpg): every frame's intermediate
                                      // maps come back to the host once it is complete, which takes the pipeline down to one frame
+        bool device_previews = true; // the scaled previews 0000000X_s.png are resized on the GPU and written by finish() (sequence drivers);
+                                     // false: load_data writes them from the decoded pictures before the GPU is needed, like the reference
         const PrepareSetup* prep = nullptr;   // prepare-less mode: the calibration directory (jobs with raw = true need it)
         bool save_undistorted = false;        // ... and whether undistorted/0000000X.png are written all the same
     };
@@ -116,7 +123,7 @@ public:
         if (!ctx_) return;
         (void)wass_ctx_synchronize(ctx_);
         release_buffers();
-        for (auto& o : out_) { if (o.xyzc) wass_pinned_free(ctx_, o.xyzc); if (o.inl) wass_pinned_free(ctx_, o.inl); if (o.inl_text) wass_pinned_free(ctx_, o.inl_text); for (auto& u : o.und) if (u) wass_pinned_free(ctx_, u); if (o.ccmask) wass_pinned_free(ctx_, o.ccmask); }
+        for (auto& o : out_) { if (o.xyzc) wass_pinned_free(ctx_, o.xyzc); if (o.inl) wass_pinned_free(ctx_, o.inl); if (o.inl_text) wass_pinned_free(ctx_, o.inl_text); for (auto& u : o.prev) if (u) wass_pinned_free(ctx_, u); for (auto& u : o.und) if (u) wass_pinned_free(ctx_, u); if (o.ccmask) wass_pinned_free(ctx_, o.ccmask); }
         wass_ctx_destroy(ctx_);
     }
     // the pipeline's context, created if need be (owner thread); nullptr when there is no usable GPU
@@ -162,6 +169,8 @@ public:
                 if (!images_loaded(env)) { job.rc = -1; return; }
                 job.img_w = env.left.w; job.img_h = env.left.h;
                 input_scale_outputs(env, cfg_, false, nullptr, &job.prev_w, &job.prev_h);
+            } else if (opt_.device_previews) {
+                if (!load_data(env, cfg_, nullptr, nullptr, false, &job.prev_w, &job.prev_h)) { job.rc = -1; return; }   // previews: on the GPU (submit)
             } else if (!load_data(env, cfg_, nullptr, nullptr)) { job.rc = -1; return; }
             job.t_loaded = Timer::now();
             marker(job, 10);
@@ -263,7 +272,7 @@ public:
             const int k = job.in_slot;
             const int rl[4] = { env.roi_l.x, env.roi_l.y, env.roi_l.width, env.roi_l.height };
             const int rr[4] = { env.roi_r.x, env.roi_r.y, env.roi_r.width, env.roi_r.height };
-            job.out_slot = acquire_out((size_t)rr[2] * rr[3], job.raw ? (size_t)W_ * H_ : 0, opt_.debug_pictures);
+            job.out_slot = acquire_out((size_t)rr[2] * rr[3], job.raw && opt_.save_undistorted ? (size_t)W_ * H_ : 0, opt_.debug_pictures);
             if (job.raw) {
                 // ---- wass_prepare's process_image (wass_prepare.cpp:257-275) on the device: optional CLAHE, cv::undistort.  The
                 // camera a picture came from decides its parameters -- rectify_plan may have swapped left and right since.
@@ -277,8 +286,32 @@ public:
                         src = in_[k].d_tmp;
                     }
                     check(wass_undistort_dev(ctx_, src, W_, H_, (size_t)W_, ps.intr[cam].d.data(), ps.dist[cam].d.data(), (int)ps.dist[cam].d.size(), dst), "wass_undistort");
-                    // back to the host for the scaled previews (and undistorted/*.png when asked for): lands with the frame's result
-                    check(wass_download_async(ctx_, out_[job.out_slot].und[side], dst, (size_t)W_ * H_), "wass_download_async");
+                    // back to the host only when undistorted/*.png are asked for (the previews are resized on the device, below)
+                    if (opt_.save_undistorted) check(wass_download_async(ctx_, out_[job.out_slot].und[side], dst, (size_t)W_ * H_), "wass_download_async");
+                }
+            }
+            // ---- the scaled previews 0000000X_s.png of load_data (:401-417): cv::resize(INTER_CUBIC) of the two (undistorted) pictures,
+            // on the device; they come back with the frame's result and are deflated by the writer thread (finish)
+            if (job.prev_w > 0 && job.prev_h > 0) {
+                const size_t pn = (size_t)job.prev_w * job.prev_h;
+                OutSet& o = out_[job.out_slot];
+                for (int side = 0; side < 2; ++side) {
+                    uint8_t*& dp = side == 0 ? in_[k].d_pl : in_[k].d_pr;
+                    if (in_[k].prev_cap < pn) { if (dp) wass_device_free(ctx_, dp); dp = nullptr; }
+                    if (!dp) { void* p = nullptr; check(wass_device_alloc(ctx_, pn + 4, &p), "wass_device_alloc"); dp = (uint8_t*)p; }
+                }
+                in_[k].prev_cap = std::max(in_[k].prev_cap, pn);
+                for (int side = 0; side < 2; ++side) {
+                    if (o.prev_cap[side] < pn) {
+                        if (o.prev[side]) wass_pinned_free(ctx_, o.prev[side]);
+                        o.prev[side] = nullptr; o.prev_cap[side] = 0;
+                        void* p = nullptr;
+                        check(wass_pinned_alloc(ctx_, pn, &p), "wass_pinned_alloc");
+                        o.prev[side] = (uint8_t*)p; o.prev_cap[side] = pn;
+                    }
+                    uint8_t* dp = side == 0 ? in_[k].d_pl : in_[k].d_pr;
+                    check(wass_resize_cubic_u8_dev(ctx_, side == 0 ? in_[k].d_l : in_[k].d_r, W_, H_, (size_t)W_, dp, job.prev_w, job.prev_h), "wass_resize_cubic_u8");
+                    check(wass_download_async(ctx_, o.prev[side], dp, pn), "wass_download_async");
                 }
             }
             // ---- rectify(): the resampling (:515-528, 600-607), ROI crop fused, from the device-resident pictures
@@ -362,7 +395,7 @@ public:
             // one case in which the host still has to format them (a number outside the device formatter's domain)
             check(wass_mesh_finish_frame_async_ex2(ctx_, mesh, cfg_.get_double("ZGAP_PERCENTILE"), uv_.data(), rounds, cfg_.get_double("PLANE_RANSAC_THRESHOLD"),
                                                    &rp_, cfg_.get_double("PLANE_MAX_DISTANCE"), out_[slot].xyzc, out_[slot].xyzc_cap,
-                                                   opt_.inliers_file ? out_[slot].inl : nullptr, opt_.inliers_file ? out_[slot].inl_cap : 0, 10,
+                                                   opt_.inliers_file && !device_text_ ? out_[slot].inl : nullptr, opt_.inliers_file ? out_[slot].inl_cap : 0, 10,
                                                    opt_.debug_pictures ? out_[slot].ccmask : nullptr,
                                                    opt_.inliers_file && device_text_ ? out_[slot].inl_text : nullptr, opt_.inliers_file && device_text_ ? out_[slot].inl_text_cap : 0),
                   "wass_mesh_finish_frame_async");
@@ -486,19 +519,25 @@ public:
                     WLOGI << "total data size: " << ((double)r.xyzc_bytes / 1E6) << " MB";
                     WLOG_SCOPE("wass_stereo");
                 }
-                if (job.raw) {
-                    // the scaled previews of load_data (:413-418) and, on request, wass_prepare's own output: from the undistorted
-                    // pictures that came back with the result (und[0] = the picture that ended up LEFT, und[1] = right)
+                if (job.prev_w > 0 && job.prev_h > 0) {
+                    // the scaled previews of load_data (:413-418), resized on the device: prev[0] = the picture that ended up LEFT, prev[1] = right
+                    const OutSet& o = out_[job.out_slot];
+                    const size_t pn = (size_t)job.prev_w * job.prev_h;
+                    Image cam[2] = { Image(job.prev_w, job.prev_h), Image(job.prev_w, job.prev_h) };
+                    memcpy(cam[env.left_index].px.data(), o.prev[0], pn);
+                    memcpy(cam[env.right_index].px.data(), o.prev[1], pn);
+                    write_png_gray(path_join(env.workdir, "00000000_s.png"), cam[0]);
+                    write_png_gray(path_join(env.workdir, "00000001_s.png"), cam[1]);
+                }
+                if (job.raw && opt_.save_undistorted) {
+                    // wass_prepare's own output, on request: the undistorted pictures came back with the result (und[0] = LEFT, und[1] = right)
                     const OutSet& o = out_[job.out_slot];
                     const size_t n = (size_t)job.img_w * job.img_h;
                     Image cam[2] = { Image(job.img_w, job.img_h), Image(job.img_w, job.img_h) };
                     memcpy(cam[env.left_index].px.data(), o.und[0], n);
                     memcpy(cam[env.right_index].px.data(), o.und[1], n);
-                    if (job.prev_w > 0 && job.prev_h > 0) write_previews(env.workdir, cam[0], cam[1], job.prev_w, job.prev_h);
-                    if (opt_.save_undistorted) {
-                        write_png_gray(path_join(path_join(env.workdir, "undistorted"), "00000000.png"), cam[0]);
-                        write_png_gray(path_join(path_join(env.workdir, "undistorted"), "00000001.png"), cam[1]);
-                    }
+                    write_png_gray(path_join(path_join(env.workdir, "undistorted"), "00000000.png"), cam[0]);
+                    write_png_gray(path_join(path_join(env.workdir, "undistorted"), "00000001.png"), cam[1]);
                 }
                 marker(job, 100);
                 // the time table (render.hpp:175-191) with the reference's rows.  A pipelined frame has no per-stage WALL times (its
@@ -566,9 +605,11 @@ public:
 
 private:
     struct InSet { uint8_t *h_l = nullptr, *h_r = nullptr, *d_l = nullptr, *d_r = nullptr, *d_cl = nullptr, *d_cr = nullptr, *d_ml = nullptr, *d_mr = nullptr,
-                           *d_rawl = nullptr, *d_rawr = nullptr, *d_tmp = nullptr, *h_fl = nullptr, *h_fr = nullptr, *d_fl = nullptr, *d_fr = nullptr; };
+                           *d_rawl = nullptr, *d_rawr = nullptr, *d_tmp = nullptr, *h_fl = nullptr, *h_fr = nullptr, *d_fl = nullptr, *d_fr = nullptr,
+                           *d_pl = nullptr, *d_pr = nullptr; size_t prev_cap = 0; };
     struct OutSet { void* xyzc = nullptr; size_t xyzc_cap = 0; double* inl = nullptr; size_t inl_cap = 0; uint8_t* und[2] = { nullptr, nullptr }; size_t und_cap = 0;
-                    uint8_t* ccmask = nullptr; size_t cc_cap = 0; char* inl_text = nullptr; size_t inl_text_cap = 0; };
+                    uint8_t* ccmask = nullptr; size_t cc_cap = 0; char* inl_text = nullptr; size_t inl_text_cap = 0;
+                    uint8_t* prev[2] = { nullptr, nullptr }; size_t prev_cap[2] = { 0, 0 }; };
 
     void check(int rc, const char* what) const { if (rc != WASS_OK) throw GpuError(std::string(what) + ": " + wass_last_error(ctx_)); }
     uint64_t sgm_calls() const { uint64_t n = 0; (void)wass_sgm_call_count(ctx_, &n); return n; }
@@ -589,6 +630,12 @@ private:
         WLOG_SCOPE("wass_stereo");
         if (wass_ctx_frame_result(ctx_, &j->res) != WASS_OK) { WLOGE << "wass_ctx_frame_result: " << wass_last_error(ctx_); j->rc = -1; }
         j->t_result = Timer::now();
+        // a number the device formatter does not cover (inf, nan, |v| >= 1e6 or < 1e-22): the points come over for the host's formatter --
+        // now, before the next frame's tail reuses the device buffer
+        if (j->rc == 0 && opt_.inliers_file && device_text_ && j->res.inliers_text_unsupported != 0 && j->out_slot >= 0) {
+            uint64_t got = 0;
+            if (wass_ctx_frame_inliers(ctx_, out_[j->out_slot].inl, out_[j->out_slot].inl_cap, &got) != WASS_OK) { WLOGE << "wass_ctx_frame_inliers: " << wass_last_error(ctx_); j->rc = -1; }
+        }
         // stage times of the frame's SGM call: the last call, or the last but one if another frame has been enqueued since
         const long long behind = (long long)sgm_calls() - j->sgm_call;
         j->have_sgm = behind == 0 ? wass_sgm_last_timings(ctx_, &j->sgm) == WASS_OK : (behind == 1 && wass_sgm_prev_timings(ctx_, &j->sgm) == WASS_OK);
@@ -624,7 +671,8 @@ private:
     void release_buffers()
     {
         for (auto& s : in_) {
-            for (uint8_t** p : { &s.d_l, &s.d_r, &s.d_cl, &s.d_cr, &s.d_ml, &s.d_mr, &s.d_rawl, &s.d_rawr, &s.d_tmp, &s.d_fl, &s.d_fr }) { if (*p) wass_device_free(ctx_, *p); *p = nullptr; }
+            for (uint8_t** p : { &s.d_l, &s.d_r, &s.d_cl, &s.d_cr, &s.d_ml, &s.d_mr, &s.d_rawl, &s.d_rawr, &s.d_tmp, &s.d_fl, &s.d_fr, &s.d_pl, &s.d_pr }) { if (*p) wass_device_free(ctx_, *p); *p = nullptr; }
+            s.prev_cap = 0;
             for (uint8_t** p : { &s.h_l, &s.h_r, &s.h_fl, &s.h_fr }) { if (*p) wass_pinned_free(ctx_, *p); *p = nullptr; }
         }
         for (auto& p : d_disp16_) { if (p) wass_device_free(ctx_, p); p = nullptr; }

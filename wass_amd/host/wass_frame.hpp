@@ -186,7 +186,8 @@ void input_scale_outputs(Env& env, const Config& cfg, bool previews, BgTask* bg,
     }
 }
 
-bool load_data(Env& env, const Config& cfg, Preload* pre = nullptr, BgTask* bg = nullptr)    // :337-445
+// previews = false: the two scaled pictures are left to the caller (the pipelined chain resizes them on the GPU); *pnw, *pnh: their size
+bool load_data(Env& env, const Config& cfg, Preload* pre = nullptr, BgTask* bg = nullptr, bool previews = true, int* pnw = nullptr, int* pnh = nullptr)    // :337-445
 {
     WLOG_SCOPE("load_data");
     if (!load_calibration(env)) return false;
@@ -197,7 +198,7 @@ bool load_data(Env& env, const Config& cfg, Preload* pre = nullptr, BgTask* bg =
         env.left = std::move(pre->left); env.right = std::move(pre->right);
     }
     if (!images_loaded(env)) return false;
-    input_scale_outputs(env, cfg, true, bg);
+    input_scale_outputs(env, cfg, previews, bg, pnw, pnh);
     return true;
 }
 

@@ -48,6 +48,7 @@ int main(int argc, char* argv[])
             FramePipeline::Options fo;
             fo.out_slots = 1;
             fo.live = true;
+            fo.device_previews = false;      // one frame: load_data writes the previews before the GPU is needed, like the reference
             fo.debug_pictures = debug_images;
             FramePipeline pl(dev_env ? atoi(dev_env) : 0, cfg, argv[1], fo);
             FrameJob job;

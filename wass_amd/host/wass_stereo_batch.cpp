@@ -293,15 +293,19 @@ int worker_pipelined(int rank, int world, int device, bool distinct_gpus, const 
             d.clear();
         };
         for (size_t pos = 0; pos < n; ++pos) {
-            FrameJob *cur, *nxt = nullptr;
+            FrameJob *cur, *nxt = nullptr, *nxt2 = nullptr;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv_ready.wait(lk, [&]() { return ready[pos] != 0; });
                 cur = jobs[pos].get();
                 if (pos + 1 < n && ready[pos + 1]) nxt = jobs[pos + 1].get();
+                if (nxt && pos + 2 < n && ready[pos + 2]) nxt2 = jobs[pos + 2].get();
             }
             pl.stage(*cur);
-            if (nxt && nxt->rc == 0 && !nxt->skipped && pl.same_geometry(*nxt)) pl.stage(*nxt);   // its upload runs underneath this frame
+            // uploads run two frames ahead, in order (FramePipeline::NIN): underneath this frame, in front of its downloads in the copy stream
+            const bool ahead1 = nxt && nxt->rc == 0 && !nxt->skipped && pl.same_geometry(*nxt);
+            if (ahead1) pl.stage(*nxt);
+            if (ahead1 && nxt2 && nxt2->rc == 0 && !nxt2->skipped && pl.same_geometry(*nxt2)) pl.stage(*nxt2);
             pl.submit(*cur, done);
             // the decoded pictures have gone to the pinned ring (the debug pictures still want their size)
             if (!po.debug_pictures) { cur->env.left = Image(); cur->env.right = Image(); }

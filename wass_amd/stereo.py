@@ -199,6 +199,14 @@ class Context:
         self._check(self._lib.wass_ctx_frame_result(self._h, C.byref(res)))
         return res
 
+    def frame_inliers(self, n_points: int) -> np.ndarray:
+        """The selected inlier points of the frame whose result was read last ((n, 3) float64), fetched on demand: the text-only form
+        of the frame tail leaves them on the device.  Valid until the next finish_frame_async of this context."""
+        out = np.empty((max(int(n_points), 1), 3), np.float64)
+        n = C.c_uint64()
+        self._check(self._lib.wass_ctx_frame_inliers(self._h, out.ctypes.data, out.shape[0], C.byref(n)))
+        return out[:int(n.value)]
+
     # ---- rectification resamplers (wass_stereo.cpp:515-516, 603-604) ----------
     @staticmethod
     def _roi(roi):
@@ -441,11 +449,19 @@ class Mesh:
 
     def finish_frame_async(self, uv, dst_ptr: int, capacity: int, percentile=99.0, ransac_thr=1.0, max_distance=1.5,
                            xmin=-9999., xmax=9999., ymin=-9999., ymax=9999., refine_max_distance=70.0, weight_by_distance=True,
-                           central_third_only=False) -> None:
+                           central_third_only=False, inliers_ptr: int = 0, inliers_capacity: int = 0, inliers_every: int = 10,
+                           inliers_text_ptr: int = 0, inliers_text_capacity: int = 0) -> None:
         """remove_outliers -> fit_plane -> xyzC encode + download, enqueued without a host synchronisation
-        (wass_stereo.cpp:2046-2123); Context.frame_result() waits and reports."""
+        (wass_stereo.cpp:2046-2123); Context.frame_result() waits and reports.  inliers_ptr (pinned, capacity in points of 3 doubles):
+        also every inliers_every-th refinement inlier; inliers_text_ptr (pinned, 40 bytes per point): also the TEXT of
+        plane_refinement_inliers.xyz, formatted on the device (wass_mesh_finish_frame_async_ex2)."""
         uv = np.ascontiguousarray(uv, np.int32)
         rp = RefineParams(xmin, xmax, ymin, ymax, refine_max_distance, int(weight_by_distance), int(central_third_only))
+        if inliers_ptr or inliers_text_ptr:
+            self.ctx._check(self.ctx._lib.wass_mesh_finish_frame_async_ex2(self.ctx._h, self._h, percentile, uv.ctypes.data, len(uv), ransac_thr, C.byref(rp),
+                                                                           max_distance, dst_ptr, capacity, inliers_ptr or None, inliers_capacity, inliers_every, None,
+                                                                           inliers_text_ptr or None, inliers_text_capacity))
+            return
         self.ctx._check(self.ctx._lib.wass_mesh_finish_frame_async(self.ctx._h, self._h, percentile, uv.ctypes.data, len(uv),
                                                                    ransac_thr, C.byref(rp), max_distance, dst_ptr, capacity))
 
