@@ -20,6 +20,8 @@ Prints ONE JSON line (rank 0) with BASELINE.json's metric plus
   cpu_baseline          -- the CPU oracle (5-path, whole path) timed on this box's host cores (rank 0, N = 1)
   cxx_driver            -- the shipped C++ sequence driver (wass_stereo_batch, one worker process per GPU) on a config-B sequence
                            of workdirs with every consumed output written: the product's own pairs/s, same run
+  wasscli_unchanged     -- 4 concurrent `wass_stereo <config> <workdir>` processes (what wasscli starts, unedited) over a config-B
+                           sequence, served by the per-GPU resident worker the first of them starts
   mode_5path            -- config B in the mode the reference runs (MODE_SGBM, wass_stereo.cpp:775-777): pairs/s of the whole
                            chain, aggregation ms against its own (2*5+4) B/cell roofline
 """
@@ -397,6 +399,65 @@ def cxx_driver_record(ndirs: int, frames: int = 8, replicate: int = 24, decode_t
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def wasscli_unchanged_record(ndirs: int, frames: int = 8, replicate: int = 12, parallel: int = 4):
+    """What wasscli gets WITHOUT being edited: cli/wasscli/wasscli.py:326-346 starts one `wass_stereo <config> <workdir>` process per
+    frame, NUM_PARALLEL_PROCESSES (4) at a time.  The same here -- `parallel` concurrent wass_stereo processes over a config-B sequence
+    of workdirs -- with the executable handing its frame to the per-GPU resident worker it starts on demand (wass_amd/host/
+    stereo_server.hpp), and, for comparison, a few frames with WASS_NO_SERVER=1 (every process initialises HIP and computes its own
+    frame: round 4).  WASS_DEBUG_IMAGES=0 as in cxx_driver (the reference's eight debug JPEGs per frame are half a second of host time)."""
+    import shutil
+    import subprocess
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    from wass_amd import build
+    build.build_host()
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    tmp = tempfile.mkdtemp(prefix="wass_bench_cli_", dir=base)
+    sockdir = os.path.join(tmp, "sock")
+    os.makedirs(sockdir)
+    try:
+        seq, cfg, n = make_sequence(tmp, frames, replicate, ndirs)
+        env = dict(os.environ, WASS_DEBUG_IMAGES="0", WASS_SERVER_DIR=sockdir, WASS_SERVER_IDLE="5")
+        env.pop("WASS_NO_SERVER", None)
+
+        def one(i, e):
+            t = time.perf_counter()
+            r = subprocess.run([build.CLI, cfg, os.path.join(seq, "%06d_wd" % i)], capture_output=True, text=True, env=e)
+            return r.returncode, time.perf_counter() - t, time.perf_counter()
+        # the first caller starts the server (HIP start-up, scratch allocation): reported separately
+        t0 = time.perf_counter()
+        rc0, first_s, _ = one(0, env)
+        with ThreadPoolExecutor(parallel) as ex:
+            t1 = time.perf_counter()
+            res = list(ex.map(lambda i: one(i, env), range(1, n)))
+            t2 = time.perf_counter()
+        bad = [rc for rc, _, _ in res if rc != 0] + ([rc0] if rc0 != 0 else [])
+        lat = sorted(s for _, s, _ in res)
+        rec = {"pairs_per_sec": round((n - 1) / (t2 - t1), 2), "pairs_per_sec_incl_server_start": round(n / (t2 - t0), 2), "frames": n,
+               "parallel_processes": parallel, "first_call_s": round(first_s, 3), "median_call_s": round(lat[len(lat) // 2], 4),
+               "failed_calls": len(bad), "ndirs": ndirs,
+               "how": f"{parallel} concurrent `wass_stereo <config> <workdir>` processes (a thread pool, as wasscli's thread_map) over {n} config-B "
+                      "workdirs; each hands its frame to the per-GPU resident worker started by the first; WASS_DEBUG_IMAGES=0; output to " + base}
+        # round 4's behaviour on a few frames: every process computes its own frame
+        env0 = dict(env, WASS_NO_SERVER="1")
+        for i in range(8):
+            for f in ("mesh_cam.xyzC", "plane.txt"):
+                try:
+                    os.remove(os.path.join(seq, "%06d_wd" % i, f))
+                except OSError:
+                    pass
+        with ThreadPoolExecutor(parallel) as ex:
+            t1 = time.perf_counter()
+            res0 = list(ex.map(lambda i: one(i, env0), range(8)))
+            t2 = time.perf_counter()
+        rec["without_server"] = {"pairs_per_sec": round(8 / (t2 - t1), 2), "frames": 8, "failed_calls": len([1 for rc, _, _ in res0 if rc != 0]),
+                                 "median_call_s": round(sorted(s for _, s, _ in res0)[4], 3)}
+        return rec
+    finally:
+        time.sleep(0.2)
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -418,7 +479,7 @@ def main():
     ap.add_argument("--inlier-text", action="store_true",
                     help="also produce plane_refinement_inliers.xyz (every 10th refinement inlier, text formatted on the device) per frame, like "
                          "the C++ driver does; not part of the metric's pass")
-    ap.add_argument("--no-cxx-driver", action="store_true", help="skip the C++ sequence driver's own throughput (cxx_driver)")
+    ap.add_argument("--no-cxx-driver", action="store_true", help="skip the C++ sequence driver's own throughput (cxx_driver) and wasscli_unchanged")
     ap.add_argument("--stage", default="full", choices=("full", "sgm"),
                     help="full = a1-a20 (SGBM, clean-up, triangulation, plane fit, xyzC); sgm = a1-a6 only")
     ap.add_argument("--rccl-single-rank", action="store_true",
@@ -771,6 +832,10 @@ def main():
                 line["cxx_driver"] = cxx_driver_record(args.ndirs)
             except Exception as e:                          # the headline must not depend on a scratch directory
                 line["cxx_driver"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                line["wasscli_unchanged"] = wasscli_unchanged_record(args.ndirs)
+            except Exception as e:
+                line["wasscli_unchanged"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.config)
     # N > 1: the PRODUCT's scaling point beside the harness's -- the shipped sequence driver with one worker per GPU, run by rank 0

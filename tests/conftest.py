@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# wass_stereo hands its frame to a per-GPU resident worker when it can (wass_amd/host/stereo_server.hpp).  The tests of the executable
+# itself run it in-process; tests/test_server.py switches the server on, with a socket directory and an idle time-out of its own.
+os.environ.setdefault("WASS_NO_SERVER", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -1,0 +1,149 @@
+"""The resident worker behind the unchanged command line (wass_amd/host/stereo_server.hpp).
+
+wasscli starts one `wass_stereo <config> <workdir>` process per frame, four at a time (cli/wasscli/wasscli.py:326-346).  Here such
+a process hands its frame to a per-GPU server that the first caller starts: same files, same stdout, same exit code.
+CPU: the mechanics (start on demand, concurrent callers, relayed log and exit code, idle time-out, WASS_NO_SERVER).
+GPU: 4 concurrent callers over 32 workdirs -- what thread_map(..., max_workers=4) does -- against one process per frame in-process."""
+import os
+import shutil
+import subprocess
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+from test_cli import make_workdir
+
+NAMES = ("mesh_cam.xyzC", "plane.txt", "plane_refinement_inliers.xyz", "P0cam.txt", "P1cam.txt", "Cam0_poseR.txt", "Cam1_poseT.txt", "K0_small.txt",
+         "K1_small.txt", "scale.txt", "00000000_s.png", "00000001_s.png", "stereo_config.txt")
+
+
+@pytest.fixture(scope="module")
+def cli():
+    from wass_amd import build
+    return build.build_host()
+
+
+def _env(sockdir, **kw):
+    e = dict(os.environ, WASS_SERVER_DIR=str(sockdir), WASS_SERVER_IDLE="2", **kw)
+    e.pop("WASS_NO_SERVER", None)
+    return e
+
+
+def _servers(sockdir):
+    out = subprocess.run(["ps", "-ww", "-eo", "pid,args"], capture_output=True, text=True).stdout
+    return [l for l in out.splitlines() if "--server" in l and str(sockdir) in l]
+
+
+def _wait_gone(sockdir, seconds=15):
+    t0 = time.time()
+    while _servers(sockdir) and time.time() - t0 < seconds:
+        time.sleep(0.2)
+    return not _servers(sockdir)
+
+
+def test_server_is_started_on_demand_relays_log_and_exit_code_and_goes_away(cli, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the no-GPU behaviour is tested on the build container")
+    wd, cfg, *_ = make_workdir(str(tmp_path), 160, 120, 32)
+    sock = tmp_path / "sock"
+    sock.mkdir()
+    a = subprocess.run([cli, cfg, wd], capture_output=True, text=True, env=_env(sock, WASS_DEBUG_IMAGES="0"))
+    assert len(_servers(sock)) == 1                                   # started by the first caller, still there
+    b = subprocess.run([cli, cfg, wd], capture_output=True, text=True, env=_env(sock, WASS_DEBUG_IMAGES="0"))
+    ref = subprocess.run([cli, cfg, wd], capture_output=True, text=True, env=dict(os.environ, WASS_NO_SERVER="1", WASS_DEBUG_IMAGES="0"))
+    for r in (a, b):
+        assert r.returncode == ref.returncode == 255                  # no GPU: a loud failure, whoever computes the frame
+        assert "no usable MI355X GPU" in r.stdout and "wass_stereo  v." in r.stdout
+        assert "[P|10|100]" in r.stdout                               # the markers that were reached come through
+    assert os.path.exists(os.path.join(wd, "wass_stereo_log.txt"))
+    assert _wait_gone(sock), "the server outlived its idle time-out"
+    assert not [f for f in os.listdir(sock) if f.endswith(".sock")]   # and took its socket with it
+
+
+def test_concurrent_callers_share_one_server(cli, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the no-GPU behaviour is tested on the build container")
+    wds = []
+    for i in range(6):
+        t = tmp_path / f"mk{i}"
+        t.mkdir()
+        wd, cfg, *_ = make_workdir(str(t), 160, 120, 32, frame=i)
+        wds.append((wd, cfg))
+    sock = tmp_path / "sock"
+    sock.mkdir()
+    with ThreadPoolExecutor(4) as ex:
+        res = list(ex.map(lambda wc: subprocess.run([cli, wc[1], wc[0]], capture_output=True, text=True, env=_env(sock, WASS_DEBUG_IMAGES="0")), wds))
+    assert all(r.returncode == 255 and "Reconstructing" in r.stdout for r in res)
+    for (wd, _), r in zip(wds, res):
+        assert wd in r.stdout                                         # every caller got ITS frame's log
+    assert len(_servers(sock)) <= 1
+    _wait_gone(sock)
+
+
+def test_no_server_switch_and_ineligible_configurations_stay_in_process(cli, tmp_path):
+    wd, cfg, *_ = make_workdir(str(tmp_path), 160, 120, 32)
+    sock = tmp_path / "sock"
+    sock.mkdir()
+    subprocess.run([cli, cfg, wd], capture_output=True, text=True, env=dict(_env(sock), WASS_NO_SERVER="1"))
+    assert not os.listdir(sock)
+    subprocess.run([cli, cfg, wd, "--rectify-only"], capture_output=True, text=True, env=_env(sock))
+    assert not os.listdir(sock)
+    open(cfg, "a").write("SAVE_AS_PLY=true\n")                        # needs the whole mesh on the host: not the chain's business
+    subprocess.run([cli, cfg, wd], capture_output=True, text=True, env=_env(sock))
+    assert not os.listdir(sock)
+
+
+@pytest.mark.gpu
+def test_four_concurrent_callers_over_32_workdirs_write_the_files_of_in_process_runs(cli, tmp_path):
+    w, h, D = 320, 240, 64
+    nd, nrep = 8, 4
+    seq_a, seq_b = tmp_path / "a", tmp_path / "b"
+    cfg = None
+    for i in range(nd):
+        t = tmp_path / f"mk{i}"
+        t.mkdir()
+        wd, cfg, *_ = make_workdir(str(t), w, h, D, frame=i)
+        for rep in range(nrep):
+            for seq in (seq_a, seq_b):
+                shutil.copytree(wd, seq / ("%06d_wd" % (rep * nd + i)))
+    n = nd * nrep
+    sock = tmp_path / "sock"
+    sock.mkdir()
+    for i in range(nd):                                                  # the reference's way, in-process: one per distinct frame is enough
+        r = subprocess.run([cli, cfg, str(seq_a / ("%06d_wd" % i))], capture_output=True, text=True, env=dict(os.environ, WASS_NO_SERVER="1", WASS_DEBUG_IMAGES="0"))
+        assert r.returncode == 0, r.stdout[-1500:]
+    t0 = time.time()
+    with ThreadPoolExecutor(4) as ex:                                    # wasscli: thread_map(..., max_workers=4)
+        res = list(ex.map(lambda i: subprocess.run([cli, cfg, str(seq_b / ("%06d_wd" % i))], capture_output=True, text=True,
+                                                   env=_env(sock, WASS_DEBUG_IMAGES="0")), range(n)))
+    dt = time.time() - t0
+    assert len(_servers(sock)) == 1
+    for i, r in enumerate(res):
+        assert r.returncode == 0, r.stdout[-1500:]
+        for marker in ("[P|10|100]", "[P|20|100]", "[P|40|100]", "[P|60|100]", "[P|80|100]", "[P|90|100]", "[P|100|100]", "All done.", "wass_stereo  v."):
+            assert marker in r.stdout, (i, marker)
+        assert ("%06d_wd" % i) in r.stdout
+        for name in NAMES + ("H0_rect.txt", "H1_rect.txt"):
+            a = (seq_a / ("%06d_wd" % (i % nd)) / name).read_bytes()
+            assert a == (seq_b / ("%06d_wd" % i) / name).read_bytes(), f"frame {i}: {name} differs"
+    print(f"{n} frames through the server with 4 callers: {n / dt:.1f} frames/s")
+    assert _wait_gone(sock)
+
+
+@pytest.mark.gpu
+def test_server_draws_the_debug_pictures_too(cli, tmp_path):
+    wd, cfg, *_ = make_workdir(str(tmp_path), 320, 240, 64)
+    wd2 = str(tmp_path / "b_wd")
+    shutil.copytree(wd, wd2)
+    sock = tmp_path / "sock"
+    sock.mkdir()
+    a = subprocess.run([cli, cfg, wd], capture_output=True, text=True, env=dict(os.environ, WASS_NO_SERVER="1", WASS_DEBUG_FORMAT="png"))
+    b = subprocess.run([cli, cfg, wd2], capture_output=True, text=True, env=_env(sock, WASS_DEBUG_FORMAT="png"))
+    assert a.returncode == 0 and b.returncode == 0, a.stdout[-800:] + b.stdout[-800:]
+    for name in ("stereo.png", "stereo_input.png", "disparity_stereo_ouput.png", "disparity_final_scaled.png", "disparity_coverage.png",
+                 "graph_components.png", "undistorted/R0.png", "undistorted/R1.png", "mesh_cam.xyzC", "plane.txt"):
+        assert open(os.path.join(wd, name), "rb").read() == open(os.path.join(wd2, name), "rb").read(), name
+    _wait_gone(sock)

@@ -42,6 +42,7 @@ inline bool pipeline_eligible(const Config& cfg, std::string* why = nullptr)
 struct FrameJob {
     size_t index = 0;
     std::string workdir;
+    std::string config_path;         // as the caller named it, for the log (empty: the pipeline's)
     Env env;
     std::string log;                 // the frame's wass_stereo_log.txt, in the order the reference writes it
     int rc = 0;                      // -1: the frame failed (the log says why)
@@ -84,6 +85,8 @@ public:
         int out_slots = 4;           // pinned output sets (file image + inlier points) that writer threads may hold at once
         bool inliers_file = true;    // plane_refinement_inliers.xyz (a debug artefact of the reference; 14 MB of text per 5-megapixel frame)
         bool live = false;           // single-frame executable: echo log and progress markers to stdout as the phases end
+        bool echo = true;            // live && !echo: the markers are recorded in the frame's log but nothing is printed here (the resident
+                                     // worker relays the log to the wass_stereo process that sent the frame, stereo_server.hpp)
         bool debug_pictures = false; // the reference's debug pictures (stereo.jpg ... graph_components.jpg): every frame's intermediate
                                      // maps come back to the host once it is complete, which takes the pipeline down to one frame
         bool device_previews = true; // the scaled previews 0000000X_s.png are resized on the GPU and written by finish() (sequence drivers);
@@ -153,7 +156,7 @@ public:
                 if (opt_.save_undistorted) create_directories(path_join(env.workdir, "undistorted"));
                 write_prepared_calibration(env.workdir, *opt_.prep);
             }
-            WLOGI << "Loading configuration file " << config_path_;
+            WLOGI << "Loading configuration file " << (job.config_path.empty() ? config_path_ : job.config_path);
             if (save_configuration(cfg_, path_join(env.workdir, "stereo_config.txt")) != 0) WLOGE << "Unable to save stereo configuration file";
             job.ransac_seed = (unsigned int)time(0);
             if (cfg_.get_int("RANDOM_SEED") != -1) { job.ransac_seed = (unsigned int)cfg_.get_int("RANDOM_SEED"); WLOGI << "random seed set to: " << cfg_.get_int("RANDOM_SEED"); }
@@ -587,7 +590,7 @@ public:
     // single-frame executable: what the phases have logged since the last call goes to stdout, markers included
     void flush_live(FrameJob& job)
     {
-        if (!opt_.live) return;
+        if (!opt_.live || !opt_.echo) return;
         size_t p = live_pos_;
         const std::string& log = job.log;
         while (p < log.size()) {
@@ -602,6 +605,7 @@ public:
     }
 
     int frames_submitted() const { return nsub_; }
+    bool pending() const { return pending_ != nullptr || !early_.empty(); }   // a submitted frame has not been handed out yet (flush() returns it)
 
 private:
     struct InSet { uint8_t *h_l = nullptr, *h_r = nullptr, *d_l = nullptr, *d_r = nullptr, *d_cl = nullptr, *d_cr = nullptr, *d_ml = nullptr, *d_mr = nullptr,

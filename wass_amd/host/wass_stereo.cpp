@@ -6,12 +6,15 @@
 // Same argv, exit codes, config format, workdir inputs/outputs, stdout progress markers and log format as the
 // reference; the per-frame work is wass_frame.hpp.  There is NO CPU implementation of the hot
 // path here: without a GPU (or without libwassgpu.so) the program fails with exit code -1.
-#include "frame_pipeline.hpp"
+#include "stereo_server.hpp"
 
 using namespace wassframe;
 
 int main(int argc, char* argv[])
 {
+    // the resident worker that later wass_stereo processes hand their frames to (stereo_server.hpp); started by the first of them
+    if (argc >= 3 && std::string("--server") == argv[1]) return wassserver::server_main(argv[2], argc >= 4 ? atoi(argv[3]) : 0);
+
     std::cout << "wass_stereo  v. " << WASS_AMD_VERSION << std::endl;
     std::cout << "----------------------------------------------" << std::endl;
     std::cout << " [Release] MI355X / gfx950 HIP build, " << wass_version() << std::endl << std::endl;
@@ -42,8 +45,30 @@ int main(int argc, char* argv[])
         Config cfg;
         register_wass_stereo_options(cfg);
         bool ok = false;
-        { std::ifstream ifs(argv[1]); if (ifs.is_open()) { try { cfg.load(ifs); ok = pipeline_eligible(cfg); } catch (const std::runtime_error&) {} } }
+        std::string cfg_text;
+        {
+            std::ifstream ifs(argv[1]);
+            if (ifs.is_open()) {
+                std::stringstream ss;
+                ss << ifs.rdbuf();
+                cfg_text = ss.str();
+                std::istringstream is(cfg_text);
+                try { cfg.load(is); ok = pipeline_eligible(cfg); } catch (const std::runtime_error&) {}
+            }
+        }
         const char* dev_env = getenv("WASS_GPU_DEVICE");
+        // A per-GPU server computes the frame when there is one or one can be started: same files, same output, same exit code, without
+        // this process ever initialising HIP (WASS_NO_SERVER=1: everything below runs here, as in round 4).
+        const char* no_srv = getenv("WASS_NO_SERVER");
+        if (ok && !(no_srv && atoi(no_srv) != 0)) {
+            char self[4096];
+            const ssize_t sl = readlink("/proc/self/exe", self, sizeof self - 1);
+            if (sl > 0) {
+                self[sl] = 0;
+                const int rc = wassserver::client_run(self, argv[1], cfg_text, argv[2], debug_images);
+                if (rc != -2) return rc;
+            }
+        }
         if (ok) {
             FramePipeline::Options fo;
             fo.out_slots = 1;
