@@ -93,11 +93,22 @@ def test_config_b_full_chain_vs_oracle(oracle, pair_b):
     run (wass_amd.batch.FramePipeline), against the oracle chain stage by stage -- 5 M points through the radix
     select (PovMesh.cpp:888-926), the union-find (:929-987), RANSAC scoring (:665-777), crop / refine (:780-815,
     :581-660) and the xyzC encoder (:377-460)."""
+    _full_chain_vs_oracle(oracle, 2456, 2058, 256, *pair_b)
+
+
+def test_config_e_full_chain_vs_oracle(oracle):
+    """The same at config E (3840 x 2160, D = 512, 5 paths): 8.3 M grid points through the radix select, the union-find, the RANSAC
+    scoring, crop / refine and the encoder -- the tail a7-a20 had only ever been compared with the oracle at config B's size (and the
+    SGM stage of config E on a 600-row band).  About a minute of scalar oracle."""
+    w, h, D = 3840, 2160, 512
+    right, left = synth.make_pair(w, h, D, frame_idx=5)
+    _full_chain_vs_oracle(oracle, w, h, D, right, left)
+
+
+def _full_chain_vs_oracle(oracle, w, h, D, right, left):
     import torch
     import wass_amd
     from wass_amd.batch import FramePipeline
-    w, h, D = 2456, 2058, 256
-    right, left = pair_b
     p = default_sgm_params(D, ndirs=5)
     rig = synth.rig_geometry(w, h)
     roi = (0, 0, w, h)
