@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The shipped C++ sequence driver on ONE prepared config-B sequence, alternating environments (the sequence is built once):
 
-    python scripts/cxx_ab.py [--rounds 3] [--replicate 16] [--prof DIR] "VAR=a" "VAR=b" ...
+    python scripts/cxx_ab.py [--rounds 3] [--replicate 16] [--prof DIR] "VAR=a" "VAR=b +driver-option=value" ...
 
 Each run deletes the previous run's outputs first.  --prof DIR: additionally one rocprofv3 --kernel-trace --stats run of the first
 environment on a short sequence, summary of the tail kernels printed."""
@@ -34,11 +34,15 @@ def clean(seq):
 def run(seq, cfg, env, extra=()):
     clean(seq)
     e = dict(os.environ)
+    args = []
     for kv in env.split():
+        if kv.startswith("+"):                                      # a driver option: +no-inliers-file, +decode-threads=12 ... (-- would be argparse's)
+            args += ("--" + kv[1:]).split("=", 1)
+            continue
         k, v = kv.split("=", 1)
         e[k] = v
     t0 = time.perf_counter()
-    r = subprocess.run([*extra, build.BATCH, cfg, "--sequence", seq, "--gpus", "1"], capture_output=True, text=True, env=e)
+    r = subprocess.run([*extra, build.BATCH, cfg, "--sequence", seq, "--gpus", "1", *args], capture_output=True, text=True, env=e)
     wall = time.perf_counter() - t0
     steady = cpu = None
     for line in r.stdout.splitlines():
@@ -70,14 +74,14 @@ def main():
             for wd in sorted(glob.glob(os.path.join(seq, "*_wd")))[24:]:
                 shutil.rmtree(wd)
             os.environ["TMPDIR"] = "/tmp"
-            rc, *_ = run(seq, cfg, a.envs[0], extra=("rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", a.prof, "-o", "run", "--"))
+            rc, *_ = run(seq, cfg, a.envs[0] + " +in-process", extra=("rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", a.prof, "-o", "run", "--"))
             st = glob.glob(os.path.join(a.prof, "**", "*kernel_stats.csv"), recursive=True)
             if st:
                 import csv
                 print("kernel, calls, avg_us")
                 for r in csv.DictReader(open(st[0])):
                     nm = r["Name"].split("(")[0].replace("void wass::", "").replace("wass::", "")
-                    if float(r["TotalDurationNs"]) > 2e5 and not nm.startswith(("k_pair", "k_ckpt", "k_rowsweep", "k_hsum", "k_vsum")):
+                    if float(r["TotalDurationNs"]) > 2e5:
                         print(f"  {nm[:50]:50s} {r['Calls']:>5s} {float(r['AverageNs']) / 1e3:9.1f}")
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

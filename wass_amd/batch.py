@@ -96,7 +96,6 @@ class FramePipeline:
         img = d_right_image if d_right_image is not None else d_right
         mesh, _ = ctx.triangulate_dev(self._dispf, self.w, self.h, self.roi_l, self.roi_r, self.geom, img, d_left_mask,
                                       d_right_mask, self.min_angle, None, 1.0, count=False)
-        prev = self._collect()
         host = self._host[k]
         extra = {}
         if self._inl_text is not None:
@@ -105,6 +104,9 @@ class FramePipeline:
         mesh.finish_frame_async(self._uv, host.data_ptr(), host.numel(), self.pct, self.ransac_thr, self.max_distance,
                                 **self.refine, **extra)
         mesh.close()
+        # the previous frame's record is read AFTER this frame's tail has been enqueued (two frames may be pending since round 5):
+        # the tail stream goes from one frame's tail straight into the next one's
+        prev = self._collect()
         self._pending = (self._n, host, k)
         self._n += 1
         return prev

@@ -102,7 +102,9 @@ int wass_ctx_create(int device_id, wass_ctx** out)
     if (hipStreamCreateWithFlags(&c->tail, hipStreamNonBlocking) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
     if (hipEventCreateWithFlags(&c->ev_post, hipEventDisableTiming) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
     if (hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
-    if (hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming | (getenv("WASS_SPIN_WAIT") ? 0 : hipEventBlockingSync)) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
+    for (auto& fs : c->fslot)
+        if (hipEventCreateWithFlags(&fs.ev_copy, hipEventDisableTiming | (getenv("WASS_SPIN_WAIT") ? 0 : hipEventBlockingSync)) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
+    c->ev_copy = c->fslot[0].ev_copy;                      // "the most recently recorded download event": an alias of one of the two
     for (auto& set : c->evs)
         for (auto& e : set)
             if (hipEventCreate(&e) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
@@ -128,7 +130,7 @@ void wass_ctx_destroy(wass_ctx* c)
     mesh_pool_ctx_alive(c, false);
     mesh_pool_purge(c);
     for (Buf* b : { &c->bt1, &c->bt2, &c->hsum, &c->C, &c->S, &c->ckpt, &c->sel_d16, &c->sel_key, &c->raw,
-                    &c->flags, &c->tmp_in0, &c->tmp_in1, &c->tmp_out, &c->tmp_mask, &c->fA, &c->fB, &c->fC, &c->fD, &c->fE, &c->uf, &c->rs_r, &c->rs_l, &c->raw2, &c->grid, &c->scratch, &c->counters, &c->tri_cnt, &c->inl, &c->clahe_lut, &c->ccmask, &c->und_cache[0].xy, &c->und_cache[1].xy, &c->dstate, &c->rect_tab, &c->rect_mx, &c->rect_my, &c->xyzc, &c->limits })
+                    &c->flags, &c->tmp_in0, &c->tmp_in1, &c->tmp_out, &c->tmp_mask, &c->fA, &c->fB, &c->fC, &c->fD, &c->fE, &c->uf, &c->rs_r, &c->rs_l, &c->raw2, &c->grid, &c->scratch, &c->counters, &c->tri_cnt, &c->inl, &c->inl2, &c->clahe_lut, &c->ccmask, &c->und_cache[0].xy, &c->und_cache[1].xy, &c->dstate, &c->rect_tab, &c->rect_mx, &c->rect_my, &c->xyzc, &c->limits })
         release(*b);
     for (auto& set : c->evs) for (auto& e : set) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_ckpt) if (e) (void)hipEventDestroy(e);
@@ -138,7 +140,8 @@ void wass_ctx_destroy(wass_ctx* c)
     if (c->tail) { (void)hipStreamSynchronize(c->tail); (void)hipStreamDestroy(c->tail); }
     if (c->ev_post) (void)hipEventDestroy(c->ev_post);
     if (c->h_flags) (void)hipHostFree(c->h_flags);
-    if (c->h_frame) (void)hipHostFree(c->h_frame);
+    for (auto& fs : c->fslot) { if (fs.h_frame) (void)hipHostFree(fs.h_frame); if (fs.ev_copy) (void)hipEventDestroy(fs.ev_copy); }
+    if (c->ev_stage2) (void)hipEventDestroy(c->ev_stage2);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
     if (c->ev_producer) (void)hipEventDestroy(c->ev_producer);
@@ -146,7 +149,6 @@ void wass_ctx_destroy(wass_ctx* c)
     if (c->ev_dl_tail) (void)hipEventDestroy(c->ev_dl_tail);
     for (auto& set : c->ev_tail_sets) for (auto& e : set) if (e) (void)hipEventDestroy(e);
     if (c->ev_pack) (void)hipEventDestroy(c->ev_pack);
-    if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     for (auto& u : c->uploads) if (u.ev) (void)hipEventDestroy(u.ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

@@ -132,15 +132,25 @@ struct wass_ctx {
     wass::Buf scratch;             // mesh stages: gaps / labels / partial sums / packed output
     wass::Buf xyzc;                // packed u16 triples of mesh_cam.xyzC (own buffer: downloaded asynchronously)
     wass::Buf limits;              // striped min/max keys of the frame tail
-    void* h_frame = nullptr;       // pinned: device state record of the last wass_mesh_finish_frame_async
+    // Up to TWO frames may be pending (round 5): a driver enqueues frame n's tail BEFORE it reads frame n-1's record, so that the tail
+    // stream never waits for the previous frame's downloads plus a host round trip (with one record per context that chain, not the
+    // SGM stage, set the C++ driver's frame period).  Everything a pending frame's record needs is per slot; slot = frame number & 1.
+    struct FrameSlot {
+        void* h_frame = nullptr;   // pinned: the device state record as downloaded
+        hipEvent_t ev_copy = nullptr;   // the frame's downloads have finished
+        int inl_every = 0;         // > 0: the frame also selected every n-th refinement inlier
+        bool inl_text = false;     // ... and formatted plane_refinement_inliers.xyz on the device
+        size_t inl_cap = 0;        // ... capacity (points) of the selection
+        unsigned long long sgm_call = 0;   // 1-based index of the SGM call whose disparity the frame was built from
+        int tail_set = 0;          // the timing-event set its tail was recorded into
+    } fslot[2];
+    unsigned long long nframe_enq = 0, nframe_col = 0;   // frame tails enqueued / records read
+    int ds_slot = 0;               // which of the two device state records (and inlier buffers) the stage helpers use
+    wass::Buf inl2;                // the odd frames' selected inliers (the even frames' live in `inl`)
+    void* h_frame = nullptr;       // (alias of the last collected slot's record)
     bool frame_pending = false;
-    int frame_inl_every = 0;       // > 0: the pending frame also selected every n-th refinement inlier
-    bool frame_collected = false;  // wass_ctx_frame_result has been read for the last wass_mesh_finish_frame_async* call
-    bool frame_inl_text = false;   // ... and formatted plane_refinement_inliers.xyz on the device
-    size_t frame_inl_cap = 0;      // ... capacity (points) of the selection in c->inl
-    unsigned long long frame_sgm_call = 0;   // 1-based index of the SGM call whose disparity the pending frame was built from
     void* h_stage = nullptr;       // pinned source images of the frame tail's small H2D copies (mesh.hip host_stage)
-    hipEvent_t ev_stage = nullptr;
+    hipEvent_t ev_stage = nullptr, ev_stage2 = nullptr;   // the RANSAC triplets' staging areas (two, alternated) have been copied to the device
     hipEvent_t ev_producer = nullptr; // wass_ctx_wait_for_stream
     hipEvent_t ev_dl = nullptr;        // wass_download_async: orders the copy stream after the SGM stream
     hipEvent_t ev_dl_tail = nullptr;   // ... and after the tail stream
@@ -162,7 +172,6 @@ struct wass_ctx {
     hipEvent_t* ev_tail = ev_tail_sets[0];  // set of the last triangulation
     int tail_set = 0;
     bool tail_timed[2] = {};
-    int frame_tail_set = 0;        // the set the pending frame's tail was recorded into
     wass::Buf ccmask;              // valid mask after the outlier removal, kept for graph_components.jpg when asked for
     // wass_upload_async: uploads in flight on the copy stream, by destination; consumers wait for the matching event
     struct UploadSlot { const char* dst = nullptr; size_t n = 0; hipEvent_t ev = nullptr; bool pending = false, consumed = false; };

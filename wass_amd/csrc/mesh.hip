@@ -852,12 +852,15 @@ __global__ void __launch_bounds__(256) k_inlier_pack(const uint8_t* __restrict__
 // from the doubles instead, as before.
 constexpr int INL_LINE_MAX = 40;
 // pass 1: a block formats 256 lines into LDS (a thread's line is a string of single bytes: in HBM that is 40 partial cache-line
-// writes per thread, 64 different lines per instruction), packs them back to back and writes them to the block's staging area
-// with coalesced stores; blockbytes[b] = their length.  pass 2 (after the scan): the blocks' chunks copied to their final offsets.
+// writes per thread, 64 different lines per instruction), packs them back to back -- still in LDS -- and writes the packed chunk to
+// the block's staging area as dwords; blockbytes[b] = its length.  pass 2 (after the scan): the chunks copied to their final
+// offsets, again as dwords (the destination's alignment differs from the source's: two source dwords and a byte funnel shift per
+// destination dword).  Byte-granular global traffic made these two kernels 0.36 ms per frame, which a saturated GPU charges in full.
 __global__ void __launch_bounds__(256) k_inl_text_format(const double* __restrict__ pts, const unsigned int* __restrict__ total, unsigned int every,
                                                          char* __restrict__ staging, unsigned int* __restrict__ blockbytes, unsigned int* __restrict__ bad_out)
 {
-    __shared__ char lines[256][INL_LINE_MAX];
+    __shared__ __attribute__((aligned(16))) char lines[256][INL_LINE_MAX];
+    __shared__ __attribute__((aligned(16))) char packed[256 * INL_LINE_MAX + 16];
     __shared__ unsigned int wsum[4];
     const unsigned int nsel = (*total + every - 1) / every;
     const unsigned int j = blockIdx.x * 256 + threadIdx.x;
@@ -882,12 +885,13 @@ __global__ void __launch_bounds__(256) k_inl_text_format(const double* __restric
     __syncthreads();
     unsigned int off = incl - len;
     for (int q = 0; q < wv; ++q) off += wsum[q];
-    char* const dst = staging + (size_t)blockIdx.x * (256 * INL_LINE_MAX);
-    for (int i = 0; i < 64; ++i) {                         // the wave's 64 lines, one after the other, lane l taking byte l
-        const unsigned int li = (unsigned)__shfl((int)len, i), oi = (unsigned)__shfl((int)off, i);
-        if ((unsigned)lane < li) dst[oi + lane] = lines[wv * 64 + i][lane];
-    }
-    if (threadIdx.x == 0) blockbytes[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    const unsigned int btot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    for (unsigned int i = 0; i < len; ++i) packed[off + i] = lines[threadIdx.x][i];     // LDS to LDS: every thread its own line
+    __syncthreads();
+    uint32_t* const dst = (uint32_t*)(staging + (size_t)blockIdx.x * (256 * INL_LINE_MAX));
+    const uint32_t* const src = (const uint32_t*)packed;
+    for (unsigned int i = threadIdx.x; i < (btot + 3) / 4; i += 256) dst[i] = src[i];   // (the last dword's pad bytes are never copied on)
+    if (threadIdx.x == 0) blockbytes[blockIdx.x] = btot;
     if (bad) atomicAdd(bad_out, bad);
 }
 __global__ void __launch_bounds__(256) k_inl_text_pack(const char* __restrict__ staging, const unsigned int* __restrict__ blockoff,
@@ -895,8 +899,31 @@ __global__ void __launch_bounds__(256) k_inl_text_pack(const char* __restrict__ 
 {
     const unsigned int b = blockIdx.x;
     const unsigned int o0 = blockoff[b], o1 = b + 1 < nblocks ? blockoff[b + 1] : *text_total;
-    const char* src = staging + (size_t)b * (256 * INL_LINE_MAX);
-    for (unsigned int i = threadIdx.x; i < o1 - o0; i += 256) out[o0 + i] = src[i];
+    const unsigned int nbytes = o1 - o0;
+    if (nbytes == 0) return;
+    const char* src = staging + (size_t)b * (256 * INL_LINE_MAX);                       // dword aligned
+    char* const d = out + o0;
+    // head bytes up to the destination's next dword boundary, whole dwords, tail bytes
+    const unsigned int head = min(nbytes, (unsigned int)((4 - ((uintptr_t)d & 3)) & 3));
+    if (threadIdx.x < head) d[threadIdx.x] = src[threadIdx.x];
+    const unsigned int nd = (nbytes - head) / 4;
+    const uint32_t* const s32 = (const uint32_t*)src;
+    uint32_t* const d32 = (uint32_t*)(d + head);
+    for (unsigned int i = threadIdx.x; i < nd; i += 256) {
+        const uint32_t lo = s32[i], hi = head ? s32[i + 1] : 0u;
+        d32[i] = head ? __builtin_amdgcn_alignbyte(hi, lo, head) : lo;
+    }
+    const unsigned int done = head + 4 * nd;
+    if (threadIdx.x < nbytes - done) d[done + threadIdx.x] = src[done + threadIdx.x];
+}
+
+__global__ void k_inl_text_totals(DevState* __restrict__ ds, const unsigned int* __restrict__ text_total)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const bool have = ds->ransac_found != 0;
+        ds->inl_text_bytes = have ? text_total[0] : 0ull;
+        ds->inl_text_bad = have ? text_total[1] : 0u;
+    }
 }
 
 // smallest-eigenvalue eigenvector of a symmetric 3x3 (cyclic Jacobi); stands in for row 2 of cv::SVD's vt
@@ -1068,16 +1095,19 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(unsigned int* __restrict__
 {
     // exclusive scan of nb counts by one workgroup: each of the 16 waves owns a contiguous range and reads it 64 at a time
     // (coalesced, independent loads); range totals meet in LDS, then every wave rewrites its range with a running carry
+    // any number of waves up to 16 (blockDim.x / 64).  Launched with 256 threads in the frame tail: a 1024-thread workgroup needs four free
+    // wave slots on every SIMD of ONE compute unit, and underneath the next frame's aggregation kernels (five waves per SIMD) that can
+    // mean waiting for one of their workgroups to retire -- with the whole tail stream queued behind it.
     __shared__ unsigned int wtot[16];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int per = ((nb + 15) / 16 + 63) & ~63, begin = min(nb, wv * per), end = min(nb, begin + per);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
+    const int per = ((nb + nw - 1) / nw + 63) & ~63, begin = min(nb, wv * per), end = min(nb, begin + per);
     unsigned int sum = 0;
     for (int i = begin + lane; i < end; i += 64) sum += cnt[i];
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
     if (lane == 0) wtot[wv] = sum;
     __syncthreads();
     unsigned int carry = 0, all = 0;
-    for (int k = 0; k < 16; ++k) { if (k < wv) carry += wtot[k]; all += wtot[k]; }
+    for (int k = 0; k < nw; ++k) { if (k < wv) carry += wtot[k]; all += wtot[k]; }
     if (threadIdx.x == 0) *total = all;
     for (int base = begin; base < end; base += 64) {
         const int i = base + lane;
@@ -1551,11 +1581,13 @@ __global__ void __launch_bounds__(256) k_xyzc_pack_dev(const uint8_t* __restrict
 }
 
 constexpr size_t DSTATE_HIST_OFF = (sizeof(DevState) + 255) & ~(size_t)255;
+constexpr size_t DSTATE_STRIDE = (DSTATE_HIST_OFF + (size_t)GAP_HIST_COPIES * GAP_BINS * 4 + 255) & ~(size_t)255;
+// two records (+ histograms), alternated by the frame tail (wass_ctx::ds_slot): frame n's is downloaded while frame n+1's is being built
 static int dstate(wass_ctx* c, DevState** ds)
 {
-    int rc = ensure(c, c->dstate, DSTATE_HIST_OFF + (size_t)GAP_HIST_COPIES * GAP_BINS * 4);
+    int rc = ensure(c, c->dstate, 2 * DSTATE_STRIDE);
     if (rc) return rc;
-    *ds = (DevState*)c->dstate.p;
+    *ds = (DevState*)((char*)c->dstate.p + (size_t)(c->ds_slot & 1) * DSTATE_STRIDE);
     return WASS_OK;
 }
 
@@ -1611,7 +1643,8 @@ int wass_mesh_keep_biggest_component(wass_ctx* c, wass_mesh* m, double zgap, uin
 // copy from pageable or stack memory is only safe if the runtime happens to stage it before returning; these copies
 // are enqueued and never waited for, so their sources must outlive the call: [DevState init | limits init | uv samples].
 constexpr size_t STAGE_UV_OFF = 4096 + NSLOT * 6 * 8;
-constexpr size_t STAGE_BYTES = STAGE_UV_OFF + 1800 * 24;      // PLANE_RANSAC_ROUNDS <= 1800 (LDS limit of k_ransac_score)
+constexpr size_t STAGE_UV_BYTES = 1800 * 24;                  // PLANE_RANSAC_ROUNDS <= 1800 (LDS limit of k_ransac_score)
+constexpr size_t STAGE_BYTES = STAGE_UV_OFF + 2 * STAGE_UV_BYTES;   // two areas, alternated: the host never waits for the previous frame's copy
 static int host_stage(wass_ctx* c, unsigned char** out)
 {
     static_assert(sizeof(DevState) <= 4096, "DevState init image");
@@ -1625,7 +1658,8 @@ static int host_stage(wass_ctx* c, unsigned char** out)
         memcpy(p, &init, sizeof init);
         unsigned long long* lim = (unsigned long long*)(p + 4096);
         for (int i = 0; i < NSLOT; ++i) for (int k = 0; k < 6; ++k) lim[i * 6 + k] = k < 3 ? ~0ull : 0ull;
-        if (hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming) != hipSuccess) return set_err(c, WASS_ERR_DEVICE, "hipEventCreate failed");
+        if (hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_stage2, hipEventDisableTiming) != hipSuccess)
+            return set_err(c, WASS_ERR_DEVICE, "hipEventCreate failed");
     }
     *out = (unsigned char*)c->h_stage;
     return WASS_OK;
@@ -1639,7 +1673,7 @@ static int enqueue_remove_outliers(wass_ctx* c, wass_mesh* m, double percentile,
     unsigned int* hist = (unsigned int*)((char*)ds + DSTATE_HIST_OFF);      // 256-byte aligned: one fill kernel, not three
     unsigned char* stage = nullptr;
     if ((rc = host_stage(c, &stage))) return rc;
-    WASS_HIP(c, hipStreamWaitEvent(c->ts(), c->ev_copy, 0));            // the copy stream may still be reading the last frame's record
+    WASS_HIP(c, hipStreamWaitEvent(c->ts(), c->fslot[c->ds_slot & 1].ev_copy, 0));   // the download that read THIS record: two frames ago
     WASS_HIP(c, hipMemcpyAsync(ds, stage, sizeof(DevState), hipMemcpyHostToDevice, c->ts()));
     WASS_HIP(c, hipMemsetAsync(hist, 0, (size_t)GAP_HIST_COPIES * GAP_BINS * 4, c->ts()));
     for (int pass = 0; pass < GAP_PASSES; ++pass) {
@@ -1870,7 +1904,7 @@ int wass_mesh_refinement_inliers(wass_ctx* c, wass_mesh* m, const wass_refine_pa
     double* dout = (double*)((char*)c->scratch.p + off_out);
     hipStream_t s = c->ts();
     hipLaunchKernelGGL(k_inlier_counts, dim3(nb), dim3(256), 0, s, m->valid, m->x, m->y, m->z, m->w, n, rd, bcnt);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, bcnt, (int)nb, total);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, s, bcnt, (int)nb, total);
     hipLaunchKernelGGL(k_inlier_pack, dim3(nb), dim3(256), 0, s, m->valid, m->x, m->y, m->z, m->w, n, rd, (const unsigned int*)bcnt,
                        (unsigned)every, dout);
     unsigned int ht = 0;
@@ -1919,10 +1953,14 @@ static int enqueue_fit_plane(wass_ctx* c, wass_mesh* m, const int32_t* uv, int r
         // copy out of it was enqueued a whole frame ago; wait for it before overwriting)
         unsigned char* stage = nullptr;
         if ((rc = host_stage(c, &stage))) return rc;
-        if (c->stage_uv_busy) WASS_HIP(c, hipEventSynchronize(c->ev_stage));
-        memcpy(stage + STAGE_UV_OFF, uv, (size_t)rounds * 24);
-        WASS_HIP(c, hipMemcpyAsync(duv, stage + STAGE_UV_OFF, (size_t)rounds * 24, hipMemcpyHostToDevice, s));
-        WASS_HIP(c, hipEventRecord(c->ev_stage, s));
+        // (two areas, alternated with the frame slot: the copy out of THIS one was enqueued two frames ago)
+        const int ua = c->ds_slot & 1;
+        hipEvent_t evs = ua ? c->ev_stage2 : c->ev_stage;
+        unsigned char* area = stage + STAGE_UV_OFF + (size_t)ua * STAGE_UV_BYTES;
+        if (c->stage_uv_busy) WASS_HIP(c, hipEventSynchronize(evs));
+        memcpy(area, uv, (size_t)rounds * 24);
+        WASS_HIP(c, hipMemcpyAsync(duv, area, (size_t)rounds * 24, hipMemcpyHostToDevice, s));
+        WASS_HIP(c, hipEventRecord(evs, s));
         c->stage_uv_busy = true;
     }
     hipLaunchKernelGGL(k_ransac_planes, dim3((rounds + 63) / 64), dim3(64), 0, s, m->valid, m->x, m->y, m->z, m->w, (const int32_t*)duv,
@@ -2007,8 +2045,15 @@ int wass_mesh_finish_frame_async_ex2(wass_ctx* c, wass_mesh* m, double percentil
     const size_t n = m->n();
     if (capacity < 148 + n * 6)
         return set_err(c, WASS_ERR_INVALID_ARG, "the asynchronous form needs room for every grid point: %zu bytes", 148 + n * 6);
-    if (!c->h_frame && hipHostMalloc((void**)&c->h_frame, sizeof(DevState) + 64, hipHostMallocDefault) != hipSuccess)
+    if (c->nframe_enq - c->nframe_col >= 2)
+        return set_err(c, WASS_ERR_INVALID_ARG, "two frames are pending already: read the older one's record first (wass_ctx_frame_result)");
+    const int slot = (int)(c->nframe_enq & 1);
+    wass_ctx::FrameSlot& fs = c->fslot[slot];
+    if (!fs.h_frame && hipHostMalloc((void**)&fs.h_frame, sizeof(DevState) + 64, hipHostMallocDefault) != hipSuccess)
         return set_err(c, WASS_ERR_NO_MEMORY, "hipHostMalloc failed");
+    c->ds_slot = slot;                                     // the stage helpers below build THIS slot's record
+    wass::Buf& inlbuf = slot ? c->inl2 : c->inl;           // ... and the selection lives in this slot's buffer
+    hipEvent_t ev_prev = c->ev_copy;                       // the previous frame's downloads (they read the shared file image and masks)
     DevState* ds = nullptr;
     unsigned long long* kept1 = nullptr;
     int rc;
@@ -2017,7 +2062,7 @@ int wass_mesh_finish_frame_async_ex2(wass_ctx* c, wass_mesh* m, double percentil
     if ((rc = enqueue_remove_outliers(c, m, percentile, &ds))) return rc;
     if (component_mask_dst) {                              // what cluster_biggest_connected_component left valid (graph_components.jpg)
         if ((rc = ensure(c, c->ccmask, n))) return rc;
-        WASS_HIP(c, hipStreamWaitEvent(c->ts(), c->ev_copy, 0));
+        WASS_HIP(c, hipStreamWaitEvent(c->ts(), ev_prev, 0));
         WASS_HIP(c, hipMemcpyAsync(c->ccmask.p, m->valid, n, hipMemcpyDeviceToDevice, c->ts()));
     }
     if ((rc = enqueue_fit_plane(c, m, uv, rounds, ransac_thr, rp, max_distance, &ds, &kept1, false))) return rc;
@@ -2031,6 +2076,7 @@ int wass_mesh_finish_frame_async_ex2(wass_ctx* c, wass_mesh* m, double percentil
     // enqueue_fit_plane has just applied; the final crop (below) has not run yet -- the point main() collects them at
     size_t inl_copy = 0, text_copy = 0;
     const char* text_src = nullptr;
+    const unsigned int* text_totals = nullptr;             // [0] bytes of text, [1] numbers not formatted: written on the copy stream
     unsigned int* inl_total = nullptr;
     if (inliers_dst || inliers_text_dst) {
         RefineDev rd;
@@ -2046,26 +2092,29 @@ int wass_mesh_finish_frame_async_ex2(wass_ctx* c, wass_mesh* m, double percentil
         const size_t text_off = (256 + cap * 24 + (size_t)nb2 * 4 + 255) & ~(size_t)255;
         if (inliers_text_dst && inliers_text_capacity < cap * INL_LINE_MAX)
             return set_err(c, WASS_ERR_INVALID_ARG, "inliers_text_dst must hold %zu bytes", cap * (size_t)INL_LINE_MAX);
-        if ((rc = ensure(c, c->inl, text_off + (inliers_text_dst ? cap * INL_LINE_MAX + (size_t)nb2 * 256 * INL_LINE_MAX + 256 : 0)))) return rc;   // text, staging
-        inl_total = (unsigned int*)c->inl.p;                       // [0]: number of refinement inliers, [2]: bytes of text, [3]: numbers not formatted; points from byte 256
+        if ((rc = ensure(c, inlbuf, text_off + (inliers_text_dst ? cap * INL_LINE_MAX + (size_t)nb2 * 256 * INL_LINE_MAX + 256 : 0)))) return rc;   // text, staging
+        inl_total = (unsigned int*)inlbuf.p;                       // [0]: number of refinement inliers, [2]: bytes of text, [3]: numbers not formatted; points from byte 256
         unsigned int* bc = (unsigned int*)((char*)c->scratch.p + 64);
-        double* dout = (double*)((char*)c->inl.p + 256);
-        WASS_HIP(c, hipStreamWaitEvent(s, c->ev_copy, 0));        // the previous frame's download of this buffer
+        double* dout = (double*)((char*)inlbuf.p + 256);
+        WASS_HIP(c, hipStreamWaitEvent(s, fs.ev_copy, 0));        // the download (and the text kernels) that read THIS buffer: two frames ago
         hipLaunchKernelGGL(k_inlier_counts, dim3(nb), dim3(256), 0, s, m->valid, m->x, m->y, m->z, m->w, n, rd, bc);
-        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, bc, (int)nb, inl_total);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, s, bc, (int)nb, inl_total);
         hipLaunchKernelGGL(k_inlier_pack, dim3(nb), dim3(256), 0, s, m->valid, m->x, m->y, m->z, m->w, n, rd, (const unsigned int*)bc,
                            (unsigned)inliers_every, dout);
         inl_copy = inliers_dst ? cap * 24 : 0;                    // (text only: the points stay on the device, wass_ctx_frame_inliers fetches them on demand)
         if (inliers_text_dst) {                                   // the file's text, formatted here (fmt_g6.h)
-            unsigned int* bb = (unsigned int*)((char*)c->inl.p + 256 + cap * 24);
-            char* staging = (char*)c->inl.p + text_off + cap * INL_LINE_MAX;
+            unsigned int* bb = (unsigned int*)((char*)inlbuf.p + 256 + cap * 24);
+            char* staging = (char*)inlbuf.p + text_off + cap * INL_LINE_MAX;
+            // (On the tail stream.  Putting these kernels on the copy stream behind an event, or into a small persistent grid held to one
+            // wave per SIMD, changed nothing / made it worse: what they cost the C++ driver is their share of a tail stream that is
+            // nearly as long as the SGM stage by now -- NOTES/tail_and_host.md, round 5.)
             WASS_HIP(c, hipMemsetAsync(inl_total + 2, 0, 8, s));
             hipLaunchKernelGGL(k_inl_text_format, dim3(nb2), dim3(256), 0, s, (const double*)dout, (const unsigned int*)inl_total, (unsigned)inliers_every, staging,
                                bb, inl_total + 3);
-            hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, bb, (int)nb2, inl_total + 2);
+            hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, s, bb, (int)nb2, inl_total + 2);
             // Pinned host memory is mapped into the device's address space: the packing kernel then writes the text straight into the
             // caller's buffer -- exactly the file's bytes cross PCIe, where a copy would have to move the 40-bytes-per-point worst
-            // case (the length is only known on the device), as one more blit kernel on the copy stream in front of the next upload.
+            // case (the length is only known on the device).
             char* direct = nullptr;
             {
                 hipPointerAttribute_t at;
@@ -2073,13 +2122,14 @@ int wass_mesh_finish_frame_async_ex2(wass_ctx* c, wass_mesh* m, double percentil
                 else (void)hipGetLastError();
             }
             hipLaunchKernelGGL(k_inl_text_pack, dim3(nb2), dim3(256), 0, s, (const char*)staging, (const unsigned int*)bb, (const unsigned int*)(inl_total + 2), nb2,
-                               direct ? direct : (char*)c->inl.p + text_off);
-            if (direct) { c->frame_inl_cap = cap; goto text_done; }
+                               direct ? direct : (char*)inlbuf.p + text_off);
+            text_totals = inl_total + 2;
+            if (direct) goto text_done;
             text_copy = cap * INL_LINE_MAX;
-            text_src = (const char*)c->inl.p + text_off;
+            text_src = (const char*)inlbuf.p + text_off;
         text_done:;
         }
-        c->frame_inl_cap = cap;
+        fs.inl_cap = cap;
     }
     hipLaunchKernelGGL(k_frame_rt, dim3(1), dim3(64), 0, s, ds);
     unsigned char* stage = nullptr;
@@ -2090,32 +2140,34 @@ int wass_mesh_finish_frame_async_ex2(wass_ctx* c, wass_mesh* m, double percentil
     unsigned int* total = (unsigned int*)c->scratch.p;
     unsigned int* bcnt = (unsigned int*)((char*)c->scratch.p + 64);
     unsigned char* img = (unsigned char*)c->xyzc.p;
-    WASS_HIP(c, hipStreamWaitEvent(s, c->ev_copy, 0));                    // a previous download still reading the image
+    WASS_HIP(c, hipStreamWaitEvent(s, ev_prev, 0));                       // the previous frame's download still reading the image
     hipLaunchKernelGGL(k_crop_limits_counts_dev, dim3((nb + CLC_CHUNKS - 1) / CLC_CHUNKS), dim3(256), 0, s, m->valid, m->x, m->y, m->z, n,
                        (const DevState*)ds, max_distance, kept1 + NSLOT, lim, bcnt, nb);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, bcnt, (int)nb, total);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, s, bcnt, (int)nb, total);
     hipLaunchKernelGGL(k_frame_header, dim3(1), dim3(64), 0, s, ds, (const unsigned long long*)lim, (const unsigned int*)total,
                        (const unsigned long long*)kept1, img, (const unsigned long long*)c->tri_cnt.p, (const unsigned int*)inl_total,
-                       inliers_text_dst ? (const unsigned int*)(inl_total + 2) : (const unsigned int*)nullptr);
+                       (const unsigned int*)nullptr);
     hipLaunchKernelGGL(k_xyzc_pack_dev, dim3(nb), dim3(256), 0, s, m->valid, m->x, m->y, m->z, n, (const DevState*)ds,
                        (const unsigned int*)bcnt, (uint16_t*)(img + 148));
     WASS_HIP(c, hipGetLastError());
     if (timed) { (void)hipEventRecord(c->ev_tail[5], s); c->tail_timed[c->tail_set] = true; }
-    c->frame_tail_set = c->tail_set;
+    fs.tail_set = c->tail_set;
+    if (text_totals) hipLaunchKernelGGL(k_inl_text_totals, dim3(1), dim3(64), 0, s, ds, text_totals);   // after the header kernel's write of the record
     WASS_HIP(c, hipEventRecord(c->ev_pack, s));
     WASS_HIP(c, hipStreamWaitEvent(c->copy, c->ev_pack, 0));
-    WASS_HIP(c, hipMemcpyAsync(c->h_frame, ds, sizeof(DevState), hipMemcpyDeviceToHost, c->copy));
+    WASS_HIP(c, hipMemcpyAsync(fs.h_frame, ds, sizeof(DevState), hipMemcpyDeviceToHost, c->copy));
     WASS_HIP(c, hipMemcpyAsync(dst, img, 148 + n * 6, hipMemcpyDeviceToHost, c->copy));
-    if (inl_copy) WASS_HIP(c, hipMemcpyAsync(inliers_dst, (const char*)c->inl.p + 256, inl_copy, hipMemcpyDeviceToHost, c->copy));
+    if (inl_copy) WASS_HIP(c, hipMemcpyAsync(inliers_dst, (const char*)inlbuf.p + 256, inl_copy, hipMemcpyDeviceToHost, c->copy));
     // (the text's length is only known on the device: the copy takes what a frame of this size can need at most -- 0.1 ms per MB)
     if (text_copy) WASS_HIP(c, hipMemcpyAsync(inliers_text_dst, text_src, text_copy, hipMemcpyDeviceToHost, c->copy));
     if (component_mask_dst) WASS_HIP(c, hipMemcpyAsync(component_mask_dst, c->ccmask.p, n, hipMemcpyDeviceToHost, c->copy));
-    WASS_HIP(c, hipEventRecord(c->ev_copy, c->copy));
-    c->frame_inl_every = (inliers_dst || inliers_text_dst) ? inliers_every : 0;
-    c->frame_inl_text = inliers_text_dst != nullptr;
+    WASS_HIP(c, hipEventRecord(fs.ev_copy, c->copy));
+    c->ev_copy = fs.ev_copy;                  // "the most recently recorded download event"
+    fs.inl_every = (inliers_dst || inliers_text_dst) ? inliers_every : 0;
+    fs.inl_text = inliers_text_dst != nullptr;
+    fs.sgm_call = c->nsgm;                    // the SGM call that fed this frame is the last one enqueued (0: none)
     c->frame_pending = true;
-    c->frame_collected = false;
-    c->frame_sgm_call = c->nsgm;              // the SGM call that fed this frame is the last one enqueued (0: none)
+    ++c->nframe_enq;
     return WASS_OK;
 }
 
@@ -2126,13 +2178,17 @@ int wass_format_g6(double v, char* out) { return out ? wass::fmt_g6(v, out) : -1
 int wass_ctx_frame_inliers(wass_ctx* c, double* dst, size_t capacity_points, uint64_t* n_out)
 {
     if (!c || !dst) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
-    if (!c->frame_collected || c->frame_inl_every <= 0 || !c->inl.p) return set_err(c, WASS_ERR_INVALID_ARG, "no collected frame with an inlier selection");
+    if (c->nframe_col == 0) return set_err(c, WASS_ERR_INVALID_ARG, "no collected frame");
+    const int slot = (int)((c->nframe_col - 1) & 1);       // the frame whose record was read last; its buffer lives until the frame after next
+    const wass_ctx::FrameSlot& fs = c->fslot[slot];
+    const wass::Buf& inlbuf = slot ? c->inl2 : c->inl;
+    if (fs.inl_every <= 0 || !inlbuf.p || !fs.h_frame) return set_err(c, WASS_ERR_INVALID_ARG, "no collected frame with an inlier selection");
     WASS_HIP(c, hipSetDevice(c->device));
-    const DevState& h = *(const DevState*)c->h_frame;
-    const uint64_t n = ((uint64_t)h.ninl_sel + (uint64_t)c->frame_inl_every - 1) / (uint64_t)c->frame_inl_every;
-    if (n > capacity_points || n > c->frame_inl_cap) return set_err(c, WASS_ERR_INVALID_ARG, "dst must hold %llu points", (unsigned long long)n);
-    WASS_HIP(c, hipStreamSynchronize(c->ts()));
-    WASS_HIP(c, hipMemcpy(dst, (const char*)c->inl.p + 256, (size_t)n * 24, hipMemcpyDeviceToHost));
+    const DevState& h = *(const DevState*)fs.h_frame;
+    const uint64_t n = ((uint64_t)h.ninl_sel + (uint64_t)fs.inl_every - 1) / (uint64_t)fs.inl_every;
+    if (n > capacity_points || n > fs.inl_cap) return set_err(c, WASS_ERR_INVALID_ARG, "dst must hold %llu points", (unsigned long long)n);
+    // (the frame's own downloads have completed -- its record was read -- so its selection is complete; a plain blocking copy)
+    WASS_HIP(c, hipMemcpy(dst, (const char*)inlbuf.p + 256, (size_t)n * 24, hipMemcpyDeviceToHost));
     if (n_out) *n_out = n;
     return WASS_OK;
 }
@@ -2140,10 +2196,12 @@ int wass_ctx_frame_inliers(wass_ctx* c, double* dst, size_t capacity_points, uin
 int wass_ctx_frame_result(wass_ctx* c, wass_frame_result* out)
 {
     if (!c || !out) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
-    if (!c->frame_pending) return set_err(c, WASS_ERR_INVALID_ARG, "no wass_mesh_finish_frame_async call to wait for");
-    WASS_HIP(c, hipEventSynchronize(c->ev_copy));
-    c->frame_collected = true;
-    const DevState& h = *(const DevState*)c->h_frame;
+    if (c->nframe_col >= c->nframe_enq) return set_err(c, WASS_ERR_INVALID_ARG, "no wass_mesh_finish_frame_async call to wait for");
+    const wass_ctx::FrameSlot& fs = c->fslot[c->nframe_col & 1];   // the OLDER of the pending frames
+    WASS_HIP(c, hipEventSynchronize(fs.ev_copy));
+    ++c->nframe_col;
+    c->h_frame = fs.h_frame;
+    const DevState& h = *(const DevState*)fs.h_frame;
     memset(out, 0, sizeof *out);
     out->zgap = h.zgap; out->n_gaps = h.sel_total; out->component_size = h.ccl_best >> 32;
     out->found = h.ransac_found; out->refine_ok = h.refine_ok;
@@ -2153,18 +2211,18 @@ int wass_ctx_frame_result(wass_ctx* c, wass_frame_result* out)
     out->n_points = h.npts;
     out->xyzc_bytes = 148 + (uint64_t)h.npts * 6;
     out->n_triangulated = h.ntri;
-    if (c->tail_timed[c->frame_tail_set]) {                  // all six events lie before the download this function has waited for
-        hipEvent_t* const ev = c->ev_tail_sets[c->frame_tail_set];   // the PENDING frame's set: the next frame may have been triangulated already
+    if (c->tail_timed[fs.tail_set]) {                        // all six events lie before the download this function has waited for
+        hipEvent_t* const ev = c->ev_tail_sets[fs.tail_set];       // the frame's own set: the next frame may have been triangulated already
         for (int k = 0; k < 5; ++k)
             if (hipEventElapsedTime(&out->stage_ms[k], ev[k], ev[k + 1]) != hipSuccess) out->stage_ms[k] = 0.0f;
     }
-    out->n_inliers_out = c->frame_inl_every > 0 ? ((uint64_t)h.ninl_sel + (uint64_t)c->frame_inl_every - 1) / (uint64_t)c->frame_inl_every : 0;
-    out->inliers_text_bytes = c->frame_inl_text ? h.inl_text_bytes : 0;
-    out->inliers_text_unsupported = c->frame_inl_text ? h.inl_text_bad : 0;
-    if (c->frame_sgm_call > 0 && c->nsgm - c->frame_sgm_call < 2) {
+    out->n_inliers_out = fs.inl_every > 0 ? ((uint64_t)h.ninl_sel + (uint64_t)fs.inl_every - 1) / (uint64_t)fs.inl_every : 0;
+    out->inliers_text_bytes = fs.inl_text ? h.inl_text_bytes : 0;
+    out->inliers_text_unsupported = fs.inl_text ? h.inl_text_bad : 0;
+    if (fs.sgm_call > 0 && c->nsgm - fs.sgm_call < 2) {
         // status word of the frame's SGM call: copied to pinned memory in stream order long before the download this
         // function has just waited for; the slot is reused two calls later
-        const uint32_t fl = c->h_flags[4 * (int)((c->frame_sgm_call - 1) & 1)];
+        const uint32_t fl = c->h_flags[4 * (int)((fs.sgm_call - 1) & 1)];
         out->sgm_cost_overflow = (int)(fl & 1);
         out->sgm_timeout = (int)((fl >> 1) & 1);
     } else {
@@ -2216,7 +2274,7 @@ static int encode_xyzc_impl(wass_ctx* c, wass_mesh* m, const double plane[4], vo
     WASS_HIP(c, hipMemcpyAsync(lim, init, sizeof init, hipMemcpyHostToDevice, c->ts()));
     hipLaunchKernelGGL(k_xyzc_limits, dim3(1024), dim3(256), 0, c->ts(), m->valid, m->x, m->y, m->z, n, rt, lim);
     hipLaunchKernelGGL(k_block_counts, dim3(nb), dim3(256), 0, c->ts(), m->valid, n, bcnt);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, c->ts(), bcnt, (int)nb, total);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, c->ts(), bcnt, (int)nb, total);
     unsigned long long hs[NSLOT * 6], hl[6] = { ~0ull, ~0ull, ~0ull, 0, 0, 0 };
     unsigned int npts = 0;
     WASS_HIP(c, hipMemcpyAsync(hs, lim, sizeof hs, hipMemcpyDeviceToHost, c->ts()));

@@ -123,6 +123,12 @@ public:
     }
     ~FramePipeline()
     {
+        if (timing_ && nsub_ > 0) {
+            static const char* nm[7] = { "out slot + raw + previews", "rectify + masks", "wass_sgm_disparity_dev", "postprocess", "triangulate", "finish_frame_async", "collect previous (wait)" };
+            fprintf(stderr, "FramePipeline: submit() per frame over %d frames:", nsub_);
+            for (int k = 0; k < 7; ++k) fprintf(stderr, "  %s %.2f ms", nm[k], 1e3 * lap_[k] / nsub_);
+            fprintf(stderr, "\n");
+        }
         if (!ctx_) return;
         (void)wass_ctx_synchronize(ctx_);
         release_buffers();
@@ -271,6 +277,8 @@ public:
         job.t_submit0 = Timer::now();
         Env& env = job.env;
         wass_mesh* mesh = nullptr;
+        double tp = job.t_submit0;                        // WASS_PIPE_TIMING=1: where the submitting thread's time goes (printed when the pipeline is destroyed)
+        auto lap = [&](int k) { if (timing_) { const double t = Timer::now(); lap_[k] += t - tp; tp = t; } };
         try {
             const int k = job.in_slot;
             const int rl[4] = { env.roi_l.x, env.roi_l.y, env.roi_l.width, env.roi_l.height };
@@ -317,6 +325,7 @@ public:
                     check(wass_download_async(ctx_, o.prev[side], dp, pn), "wass_download_async");
                 }
             }
+            lap(0);
             // ---- rectify(): the resampling (:515-528, 600-607), ROI crop fused, from the device-resident pictures
             WLOG_SCOPE("rectify");
             if (env.use_custom) {
@@ -336,6 +345,7 @@ public:
                 if (mask_l) check(wass_camera_mask_dev(ctx_, burned ? in_[k].d_l : nullptr, job.fmask[0].empty() ? nullptr : in_[k].d_fl, n, in_[k].d_ml), "wass_camera_mask");
                 if (mask_r) check(wass_camera_mask_dev(ctx_, burned ? in_[k].d_r : nullptr, job.fmask[1].empty() ? nullptr : in_[k].d_fr, n, in_[k].d_mr), "wass_camera_mask");
             }
+            lap(1);
             // ---- sgbm_dense_stereo (:764-1020)
             WLOG_SCOPE("sgbm_dense_stereo");
             const int cw = rr[2], ch = rr[3];
@@ -348,6 +358,7 @@ public:
             int16_t* d16 = d_disp16_[job.disp_slot];
             check(wass_sgm_disparity_dev(ctx_, in_[k].d_cr, in_[k].d_cl, cw, ch, (size_t)cw, &sp_, d16), "wass_sgm_disparity");
             job.sgm_call = (long long)sgm_calls();         // the library's own count: no shadow counter to fall out of step after a failed frame
+            lap(2);
             const int dil = cfg_.get_int("DISP_DILATE_STEPS"), ero = cfg_.get_int("DISP_EROSION_STEPS"), med = cfg_.get_int("MEDIAN_FILTER_WSIZE");
             if (dil > 0) WLOGI << "applying dilate filter (" << dil << " steps)"; else WLOGI << "dilate filter skipped.";
             if (ero > 0) WLOGI << "applying erode filter (" << ero << " steps)"; else WLOGI << "erode filter skipped.";
@@ -359,6 +370,7 @@ public:
             check(wass_disparity_postprocess_ex_dev(ctx_, d16, cw, ch, &sp_, dil, ero, med, cc_threshold, cw, ch, d_dispf_), "wass_disparity_postprocess");
             WLOGI << "dense stereo completed successfully";
             marker(job, 40);
+            lap(3);
             // ---- triangulate (:1039-1386)
             WLOG_SCOPE("triangulate");
             wass_geom g;
@@ -384,8 +396,7 @@ public:
             check(wass_triangulate_dev(ctx_, d_dispf_, W_, H_, rl, rr, &g, in_[k].d_r, W_, H_, mask_l ? in_[k].d_ml : nullptr,
                                        mask_r ? in_[k].d_mr : nullptr, &tp, &mesh, nullptr), "wass_triangulate");
             WLOGI << "... 100%";
-            // ---- the previous frame: its record and file image have arrived while this one was being enqueued
-            if (FrameJob* p = collect()) done.push_back(p);
+            lap(4);
             // ---- the mesh tail (:2046-2123), decided on the device
             const int rounds = cfg_.get_int("PLANE_RANSAC_ROUNDS");
             if (uv_.empty() || uv_seed_ != job.ransac_seed || uv_w_ != rr[2] || uv_h_ != rr[3]) {
@@ -405,6 +416,13 @@ public:
             if (opt_.debug_pictures) job.mesh = mesh;       // its rejection codes are fetched when the frame is collected
             else wass_mesh_destroy(mesh);                   // back to the context's pool; the kernels enqueued on it run in stream order
             mesh = nullptr;
+            lap(5);
+            // ---- the previous frame: its record and file image have arrived while this one was being enqueued.  Read AFTER this frame's
+            // tail has been enqueued (the library keeps two frames pending since round 5): the tail stream then goes from frame n-1's tail
+            // straight into frame n's, instead of idling for frame n-1's downloads plus this thread's wake-up -- that chain, not the SGM
+            // stage, was what set the driver's frame period once the tail had grown by the inlier selection and the previews.
+            if (FrameJob* p = collect()) done.push_back(p);
+            lap(6);
             pending_ = &job;
             ++nsub_;
             if (const char* dd = getenv("WASS_PIPE_DUMP")) {          // debugging aid: the frame's intermediate maps, as raw bytes
@@ -819,6 +837,8 @@ private:
     int nsub_ = 0;
     std::vector<FrameJob*> early_;   // frames collected before their turn (ensure_buffers); handed out by the next submit / flush
     size_t live_pos_ = 0;
+    bool timing_ = getenv("WASS_PIPE_TIMING") && atoi(getenv("WASS_PIPE_TIMING")) != 0;
+    double lap_[7] = {};
     // WASS_HOST_INLIER_TEXT=1: the round-4 form (the host formats the inlier file from the downloaded points); same bytes either way
     bool device_text_ = !(getenv("WASS_HOST_INLIER_TEXT") && atoi(getenv("WASS_HOST_INLIER_TEXT")) != 0);
 };

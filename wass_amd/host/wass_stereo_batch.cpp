@@ -366,7 +366,7 @@ int main(int argc, char* argv[])
     std::vector<std::string> wds;
     std::string outdir;
     int gpus = 1, ppg = 1, tpp = 1;
-    bool verbose = false, skip_existing = false, debug_images = false, stage_by_stage = false;
+    bool verbose = false, skip_existing = false, debug_images = false, stage_by_stage = false, in_process = false;
     PipeOptions po;
     std::string raw_calibdir, cam0_dir, cam1_dir, raw_out;
     long max_frames = -1;
@@ -383,6 +383,7 @@ int main(int argc, char* argv[])
         else if (a == "--decode-threads" && i + 1 < argc) po.decode_threads = atoi(argv[++i]);
         else if (a == "--writer-threads" && i + 1 < argc) po.writer_threads = atoi(argv[++i]);
         else if (a == "--no-inliers-file") po.inliers_file = false;
+        else if (a == "--in-process") in_process = true;           // one worker, not forked: lets a profiler (rocprofv3) see the GPU work
         else if (a == "--raw" && i + 1 < argc) raw_calibdir = argv[++i];
         else if (a == "--cam0" && i + 1 < argc) cam0_dir = argv[++i];
         else if (a == "--cam1" && i + 1 < argc) cam1_dir = argv[++i];
@@ -462,9 +463,17 @@ int main(int argc, char* argv[])
     const double t0 = now();
     std::vector<pid_t> pids(world);
     std::vector<int> fds(world);
+    std::thread inproc;
     for (int r = 0; r < world; ++r) {          // fork BEFORE any HIP call in this process: every worker initialises its own runtime
         int pfd[2];
         if (pipe(pfd) != 0) { perror("pipe"); return -1; }
+        if (in_process && world == 1 && pipelined) {
+            // profiling aid: the worker as a thread of this process (records still travel through the pipe; verbose, so that stdout stays ours)
+            const int wfd = pfd[1];
+            inproc = std::thread([&, wfd]() { (void)worker_pipelined(0, 1, 0, distinct, uid, cfg, config, wds, true, skip_existing, wfd, po); close(wfd); });
+            pids[r] = -1; fds[r] = pfd[0];
+            continue;
+        }
         const pid_t pid = fork();
         if (pid < 0) { perror("fork"); return -1; }
         if (pid == 0) {
@@ -539,8 +548,10 @@ int main(int argc, char* argv[])
                 }
             }
         }
+        if (inproc.joinable()) inproc.join();
         for (int r = 0; r < world; ++r) {
             int st = 0;
+            if (pids[r] < 0) continue;
             waitpid(pids[r], &st, 0);
             if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) { std::cerr << "worker " << r << " failed (status " << st << ")" << std::endl; ok = false; }
         }
