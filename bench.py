@@ -559,7 +559,7 @@ def main():
         host.append((r.cpu().pin_memory(), l.cpu().pin_memory()))
     del r, l
     torch.cuda.synchronize()
-    NBUF = 3                                             # a frame's inputs must stay untouched until two more were submitted
+    NBUF = 4                                             # a frame's inputs must stay untouched until its record has been read: two frames stay pending
     # resident pass: every distinct frame (both pictures + the burned-area mask of the right one) sits in HBM before the clock
     # starts.  PCIe pass: a ring of three input sets, frame i+1 uploaded from pinned memory right before frame i is submitted
     # (what the C++ driver does after decoding) through wass_upload_async -- the context's copy stream + an event the SGM
@@ -609,7 +609,8 @@ def main():
 
         def barrier():
             if pipe is not None:
-                keep(pipe.flush())
+                for o in pipe.drain():
+                    keep(o)
             torch.cuda.synchronize()
             if dist is not None:
                 dist.barrier()
@@ -625,15 +626,17 @@ def main():
             tm["agg"].append(t.aggregate_ms); tm["cost"].append(t.cost_ms); tm["sel"].append(t.select_ms); tm["sgm"].append(t.total_ms)
             tm["vsum"].append(t.vsum_ms); tm["pre"].append(t.prefilter_ms); tm["med"].append(t.median_ms)
 
-        # Stage timings come from hipEvents recorded on the context's own stream; frame n's are read after frame n+1 has been
-        # enqueued (two event sets), so the reader never drains the pipeline
+        # Stage timings come from hipEvents recorded on the context's own stream; call n's are read after call n+2 has been
+        # enqueued (the library keeps four sets), so the reader never waits for a frame that is still running
         t0 = time.perf_counter()
+        c0 = ctx.sgm_call_count()
         for i in range(steps):
             step(warmup + i)
-            if i > 0:
-                take(ctx.sgm_timings(previous=True))
-        take(ctx.sgm_timings())
+            if i > 1:
+                take(ctx.sgm_call_timings(c0 + i - 1))
         barrier()
+        for k in range(max(steps - 2, 0), steps):
+            take(ctx.sgm_call_timings(c0 + k + 1))
         return {"elapsed": time.perf_counter() - t0, "planes": planes, "npts": npts_hist, "nbytes": nbytes_hist, "overflows": overflows, "tm": tm}
 
     # the metric's pass includes the H2D of both pictures.  (Round 4 had the resident pass as `value`; the two

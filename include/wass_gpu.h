@@ -151,6 +151,8 @@ int wass_sgm_prev_timings(wass_ctx* ctx, wass_sgm_timings* out);
 /* number of wass_sgm_disparity[_dev] calls of this context that were enqueued completely (a failed call does not count): a
  * pipelined driver remembers the value after its frame's call and later picks last / prev timings by the difference */
 int wass_sgm_call_count(wass_ctx* ctx, uint64_t* n_calls);
+/* stage times of call number `call` (1-based, as counted by wass_sgm_call_count right after the call); the last four calls are kept */
+int wass_sgm_call_timings(wass_ctx* ctx, uint64_t call, wass_sgm_timings* out);
 
 /* Device-side canary for the aggregation kernels: runs one synthetic w x h pair with num_disp disparities through the
  * production schedule (checkpoint sweeps, pair kernels with recomputation, row fusion) and through one plain sweep per path,

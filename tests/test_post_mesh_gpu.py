@@ -543,9 +543,9 @@ def test_frame_pipeline_matches_stage_by_stage(gpu_ctx, oracle):
             o = pipe.submit(dr, dl, d_right_mask=m)
             if o is not None:
                 outs.append((o.index, o.plane.copy(), o.xyzc.tobytes()))
-        o = pipe.flush()
-        outs.append((o.index, o.plane.copy(), o.xyzc.tobytes()))
-        assert pipe.flush() is None
+        for o in pipe.drain():
+            outs.append((o.index, o.plane.copy(), o.xyzc.tobytes()))
+        assert pipe.flush() is None and pipe.drain() == []
     assert [i for i, _, _ in outs] == [0, 1, 2, 3]
     for (_, pl, by), (rpl, rby) in zip(outs, ref):
         np.testing.assert_array_equal(pl, rpl)
@@ -572,8 +572,8 @@ def test_inlier_text_from_the_device_equals_printf(gpu_ctx):
         o = pipe.submit(r, l, d_right_image=r, d_right_mask=mask)
         if o is not None:
             outs.append((o.inliers_xyz.copy(), bytes(o.inliers_text)))
-    o = pipe.flush()
-    outs.append((o.inliers_xyz.copy(), bytes(o.inliers_text)))
+    for o in pipe.drain():
+        outs.append((o.inliers_xyz.copy(), bytes(o.inliers_text)))
     assert len(outs) == 3
     for xyz, text in outs:
         assert len(xyz) > 1000

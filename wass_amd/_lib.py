@@ -102,6 +102,7 @@ SYMBOLS = {
     "wass_sgm_last_timings": (_i, [_vp, C.POINTER(SgmTimings)]),
     "wass_sgm_prev_timings": (_i, [_vp, C.POINTER(SgmTimings)]),
     "wass_sgm_call_count": (_i, [_vp, C.POINTER(C.c_uint64)]),
+    "wass_sgm_call_timings": (_i, [_vp, C.c_uint64, C.POINTER(SgmTimings)]),
     "wass_sgm_debug_fetch": (_i, [_vp, _vp, _vp, _vp]),
     "wass_sgm_probe_vsum": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "wass_sgm_selftest": (_i, [_vp, _i, _i, _i, _i, C.POINTER(C.c_uint64)]),

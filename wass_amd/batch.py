@@ -39,8 +39,8 @@ class FramePipeline:
 
     submit() enqueues a whole frame -- SGM on the context's main stream, disparity clean-up, triangulation, outlier
     removal, plane fit and the xyzC encoder on its tail stream, the file image on its copy stream -- and returns the
-    output of the PREVIOUS frame, whose download has finished while this one was being enqueued.  flush() returns the
-    last one.  Lifetime contract: the tail of frame i keeps reading d_right_image and the masks while frame i+1 is
+    output of the frame BEFORE LAST (two frames stay pending; None for the first two calls), whose download finished a
+    whole frame ago.  drain() returns the outputs still pending, in order; flush() the last of them.  Lifetime contract: the tail of frame i keeps reading d_right_image and the masks while frame i+1 is
     being prepared, so the caller must leave every input of frame i untouched until submit() of frame i+2 has
     returned (or flush()); ordering against the stream that produced the inputs is handled here.  Inputs are rectified crops resident in HBM (torch uint8 CUDA tensors); stage parameters are the
     defaults of wass_stereo unless given.
@@ -65,9 +65,10 @@ class FramePipeline:
         # two disparity buffers, alternated: the clean-up of frame i reads one while the SGM stage of frame i+1 writes
         # the other; two pinned file images, alternated: frame i's is read by the caller while frame i+1's is written
         self._disp16 = [torch.empty((height, width), dtype=torch.int16, device=dev) for _ in range(2)]
+        self.NBUF = 4                                      # output sets: two frames pending, one in the caller's hands, one being enqueued
         self._dispf = torch.empty((height, width), dtype=torch.float32, device=dev)
         mw, mh = self.roi_r[2], self.roi_r[3]
-        self._host = [torch.empty(148 + 6 * mw * mh, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+        self._host = [torch.empty(148 + 6 * mw * mh, dtype=torch.uint8, pin_memory=True) for _ in range(self.NBUF)]
         # wass_stereo seeds rand() once per process = once per frame (wass_stereo.cpp:1864-1872), so every frame of a
         # sequence draws the same RANSAC triplets for a given grid size: draw them once
         self._uv = stereo.ransac_sample(mw, mh, ransac_rounds, random_seed)
@@ -77,10 +78,10 @@ class FramePipeline:
         self._keep_points = keep_inlier_points
         if inliers_text:
             cap = (mw * mh + 9) // 10
-            self._inl_text = [torch.empty(cap * 40, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+            self._inl_text = [torch.empty(cap * 40, dtype=torch.uint8, pin_memory=True) for _ in range(self.NBUF)]
             self._inl_cap = cap
         self._n = 0
-        self._pending = None
+        self._pending = []                                 # submitted, record not read yet: at most two (the library's limit)
         ctx.set_tail_overlap(tail_overlap)
 
     def submit(self, d_right, d_left, d_right_image=None, d_left_mask=None, d_right_mask=None):
@@ -96,39 +97,47 @@ class FramePipeline:
         img = d_right_image if d_right_image is not None else d_right
         mesh, _ = ctx.triangulate_dev(self._dispf, self.w, self.h, self.roi_l, self.roi_r, self.geom, img, d_left_mask,
                                       d_right_mask, self.min_angle, None, 1.0, count=False)
-        host = self._host[k]
+        # two frames stay pending (the library's limit): the record read here belongs to a tail that ended a whole frame ago, so this
+        # thread does not wait and the next frame's SGM stage is queued before the current one has finished
+        prev = self._collect() if len(self._pending) >= 2 else None
+        kb = self._n % self.NBUF
+        host = self._host[kb]
         extra = {}
         if self._inl_text is not None:
             extra = dict(inliers_capacity=self._inl_cap, inliers_every=10,
-                         inliers_text_ptr=self._inl_text[k].data_ptr(), inliers_text_capacity=self._inl_text[k].numel())
+                         inliers_text_ptr=self._inl_text[kb].data_ptr(), inliers_text_capacity=self._inl_text[kb].numel())
         mesh.finish_frame_async(self._uv, host.data_ptr(), host.numel(), self.pct, self.ransac_thr, self.max_distance,
                                 **self.refine, **extra)
         mesh.close()
-        # the previous frame's record is read AFTER this frame's tail has been enqueued (two frames may be pending since round 5):
-        # the tail stream goes from one frame's tail straight into the next one's
-        prev = self._collect()
-        self._pending = (self._n, host, k)
+        self._pending.append((self._n, host, kb))
         self._n += 1
         return prev
 
     def _collect(self):
-        if self._pending is None:
+        if not self._pending:
             return None
-        idx, host, k = self._pending
-        fr = self.ctx.frame_result()
-        self._pending = None
+        idx, host, kb = self._pending.pop(0)
+        fr = self.ctx.frame_result()                       # the OLDEST pending frame's record
         out = FrameOutput(idx, fr, host[:int(fr.xyzc_bytes)].numpy())
         if self._inl_text is not None:
             # the bytes of plane_refinement_inliers.xyz (valid like xyzc: until two more frames have been submitted); None: a number
             # was outside the device formatter's domain and the caller has to format inliers_xyz itself.  The points stay on the
-            # device unless they are needed for that (or asked for): fetched here, before the next frame's tail reuses the buffer
-            out.inliers_text = None if fr.inliers_text_unsupported else self._inl_text[k][:int(fr.inliers_text_bytes)].numpy()
+            # device unless they are needed for that (or asked for): fetched here, before the frame after next reuses the buffer
+            out.inliers_text = None if fr.inliers_text_unsupported else self._inl_text[kb][:int(fr.inliers_text_bytes)].numpy()
             out.inliers_xyz = self.ctx.frame_inliers(fr.n_inliers_out) if (fr.inliers_text_unsupported or self._keep_points) else None
         return out
 
+    def drain(self):
+        """Wait for every submitted frame; their outputs in submission order."""
+        outs = []
+        while self._pending:
+            outs.append(self._collect())
+        return outs
+
     def flush(self):
-        """Wait for the last submitted frame."""
-        return self._collect()
+        """Wait for every submitted frame and return the LAST one's output (drain() returns all of them)."""
+        outs = self.drain()
+        return outs[-1] if outs else None
 
 
 def shard(n_frames: int, rank: int, world: int) -> list[int]:

@@ -113,7 +113,7 @@ int wass_ctx_create(int device_id, wass_ctx** out)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
     if (ensure(c, c->flags, 64) != WASS_OK) { wass_ctx_destroy(c); return WASS_ERR_NO_MEMORY; }
     if (hipHostMalloc((void**)&c->h_flags, 64, hipHostMallocDefault) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_NO_MEMORY; }
-    c->h_flags[0] = c->h_flags[4] = 0;
+    for (int k = 0; k < 16; ++k) c->h_flags[k] = 0;       // one status word per timing set, 16 bytes apart
     if (const char* e = getenv("WASS_DIAG_FUSE")) c->diag_fuse = atoi(e) != 0;   // 1: the three-guest schedule of round 5 (A/B runs on one box)
     mesh_pool_ctx_alive(c, true);
     *out = c;
@@ -296,7 +296,7 @@ int wass_sgm_disparity_dev(wass_ctx* c, const uint8_t* d_right, const uint8_t* d
 
     hipStream_t s = c->stream;
     c->timings_valid = false;
-    const int set = (int)(c->nsgm & 1);
+    const int set = (int)(c->nsgm % wass_ctx::NSGM_SETS);
     c->ev = c->evs[set];
     WASS_HIP(c, hipEventRecord(c->ev[0], s));
     // wass_stereo.cpp:820-831: zero images, left at column D+off-comp, right at column D -- the padded pictures are not
@@ -337,7 +337,7 @@ int wass_sgm_disparity_dev(wass_ctx* c, const uint8_t* d_right, const uint8_t* d
 // timings of SGM call number `call` (0-based), which must be one of the last two
 static int read_timings(wass_ctx* c, unsigned long long call, wass_sgm_timings* out)
 {
-    const int set = (int)(call & 1);
+    const int set = (int)(call % wass_ctx::NSGM_SETS);
     hipEvent_t* ev = c->evs[set];
     WASS_HIP(c, hipEventSynchronize(ev[6]));
     wass_sgm_timings t = {};
@@ -361,6 +361,15 @@ int wass_sgm_last_timings(wass_ctx* c, wass_sgm_timings* out)
     if (!c || !out) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
     if (!c->timings_valid || c->nsgm == 0) return set_err(c, WASS_ERR_INVALID_ARG, "no completed wass_sgm_disparity call");
     return read_timings(c, c->nsgm - 1, out);
+}
+
+int wass_sgm_call_timings(wass_ctx* c, uint64_t call, wass_sgm_timings* out)
+{
+    if (!c || !out) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    if (call == 0 || call > c->nsgm || c->nsgm - call >= (uint64_t)wass_ctx::NSGM_SETS)
+        return set_err(c, WASS_ERR_INVALID_ARG, "the timings of call %llu are gone (calls so far: %llu, kept: the last %d)", (unsigned long long)call,
+                       (unsigned long long)c->nsgm, wass_ctx::NSGM_SETS);
+    return read_timings(c, call - 1, out);
 }
 
 int wass_sgm_call_count(wass_ctx* c, uint64_t* n_calls)
@@ -478,7 +487,7 @@ int wass_sgm_disparity(wass_ctx* c, const uint8_t* right, const uint8_t* left, i
     if (rc) return rc;
     WASS_HIP(c, hipMemcpyAsync(disp16_out, c->tmp_out.p, no * 2, hipMemcpyDeviceToHost, c->stream));
     WASS_HIP(c, hipStreamSynchronize(c->stream));
-    const uint32_t fl = c->h_flags[4 * (int)((c->nsgm - 1) & 1)];
+    const uint32_t fl = c->h_flags[4 * (int)((c->nsgm - 1) % wass_ctx::NSGM_SETS)];
     if (fl & 1)
         return set_err(c, WASS_ERR_COST_OVERFLOW,
                        "block cost + P2 exceeded 32767: outside the range where the reference is well defined");

@@ -168,10 +168,10 @@ struct wass_ctx {
     // percentile found, [3] biggest component kept, [4] RANSAC plane picked, [5] file image packed.  Created on first use.
     // Two sets, alternated by wass_triangulate[_dev]: a pipelined driver enqueues frame n+1's triangulation BEFORE it reads frame
     // n's record, so one set would be re-recorded under the reader (every frame but the last of a sequence had all-zero rows).
-    hipEvent_t ev_tail_sets[2][6] = {};
+    hipEvent_t ev_tail_sets[4][6] = {};    // (four: with two frames pending a record is read after two more triangulations)
     hipEvent_t* ev_tail = ev_tail_sets[0];  // set of the last triangulation
     int tail_set = 0;
-    bool tail_timed[2] = {};
+    bool tail_timed[4] = {};
     wass::Buf ccmask;              // valid mask after the outlier removal, kept for graph_components.jpg when asked for
     // wass_upload_async: uploads in flight on the copy stream, by destination; consumers wait for the matching event
     struct UploadSlot { const char* dst = nullptr; size_t n = 0; hipEvent_t ev = nullptr; bool pending = false, consumed = false; };
@@ -187,10 +187,12 @@ struct wass_ctx {
     wass::Buf clahe_lut;           // per-tile look-up tables of wass_clahe_dev
     // stage events of the SGM call, two sets used alternately so that the timings of call n can be read after call
     // n+1 has been enqueued (a lagging reader never stalls the pipeline)
-    hipEvent_t evs[2][8] = {};
+    // (four sets, not two, since round 5: a driver that runs two frames ahead reads call n's timings after call n+2 has been enqueued)
+    static constexpr int NSGM_SETS = 4;
+    hipEvent_t evs[NSGM_SETS][8] = {};
     hipEvent_t* ev = evs[0];       // set of the last call
     unsigned long long nsgm = 0;   // SGM calls so far
-    int launches[2] = {};
+    int launches[NSGM_SETS] = {};
     hipStream_t side = nullptr;    // checkpoint sweeps run ahead here
     hipEvent_t ev_cost = nullptr, ev_ckpt[4] = {};
     void* coll_comm = nullptr;     // ncclComm_t of wass_coll_init (coll.hip); coll_buf: 64 doubles of HBM for the all-reduce

@@ -1312,7 +1312,7 @@ int wass_triangulate_dev(wass_ctx* c, const float* d_disp, int W, int H, const i
         for (auto& set : c->ev_tail_sets)
             for (auto& e : set)
                 if (hipEventCreate(&e) != hipSuccess) { e = nullptr; wass_mesh_destroy(m); return set_err(c, WASS_ERR_DEVICE, "hipEventCreate failed"); }
-    c->tail_set ^= 1;                            // the previous frame's set stays readable until the triangulation after this one
+    c->tail_set = (c->tail_set + 1) & 3;         // a frame's set stays readable for three more triangulations (two frames may be pending)
     c->ev_tail = c->ev_tail_sets[c->tail_set];
     (void)hipEventRecord(c->ev_tail[0], c->ts());
     c->tail_timed[c->tail_set] = false;
@@ -2219,10 +2219,10 @@ int wass_ctx_frame_result(wass_ctx* c, wass_frame_result* out)
     out->n_inliers_out = fs.inl_every > 0 ? ((uint64_t)h.ninl_sel + (uint64_t)fs.inl_every - 1) / (uint64_t)fs.inl_every : 0;
     out->inliers_text_bytes = fs.inl_text ? h.inl_text_bytes : 0;
     out->inliers_text_unsupported = fs.inl_text ? h.inl_text_bad : 0;
-    if (fs.sgm_call > 0 && c->nsgm - fs.sgm_call < 2) {
+    if (fs.sgm_call > 0 && c->nsgm - fs.sgm_call < (unsigned long long)wass_ctx::NSGM_SETS) {
         // status word of the frame's SGM call: copied to pinned memory in stream order long before the download this
-        // function has just waited for; the slot is reused two calls later
-        const uint32_t fl = c->h_flags[4 * (int)((fs.sgm_call - 1) & 1)];
+        // function has just waited for; the slot is reused four calls later
+        const uint32_t fl = c->h_flags[4 * (int)((fs.sgm_call - 1) % wass_ctx::NSGM_SETS)];
         out->sgm_cost_overflow = (int)(fl & 1);
         out->sgm_timeout = (int)((fl >> 1) & 1);
     } else {

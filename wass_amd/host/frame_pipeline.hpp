@@ -80,7 +80,7 @@ public:
     // upload staged right before frame n is submitted queues behind frame n-1's downloads, which wait for frame n-1's tail -- and
     // that tail ends late in frame n.  One frame ahead that was the upload frame n+1 was waiting for (a 0.5 ms stall per frame once
     // the downloads grew by the inlier text); two ahead it is frame n+2's, with a whole frame of slack.
-    static constexpr int NIN = 4;
+    static constexpr int NIN = 6;    // (two staged ahead, the one being submitted, two pending, one whose tail may still read its picture)
     struct Options {
         int out_slots = 4;           // pinned output sets (file image + inlier points) that writer threads may hold at once
         bool inliers_file = true;    // plane_refinement_inliers.xyz (a debug artefact of the reference; 14 MB of text per 5-megapixel frame)
@@ -124,7 +124,7 @@ public:
     ~FramePipeline()
     {
         if (timing_ && nsub_ > 0) {
-            static const char* nm[7] = { "out slot + raw + previews", "rectify + masks", "wass_sgm_disparity_dev", "postprocess", "triangulate", "finish_frame_async", "collect previous (wait)" };
+            static const char* nm[7] = { "out slot + raw + previews", "rectify + masks", "wass_sgm_disparity_dev", "postprocess", "triangulate", "collect the frame before last", "finish_frame_async" };
             fprintf(stderr, "FramePipeline: submit() per frame over %d frames:", nsub_);
             for (int k = 0; k < 7; ++k) fprintf(stderr, "  %s %.2f ms", nm[k], 1e3 * lap_[k] / nsub_);
             fprintf(stderr, "\n");
@@ -265,14 +265,14 @@ public:
     {
         struct Early { FramePipeline* p; std::vector<FrameJob*>& d; size_t at; ~Early() { d.insert(d.begin() + (long)at, p->early_.begin(), p->early_.end()); p->early_.clear(); } } early{ this, done, done.size() };
         if (job.rc != 0 || job.skipped) {                 // nothing to enqueue: keep the order
-            if (FrameJob* p = collect()) done.push_back(p);
+            while (FrameJob* p = collect()) done.push_back(p);
             done.push_back(&job);
             return;
         }
         stage(job);
-        if (job.rc != 0) { if (FrameJob* p = collect()) done.push_back(p); done.push_back(&job); return; }
+        if (job.rc != 0) { while (FrameJob* p = collect()) done.push_back(p); done.push_back(&job); return; }
         // debug pictures: the previous frame's maps are fetched from buffers this frame is about to overwrite
-        if (opt_.debug_pictures) if (FrameJob* p = collect()) done.push_back(p);
+        if (opt_.debug_pictures) while (FrameJob* p = collect()) done.push_back(p);
         LogSinkScope sink(&job.log);
         job.t_submit0 = Timer::now();
         Env& env = job.env;
@@ -397,6 +397,12 @@ public:
                                        mask_r ? in_[k].d_mr : nullptr, &tp, &mesh, nullptr), "wass_triangulate");
             WLOGI << "... 100%";
             lap(4);
+            // ---- the frame before last: TWO frames stay pending (the library's limit), so the record read here belongs to a tail that
+            // ended a whole frame ago -- this thread does not wait, and the next frame's SGM stage is in the queue before the current
+            // one has finished.  (Reading the previous frame's record here instead -- one frame pending -- put tail + downloads + this
+            // thread's enqueue work, 8.8 ms, on the path between two SGM stages of 7.6 ms: 114 instead of 125 frames/s.)
+            while (pend_.size() >= 2) if (FrameJob* p = collect()) done.push_back(p);
+            lap(5);
             // ---- the mesh tail (:2046-2123), decided on the device
             const int rounds = cfg_.get_int("PLANE_RANSAC_ROUNDS");
             if (uv_.empty() || uv_seed_ != job.ransac_seed || uv_w_ != rr[2] || uv_h_ != rr[3]) {
@@ -416,14 +422,8 @@ public:
             if (opt_.debug_pictures) job.mesh = mesh;       // its rejection codes are fetched when the frame is collected
             else wass_mesh_destroy(mesh);                   // back to the context's pool; the kernels enqueued on it run in stream order
             mesh = nullptr;
-            lap(5);
-            // ---- the previous frame: its record and file image have arrived while this one was being enqueued.  Read AFTER this frame's
-            // tail has been enqueued (the library keeps two frames pending since round 5): the tail stream then goes from frame n-1's tail
-            // straight into frame n's, instead of idling for frame n-1's downloads plus this thread's wake-up -- that chain, not the SGM
-            // stage, was what set the driver's frame period once the tail had grown by the inlier selection and the previews.
-            if (FrameJob* p = collect()) done.push_back(p);
             lap(6);
-            pending_ = &job;
+            pend_.push_back(&job);
             ++nsub_;
             if (const char* dd = getenv("WASS_PIPE_DUMP")) {          // debugging aid: the frame's intermediate maps, as raw bytes
                 auto dump = [&](const char* name, const void* d, size_t nb) {
@@ -442,7 +442,7 @@ public:
             WLOGE << e.what();
             job.rc = -1;
             if (job.out_slot >= 0) { release_out(job.out_slot); job.out_slot = -1; }
-            if (FrameJob* p = collect()) done.push_back(p);
+            while (FrameJob* p = collect()) done.push_back(p);
             done.push_back(&job);
         }
     }
@@ -452,7 +452,7 @@ public:
     {
         done.insert(done.end(), early_.begin(), early_.end());
         early_.clear();
-        if (FrameJob* p = collect()) done.push_back(p);
+        while (FrameJob* p = collect()) done.push_back(p);
     }
 
     // ---- phase 3 (any thread): everything that is written from the result record (:1374, 1993, 2046-2139)
@@ -623,7 +623,7 @@ public:
     }
 
     int frames_submitted() const { return nsub_; }
-    bool pending() const { return pending_ != nullptr || !early_.empty(); }   // a submitted frame has not been handed out yet (flush() returns it)
+    bool pending() const { return !pend_.empty() || !early_.empty(); }   // a submitted frame has not been handed out yet (flush() returns it)
 
 private:
     struct InSet { uint8_t *h_l = nullptr, *h_r = nullptr, *d_l = nullptr, *d_r = nullptr, *d_cl = nullptr, *d_cr = nullptr, *d_ml = nullptr, *d_mr = nullptr,
@@ -645,9 +645,9 @@ private:
 
     FrameJob* collect()
     {
-        if (!pending_) return nullptr;
-        FrameJob* j = pending_;
-        pending_ = nullptr;
+        if (pend_.empty()) return nullptr;
+        FrameJob* j = pend_.front();                      // the oldest pending frame: the library hands the records out in order
+        pend_.pop_front();
         LogSinkScope sink(&j->log);
         WLOG_SCOPE("wass_stereo");
         if (wass_ctx_frame_result(ctx_, &j->res) != WASS_OK) { WLOGE << "wass_ctx_frame_result: " << wass_last_error(ctx_); j->rc = -1; }
@@ -658,9 +658,8 @@ private:
             uint64_t got = 0;
             if (wass_ctx_frame_inliers(ctx_, out_[j->out_slot].inl, out_[j->out_slot].inl_cap, &got) != WASS_OK) { WLOGE << "wass_ctx_frame_inliers: " << wass_last_error(ctx_); j->rc = -1; }
         }
-        // stage times of the frame's SGM call: the last call, or the last but one if another frame has been enqueued since
-        const long long behind = (long long)sgm_calls() - j->sgm_call;
-        j->have_sgm = behind == 0 ? wass_sgm_last_timings(ctx_, &j->sgm) == WASS_OK : (behind == 1 && wass_sgm_prev_timings(ctx_, &j->sgm) == WASS_OK);
+        // stage times of the frame's own SGM call (the library keeps the last four)
+        j->have_sgm = j->sgm_call > 0 && wass_sgm_call_timings(ctx_, (uint64_t)j->sgm_call, &j->sgm) == WASS_OK;
         if (opt_.debug_pictures && j->mesh) {
             // the maps the debug pictures are drawn from (nothing else has been enqueued since this frame: see submit)
             try {
@@ -709,7 +708,7 @@ private:
         if (W == W_ && H == H_ && roi_l.width == cwl_ && roi_l.height == chl_ && roi_r.width == cwr_ && roi_r.height == chr_) return;
         check(wass_ctx_synchronize(ctx_), "wass_ctx_synchronize");
         // debug pictures: the pending frame's maps are fetched from these buffers when it is collected -- do that first
-        if (opt_.debug_pictures) if (FrameJob* p = collect()) early_.push_back(p);
+        if (opt_.debug_pictures) while (FrameJob* p = collect()) early_.push_back(p);
         release_buffers();
         W_ = W; H_ = H; cwl_ = roi_l.width; chl_ = roi_l.height; cwr_ = roi_r.width; chr_ = roi_r.height;
         const size_t n = (size_t)W * H + 4;
@@ -833,7 +832,7 @@ private:
     std::vector<bool> out_free_;
     std::mutex out_mu_;
     std::condition_variable out_cv_;
-    FrameJob* pending_ = nullptr;
+    std::deque<FrameJob*> pend_;     // submitted, record not read yet: at most two
     int nsub_ = 0;
     std::vector<FrameJob*> early_;   // frames collected before their turn (ensure_buffers); handed out by the next submit / flush
     size_t live_pos_ = 0;

@@ -150,6 +150,19 @@ class Context:
         self._check(f(self._h, C.byref(t)))
         return t
 
+    def sgm_call_count(self) -> int:
+        """SGM calls of this context that were enqueued completely (the 1-based number of the last one)."""
+        n = C.c_uint64()
+        self._check(self._lib.wass_sgm_call_count(self._h, C.byref(n)))
+        return int(n.value)
+
+    def sgm_call_timings(self, call: int) -> SgmTimings:
+        """Stage times of SGM call number `call` (1-based; the last four calls are kept): a driver that runs two frames ahead reads
+        call n's after call n+2 has been enqueued, without waiting for anything that is still running."""
+        t = SgmTimings()
+        self._check(self._lib.wass_sgm_call_timings(self._h, int(call), C.byref(t)))
+        return t
+
     def sgm_debug_fetch(self, w: int, h: int, params: SgmParams, want=("C", "S", "raw")):
         """Intermediates of the last sgm_disparity call (test hook)."""
         off = max(params.disp_offset, 0)
