@@ -89,6 +89,9 @@ public:
                                      // worker relays the log to the wass_stereo process that sent the frame, stereo_server.hpp)
         bool debug_pictures = false; // the reference's debug pictures (stereo.jpg ... graph_components.jpg): every frame's intermediate
                                      // maps come back to the host once it is complete, which takes the pipeline down to one frame
+        int max_pending = 2;         // frames whose record has not been read when the next tail is enqueued: 2 keeps a sequence driver two frames
+                                     // ahead of the GPU (throughput); 1 hands a frame out one submission earlier (latency: the resident worker,
+                                     // whose callers each wait for ONE frame)
         bool device_previews = true; // the scaled previews 0000000X_s.png are resized on the GPU and written by finish() (sequence drivers);
                                      // false: load_data writes them from the decoded pictures before the GPU is needed, like the reference
         const PrepareSetup* prep = nullptr;   // prepare-less mode: the calibration directory (jobs with raw = true need it)
@@ -401,7 +404,7 @@ public:
             // ended a whole frame ago -- this thread does not wait, and the next frame's SGM stage is in the queue before the current
             // one has finished.  (Reading the previous frame's record here instead -- one frame pending -- put tail + downloads + this
             // thread's enqueue work, 8.8 ms, on the path between two SGM stages of 7.6 ms: 114 instead of 125 frames/s.)
-            while (pend_.size() >= 2) if (FrameJob* p = collect()) done.push_back(p);
+            while ((int)pend_.size() >= std::max(1, std::min(2, opt_.max_pending))) if (FrameJob* p = collect()) done.push_back(p);
             lap(5);
             // ---- the mesh tail (:2046-2123), decided on the device
             const int rounds = cfg_.get_int("PLANE_RANSAC_ROUNDS");

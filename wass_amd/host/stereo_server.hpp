@@ -297,6 +297,7 @@ inline int server_main(const std::string& sock, int device)
                         fo.out_slots = nwr + 2;
                         fo.live = true;                          // the progress markers go into the frame's log ...
                         fo.echo = false;                         // ... which is relayed to the client, not printed here
+                        fo.max_pending = 1;                      // every caller waits for ONE frame: hand it out as early as possible
                         fo.debug_pictures = debug;
                         slot->debug = debug;
                         fo.inliers_file = true;
