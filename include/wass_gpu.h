@@ -335,7 +335,11 @@ int wass_mesh_fit_plane(wass_ctx* ctx, wass_mesh* m, const int32_t* uv_triplets,
  * wass_mesh_encode_xyzc(plane = NULL)).  dst receives the file image (148-byte header + 6 bytes per point; it must
  * hold 148 + 6*width*height bytes, pinned memory recommended) through the context's copy stream.
  * wass_ctx_frame_result() waits for that download and reports what the stage-by-stage calls would have returned;
- * the number of valid bytes in dst is result.xyzc_bytes.  One frame may be pending per context. */
+ * the number of valid bytes in dst is result.xyzc_bytes.  TWO frames may be pending per context (round 5): a driver enqueues
+ * frame n+1's tail before it reads frame n's record, so that the tail stream goes from one frame's tail straight into the next
+ * one's; wass_ctx_frame_result() hands the records out in submission order, a third wass_mesh_finish_frame_async* call without a
+ * read in between is refused.  dst (and inliers_dst / inliers_text_dst) of a pending frame must stay untouched until its record
+ * has been read. */
 typedef struct {
     double   zgap;  uint64_t n_gaps, component_size;
     int      found, refine_ok;      /* refine_ok == 0 with found == 1: fewer than 3 refinement inliers (the

@@ -83,6 +83,34 @@ def test_concurrent_callers_share_one_server(cli, tmp_path):
     _wait_gone(sock)
 
 
+def test_a_killed_server_costs_time_never_a_frame(cli, tmp_path):
+    """The server is killed while idle (its socket file stays behind, nobody listens): the next caller finds the stale socket,
+    takes the lock, starts a fresh server and gets its answer; a caller that cannot start one computes the frame itself."""
+    import signal
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the no-GPU behaviour is tested on the build container")
+    wd, cfg, *_ = make_workdir(str(tmp_path), 160, 120, 32)
+    sock = tmp_path / "sock"
+    sock.mkdir()
+    a = subprocess.run([cli, cfg, wd], capture_output=True, text=True, env=_env(sock, WASS_DEBUG_IMAGES="0"))
+    srv = _servers(sock)
+    assert len(srv) == 1
+    os.kill(int(srv[0].split()[0]), signal.SIGKILL)
+    time.sleep(0.3)
+    assert [f for f in os.listdir(sock) if f.endswith(".sock")]                 # the stale socket is still there
+    b = subprocess.run([cli, cfg, wd], capture_output=True, text=True, env=_env(sock, WASS_DEBUG_IMAGES="0"))
+    assert b.returncode == a.returncode == 255 and "Reconstructing" in b.stdout    # answered (by a new server)
+    assert len(_servers(sock)) == 1
+    _wait_gone(sock)
+    # a socket "directory" that is a plain file: neither lock nor socket can be created, the caller computes (here: fails loudly) in-process
+    notdir = tmp_path / "notdir"
+    notdir.write_text("x")
+    c = subprocess.run([cli, cfg, wd], capture_output=True, text=True, env=_env(notdir, WASS_DEBUG_IMAGES="0"))
+    assert c.returncode == 255 and "no usable MI355X GPU" in c.stdout
+    assert not _servers(notdir)
+
+
 def test_no_server_switch_and_ineligible_configurations_stay_in_process(cli, tmp_path):
     wd, cfg, *_ = make_workdir(str(tmp_path), 160, 120, 32)
     sock = tmp_path / "sock"

@@ -271,8 +271,10 @@ inline Image read_png_gray(const std::string& filename)
         throw std::runtime_error(filename + ": only non-interlaced 8-bit grey/RGB(A) PNG files are supported");
     const int ch = ctype == 0 ? 1 : (ctype == 4 ? 2 : (ctype == 2 ? 3 : 4));
     const size_t stride = (size_t)w * ch;
-    std::vector<uint8_t> raw((stride + 1) * h);
-    if (!zlib_inflate_exact(f.data() + zpos, zlen, raw.data(), raw.size()))
+    const size_t rawn = (stride + 1) * h;
+    std::unique_ptr<uint8_t[]> rawbuf(new uint8_t[rawn]);      // (not a vector: zero-filling 5 MB that inflate overwrites is a millisecond per picture)
+    uint8_t* const raw = rawbuf.get();
+    if (!zlib_inflate_exact(f.data() + zpos, zlen, raw, rawn))
         throw std::runtime_error(filename + ": zlib inflate failed");
     std::vector<uint8_t> cur(stride), prev(stride, 0);
     Image img(w, h);
