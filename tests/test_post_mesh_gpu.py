@@ -578,3 +578,52 @@ def test_inlier_text_from_the_device_equals_printf(gpu_ctx):
     for xyz, text in outs:
         assert len(xyz) > 1000
         assert text == "".join("%g %g %g\n" % tuple(p) for p in xyz).encode()
+
+
+def test_two_frames_may_be_pending_and_records_come_back_in_order(gpu_ctx):
+    """wass_mesh_finish_frame_async*: two frames may be pending per context (a driver enqueues frame n+1's tail before it reads frame
+    n's record); a third call without a read in between is refused; wass_ctx_frame_result hands the records out in submission order
+    and refuses when nothing is pending."""
+    import torch
+    clouds = [_cloud(seed=k) for k in (0, 3, 5)]
+    h, w = clouds[0][0].shape
+    uv = wass_amd.ransac_sample(w, h, 400, 12345)
+    ref = []
+    for valid, p3d, _ in clouds:                               # each frame alone, stage by stage
+        a = gpu_ctx.mesh_upload(valid, p3d)
+        a.remove_outliers(99.0)
+        res = a.fit_plane(uv, 1.0, 1.5)
+        ref.append(a.encode_xyzc(np.array(res.plane[:])))
+    assert len({len(b) for b in ref}) == 3                     # three different frames
+    pins = [torch.zeros(148 + 6 * w * h, dtype=torch.uint8).pin_memory() for _ in range(3)]
+    m = [gpu_ctx.mesh_upload(v, p) for v, p, _ in clouds]
+    m[0].finish_frame_async(uv, pins[0].data_ptr(), pins[0].numel()); m[0].close()
+    m[1].finish_frame_async(uv, pins[1].data_ptr(), pins[1].numel()); m[1].close()
+    with pytest.raises(wass_amd.WassError):                    # a third pending frame is refused ...
+        m[2].finish_frame_async(uv, pins[2].data_ptr(), pins[2].numel())
+    r0 = gpu_ctx.frame_result()                                # ... until the oldest record has been read
+    m[2].finish_frame_async(uv, pins[2].data_ptr(), pins[2].numel()); m[2].close()
+    r1 = gpu_ctx.frame_result()
+    r2 = gpu_ctx.frame_result()
+    with pytest.raises(wass_amd.WassError):
+        gpu_ctx.frame_result()                                 # nothing pending any more
+    for k, r in enumerate((r0, r1, r2)):
+        assert r.found and r.xyzc_bytes == len(ref[k])
+        assert pins[k][:r.xyzc_bytes].numpy().tobytes() == ref[k]
+
+
+def test_sgm_call_timings_serve_the_last_four_calls(gpu_ctx):
+    """wass_sgm_call_timings: a driver two frames ahead reads the event times of call n-2 while n is running; four sets are kept."""
+    rng = np.random.default_rng(5)
+    r = rng.integers(0, 256, (96, 256), dtype=np.uint8)
+    l = np.roll(r, 7, axis=1)
+    p = default_sgm_params(64, ndirs=8)
+    for _ in range(6):
+        gpu_ctx.sgm_disparity(r, l, p)
+    n = gpu_ctx.sgm_call_count()
+    assert n >= 6
+    for call in (n, n - 1, n - 2, n - 3):
+        assert gpu_ctx.sgm_call_timings(call).total_ms > 0
+    for call in (n + 1, n - 4, 0):
+        with pytest.raises(wass_amd.WassError):
+            gpu_ctx.sgm_call_timings(call)
