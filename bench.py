@@ -417,7 +417,8 @@ def wasscli_unchanged_record(ndirs: int, frames: int = 8, replicate: int = 12, p
     os.makedirs(sockdir)
     try:
         seq, cfg, n = make_sequence(tmp, frames, replicate, ndirs)
-        env = dict(os.environ, WASS_DEBUG_IMAGES="0", WASS_SERVER_DIR=sockdir, WASS_SERVER_IDLE="5")
+        tlog = os.path.join(tmp, "server_timing.log")
+        env = dict(os.environ, WASS_DEBUG_IMAGES="0", WASS_SERVER_DIR=sockdir, WASS_SERVER_IDLE="5", WASS_SERVER_TIMING=tlog)
         env.pop("WASS_NO_SERVER", None)
 
         def one(i, e):
@@ -438,6 +439,25 @@ def wasscli_unchanged_record(ndirs: int, frames: int = 8, replicate: int = 12, p
                "failed_calls": len(bad), "ndirs": ndirs,
                "how": f"{parallel} concurrent `wass_stereo <config> <workdir>` processes (a thread pool, as wasscli's thread_map) over {n} config-B "
                       "workdirs; each hands its frame to the per-GPU resident worker started by the first; WASS_DEBUG_IMAGES=0; output to " + base}
+        # where a caller's waiting time went, as the server saw it (WASS_SERVER_TIMING: medians over the frames above)
+        try:
+            rows = [l.split() for l in open(tlog) if " total " in l][1:]
+            med = lambda k: round(sorted(float(r[r.index(k) + 1]) for r in rows)[len(rows) // 2], 1)
+            rec["server_ms_per_call"] = {k: med(k) for k in ("decode", "queue", "gpu", "files", "total")}
+        except Exception as e:
+            rec["server_ms_per_call"] = {"error": f"{type(e).__name__}: {e}"}
+        # wasscli's own menu ("Set number of parallel workers", wasscli.py:440-454) raises NUM_PARALLEL_PROCESSES without an edit: 8 callers
+        with ThreadPoolExecutor(2 * parallel) as ex:
+            t1 = time.perf_counter()
+            res8 = list(ex.map(lambda i: one(i, env), range(1, n)))
+            t2 = time.perf_counter()
+        rec["parallel_%d" % (2 * parallel)] = {"pairs_per_sec": round((n - 1) / (t2 - t1), 2), "failed_calls": len([1 for rc, _, _ in res8 if rc != 0]),
+                                              "median_call_s": round(sorted(s for _, s, _ in res8)[len(res8) // 2], 4)}
+        try:
+            rows = [l.split() for l in open(tlog) if " total " in l][n + 1:]
+            rec["parallel_%d" % (2 * parallel)]["server_ms_per_call"] = {k: med(k) for k in ("decode", "queue", "gpu", "files", "total")}
+        except Exception:
+            pass
         # round 4's behaviour on a few frames: every process computes its own frame
         env0 = dict(env, WASS_NO_SERVER="1")
         for i in range(8):

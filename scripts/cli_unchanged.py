@@ -1,0 +1,11 @@
+#!/usr/bin/env python3
+"""scripts/cli_unchanged.py [ndirs] -- bench.py's `wasscli_unchanged` record alone (4 and 8 concurrent `wass_stereo <config> <workdir>` callers over
+a config-B sequence, served by the resident worker), with the server's per-call time table: for work on the per-frame client / server."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench
+
+print(json.dumps(bench.wasscli_unchanged_record(int(sys.argv[1]) if len(sys.argv) > 1 else 8)))

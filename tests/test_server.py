@@ -175,3 +175,35 @@ def test_server_draws_the_debug_pictures_too(cli, tmp_path):
                  "graph_components.png", "undistorted/R0.png", "undistorted/R1.png", "mesh_cam.xyzC", "plane.txt"):
         assert open(os.path.join(wd, name), "rb").read() == open(os.path.join(wd2, name), "rb").read(), name
     _wait_gone(sock)
+
+
+def test_the_per_frame_client_carries_no_gpu_runtime_and_no_computation(cli, tmp_path):
+    """`wass_stereo` (wass_stereo_client.cpp) is what wasscli starts once per frame: it must not map libwassgpu / the HIP runtime (10 ms
+    of every call), its banner is the full program's, and without the full program next to it the call fails -- it computes nothing."""
+    import ctypes
+    from wass_amd import build
+    assert cli == build.CLI and os.path.exists(build.CLI_GPU)
+    needed = subprocess.run(["readelf", "-d", build.CLI], capture_output=True, text=True).stdout
+    assert "NEEDED" in needed
+    for lib in ("wassgpu", "amdhip", "hsa-runtime", "libz"):
+        assert lib not in needed
+    assert "wassgpu" in subprocess.run(["readelf", "-d", build.CLI_GPU], capture_output=True, text=True).stdout
+    # one banner, whoever prints it
+    lib = ctypes.CDLL(build.SO)
+    lib.wass_version.restype = ctypes.c_char_p
+    src = open(os.path.join(os.path.dirname(build.CLI), "..", "host", "stereo_client.hpp")).read()
+    assert '#define WASS_GPU_LIBRARY_VERSION "%s"' % lib.wass_version().decode() in src
+    wd, cfg, *_ = make_workdir(str(tmp_path), 160, 120, 32)
+    env = dict(os.environ, WASS_NO_SERVER="1", WASS_DEBUG_IMAGES="0")
+    a = subprocess.run([build.CLI, cfg, wd], capture_output=True, text=True, env=env)
+    b = subprocess.run([build.CLI_GPU, cfg, wd], capture_output=True, text=True, env=env)
+    assert a.returncode == b.returncode and a.stdout.count("wass_stereo  v.") == b.stdout.count("wass_stereo  v.") == 1
+    strip = lambda s: [l for l in s.splitlines() if "secs" not in l and "Total" not in l]
+    assert strip(a.stdout)[:6] == strip(b.stdout)[:6]
+    # alone in a directory: nothing to hand the frame to
+    alone = tmp_path / "bin"
+    alone.mkdir()
+    shutil.copy(build.CLI, alone / "wass_stereo")
+    c = subprocess.run([str(alone / "wass_stereo"), cfg, wd], capture_output=True, text=True, env=env)
+    assert c.returncode == 255 and "cannot start" in c.stderr and "wass_stereo_gpu" in c.stderr
+    assert not os.path.exists(os.path.join(wd, "mesh_cam.xyzC"))

@@ -79,7 +79,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 HOST_DIR = os.path.join(_HERE, "host")
 BIN_DIR = os.path.join(_HERE, "bin")
-CLI = os.path.join(BIN_DIR, "wass_stereo")
+CLI = os.path.join(BIN_DIR, "wass_stereo")            # what wasscli starts: the client of the resident worker (no HIP behind it)
+CLI_GPU = os.path.join(BIN_DIR, "wass_stereo_gpu")    # the full program: the client execs it for everything a server does not take
 BATCH = os.path.join(BIN_DIR, "wass_stereo_batch")
 PREPARE = os.path.join(BIN_DIR, "wass_prepare")
 
@@ -89,11 +90,12 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     build(force=False)
     os.makedirs(BIN_DIR, exist_ok=True)
     deps = sorted(glob.glob(os.path.join(HOST_DIR, "*.hpp"))) + [os.path.join(_HERE, "..", "include", "wass_gpu.h"), SO]
-    for name, exe in (("wass_stereo.cpp", CLI), ("wass_stereo_batch.cpp", BATCH), ("wass_prepare.cpp", PREPARE)):
+    for name, exe in (("wass_stereo_client.cpp", CLI), ("wass_stereo.cpp", CLI_GPU), ("wass_stereo_batch.cpp", BATCH), ("wass_prepare.cpp", PREPARE)):
         src = os.path.join(HOST_DIR, name)
         if force or _newer(src, exe, deps):
-            cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", "-Wno-unused-function", src, "-o", exe,
-                   "-L" + _HERE, "-lwassgpu", "-lz", "-pthread", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath-link," + "/opt/rocm/lib"]
+            cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", "-Wno-unused-function", src, "-o", exe]
+            if exe != CLI:                       # the per-frame client links nothing of ours: it must start in a millisecond
+                cmd += ["-L" + _HERE, "-lwassgpu", "-lz", "-pthread", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath-link," + "/opt/rocm/lib"]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

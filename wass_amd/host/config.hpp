@@ -148,4 +148,18 @@ inline void register_wass_stereo_options(Config& c)
     c.add(T::INT, "DENSE_PATHS", "5", "SGBM aggregation paths: 5 = cv::StereoSGBM MODE_SGBM (reference behaviour), 8 = MODE_HH (full DP)");
 }
 
+// Which configurations the device-resident chain covers (frame_pipeline.hpp); the others keep the stage-by-stage calls.  Lives here,
+// above nothing but the parser, because the per-frame client (wass_stereo_client.cpp) asks the same question without the library.
+inline bool pipeline_eligible(const Config& cfg, std::string* why = nullptr)
+{
+    auto no = [&](const char* w) { if (why) *why = w; return false; };
+    if (cfg.get_double("DENSE_SCALE") != 1.0) return no("DENSE_SCALE != 1 (maps of two sizes)");
+    if (cfg.get_bool("SAVE_FULL_MESH")) return no("SAVE_FULL_MESH (the mesh before the plane stages goes to the host)");
+    if (cfg.get_bool("SAVE_AS_PLY")) return no("SAVE_AS_PLY (the whole mesh goes to the host)");
+    if (!cfg.get_bool("SAVE_COMPRESSED")) return no("SAVE_COMPRESSED=false (the whole mesh goes to the host)");
+    const int rounds = cfg.get_int("PLANE_RANSAC_ROUNDS");
+    if (rounds <= 0 || rounds > 1800) return no("PLANE_RANSAC_ROUNDS outside 1..1800");
+    return true;
+}
+
 }  // namespace wasshost

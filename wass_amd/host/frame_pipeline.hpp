@@ -27,18 +27,6 @@
 
 namespace wassframe {
 
-inline bool pipeline_eligible(const Config& cfg, std::string* why = nullptr)
-{
-    auto no = [&](const char* w) { if (why) *why = w; return false; };
-    if (cfg.get_double("DENSE_SCALE") != 1.0) return no("DENSE_SCALE != 1 (maps of two sizes)");
-    if (cfg.get_bool("SAVE_FULL_MESH")) return no("SAVE_FULL_MESH (the mesh before the plane stages goes to the host)");
-    if (cfg.get_bool("SAVE_AS_PLY")) return no("SAVE_AS_PLY (the whole mesh goes to the host)");
-    if (!cfg.get_bool("SAVE_COMPRESSED")) return no("SAVE_COMPRESSED=false (the whole mesh goes to the host)");
-    const int rounds = cfg.get_int("PLANE_RANSAC_ROUNDS");
-    if (rounds <= 0 || rounds > 1800) return no("PLANE_RANSAC_ROUNDS outside 1..1800");
-    return true;
-}
-
 struct FrameJob {
     size_t index = 0;
     std::string workdir;
@@ -101,7 +89,7 @@ public:
     // The context is created on `device` when the first frame needs the GPU (as wass_stereo does: a sequence whose frames
     // are all finished, or all unreadable, never initialises HIP); a frame that finds no GPU fails loudly.
     FramePipeline(int device, const Config& cfg, const std::string& config_path, const Options& opt)
-        : device_(device), cfg_(cfg), config_path_(config_path), opt_(opt)
+        : device_(device), cfg_(cfg), config_path_(config_path), opt_(opt), max_pending_(opt.max_pending)
     {
         sp_.min_disp = cfg.get_int("MIN_DISPARITY");
         sp_.num_disp = cfg.get_int("MAX_DISPARITY");
@@ -404,7 +392,7 @@ public:
             // ended a whole frame ago -- this thread does not wait, and the next frame's SGM stage is in the queue before the current
             // one has finished.  (Reading the previous frame's record here instead -- one frame pending -- put tail + downloads + this
             // thread's enqueue work, 8.8 ms, on the path between two SGM stages of 7.6 ms: 114 instead of 125 frames/s.)
-            while ((int)pend_.size() >= std::max(1, std::min(2, opt_.max_pending))) if (FrameJob* p = collect()) done.push_back(p);
+            while ((int)pend_.size() >= std::max(1, std::min(2, max_pending_))) if (FrameJob* p = collect()) done.push_back(p);
             lap(5);
             // ---- the mesh tail (:2046-2123), decided on the device
             const int rounds = cfg_.get_int("PLANE_RANSAC_ROUNDS");
@@ -506,10 +494,9 @@ public:
                     WLOG_SCOPE("wass_stereo");
                     if (opt_.inliers_file) {
                         const std::string ip = path_join(env.workdir, "plane_refinement_inliers.xyz");
-                        if (device_text_ && r.inliers_text_unsupported == 0 && (r.inliers_text_bytes > 0 || r.n_inliers_out == 0)) {
-                            std::ofstream ofs(ip.c_str(), std::ios::binary);
-                            ofs.write(out_[job.out_slot].inl_text, (std::streamsize)r.inliers_text_bytes);
-                        } else write_inliers_xyz(ip, out_[job.out_slot].inl, (size_t)r.n_inliers_out);      // the host's formatter (hostio.hpp fmt_g6)
+                        if (device_text_ && r.inliers_text_unsupported == 0 && (r.inliers_text_bytes > 0 || r.n_inliers_out == 0))
+                            (void)write_whole_file(ip, out_[job.out_slot].inl_text, (size_t)r.inliers_text_bytes);
+                        else write_inliers_xyz(ip, out_[job.out_slot].inl, (size_t)r.n_inliers_out);      // the host's formatter (hostio.hpp fmt_g6)
                     }
                     WLOG_SCOPE("crop_plane");
                     WLOGI << "number of points after plane cropping: " << r.kept_final;
@@ -531,13 +518,7 @@ public:
                     WLOG_SCOPE("save_as_xyz_compressed");
                     WLOGI << "saving mesh as compressed xyz file...";
                     const std::string xyzc_path = path_join(env.workdir, "mesh_cam.xyzC"), tmp = xyzc_path + ".tmp";
-                    bool ok;
-                    {
-                        std::ofstream ofs(tmp.c_str(), std::ios::binary);
-                        ok = !ofs.fail() && ofs.write((const char*)out_[job.out_slot].xyzc, (std::streamsize)r.xyzc_bytes).good();
-                        ofs.close();
-                        ok = ok && !ofs.fail();
-                    }
+                    bool ok = write_whole_file(tmp, out_[job.out_slot].xyzc, (size_t)r.xyzc_bytes);
                     ok = ok && rename(tmp.c_str(), xyzc_path.c_str()) == 0;
                     if (!ok) { WLOGE << "unable to save mesh data"; throw GpuError("write failed"); }
                     WLOGI << "total data size: " << ((double)r.xyzc_bytes / 1E6) << " MB";
@@ -626,6 +607,9 @@ public:
     }
 
     int frames_submitted() const { return nsub_; }
+    // how many frames may be pending when the next tail is enqueued (Options::max_pending), changed between submissions: the resident
+    // worker goes two deep only while callers queue up behind the GPU
+    void set_max_pending(int n) { max_pending_ = n; }
     bool pending() const { return !pend_.empty() || !early_.empty(); }   // a submitted frame has not been handed out yet (flush() returns it)
 
 private:
@@ -818,6 +802,7 @@ private:
     const Config& cfg_;
     std::string config_path_;
     Options opt_;
+    int max_pending_;
     wass_sgm_params sp_{};
     wass_refine_params rp_{};
     int W_ = 0, H_ = 0, cwl_ = 0, chl_ = 0, cwr_ = 0, chr_ = 0;

@@ -15,9 +15,13 @@ int main(int argc, char* argv[])
     // the resident worker that later wass_stereo processes hand their frames to (stereo_server.hpp); started by the first of them
     if (argc >= 3 && std::string("--server") == argv[1]) return wassserver::server_main(argv[2], argc >= 4 ? atoi(argv[3]) : 0);
 
-    std::cout << "wass_stereo  v. " << WASS_AMD_VERSION << std::endl;
-    std::cout << "----------------------------------------------" << std::endl;
-    std::cout << " [Release] MI355X / gfx950 HIP build, " << wass_version() << std::endl << std::endl;
+    // (installed as `wass_stereo_gpu`; the `wass_stereo` of the same directory is wass_stereo_client.cpp, which printed the banner
+    // already when it hands a frame over that no server took)
+    if (!getenv("WASS_BANNER_DONE")) {
+        std::cout << "wass_stereo  v. " << WASS_AMD_VERSION << std::endl;
+        std::cout << "----------------------------------------------" << std::endl;
+        std::cout << " [Release] MI355X / gfx950 HIP build, " << wass_version() << std::endl << std::endl;
+    }
 
     if (argc == 1) {
         std::cout << "Usage:" << std::endl;
@@ -60,7 +64,7 @@ int main(int argc, char* argv[])
         // A per-GPU server computes the frame when there is one or one can be started: same files, same output, same exit code, without
         // this process ever initialising HIP (WASS_NO_SERVER=1: everything below runs here, as in round 4).
         const char* no_srv = getenv("WASS_NO_SERVER");
-        if (ok && !(no_srv && atoi(no_srv) != 0)) {
+        if (ok && !(no_srv && atoi(no_srv) != 0) && !getenv("WASS_CLIENT_TRIED")) {
             char self[4096];
             const ssize_t sl = readlink("/proc/self/exe", self, sizeof self - 1);
             if (sl > 0) {
