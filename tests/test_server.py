@@ -207,3 +207,47 @@ def test_the_per_frame_client_carries_no_gpu_runtime_and_no_computation(cli, tmp
     c = subprocess.run([str(alone / "wass_stereo"), cfg, wd], capture_output=True, text=True, env=env)
     assert c.returncode == 255 and "cannot start" in c.stderr and "wass_stereo_gpu" in c.stderr
     assert not os.path.exists(os.path.join(wd, "mesh_cam.xyzC"))
+
+
+def test_read_ahead_decodes_the_next_workdirs_and_never_serves_a_changed_file(cli, tmp_path):
+    """wasscli walks 000000_wd, 000001_wd, ... in order; after two requests from one sequence directory the server inflates the PNGs of
+    the next workdirs before their callers exist (ReadAhead, stereo_server.hpp).  A pair decoded early is used only while both files
+    are still the ones that were read: a picture replaced in between is decoded again."""
+    import numpy as np
+    import torch
+    from test_cli import _write_png
+    if torch.cuda.is_available():
+        pytest.skip("the no-GPU behaviour is tested on the build container")
+    mk = tmp_path / "mk"
+    mk.mkdir()
+    wd, cfg, *_ = make_workdir(str(mk), 160, 120, 32)
+    seq = tmp_path / "seq"
+    seq.mkdir()
+    for i in range(6):
+        shutil.copytree(wd, seq / ("%06d_wd" % i))
+    sock = tmp_path / "sock"
+    sock.mkdir()
+    tlog = tmp_path / "timing.log"
+    env = _env(sock, WASS_DEBUG_IMAGES="0", WASS_SERVER_TIMING=str(tlog))
+    call = lambda i: subprocess.run([cli, cfg, str(seq / ("%06d_wd" % i))], capture_output=True, text=True, env=env)
+    for i in (0, 1):
+        assert "image 0 loaded, Size: 160x120" in call(i).stdout
+    time.sleep(0.5)                                                   # 2, 3, 4, 5 are decoded by now
+    big = np.zeros((150, 200), np.uint8)
+    for k in (0, 1):
+        _write_png(str(seq / "000002_wd" / "undistorted" / ("0000000%d.png" % k)), big)      # replaced after it was read
+    r2, r3 = call(2), call(3)
+    assert "image 0 loaded, Size: 200x150" in r2.stdout and "image 1 loaded, Size: 200x150" in r2.stdout
+    assert "image 0 loaded, Size: 160x120" in r3.stdout and "%06d_wd" % 3 in r3.stdout
+    _wait_gone(sock)
+    rows = {l.split()[0].rsplit("/", 1)[1]: l.split()[1] for l in tlog.read_text().splitlines() if " total " in l}
+    assert rows["000000_wd"] == rows["000001_wd"] == "demand"          # nothing is decoded before a sequence shows
+    assert rows["000002_wd"] == "demand" and rows["000003_wd"] == "ahead"
+    assert "1 decoded early and changed since" in tlog.read_text()
+    # switched off: everything on demand
+    tlog.unlink()
+    for i in range(4):
+        call_off = subprocess.run([cli, cfg, str(seq / ("%06d_wd" % i))], capture_output=True, text=True, env=dict(env, WASS_SERVER_READAHEAD="0"))
+        assert "image 0 loaded" in call_off.stdout
+    _wait_gone(sock)
+    assert " ahead " not in tlog.read_text()

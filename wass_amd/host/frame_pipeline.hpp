@@ -40,6 +40,7 @@ struct FrameJob {
     // wass_prepare would have turned into <workdir>/undistorted/*.png first
     bool raw = false;
     std::string c0, c1;
+    Preload* pre = nullptr;          // the workdir's two pictures, decoded ahead of the request (the resident worker's read-ahead); used and emptied by prepare
     int prev_w = 0, prev_h = 0;      // size of the scaled previews, written once the undistorted pictures are back (0: none)
     int img_w = 0, img_h = 0;        // size of the cameras' pictures (the driver drops the decoded pictures once they are staged)
     // LEFT_MASK_IMAGE / RIGHT_MASK_IMAGE (wass_stereo.cpp:1059-1087): thresholded to 0/1 on the decode thread (empty: none);
@@ -170,8 +171,8 @@ public:
                 job.img_w = env.left.w; job.img_h = env.left.h;
                 input_scale_outputs(env, cfg_, false, nullptr, &job.prev_w, &job.prev_h);
             } else if (opt_.device_previews) {
-                if (!load_data(env, cfg_, nullptr, nullptr, false, &job.prev_w, &job.prev_h)) { job.rc = -1; return; }   // previews: on the GPU (submit)
-            } else if (!load_data(env, cfg_, nullptr, nullptr)) { job.rc = -1; return; }
+                if (!load_data(env, cfg_, job.pre, nullptr, false, &job.prev_w, &job.prev_h)) { job.rc = -1; return; }   // previews: on the GPU (submit)
+            } else if (!load_data(env, cfg_, job.pre, nullptr)) { job.rc = -1; return; }
             job.t_loaded = Timer::now();
             marker(job, 10);
             auto save_cams = [&]() {

@@ -56,7 +56,142 @@ struct PipeEntry {
 struct ServerJob : FrameJob {
     int fd = -1;
     PipeEntry* entry = nullptr;
+    bool read_ahead = false;           // its pictures were decoded before it asked
     double t_accept = 0, t_decoded = 0, t_submit = 0, t_collected = 0, t_written = 0;     // WASS_SERVER_TIMING
+};
+
+// ---- read-ahead.  wasscli walks a sequence in order (000000_wd, 000001_wd, ...: wasscli.py:308-346), and every caller waits for ITS
+// frame: 16 of the 42 ms a call spends in the server are the inflation of its two PNGs.  Once two frames of one sequence directory have
+// been asked for, the pictures of the next few workdirs of that directory are decoded before their callers exist.  A decoded pair is
+// used only if both files still have the inode, size and modification time they had before AND after they were read; anything else
+// (and any workdir nobody predicted) is decoded on demand, as before.  WASS_SERVER_READAHEAD=<n> workdirs (default 6, 0 = off).
+struct FileSig {
+    bool ok = false;
+    ino_t ino = 0; off_t size = 0; timespec mtime = { 0, 0 };
+    static FileSig of(const std::string& path)
+    {
+        FileSig s;
+        struct stat st;
+        if (stat(path.c_str(), &st) == 0) { s.ok = true; s.ino = st.st_ino; s.size = st.st_size; s.mtime = st.st_mtim; }
+        return s;
+    }
+    bool operator==(const FileSig& o) const { return ok && o.ok && ino == o.ino && size == o.size && mtime.tv_sec == o.mtime.tv_sec && mtime.tv_nsec == o.mtime.tv_nsec; }
+};
+struct ReadAhead {
+    enum State { QUEUED, RUNNING, DONE, TAKEN };
+    struct Entry {
+        std::string workdir;
+        State state = QUEUED;
+        Preload pre;
+        FileSig sig[2];
+        bool valid = false;                  // the files did not change while they were read
+    };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::map<std::string, std::shared_ptr<Entry>> by_dir;
+    std::deque<std::shared_ptr<Entry>> order;          // oldest first: the cache holds at most `cap` pairs (10 MB each at 5 megapixels)
+    std::deque<std::shared_ptr<Entry>> todo;
+    std::map<std::string, int> seen;                   // requests per sequence directory
+    int depth = 6;
+    size_t cap = 16;
+    bool closed = false;
+    std::atomic<uint64_t> hits{ 0 }, misses{ 0 }, stale{ 0 };
+
+    static std::string pic(const std::string& wd, int k) { return path_join(wd, k == 0 ? "undistorted/00000000.png" : "undistorted/00000001.png"); }
+    // "<parent>/<prefix><digits><suffix>" -> the same name with the number raised by k (same width); empty when the name holds no number
+    static std::string sibling(const std::string& wd, int k)
+    {
+        std::string w = wd;
+        while (w.size() > 1 && w.back() == '/') w.pop_back();
+        const size_t slash = w.rfind('/');
+        const size_t b0 = slash == std::string::npos ? 0 : slash + 1;
+        size_t e = w.size();
+        while (e > b0 && !isdigit((unsigned char)w[e - 1])) --e;
+        size_t b = e;
+        while (b > b0 && isdigit((unsigned char)w[b - 1])) --b;
+        if (b == e || e - b > 18) return std::string();
+        const unsigned long long v = strtoull(w.substr(b, e - b).c_str(), nullptr, 10) + (unsigned long long)k;
+        char num[32];
+        snprintf(num, sizeof num, "%0*llu", (int)(e - b), v);
+        if (strlen(num) != e - b) return std::string();
+        return w.substr(0, b) + num + w.substr(e);
+    }
+    static std::string parent(const std::string& wd)
+    {
+        std::string w = wd;
+        while (w.size() > 1 && w.back() == '/') w.pop_back();
+        const size_t slash = w.rfind('/');
+        return slash == std::string::npos ? std::string(".") : w.substr(0, slash);
+    }
+    static void decode(Entry& e)
+    {
+        for (int k = 0; k < 2; ++k) e.sig[k] = FileSig::of(pic(e.workdir, k));
+        preload_images(e.workdir, e.pre);
+        e.valid = e.pre.error.empty() && e.sig[0] == FileSig::of(pic(e.workdir, 0)) && e.sig[1] == FileSig::of(pic(e.workdir, 1));
+    }
+    // A request for `wd` has arrived.  Returns its decoded pictures if they are here and still those of the files (the entry leaves the
+    // cache either way), and queues the workdirs that follow it.
+    std::shared_ptr<Entry> request(const std::string& wd)
+    {
+        std::shared_ptr<Entry> mine;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            if (depth <= 0) return nullptr;
+            auto it = by_dir.find(wd);
+            if (it != by_dir.end()) {
+                mine = it->second;
+                if (mine->state == QUEUED) { mine->state = TAKEN; mine = nullptr; }          // not started: this thread decodes it itself, now
+                else { cv.wait(lk, [&]() { return mine->state == DONE || closed; }); }
+                by_dir.erase(wd);
+                for (auto o = order.begin(); o != order.end(); ++o) if ((*o)->workdir == wd) { order.erase(o); break; }
+            }
+            const int n = ++seen[parent(wd)];
+            if (seen.size() > 64) { seen.clear(); }
+            if (n >= 2 && !closed)
+                for (int k = 1; k <= depth; ++k) {
+                    const std::string nx = sibling(wd, k);
+                    if (nx.empty() || by_dir.count(nx)) continue;
+                    if (!FileSig::of(pic(nx, 0)).ok) break;                                // the sequence ends here (or is not one)
+                    auto e = std::make_shared<Entry>();
+                    e->workdir = nx;
+                    by_dir[nx] = e;
+                    order.push_back(e);
+                    todo.push_back(e);
+                    while (order.size() > cap) {                                            // predicted and never asked for: oldest out
+                        auto old = order.front();
+                        order.pop_front();
+                        if (old->state == QUEUED) old->state = TAKEN;
+                        by_dir.erase(old->workdir);
+                    }
+                }
+            cv.notify_all();
+            if (mine && mine->state != DONE) mine = nullptr;
+        }
+        if (!mine) { ++misses; return nullptr; }
+        const bool fresh = mine->valid && mine->sig[0] == FileSig::of(pic(wd, 0)) && mine->sig[1] == FileSig::of(pic(wd, 1));
+        if (!fresh) { ++stale; return nullptr; }
+        ++hits;
+        return mine;
+    }
+    void worker()
+    {
+        for (;;) {
+            std::shared_ptr<Entry> e;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&]() { return closed || !todo.empty(); });
+                if (closed) return;
+                e = todo.front();
+                todo.pop_front();
+                if (e->state != QUEUED) continue;                                           // its caller came first, or it fell out of the cache
+                e->state = RUNNING;
+            }
+            decode(*e);
+            { std::lock_guard<std::mutex> lk(mu); e->state = DONE; }
+            cv.notify_all();
+        }
+    }
+    void close() { { std::lock_guard<std::mutex> lk(mu); closed = true; } cv.notify_all(); }
 };
 
 template <typename T> class Queue {
@@ -91,6 +226,9 @@ inline int server_main(const std::string& sock, int device)
     if (const char* e = getenv("WASS_SERVER_IDLE")) idle_s = std::max(1, atoi(e));
     if (const char* e = getenv("WASS_SERVER_DECODE")) ndec = std::max(1, atoi(e));
     if (const char* e = getenv("WASS_SERVER_WRITERS")) nwr = std::max(1, atoi(e));
+    int nra = 2;                                                   // read-ahead threads (each decodes the two pictures of a workdir side by side)
+    ReadAhead readahead;
+    if (const char* e = getenv("WASS_SERVER_READAHEAD")) readahead.depth = std::max(0, atoi(e));
     int deep_at = 2;                                               // callers waiting behind the GPU from which the chain runs two frames deep
     if (const char* e = getenv("WASS_SERVER_DEEP_AT")) deep_at = std::max(0, atoi(e));
     // WASS_SERVER_TIMING=<file>: one line per frame -- where a caller's waiting time went (decode, queue, GPU, files)
@@ -170,7 +308,13 @@ inline int server_main(const std::string& sock, int device)
             if (!exists(wd)) {
                 LogSinkScope sink(&j->log);
                 j->rc = -1;
-            } else pe->pl->prepare(*j);
+            } else {
+                std::shared_ptr<ReadAhead::Entry> ahead_of_time = readahead.request(wd);      // the pictures may be here already
+                j->pre = ahead_of_time ? &ahead_of_time->pre : nullptr;
+                j->read_ahead = ahead_of_time != nullptr;
+                pe->pl->prepare(*j);
+                j->pre = nullptr;
+            }
             j->t_decoded = Timer::now();
             ready.push(j);
         }
@@ -185,7 +329,7 @@ inline int server_main(const std::string& sock, int device)
             reply(j);
             if (tlog) {
                 std::lock_guard<std::mutex> lk(tlog_mu);
-                fprintf(tlog, "%s decode %.1f queue %.1f gpu %.1f files %.1f reply %.1f total %.1f ms\n", j->workdir.c_str(), (j->t_decoded - j->t_accept) * 1e3,
+                fprintf(tlog, "%s %s decode %.1f queue %.1f gpu %.1f files %.1f reply %.1f total %.1f ms\n", j->workdir.c_str(), j->read_ahead ? "ahead" : "demand", (j->t_decoded - j->t_accept) * 1e3,
                         (j->t_submit - j->t_decoded) * 1e3, (j->t_collected - j->t_submit) * 1e3, (j->t_written - j->t_collected) * 1e3,
                         (Timer::now() - j->t_written) * 1e3, (Timer::now() - j->t_accept) * 1e3);
                 fflush(tlog);
@@ -195,6 +339,7 @@ inline int server_main(const std::string& sock, int device)
         }
     };
     std::vector<std::thread> pool;
+    for (int t = 0; t < nra; ++t) pool.emplace_back([&]() { readahead.worker(); });
     for (int t = 0; t < ndec; ++t) pool.emplace_back(decoder);
     for (int t = 0; t < nwr; ++t) pool.emplace_back(writer);
 
@@ -276,9 +421,14 @@ inline int server_main(const std::string& sock, int device)
     }
     ready.close();
     towrite.close();
+    readahead.close();
     for (auto& t : pool) t.join();
     pipes.clear();
-    if (tlog) fclose(tlog);
+    if (tlog) {
+        fprintf(tlog, "read-ahead: %llu frames decoded before they were asked for, %llu on demand, %llu decoded early and changed since\n",
+                (unsigned long long)readahead.hits.load(), (unsigned long long)readahead.misses.load(), (unsigned long long)readahead.stale.load());
+        fclose(tlog);
+    }
     return 0;
 }
 
