@@ -251,3 +251,43 @@ def test_read_ahead_decodes_the_next_workdirs_and_never_serves_a_changed_file(cl
         assert "image 0 loaded" in call_off.stdout
     _wait_gone(sock)
     assert " ahead " not in tlog.read_text()
+
+
+def test_on_a_multi_gpu_node_frame_i_goes_to_gpu_i_mod_g_and_each_server_reads_its_own_stride_ahead(cli, tmp_path):
+    """Callers pick the GPU by the number in the workdir's name (the sequence driver's rule, frame i -> GPU i mod G): wasscli's
+    consecutive frames land on different GPUs, and the server of GPU g sees g, g+G, g+2G, ... -- which is what it reads ahead."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the no-GPU behaviour is tested on the build container")
+    mk = tmp_path / "mk"
+    mk.mkdir()
+    wd, cfg, *_ = make_workdir(str(mk), 160, 120, 32)
+    seq = tmp_path / "seq"
+    seq.mkdir()
+    for i in range(8):
+        shutil.copytree(wd, seq / ("%06d_wd" % i))
+    sock = tmp_path / "sock"
+    sock.mkdir()
+    tlog = tmp_path / "timing.log"
+    env = _env(sock, WASS_DEBUG_IMAGES="0", WASS_SERVER_TIMING=str(tlog), WASS_NUM_GPUS="2")
+    env.pop("WASS_GPU_DEVICE", None)
+    for i in range(8):
+        r = subprocess.run([cli, cfg, str(seq / ("%06d_wd" % i))], capture_output=True, text=True, env=env)
+        assert "%06d_wd" % i in r.stdout
+        if i == 1:
+            assert sorted(f for f in os.listdir(sock) if f.endswith(".sock")) == ["wass_stereo_%d_gpu0.sock" % os.getuid(), "wass_stereo_%d_gpu1.sock" % os.getuid()]
+        time.sleep(0.15)
+    assert len(_servers(sock)) == 2
+    _wait_gone(sock)
+    rows = {l.split()[0].rsplit("/", 1)[1]: l.split()[1] for l in tlog.read_text().splitlines() if " total " in l}
+    # each server: two requests on demand (0, 2 / 1, 3), then its own stride ahead (4, 6 / 5, 7)
+    assert [rows["%06d_wd" % i] for i in range(8)] == ["demand"] * 4 + ["ahead"] * 4
+    assert tlog.read_text().count("2 frames decoded before they were asked for, 2 on demand, 0 decoded early") == 2
+    # a workdir without a number, or a pinned caller: still served
+    plain = tmp_path / "plain"
+    shutil.copytree(wd, plain)
+    r = subprocess.run([cli, cfg, str(plain)], capture_output=True, text=True, env=env)
+    assert "Reconstructing" in r.stdout
+    r = subprocess.run([cli, cfg, str(seq / "000003_wd")], capture_output=True, text=True, env=dict(env, WASS_GPU_DEVICE="0"))
+    assert "000003_wd" in r.stdout
+    _wait_gone(sock)

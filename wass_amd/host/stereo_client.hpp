@@ -89,6 +89,25 @@ inline int count_gpus()
     }
     return n > 0 ? n : 1;
 }
+// The number in a workdir's name -- "<parent>/<prefix><digits><suffix>", the LAST run of digits of the last component, as in wasscli's
+// 000123_wd -- and where it sits; false when the name holds none.  Frame numbers spread callers over the GPUs of a node and let a
+// server predict which workdirs come next (stereo_server.hpp).
+inline bool workdir_number(const std::string& wd, unsigned long long* value, size_t* begin = nullptr, size_t* end = nullptr)
+{
+    size_t n = wd.size();
+    while (n > 1 && wd[n - 1] == '/') --n;
+    const size_t slash = wd.rfind('/', n ? n - 1 : 0);
+    const size_t b0 = (slash == std::string::npos || slash >= n) ? 0 : slash + 1;
+    size_t e = n;
+    while (e > b0 && !(wd[e - 1] >= '0' && wd[e - 1] <= '9')) --e;
+    size_t b = e;
+    while (b > b0 && wd[b - 1] >= '0' && wd[b - 1] <= '9') --b;
+    if (b == e || e - b > 18) return false;
+    if (value) *value = strtoull(wd.substr(b, e - b).c_str(), nullptr, 10);
+    if (begin) *begin = b;
+    if (end) *end = e;
+    return true;
+}
 inline std::string socket_path(int device)
 {
     const char* dir = getenv("WASS_SERVER_DIR");
@@ -130,9 +149,16 @@ inline void print_log(const std::string& log)
 // the caller then computes it in-process.
 inline int client_run(const char* self_exe, const char* cfg_path, const std::string& cfg_text, const char* workdir, bool debug_images)
 {
-    int device = 0;
+    // which GPU: WASS_GPU_DEVICE, else frame number mod GPUs (the sequence driver's rule: frame i -> GPU i mod G, so that wasscli's
+    // consecutive frames land on different GPUs and every server sees an arithmetic sequence it can read ahead), else pid mod GPUs
+    int device = 0, stride = 1;
     if (const char* e = getenv("WASS_GPU_DEVICE")) device = atoi(e);
-    else { const int g = count_gpus(); if (g > 1) device = (int)((unsigned)getpid() % (unsigned)g); }
+    else {
+        const int g = count_gpus();
+        unsigned long long num = 0;
+        if (g > 1 && workdir_number(workdir, &num)) { device = (int)(num % (unsigned long long)g); stride = g; }
+        else if (g > 1) device = (int)((unsigned)getpid() % (unsigned)g);
+    }
     const std::string sock = socket_path(device);
     int fd = connect_to(sock);
     if (fd < 0) {
@@ -170,7 +196,7 @@ inline int client_run(const char* self_exe, const char* cfg_path, const std::str
     char cwd[4096];
     std::string wd = workdir;
     if (!wd.empty() && wd[0] != '/' && getcwd(cwd, sizeof cwd)) wd = join_path(cwd, wd);
-    std::string opts = std::string("debug=") + (debug_images ? "1" : "0");
+    std::string opts = std::string("debug=") + (debug_images ? "1" : "0") + ";stride=" + std::to_string(stride);
     for (const char* v : { "WASS_DEBUG_FORMAT", "WASS_HOST_INLIER_TEXT" })
         if (const char* e = getenv(v)) opts += std::string(";") + v + "=" + e;
     const uint32_t n = 4;

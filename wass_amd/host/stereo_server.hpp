@@ -99,20 +99,15 @@ struct ReadAhead {
 
     static std::string pic(const std::string& wd, int k) { return path_join(wd, k == 0 ? "undistorted/00000000.png" : "undistorted/00000001.png"); }
     // "<parent>/<prefix><digits><suffix>" -> the same name with the number raised by k (same width); empty when the name holds no number
-    static std::string sibling(const std::string& wd, int k)
+    static std::string sibling(const std::string& wd, unsigned long long k)
     {
         std::string w = wd;
         while (w.size() > 1 && w.back() == '/') w.pop_back();
-        const size_t slash = w.rfind('/');
-        const size_t b0 = slash == std::string::npos ? 0 : slash + 1;
-        size_t e = w.size();
-        while (e > b0 && !isdigit((unsigned char)w[e - 1])) --e;
-        size_t b = e;
-        while (b > b0 && isdigit((unsigned char)w[b - 1])) --b;
-        if (b == e || e - b > 18) return std::string();
-        const unsigned long long v = strtoull(w.substr(b, e - b).c_str(), nullptr, 10) + (unsigned long long)k;
+        unsigned long long v = 0;
+        size_t b = 0, e = 0;
+        if (!workdir_number(w, &v, &b, &e)) return std::string();
         char num[32];
-        snprintf(num, sizeof num, "%0*llu", (int)(e - b), v);
+        snprintf(num, sizeof num, "%0*llu", (int)(e - b), v + k);
         if (strlen(num) != e - b) return std::string();
         return w.substr(0, b) + num + w.substr(e);
     }
@@ -130,8 +125,8 @@ struct ReadAhead {
         e.valid = e.pre.error.empty() && e.sig[0] == FileSig::of(pic(e.workdir, 0)) && e.sig[1] == FileSig::of(pic(e.workdir, 1));
     }
     // A request for `wd` has arrived.  Returns its decoded pictures if they are here and still those of the files (the entry leaves the
-    // cache either way), and queues the workdirs that follow it.
-    std::shared_ptr<Entry> request(const std::string& wd)
+    // cache either way), and queues the workdirs that follow it: every stride-th (a node's callers pick GPU = frame number mod GPUs).
+    std::shared_ptr<Entry> request(const std::string& wd, int stride)
     {
         std::shared_ptr<Entry> mine;
         {
@@ -149,7 +144,7 @@ struct ReadAhead {
             if (seen.size() > 64) { seen.clear(); }
             if (n >= 2 && !closed)
                 for (int k = 1; k <= depth; ++k) {
-                    const std::string nx = sibling(wd, k);
+                    const std::string nx = sibling(wd, (unsigned long long)k * (unsigned long long)std::max(1, stride));
                     if (nx.empty() || by_dir.count(nx)) continue;
                     if (!FileSig::of(pic(nx, 0)).ok) break;                                // the sequence ends here (or is not one)
                     auto e = std::make_shared<Entry>();
@@ -273,6 +268,8 @@ inline int server_main(const std::string& sock, int device)
                             recv_str(j->fd, cfgtext) && recv_str(j->fd, wd) && recv_str(j->fd, opts);
             if (!ok) { close(j->fd); delete j; --in_flight; continue; }
             const bool debug = opts.find("debug=1") != std::string::npos;
+            int stride = 1;
+            { const size_t sp = opts.find("stride="); if (sp != std::string::npos) stride = std::max(1, atoi(opts.c_str() + sp + 7)); }
             const std::string key = opts + "\n" + cfgtext;
             PipeEntry* pe;
             {
@@ -309,7 +306,7 @@ inline int server_main(const std::string& sock, int device)
                 LogSinkScope sink(&j->log);
                 j->rc = -1;
             } else {
-                std::shared_ptr<ReadAhead::Entry> ahead_of_time = readahead.request(wd);      // the pictures may be here already
+                std::shared_ptr<ReadAhead::Entry> ahead_of_time = readahead.request(wd, stride);      // the pictures may be here already
                 j->pre = ahead_of_time ? &ahead_of_time->pre : nullptr;
                 j->read_ahead = ahead_of_time != nullptr;
                 pe->pl->prepare(*j);
