@@ -291,3 +291,49 @@ def test_on_a_multi_gpu_node_frame_i_goes_to_gpu_i_mod_g_and_each_server_reads_i
     r = subprocess.run([cli, cfg, str(seq / "000003_wd")], capture_output=True, text=True, env=dict(env, WASS_GPU_DEVICE="0"))
     assert "000003_wd" in r.stdout
     _wait_gone(sock)
+
+
+def test_the_server_survives_garbage_on_its_socket(cli, tmp_path):
+    """Anything may connect to a unix socket in /tmp: a wrong magic, a truncated request, an oversized length or a caller that hangs
+    up early costs that connection only -- the next real caller is served by the same server."""
+    import socket
+    import struct
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the no-GPU behaviour is tested on the build container")
+    wd, cfg, *_ = make_workdir(str(tmp_path), 160, 120, 32)
+    sock = tmp_path / "sock"
+    sock.mkdir()
+    env = dict(_env(sock, WASS_DEBUG_IMAGES="0"), WASS_SERVER_IDLE="4")
+    a = subprocess.run([cli, cfg, wd], capture_output=True, text=True, env=env)
+    assert "Reconstructing" in a.stdout
+    srv = _servers(sock)
+    assert len(srv) == 1
+    path = str(sock / ("wass_stereo_%d_gpu0.sock" % os.getuid()))
+    s4 = lambda b: struct.pack("I", len(b)) + b
+    for payload in (b"", b"GET / HTTP/1.0\r\n\r\n", b"WSRV1\n", b"WSRV1\n" + struct.pack("I", 4) + s4(b"cfg") + b"\xff\xff\xff\x7f",
+                    b"WSRV1\n" + struct.pack("I", 9), b"WSRV1\n" + struct.pack("I", 4) + s4(b"x") + s4(b"not a configuration") + s4(b"/nonexistent") + s4(b"debug=0"),
+                    os.urandom(4096)):
+        c = socket.socket(socket.AF_UNIX)
+        c.settimeout(5)
+        c.connect(path)
+        try:
+            c.sendall(payload)
+            c.shutdown(socket.SHUT_WR)
+            c.recv(65536)                                             # a refusal, an error log or nothing -- never a hang
+        except OSError:
+            pass
+        c.close()
+    # peers that connect and say nothing: every decode thread gets one, and lets go of it after the receive time-out
+    mute = []
+    for _ in range(8):
+        c = socket.socket(socket.AF_UNIX)
+        c.connect(path)
+        mute.append(c)
+    t0 = time.time()
+    b = subprocess.run([cli, cfg, wd], capture_output=True, text=True, env=env, timeout=60)
+    assert "Reconstructing" in b.stdout and b.returncode == a.returncode and time.time() - t0 < 20
+    for c in mute:
+        c.close()
+    assert [l.split()[0] for l in _servers(sock)] == [srv[0].split()[0]]      # the SAME server, still alive
+    _wait_gone(sock)

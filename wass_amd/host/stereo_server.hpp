@@ -350,6 +350,9 @@ inline int server_main(const std::string& sock, int device)
             if (r <= 0) continue;
             const int fd = accept4(lfd, nullptr, nullptr, SOCK_CLOEXEC);
             if (fd < 0) continue;
+            // a request is a few kilobytes sent in one go: a peer that connects and then says nothing must not hold a decode thread
+            const timeval tv = { 3, 0 };
+            (void)setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
             last_activity = (long long)time(nullptr);
             ServerJob* j = new ServerJob();
             j->fd = fd;
