@@ -297,6 +297,7 @@ inline Image read_png_gray(const std::string& filename)
         throw std::runtime_error(filename + ": zlib inflate failed");
     std::vector<uint8_t> cur(stride), prev(stride, 0);
     Image img(w, h);
+    bool prev_in_picture = false;                            // the previous row went straight into the picture: `prev` is stale
     for (int y = 0; y < h; ++y) {
         const uint8_t ft = raw[(stride + 1) * y];
         const uint8_t* in = &raw[(stride + 1) * y + 1];
@@ -305,10 +306,11 @@ inline Image read_png_gray(const std::string& filename)
             uint8_t* o = &img.px[(size_t)y * w];
             if (ft == 0) memcpy(o, in, stride);
             else if (ft == 1) { uint8_t a = 0; for (size_t i = 0; i < stride; ++i) { a = (uint8_t)(in[i] + a); o[i] = a; } }
-            else { const uint8_t* up = y > 0 ? o - w : prev.data(); for (size_t i = 0; i < stride; ++i) o[i] = (uint8_t)(in[i] + up[i]); }
-            memcpy(prev.data(), o, stride);                  // a later row may use a filter of the general form
+            else { const uint8_t* up = prev_in_picture ? o - w : prev.data(); for (size_t i = 0; i < stride; ++i) o[i] = (uint8_t)(in[i] + up[i]); }
+            prev_in_picture = true;
             continue;
         }
+        if (prev_in_picture) { memcpy(prev.data(), &img.px[(size_t)(y - 1) * w], stride); prev_in_picture = false; }   // (ch == 1 here)
         for (size_t i = 0; i < stride; ++i) {
             const int a = i >= (size_t)ch ? cur[i - ch] : 0, b = prev[i], c = i >= (size_t)ch ? prev[i - ch] : 0;
             int v = in[i];
