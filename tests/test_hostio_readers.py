@@ -15,8 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def dump(tmp_path_factory):
-    exe = str(tmp_path_factory.mktemp("pngdump") / "png_dump")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "helpers", "png_dump.cpp"), "-o", exe, "-lz", "-ldl"])
+    exe = str(tmp_path_factory.mktemp("probe") / "host_probe")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "helpers", "host_probe.cpp"), "-o", exe, "-lz", "-ldl"])
     return exe
 
 
@@ -66,7 +66,7 @@ def _write_png(path, img, filters, level=6, idat_split=1):
 
 
 def _decode(dump, path):
-    r = subprocess.run([dump, path], capture_output=True)
+    r = subprocess.run([dump, "png", path], capture_output=True)
     assert r.returncode == 0, r.stderr.decode()
     w, h = struct.unpack("ii", r.stdout[:8])
     return np.frombuffer(r.stdout[8:], np.uint8).reshape(h, w)
@@ -115,7 +115,7 @@ def test_a_five_megapixel_sub_filtered_picture_like_cv_imwrite_writes(dump, tmp_
     with open(p, "wb") as fo:
         fo.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)) + b"".join(chunk(b"IDAT", z[i:i + 8192]) for i in range(0, len(z), 8192)) + chunk(b"IEND", b""))
     for env in ({}, {"WASS_NO_LIBDEFLATE": "1"}):                        # libdeflate (dlopen) and the libz fall-back
-        r = subprocess.run([dump, p], capture_output=True, env=dict(os.environ, **env))
+        r = subprocess.run([dump, "png", p], capture_output=True, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr.decode()
         np.testing.assert_array_equal(np.frombuffer(r.stdout[8:], np.uint8).reshape(h, w), img[:, :, 0])
 
@@ -131,5 +131,39 @@ def test_broken_files_are_errors_not_crashes(dump, tmp_path):
             _write_png(q, img, [7] * 20)
         else:
             open(q, "wb").write(bad)
-        r = subprocess.run([dump, q], capture_output=True)
+        r = subprocess.run([dump, "png", q], capture_output=True)
         assert r.returncode == 1 and r.stderr                            # an exception with a message, caught by the caller
+
+
+def test_calibration_matrices_as_opencv_writes_them(dump, tmp_path):
+    """cv::FileStorage's XML (what wass_prepare / the calibration tools leave in a workdir, wass_stereo.cpp:340-386): values like `1.`, `0.`,
+    `2.4560000000000000e+03`, several per line with arbitrary indentation, `<dt>d</dt>` or `<dt>f</dt>`, a comment line in front."""
+    text = """<?xml version="1.0"?>
+<!-- written by cv::FileStorage -->
+<opencv_storage>
+<intr type_id="opencv-matrix">
+  <rows>3</rows>
+  <cols>3</cols>
+  <dt>d</dt>
+  <data>
+    2.4560000000000000e+03 0. 1.2275000000000000e+03 0.
+    2.4561234567890123e+03 1.0285000000000000e+03 0. 0. 1.</data></intr>
+</opencv_storage>
+"""
+    p = tmp_path / "intrinsics_00000000.xml"
+    p.write_text(text)
+    r = subprocess.run([dump, "xml", str(p)], capture_output=True, text=True)
+    assert r.returncode == 0
+    lines = r.stdout.split()
+    assert lines[:2] == ["3", "3"]
+    assert [float(v) for v in lines[2:]] == [2456.0, 0.0, 1227.5, 0.0, 2456.1234567890123, 1028.5, 0.0, 0.0, 1.0]
+    q = tmp_path / "ext_T.xml"
+    q.write_text(text.replace("<rows>3</rows>", "<rows>3</rows>").replace("<cols>3</cols>", "<cols>1</cols>").replace("<dt>d</dt>", "<dt>f</dt>")
+                 .replace("2.4560000000000000e+03 0. 1.2275000000000000e+03 0.", "-2.50000000e+00 3.99999991e-02").replace("2.4561234567890123e+03 1.0285000000000000e+03 0. 0. 1.", "-1.25000000e-01"))
+    r = subprocess.run([dump, "xml", str(q)], capture_output=True, text=True)
+    lines = r.stdout.split()
+    assert lines[:2] == ["3", "1"] and [float(v) for v in lines[2:]] == [-2.5, 0.0399999991, -0.125]
+    bad = tmp_path / "bad.xml"
+    bad.write_text(text.replace("0. 0. 1.</data>", "</data>"))                      # six values for a 3 x 3 matrix
+    r = subprocess.run([dump, "xml", str(bad)], capture_output=True, text=True)
+    assert "matrix data truncated" in r.stdout and r.stdout.strip().endswith("0 0")    # an empty matrix: load_data then reports "invalid intrinsics"
