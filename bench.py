@@ -400,7 +400,7 @@ def cxx_driver_record(ndirs: int, frames: int = 8, replicate: int = 24, decode_t
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def wasscli_unchanged_record(ndirs: int, frames: int = 8, replicate: int = 12, parallel: int = 4):
+def wasscli_unchanged_record(ndirs: int, frames: int = 8, replicate: int = 12, parallel: int = 4, debug_images: bool = False):
     """What wasscli gets WITHOUT being edited: cli/wasscli/wasscli.py:326-346 starts one `wass_stereo <config> <workdir>` process per
     frame, NUM_PARALLEL_PROCESSES (4) at a time.  The same here -- `parallel` concurrent wass_stereo processes over a config-B sequence
     of workdirs -- with the executable handing its frame to the per-GPU resident worker it starts on demand (wass_amd/host/
@@ -419,7 +419,7 @@ def wasscli_unchanged_record(ndirs: int, frames: int = 8, replicate: int = 12, p
     try:
         seq, cfg, n = make_sequence(tmp, frames, replicate, ndirs)
         tlog = os.path.join(tmp, "server_timing.log")
-        env = dict(os.environ, WASS_DEBUG_IMAGES="0", WASS_SERVER_DIR=sockdir, WASS_SERVER_IDLE="5", WASS_SERVER_TIMING=tlog)
+        env = dict(os.environ, WASS_DEBUG_IMAGES="1" if debug_images else "0", WASS_SERVER_DIR=sockdir, WASS_SERVER_IDLE="5", WASS_SERVER_TIMING=tlog)
         env.pop("WASS_NO_SERVER", None)
 
         def one(i, e):

@@ -255,6 +255,43 @@ int wass_triangulate_dev(wass_ctx* ctx, const float* d_disp_roi, int W, int H,
                          const uint8_t* d_right_img, int img_w, int img_h,
                          const uint8_t* d_left_mask, const uint8_t* d_right_mask,
                          const wass_tri_params* tp, wass_mesh** out, uint64_t* n_pts);
+/* ---- the debug pictures of a frame, rendered and JPEG-coded on the device (replaces the cv::imwrite calls of wass_stereo.cpp:833, 854,
+ * 1001, 1017, 1381-1382, 1925 and PovMesh.cpp:982-984).  Baseline JPEG, quality 95 like cv::imwrite's default,
+ * 4:4:4, a restart marker after every row of blocks; the same bytes as the host writer of wass_amd/host/jpeg.hpp gives for the same
+ * pixels (shared integer arithmetic, csrc/jpeg_spec.h). */
+enum {
+    WASS_PIC_STEREO = 0,           /* stereo.jpg                   rectified pair side by side, ROI rectangles, a red line every 20 rows */
+    WASS_PIC_STEREO_INPUT = 1,     /* stereo_input.jpg             the two zero-padded SGBM inputs, left above right */
+    WASS_PIC_DISPARITY_RAW = 2,    /* disparity_stereo_ouput.jpg   render_disparity_float of the converted raw disparity */
+    WASS_PIC_DISPARITY_FINAL = 3,  /* disparity_final_scaled.jpg   ... of the final map */
+    WASS_PIC_COVERAGE = 4,         /* disparity_coverage.jpg       right picture, green where disparity > 1, half size */
+    WASS_PIC_R0 = 5,               /* undistorted/R0.jpg           grey where a point was triangulated, else the rejecting test's colour */
+    WASS_PIC_R1 = 6,               /* undistorted/R1.jpg           the same with the matched left pixel's grey */
+    WASS_PIC_COMPONENTS = 7,       /* graph_components.jpg         biggest component green, the other points blue, half size */
+    WASS_DEBUG_PICTURES = 8
+};
+typedef struct wass_debug_desc {
+    int W0, H0;                        /* size of the full rectified pictures */
+    int roi_l[4], roi_r[4];            /* x, y, width, height of the two crops (equal sizes) */
+    const uint8_t* d_left_crop;        /* the rectified crops the SGM stage was given (dense, roi-sized, in HBM) */
+    const uint8_t* d_right_crop;
+    const int16_t* d_disp16;           /* wass_sgm_disparity_dev's output for them */
+    const float* d_dispf;              /* wass_disparity_postprocess_dev's output */
+    int num_disp, min_disp, disp_offset;
+    double disparity_compensation;
+    int quality;                       /* 0 = 95 */
+} wass_debug_desc;
+/* One picture that exists in HBM (grey: channels 1, or r,g,b interleaved: 3) as a complete JPEG file in h_dst; synchronous. */
+int wass_jpeg_encode_dev(wass_ctx* ctx, const uint8_t* d_pixels, int w, int h, int channels, size_t pitch_bytes, int quality,
+                         uint8_t* h_dst, size_t capacity, size_t* nbytes);
+/* All eight pictures of the frame whose mesh is `mesh`, enqueued behind the frame's tail (call it after wass_mesh_finish_frame_async*
+ * with a component mask destination, before destroying the mesh).  h_dst: pinned host memory (wass_pinned_alloc) of
+ * WASS_DEBUG_PICTURES * slot_bytes; slot k receives picture k as a complete file, written by the kernels themselves.  Nothing is
+ * synchronised: wass_debug_pictures_result(ticket) waits for this frame's pictures and gives their sizes (0: the picture did not fit
+ * into its slot and was not written).  Four tickets may be outstanding. */
+int wass_debug_pictures_async(wass_ctx* ctx, const wass_mesh* mesh, const wass_debug_desc* desc, uint8_t* h_dst, size_t slot_bytes, uint64_t* ticket);
+int wass_debug_pictures_result(wass_ctx* ctx, uint64_t ticket, size_t nbytes[WASS_DEBUG_PICTURES]);
+
 /* Why triangulate kept or rejected each pixel of the grid: what the reference paints into its debug pictures
  * undistorted/R0.jpg (low nibble) and R1.jpg (high nibble), wass_stereo.cpp:1111-1119,1216-1338.  codes_out: width x
  * height bytes (host). */

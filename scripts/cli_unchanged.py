@@ -8,4 +8,5 @@ import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench
 
-print(json.dumps(bench.wasscli_unchanged_record(int(sys.argv[1]) if len(sys.argv) > 1 else 8)))
+debug = os.environ.get("CLI_DEBUG_IMAGES", "0") != "0"          # the reference's eight debug pictures per frame (its default)
+print(json.dumps(bench.wasscli_unchanged_record(int(sys.argv[1]) if len(sys.argv) > 1 else 8, replicate=3 if debug else 12, debug_images=debug)))

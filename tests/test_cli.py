@@ -188,6 +188,7 @@ def test_no_gpu_is_a_loud_failure(cli, tmp_path):
     r = run(cli, cfg, wd)
     assert r.returncode == 255 and "no usable MI355X GPU" in r.stdout
     assert not os.path.exists(os.path.join(wd, "mesh_cam.xyzC"))
+    assert r.stdout.isascii()                                       # wasscli.py:335,339 decodes the output as ASCII
 
 
 def test_no_gpu_is_a_loud_failure_in_the_pipelined_chain_too(cli, tmp_path):

@@ -153,7 +153,7 @@ def test_four_concurrent_callers_over_32_workdirs_write_the_files_of_in_process_
         assert r.returncode == 0, r.stdout[-1500:]
         for marker in ("[P|10|100]", "[P|20|100]", "[P|40|100]", "[P|60|100]", "[P|80|100]", "[P|90|100]", "[P|100|100]", "All done.", "wass_stereo  v."):
             assert marker in r.stdout, (i, marker)
-        assert ("%06d_wd" % i) in r.stdout
+        assert ("%06d_wd" % i) in r.stdout and r.stdout.isascii()     # wasscli.py:335,339: ret.stdout.decode("ascii")
         for name in NAMES + ("H0_rect.txt", "H1_rect.txt"):
             a = (seq_a / ("%06d_wd" % (i % nd)) / name).read_bytes()
             assert a == (seq_b / ("%06d_wd" % i) / name).read_bytes(), f"frame {i}: {name} differs"

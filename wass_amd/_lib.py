@@ -36,6 +36,13 @@ class SgmTimings(C.Structure):
                 ("aggregate_launches", C.c_int), ("cost_overflow", C.c_int), ("vsum_ms", C.c_float)]
 
 
+class DebugDesc(C.Structure):
+    """wass_debug_desc"""
+    _fields_ = [("W0", C.c_int), ("H0", C.c_int), ("roi_l", C.c_int * 4), ("roi_r", C.c_int * 4), ("d_left_crop", C.c_void_p),
+                ("d_right_crop", C.c_void_p), ("d_disp16", C.c_void_p), ("d_dispf", C.c_void_p), ("num_disp", C.c_int), ("min_disp", C.c_int),
+                ("disp_offset", C.c_int), ("disparity_compensation", C.c_double), ("quality", C.c_int)]
+
+
 class FrameResult(C.Structure):
     """wass_frame_result"""
     _fields_ = [("zgap", C.c_double), ("n_gaps", C.c_uint64), ("component_size", C.c_uint64), ("found", C.c_int),
@@ -148,6 +155,9 @@ SYMBOLS = {
     "wass_download": (_i, [_vp, _vp, _vp, _sz]),
     "wass_download_async": (_i, [_vp, _vp, _vp, _sz]),
     "wass_resize_cubic_u8_dev": (_i, [_vp, _vp, _i, _i, _sz, _vp, _i, _i]),
+    "wass_jpeg_encode_dev": (_i, [_vp, _vp, _i, _i, _i, _sz, _i, _vp, _sz, C.POINTER(_sz)]),
+    "wass_debug_pictures_async": (_i, [_vp, _vp, C.POINTER(DebugDesc), _vp, _sz, C.POINTER(C.c_uint64)]),
+    "wass_debug_pictures_result": (_i, [_vp, C.c_uint64, C.POINTER(_sz * 8)]),
     "wass_pinned_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "wass_pinned_free": (None, [_vp, _vp]),
     "wass_free": (None, [_vp]),

@@ -130,8 +130,11 @@ void wass_ctx_destroy(wass_ctx* c)
     mesh_pool_ctx_alive(c, false);
     mesh_pool_purge(c);
     for (Buf* b : { &c->bt1, &c->bt2, &c->hsum, &c->C, &c->S, &c->ckpt, &c->sel_d16, &c->sel_key, &c->raw,
-                    &c->flags, &c->tmp_in0, &c->tmp_in1, &c->tmp_out, &c->tmp_mask, &c->fA, &c->fB, &c->fC, &c->fD, &c->fE, &c->uf, &c->rs_r, &c->rs_l, &c->raw2, &c->grid, &c->scratch, &c->counters, &c->tri_cnt, &c->inl, &c->inl2, &c->clahe_lut, &c->ccmask, &c->und_cache[0].xy, &c->und_cache[1].xy, &c->dstate, &c->rect_tab, &c->rect_mx, &c->rect_my, &c->xyzc, &c->limits })
+                    &c->flags, &c->tmp_in0, &c->tmp_in1, &c->tmp_out, &c->tmp_mask, &c->fA, &c->fB, &c->fC, &c->fD, &c->fE, &c->uf, &c->rs_r, &c->rs_l, &c->raw2, &c->grid, &c->scratch, &c->counters, &c->tri_cnt, &c->inl, &c->inl2, &c->clahe_lut, &c->ccmask, &c->und_cache[0].xy, &c->und_cache[1].xy, &c->dstate, &c->rect_tab, &c->rect_mx, &c->rect_my, &c->xyzc, &c->limits, &c->jpeg_scratch, &c->jpeg_huff,
+                    &c->jpeg_out, &c->jpeg_info, &c->jpeg_part })
         release(*b);
+    for (auto& e : c->ev_dbg) if (e) (void)hipEventDestroy(e);
+    if (c->h_dbg_info) (void)hipHostFree(c->h_dbg_info);
     for (auto& set : c->evs) for (auto& e : set) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_ckpt) if (e) (void)hipEventDestroy(e);
     if (c->ev_cost) (void)hipEventDestroy(c->ev_cost);

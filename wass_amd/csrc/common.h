@@ -173,6 +173,14 @@ struct wass_ctx {
     int tail_set = 0;
     bool tail_timed[4] = {};
     wass::Buf ccmask;              // valid mask after the outlier removal, kept for graph_components.jpg when asked for
+    // the debug pictures rendered and JPEG-coded on the device (jpeg.hip): coefficient / offset / bit-stream scratch, Huffman tables,
+    // result words; four tickets in flight (event + header sizes + pinned result words per ticket)
+    wass::Buf jpeg_scratch, jpeg_huff, jpeg_out, jpeg_info, jpeg_part;
+    bool jpeg_tables_ready = false;
+    hipEvent_t ev_dbg[4] = {};
+    unsigned long long dbg_tickets = 0;
+    uint32_t dbg_hdr[4][8] = {};
+    uint32_t* h_dbg_info = nullptr;
     // wass_upload_async: uploads in flight on the copy stream, by destination; consumers wait for the matching event
     struct UploadSlot { const char* dst = nullptr; size_t n = 0; hipEvent_t ev = nullptr; bool pending = false, consumed = false; };
     UploadSlot uploads[8];

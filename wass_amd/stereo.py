@@ -212,6 +212,21 @@ class Context:
         self._check(self._lib.wass_ctx_frame_result(self._h, C.byref(res)))
         return res
 
+    def jpeg_encode(self, d_img, quality: int = 95) -> bytes:
+        """A picture resident in HBM (torch uint8 CUDA tensor, H x W grey or H x W x 3 r,g,b) as a complete baseline JPEG file
+        (wass_jpeg_encode_dev: the encoder of the device-side debug pictures, csrc/jpeg.hip)."""
+        import torch
+        if d_img.dtype != torch.uint8 or not d_img.is_cuda or d_img.dim() not in (2, 3) or not d_img.is_contiguous():
+            raise ValueError("expected a contiguous uint8 CUDA tensor, H x W or H x W x 3")
+        h, w = d_img.shape[:2]
+        ch = 1 if d_img.dim() == 2 else d_img.shape[2]
+        cap = w * h * ch * 2 + 4096
+        out = np.empty(cap, np.uint8)
+        n = C.c_size_t()
+        self.wait_for_stream(torch.cuda.current_stream(self.device_id).cuda_stream)
+        self._check(self._lib.wass_jpeg_encode_dev(self._h, d_img.data_ptr(), w, h, ch, w * ch, quality, out.ctypes.data, cap, C.byref(n)))
+        return out[:n.value].tobytes()
+
     def frame_inliers(self, n_points: int) -> np.ndarray:
         """The selected inlier points of the frame whose result was read last ((n, 3) float64), fetched on demand: the text-only form
         of the frame tail leaves them on the device.  Valid until the next finish_frame_async of this context."""
