@@ -284,12 +284,15 @@ typedef struct wass_debug_desc {
 /* One picture that exists in HBM (grey: channels 1, or r,g,b interleaved: 3) as a complete JPEG file in h_dst; synchronous. */
 int wass_jpeg_encode_dev(wass_ctx* ctx, const uint8_t* d_pixels, int w, int h, int channels, size_t pitch_bytes, int quality,
                          uint8_t* h_dst, size_t capacity, size_t* nbytes);
+/* width, height and channels (1 grey, 3 colour) of picture k for this frame geometry: what a caller sizes its slots by */
+int wass_debug_picture_size(const wass_debug_desc* desc, int k, int* width, int* height, int* channels);
 /* All eight pictures of the frame whose mesh is `mesh`, enqueued behind the frame's tail (call it after wass_mesh_finish_frame_async*
- * with a component mask destination, before destroying the mesh).  h_dst: pinned host memory (wass_pinned_alloc) of
- * WASS_DEBUG_PICTURES * slot_bytes; slot k receives picture k as a complete file, written by the kernels themselves.  Nothing is
- * synchronised: wass_debug_pictures_result(ticket) waits for this frame's pictures and gives their sizes (0: the picture did not fit
- * into its slot and was not written).  Four tickets may be outstanding. */
-int wass_debug_pictures_async(wass_ctx* ctx, const wass_mesh* mesh, const wass_debug_desc* desc, uint8_t* h_dst, size_t slot_bytes, uint64_t* ticket);
+ * with a component mask destination, before destroying the mesh).  h_dst: pinned host memory (wass_pinned_alloc); picture k is written
+ * as a complete file at h_dst + offset[k] by the kernels themselves, offset[0] = 0, offset[k + 1] = offset[k] + capacity[k] rounded up
+ * to a multiple of 64.  Nothing is synchronised: wass_debug_pictures_result(ticket) waits for this frame's pictures and gives their
+ * sizes (0: the picture did not fit into its slot and was not written).  Four tickets may be outstanding. */
+int wass_debug_pictures_async(wass_ctx* ctx, const wass_mesh* mesh, const wass_debug_desc* desc, uint8_t* h_dst,
+                              const size_t capacity[WASS_DEBUG_PICTURES], uint64_t* ticket);
 int wass_debug_pictures_result(wass_ctx* ctx, uint64_t ticket, size_t nbytes[WASS_DEBUG_PICTURES]);
 
 /* Why triangulate kept or rejected each pixel of the grid: what the reference paints into its debug pictures

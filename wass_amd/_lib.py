@@ -156,7 +156,8 @@ SYMBOLS = {
     "wass_download_async": (_i, [_vp, _vp, _vp, _sz]),
     "wass_resize_cubic_u8_dev": (_i, [_vp, _vp, _i, _i, _sz, _vp, _i, _i]),
     "wass_jpeg_encode_dev": (_i, [_vp, _vp, _i, _i, _i, _sz, _i, _vp, _sz, C.POINTER(_sz)]),
-    "wass_debug_pictures_async": (_i, [_vp, _vp, C.POINTER(DebugDesc), _vp, _sz, C.POINTER(C.c_uint64)]),
+    "wass_debug_pictures_async": (_i, [_vp, _vp, C.POINTER(DebugDesc), _vp, C.POINTER(_sz * 8), C.POINTER(C.c_uint64)]),
+    "wass_debug_picture_size": (_i, [C.POINTER(DebugDesc), _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "wass_debug_pictures_result": (_i, [_vp, C.c_uint64, C.POINTER(_sz * 8)]),
     "wass_pinned_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "wass_pinned_free": (None, [_vp, _vp]),

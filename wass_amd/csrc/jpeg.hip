@@ -486,12 +486,33 @@ int wass_jpeg_encode_dev(wass_ctx* c, const uint8_t* d_pixels, int w, int h, int
     return WASS_OK;
 }
 
-// The eight debug pictures of a frame, enqueued behind its tail.  h_dst must be pinned host memory (wass_pinned_alloc): the coded bytes are
-// written into it by the kernels.  Layout: WASS_DEBUG_PICTURES slots of `slot_bytes` each, slot k = picture k (wass_gpu.h) as a complete file;
-// sizes (0 = not written: too large for the slot) through wass_debug_pictures_result once the ticket's work is done.
-int wass_debug_pictures_async(wass_ctx* c, const wass_mesh* m, const wass_debug_desc* d, uint8_t* h_dst, size_t slot_bytes, uint64_t* ticket)
+static void picture_geometry(const wass_debug_desc* d, int k, int* w, int* h, int* C)
 {
-    if (!c || !m || !d || !h_dst || !ticket) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    const int W0 = d->W0, H0 = d->H0, cw = d->roi_r[2], ch = d->roi_r[3], offp = d->disp_offset > 0 ? d->disp_offset : 0;
+    switch (k) {
+        case WASS_PIC_STEREO: *w = 2 * W0; *h = H0; *C = 3; break;
+        case WASS_PIC_STEREO_INPUT: *w = cw + d->num_disp + offp; *h = 2 * ch; *C = 1; break;
+        case WASS_PIC_DISPARITY_RAW: case WASS_PIC_DISPARITY_FINAL: *w = cw; *h = ch; *C = 1; break;
+        case WASS_PIC_COVERAGE: *w = (W0 + 1) / 2; *h = (H0 + 1) / 2; *C = 3; break;
+        case WASS_PIC_R0: case WASS_PIC_R1: *w = W0; *h = H0; *C = 3; break;
+        default: *w = (cw + 1) / 2; *h = (ch + 1) / 2; *C = 3; break;
+    }
+}
+
+int wass_debug_picture_size(const wass_debug_desc* d, int k, int* width, int* height, int* channels)
+{
+    if (!d || k < 0 || k >= WASS_DEBUG_PICTURES || !width || !height || !channels) return WASS_ERR_INVALID_ARG;
+    picture_geometry(d, k, width, height, channels);
+    return WASS_OK;
+}
+
+// The eight debug pictures of a frame, enqueued behind its tail.  h_dst must be pinned host memory (wass_pinned_alloc): the coded bytes are
+// written into it by the kernels.  Layout: picture k (wass_gpu.h) as a complete file at h_dst + offset[k], offset[0] = 0,
+// offset[k + 1] = offset[k] + capacity[k] rounded up to 64; sizes (0 = not written: too large for its slot) through
+// wass_debug_pictures_result once the ticket's work is done.
+int wass_debug_pictures_async(wass_ctx* c, const wass_mesh* m, const wass_debug_desc* d, uint8_t* h_dst, const size_t capacity[WASS_DEBUG_PICTURES], uint64_t* ticket)
+{
+    if (!c || !m || !d || !h_dst || !capacity || !ticket) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
     WASS_HIP(c, hipSetDevice(c->device));
     const int W0 = d->W0, H0 = d->H0, cw = d->roi_r[2], ch = d->roi_r[3];
     if (W0 <= 0 || H0 <= 0 || cw <= 0 || ch <= 0 || d->roi_l[2] != cw || d->roi_l[3] != ch || m->w != cw || m->h != ch || !m->codes)
@@ -511,15 +532,18 @@ int wass_debug_pictures_async(wass_ctx* c, const wass_mesh* m, const wass_debug_
     const int q = d->quality > 0 ? d->quality : 95;
     const int D = d->num_disp, offp = d->disp_offset > 0 ? d->disp_offset : 0, comp = d->disp_offset > 0 ? 0 : -d->disp_offset;
     const Pasted pl{ d->d_left_crop, cw, ch, d->roi_l[0], d->roi_l[1], W0, H0 }, pr{ d->d_right_crop, cw, ch, d->roi_r[0], d->roi_r[1], W0, H0 };
-    struct Pic { int w, h, C; } pic[WASS_DEBUG_PICTURES] = {
-        { 2 * W0, H0, 3 }, { cw + D + offp, 2 * ch, 1 }, { cw, ch, 1 }, { cw, ch, 1 }, { (W0 + 1) / 2, (H0 + 1) / 2, 3 }, { W0, H0, 3 }, { W0, H0, 3 }, { (cw + 1) / 2, (ch + 1) / 2, 3 } };
+    struct Pic { int w, h, C; } pic[WASS_DEBUG_PICTURES];
+    size_t offset = 0;
     for (int k = 0; k < WASS_DEBUG_PICTURES; ++k) {
+        picture_geometry(d, k, &pic[k].w, &pic[k].h, &pic[k].C);
         std::vector<uint8_t> hdr;
         wassjpeg::file_header(hdr, pic[k].w, pic[k].h, pic[k].C, q);
-        if (slot_bytes < hdr.size() + 64 || pic[k].w > 65535 || pic[k].h > 65535) return set_err(c, WASS_ERR_INVALID_ARG, "debug pictures: slot of %zu bytes / picture %d x %d", slot_bytes, pic[k].w, pic[k].h);
-        memcpy(h_dst + (size_t)k * slot_bytes, hdr.data(), hdr.size());               // (the caller owns the buffer until it has read the result)
-        uint8_t* dst = dv + (size_t)k * slot_bytes + hdr.size();
-        const uint32_t cap = (uint32_t)std::min<size_t>(slot_bytes - hdr.size(), 0xfffffff0u);
+        if (capacity[k] < hdr.size() + 64 || pic[k].w > 65535 || pic[k].h > 65535)
+            return set_err(c, WASS_ERR_INVALID_ARG, "debug pictures: slot of %zu bytes / picture %d x %d", capacity[k], pic[k].w, pic[k].h);
+        memcpy(h_dst + offset, hdr.data(), hdr.size());                               // (the caller owns the buffer until it has read the result)
+        uint8_t* dst = dv + offset + hdr.size();
+        const uint32_t cap = (uint32_t)std::min<size_t>(capacity[k] - hdr.size(), 0xfffffff0u);
+        offset += (capacity[k] + 63) & ~(size_t)63;
         uint32_t* inf = info + 4 * k;
         switch (k) {
             case WASS_PIC_STEREO: {

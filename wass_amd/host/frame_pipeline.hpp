@@ -52,6 +52,8 @@ struct FrameJob {
     int disp_slot = 0;
     DebugMaps dbg;
     bool have_dbg = false;
+    uint64_t dbg_ticket = 0;         // the pictures were drawn and coded on the device (wass_debug_pictures_async): dbg_bytes[k] of file k in the output set
+    size_t dbg_bytes[WASS_DEBUG_PICTURES] = {};
     unsigned int ransac_seed = 0;
     int in_slot = -1, out_slot = -1;
     long long sgm_call = -1;         // which wass_sgm_disparity_dev call of the pipeline's context produced the frame's disparity
@@ -92,6 +94,11 @@ public:
     FramePipeline(int device, const Config& cfg, const std::string& config_path, const Options& opt)
         : device_(device), cfg_(cfg), config_path_(config_path), opt_(opt), max_pending_(opt.max_pending)
     {
+        if (opt_.debug_pictures) {
+            const char* e = getenv("WASS_HOST_DEBUG_PICTURES");
+            dbg_host_ = debug_png() || cfg.get_int("DENSE_DISPARITY_BIGGEST_COMPONENT_THRESHOLD") > 0 || (e && atoi(e) != 0);
+            dbg_dev_ = !dbg_host_;
+        }
         sp_.min_disp = cfg.get_int("MIN_DISPARITY");
         sp_.num_disp = cfg.get_int("MAX_DISPARITY");
         sp_.win = cfg.get_int("WINSIZE");
@@ -124,7 +131,7 @@ public:
         if (!ctx_) return;
         (void)wass_ctx_synchronize(ctx_);
         release_buffers();
-        for (auto& o : out_) { if (o.xyzc) wass_pinned_free(ctx_, o.xyzc); if (o.inl) wass_pinned_free(ctx_, o.inl); if (o.inl_text) wass_pinned_free(ctx_, o.inl_text); for (auto& u : o.prev) if (u) wass_pinned_free(ctx_, u); for (auto& u : o.und) if (u) wass_pinned_free(ctx_, u); if (o.ccmask) wass_pinned_free(ctx_, o.ccmask); }
+        for (auto& o : out_) { if (o.xyzc) wass_pinned_free(ctx_, o.xyzc); if (o.inl) wass_pinned_free(ctx_, o.inl); if (o.inl_text) wass_pinned_free(ctx_, o.inl_text); for (auto& u : o.prev) if (u) wass_pinned_free(ctx_, u); for (auto& u : o.und) if (u) wass_pinned_free(ctx_, u); if (o.ccmask) wass_pinned_free(ctx_, o.ccmask); if (o.dbg) wass_pinned_free(ctx_, o.dbg); }
         wass_ctx_destroy(ctx_);
     }
     // the pipeline's context, created if need be (owner thread); nullptr when there is no usable GPU
@@ -264,7 +271,7 @@ public:
         stage(job);
         if (job.rc != 0) { while (FrameJob* p = collect()) done.push_back(p); done.push_back(&job); return; }
         // debug pictures: the previous frame's maps are fetched from buffers this frame is about to overwrite
-        if (opt_.debug_pictures) while (FrameJob* p = collect()) done.push_back(p);
+        if (dbg_host_) while (FrameJob* p = collect()) done.push_back(p);
         LogSinkScope sink(&job.log);
         job.t_submit0 = Timer::now();
         Env& env = job.env;
@@ -411,7 +418,20 @@ public:
                                                    opt_.debug_pictures ? out_[slot].ccmask : nullptr,
                                                    opt_.inliers_file && device_text_ ? out_[slot].inl_text : nullptr, opt_.inliers_file && device_text_ ? out_[slot].inl_text_cap : 0),
                   "wass_mesh_finish_frame_async");
-            if (opt_.debug_pictures) job.mesh = mesh;       // its rejection codes are fetched when the frame is collected
+            if (dbg_dev_) {
+                // the eight pictures, rendered from the maps in HBM and coded behind the tail; the mesh's rejection codes are read in stream order
+                wass_debug_desc dd{};
+                dd.W0 = W_; dd.H0 = H_;
+                for (int i = 0; i < 4; ++i) { dd.roi_l[i] = rl[i]; dd.roi_r[i] = rr[i]; }
+                dd.d_left_crop = in_[k].d_cl; dd.d_right_crop = in_[k].d_cr;
+                dd.d_disp16 = d_disp16_[job.disp_slot]; dd.d_dispf = d_dispf_;
+                dd.num_disp = sp_.num_disp; dd.min_disp = sp_.min_disp; dd.disp_offset = sp_.disp_offset;
+                dd.disparity_compensation = env.disparity_compensation;
+                dd.quality = 95;
+                ensure_dbg(out_[slot], dd);
+                check(wass_debug_pictures_async(ctx_, mesh, &dd, out_[slot].dbg, out_[slot].dbg_cap, &job.dbg_ticket), "wass_debug_pictures_async");
+            }
+            if (dbg_host_) job.mesh = mesh;                 // its rejection codes are fetched when the frame is collected
             else wass_mesh_destroy(mesh);                   // back to the context's pool; the kernels enqueued on it run in stream order
             mesh = nullptr;
             lap(6);
@@ -457,7 +477,17 @@ public:
         if (job.rc == 0 && !job.skipped) {
             try {
                 const wass_frame_result& r = job.res;
-                if (job.have_dbg) {                          // :1910-1925, 833-1017, 1381-1382
+                static const char* const kPic[WASS_DEBUG_PICTURES] = { "stereo.jpg", "stereo_input.jpg", "disparity_stereo_ouput.jpg", "disparity_final_scaled.jpg",
+                                                                       "disparity_coverage.jpg", "undistorted/R0.jpg", "undistorted/R1.jpg", "graph_components.jpg" };
+                auto write_pic = [&](int k) {
+                    const OutSet& o = out_[job.out_slot];
+                    size_t off = 0;
+                    for (int i = 0; i < k; ++i) off += o.dbg_cap[i];
+                    if (job.dbg_bytes[k] == 0) { WLOGE << kPic[k] << ": the coded picture did not fit into its buffer, not written"; return; }
+                    if (!write_whole_file(path_join(env.workdir, kPic[k]), o.dbg + off, job.dbg_bytes[k])) WLOGE << "unable to write " << kPic[k];
+                };
+                if (job.dbg_ticket) for (int k = 0; k < WASS_PIC_COMPONENTS; ++k) write_pic(k);      // :1910-1925, 833-1017, 1381-1382
+                if (job.have_dbg) {                          // (the host's renderers: PNG form, component-option masks)
                     debug_stereo_picture(env);
                     debug_dense_pictures(env, sp_, cfg_.get_int("DENSE_DISPARITY_BIGGEST_COMPONENT_THRESHOLD"), job.dbg);
                     debug_triangulation_pictures(env, env.disparity_compensation, sp_.dense_scale, job.dbg);
@@ -469,6 +499,7 @@ public:
                 WLOG_SCOPE("wass_stereo");
                 if (r.sgm_cost_overflow == 1) WLOGE << "matching costs exceeded the int16 range; the disparity is outside the reference's defined behaviour";
                 if ((long long)r.n_triangulated < cfg_.get_int("MIN_TRIANGULATED_POINTS")) { WLOGE << "Too few points triangulated, aborting"; throw GpuError("too few points"); }
+                if (job.dbg_ticket) write_pic(WASS_PIC_COMPONENTS);
                 if (job.have_dbg) debug_components_picture(env, job.dbg);
                 WLOG_SCOPE("cluster");
                 WLOGI << "biggest component size: " << r.component_size << " (px)";
@@ -619,7 +650,27 @@ private:
                            *d_pl = nullptr, *d_pr = nullptr; size_t prev_cap = 0; };
     struct OutSet { void* xyzc = nullptr; size_t xyzc_cap = 0; double* inl = nullptr; size_t inl_cap = 0; uint8_t* und[2] = { nullptr, nullptr }; size_t und_cap = 0;
                     uint8_t* ccmask = nullptr; size_t cc_cap = 0; char* inl_text = nullptr; size_t inl_text_cap = 0;
-                    uint8_t* prev[2] = { nullptr, nullptr }; size_t prev_cap[2] = { 0, 0 }; };
+                    uint8_t* prev[2] = { nullptr, nullptr }; size_t prev_cap[2] = { 0, 0 };
+                    uint8_t* dbg = nullptr; size_t dbg_total = 0; size_t dbg_cap[WASS_DEBUG_PICTURES] = {}; };
+    // pinned room for a frame's eight coded pictures: 1 byte per pixel for grey ones, 1.5 for colour ones (quality 95 needs 0.3-0.6 on
+    // pictures of the sea; a picture that does not fit is not written and the log says so)
+    void ensure_dbg(OutSet& o, const wass_debug_desc& dd)
+    {
+        size_t cap[WASS_DEBUG_PICTURES], total = 0;
+        for (int k = 0; k < WASS_DEBUG_PICTURES; ++k) {
+            int w = 0, h = 0, c = 0;
+            check(wass_debug_picture_size(&dd, k, &w, &h, &c), "wass_debug_picture_size");
+            cap[k] = ((size_t)w * h * (c == 3 ? 3 : 2) / 2 + 65536 + 63) & ~(size_t)63;
+            total += cap[k];
+        }
+        if (o.dbg && o.dbg_total >= total && !memcmp(cap, o.dbg_cap, sizeof cap)) return;
+        if (o.dbg) wass_pinned_free(ctx_, o.dbg);
+        o.dbg = nullptr; o.dbg_total = 0;
+        void* p = nullptr;
+        check(wass_pinned_alloc(ctx_, total, &p), "wass_pinned_alloc");
+        o.dbg = (uint8_t*)p; o.dbg_total = total;
+        memcpy(o.dbg_cap, cap, sizeof cap);
+    }
 
     void check(int rc, const char* what) const { if (rc != WASS_OK) throw GpuError(std::string(what) + ": " + wass_last_error(ctx_)); }
     uint64_t sgm_calls() const { uint64_t n = 0; (void)wass_sgm_call_count(ctx_, &n); return n; }
@@ -648,7 +699,10 @@ private:
         }
         // stage times of the frame's own SGM call (the library keeps the last four)
         j->have_sgm = j->sgm_call > 0 && wass_sgm_call_timings(ctx_, (uint64_t)j->sgm_call, &j->sgm) == WASS_OK;
-        if (opt_.debug_pictures && j->mesh) {
+        if (dbg_dev_ && j->dbg_ticket) {
+            if (wass_debug_pictures_result(ctx_, j->dbg_ticket, j->dbg_bytes) != WASS_OK) { WLOGE << "wass_debug_pictures_result: " << wass_last_error(ctx_); j->dbg_ticket = 0; }
+        }
+        if (dbg_host_ && j->mesh) {
             // the maps the debug pictures are drawn from (nothing else has been enqueued since this frame: see submit)
             try {
                 Env& env = j->env;
@@ -696,7 +750,7 @@ private:
         if (W == W_ && H == H_ && roi_l.width == cwl_ && roi_l.height == chl_ && roi_r.width == cwr_ && roi_r.height == chr_) return;
         check(wass_ctx_synchronize(ctx_), "wass_ctx_synchronize");
         // debug pictures: the pending frame's maps are fetched from these buffers when it is collected -- do that first
-        if (opt_.debug_pictures) while (FrameJob* p = collect()) early_.push_back(p);
+        if (dbg_host_) while (FrameJob* p = collect()) early_.push_back(p);
         release_buffers();
         W_ = W; H_ = H; cwl_ = roi_l.width; chl_ = roi_l.height; cwr_ = roi_r.width; chr_ = roi_r.height;
         const size_t n = (size_t)W * H + 4;
@@ -829,6 +883,11 @@ private:
     double lap_[7] = {};
     // WASS_HOST_INLIER_TEXT=1: the round-4 form (the host formats the inlier file from the downloaded points); same bytes either way
     bool device_text_ = !(getenv("WASS_HOST_INLIER_TEXT") && atoi(getenv("WASS_HOST_INLIER_TEXT")) != 0);
+    // The debug pictures: drawn AND JPEG-coded on the device behind the frame's tail (wass_debug_pictures_async, csrc/jpeg.hip) -- the files'
+    // bytes are all that comes back, the chain keeps its depth.  The host's renderers (wass_frame.hpp) remain for the lossless PNG form the
+    // tests read pixels from (WASS_DEBUG_FORMAT=png), for the two extra masks of the component option and on request
+    // (WASS_HOST_DEBUG_PICTURES=1): those fetch every intermediate map when a frame is collected, one frame at a time.
+    bool dbg_dev_ = false, dbg_host_ = false;
 };
 
 }  // namespace wassframe

@@ -75,6 +75,7 @@ inline Image render_disparity_float(const float* disp, int w, int h)
     Image out(w, h);
     float mn = (float)(w + 1), mx = 0.0f;
     for (size_t i = 0; i < (size_t)w * h; ++i) { mn = std::min(disp[i], mn); mx = std::max(disp[i], mx); }
+    if (!(mx > mn)) return out;                              // an empty map: black (the reference divides by zero here; csrc/jpeg.hip does the same as this)
     for (size_t i = 0; i < (size_t)w * h; ++i) out.px[i] = (unsigned char)((disp[i] - mn) / (mx - mn) * 255.0f);
     return out;
 }
