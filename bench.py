@@ -439,7 +439,7 @@ def wasscli_unchanged_record(ndirs: int, frames: int = 8, replicate: int = 12, p
                "parallel_processes": parallel, "first_call_s": round(first_s, 3), "median_call_s": round(lat[len(lat) // 2], 4),
                "failed_calls": len(bad), "ndirs": ndirs,
                "how": f"{parallel} concurrent `wass_stereo <config> <workdir>` processes (a thread pool, as wasscli's thread_map) over {n} config-B "
-                      "workdirs; each hands its frame to the per-GPU resident worker started by the first; WASS_DEBUG_IMAGES=0; output to " + base}
+                      "workdirs; each hands its frame to the per-GPU resident worker started by the first; WASS_DEBUG_IMAGES=" + ("1" if debug_images else "0") + "; output to " + base}
         # where a caller's waiting time went, as the server saw it (WASS_SERVER_TIMING: medians over the frames above)
         try:
             rows = [l.split() for l in open(tlog) if " total " in l][1:]
@@ -459,6 +459,21 @@ def wasscli_unchanged_record(ndirs: int, frames: int = 8, replicate: int = 12, p
             rec["parallel_%d" % (2 * parallel)]["server_ms_per_call"] = {k: med(k) for k in ("decode", "queue", "gpu", "files", "total")}
         except Exception:
             pass
+        # the reference's own default: its eight debug pictures per frame (cv::imwrite, unconditional) -- here rendered and JPEG-coded on the
+        # device (csrc/jpeg.hip); the numbers above are with WASS_DEBUG_IMAGES=0
+        if not debug_images:
+            envd = dict(env, WASS_DEBUG_IMAGES="1")
+            nd = min(n, 33)
+            one(0, envd)                                                  # (the pipeline of this option set: buffers)
+            with ThreadPoolExecutor(parallel) as ex:
+                t1 = time.perf_counter()
+                resd = list(ex.map(lambda i: one(i, envd), range(1, nd)))
+                t2 = time.perf_counter()
+            pics = [f for f in ("stereo.jpg", "stereo_input.jpg", "disparity_stereo_ouput.jpg", "disparity_final_scaled.jpg", "disparity_coverage.jpg",
+                                "graph_components.jpg", "undistorted/R0.jpg", "undistorted/R1.jpg") if os.path.exists(os.path.join(seq, "%06d_wd" % 1, f))]
+            rec["with_debug_pictures"] = {"pairs_per_sec": round((nd - 1) / (t2 - t1), 2), "frames": nd - 1, "failed_calls": len([1 for rc, _, _ in resd if rc != 0]),
+                                          "median_call_s": round(sorted(s for _, s, _ in resd)[len(resd) // 2], 4), "pictures_per_frame": len(pics),
+                                          "picture_bytes_per_frame": sum(os.path.getsize(os.path.join(seq, "%06d_wd" % 1, f)) for f in pics)}
         # round 4's behaviour on a few frames: every process computes its own frame
         env0 = dict(env, WASS_NO_SERVER="1")
         for i in range(8):

@@ -181,14 +181,14 @@ __global__ void __launch_bounds__(64) k_jpeg_dct(Src src, int w, int h, int C, i
     wassjpeg::fdct8x8(blk);
     const int t = c == 0 ? 0 : 1;
     const uint8_t* aclen = hf->len[2 + t];
-    int16_t* out = coef + (size_t)id * 64;
+    int16_t* out = coef + ((size_t)(id >> 6) << 12) + (id & 63);            // groups of 64 blocks, coefficient-major: out[i * 64] (coalesced)
     int bits = 0, run = 0, dc = 0;
     constexpr uint8_t ZZ[64] = { 0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
                                  35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63 };
 #pragma unroll
     for (int i = 0; i < 64; ++i) {
         const int v = wassjpeg::quantise(blk[ZZ[i]], q.q[t][ZZ[i]], i == 0);
-        out[i] = (int16_t)v;
+        out[i * 64] = (int16_t)v;
         if (i == 0) { dc = v; continue; }
         if (v == 0) { ++run; continue; }
         bits += (run >> 4) * aclen[0xF0];
@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(64) k_jpeg_emit(const int16_t* __restrict__ co
     const int row = id / n_row, i = id - row * n_row, c = i % C, t = c == 0 ? 0 : 1;
     const unsigned long long P = (unsigned long long)ibase[row] * 8ull + bitoff[id];
     BitSink bs{ U + (P >> 5), 0ull, (int)(P & 31) };
-    const int16_t* z = coef + (size_t)id * 64;
+    const int16_t* z = coef + ((size_t)(id >> 6) << 12) + (id & 63);
     const int dc = z[0], prev = i >= C ? (int)(int16_t)(meta[id - C] & 0xffffu) : 0, diff = dc - prev;
     int s = wassjpeg::bit_size(diff);
     bs.put(hf->code[t][s], hf->len[t][s]);
@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(64) k_jpeg_emit(const int16_t* __restrict__ co
     const uint8_t* len = hf->len[2 + t];
     int run = 0;
     for (int k = 1; k < 64; ++k) {
-        const int v = z[k];
+        const int v = z[k * 64];
         if (v == 0) { ++run; continue; }
         while (run > 15) { bs.put(code[0xF0], len[0xF0]); run -= 16; }
         s = wassjpeg::bit_size(v);
@@ -375,10 +375,11 @@ int jpeg_scratch(wass_ctx* c, size_t nblk, size_t nint, size_t u_cap, JScratch& 
 {
     int rc;
     const size_t ucap4 = ((u_cap + 15) & ~(size_t)15) + 16;       // (+16: a stream that does not fit here does not fit the destination either)
-    const size_t need = nblk * 128 + nblk * 8 + nint * 20 + ucap4 + 256;
+    const size_t ngrp = (nblk + 63) / 64;
+    const size_t need = ngrp * 8192 + nblk * 8 + nint * 20 + ucap4 + 256;
     if ((rc = ensure(c, c->jpeg_scratch, need))) return rc;
     char* p = (char*)c->jpeg_scratch.p;
-    s.coef = (int16_t*)p; p += nblk * 128;
+    s.coef = (int16_t*)p; p += ngrp * 8192;
     s.meta = (uint32_t*)p; p += nblk * 4;
     s.bitoff = (uint32_t*)p; p += nblk * 4;
     s.ibits = (uint32_t*)p; p += nint * 4;

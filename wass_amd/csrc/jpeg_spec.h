@@ -110,8 +110,15 @@ WASS_JPEG_FN void fdct8x8(int* blk)
 // coef = 8 x the DCT coefficient, q = the table entry (1..255); AC amplitudes are clamped to the 10 bits baseline coding allows
 WASS_JPEG_FN int quantise(int coef, int q, bool dc)
 {
-    const int qv = q << 3, a = coef < 0 ? -coef : coef;
-    int v = (a + (qv >> 1)) / qv;
+    const int qv = q << 3, a = coef < 0 ? -coef : coef, n = a + (qv >> 1);
+#ifdef __HIP_DEVICE_COMPILE__
+    // n / qv without the integer-division sequence (64 of them per block): a float estimate corrected by one -- exact for n < 2^24
+    int v = (int)((float)n * __frcp_rn((float)qv));
+    const int r = n - v * qv;
+    v += (r >= qv) - (r < 0);
+#else
+    int v = n / qv;
+#endif
     if (!dc && v > 1023) v = 1023;
     return coef < 0 ? -v : v;
 }
@@ -124,7 +131,17 @@ WASS_JPEG_FN int scaled_q(int base, int quality)
     return v < 1 ? 1 : (v > 255 ? 255 : v);
 }
 
-WASS_JPEG_FN int bit_size(int v) { int a = v < 0 ? -v : v, n = 0; while (a) { ++n; a >>= 1; } return n; }
+WASS_JPEG_FN int bit_size(int v)
+{
+    int a = v < 0 ? -v : v;
+#ifdef __HIP_DEVICE_COMPILE__
+    return 32 - __clz(a);
+#else
+    int n = 0;
+    while (a) { ++n; a >>= 1; }
+    return n;
+#endif
+}
 
 // q[t][i], t = 0 luma / 1 chroma, natural order
 inline void quant_tables(int quality, uint8_t q[2][64])
