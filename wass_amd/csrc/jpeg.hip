@@ -32,7 +32,7 @@ using namespace wass;
 namespace {
 
 struct JQuant { uint8_t q[2][64]; };
-struct JHuffDev { uint16_t code[4][256]; uint8_t len[4][256]; };      // [DC luma, DC chroma, AC luma, AC chroma]
+struct JHuffDev { uint32_t cl[4][256]; };      // code | length << 16 of [DC luma, DC chroma, AC luma, AC chroma]: one load per symbol
 
 // ------------------------------------------------------------------ pixel sources
 // sample(x, y, c): component c of the picture's pixel (x, y); grey pictures have one component, colour ones give Y, Cb, Cr of (r, g, b)
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(64) k_jpeg_dct(Src src, int w, int h, int C, i
     }
     wassjpeg::fdct8x8(blk);
     const int t = c == 0 ? 0 : 1;
-    const uint8_t* aclen = hf->len[2 + t];
+    const uint32_t* accl = hf->cl[2 + t];
     int16_t* out = coef + ((size_t)(id >> 6) << 12) + (id & 63);            // groups of 64 blocks, coefficient-major: out[i * 64] (coalesced)
     int bits = 0, run = 0, dc = 0;
     constexpr uint8_t ZZ[64] = { 0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
@@ -191,12 +191,12 @@ __global__ void __launch_bounds__(64) k_jpeg_dct(Src src, int w, int h, int C, i
         out[i * 64] = (int16_t)v;
         if (i == 0) { dc = v; continue; }
         if (v == 0) { ++run; continue; }
-        bits += (run >> 4) * aclen[0xF0];
+        bits += (run >> 4) * (int)(accl[0xF0] >> 16);
         const int s = wassjpeg::bit_size(v);
-        bits += aclen[((run & 15) << 4) | s] + s;
+        bits += (int)(accl[((run & 15) << 4) | s] >> 16) + s;
         run = 0;
     }
-    if (run) bits += aclen[0x00];
+    if (run) bits += (int)(accl[0x00] >> 16);
     meta[id] = ((uint32_t)bits << 16) | ((uint32_t)dc & 0xffffu);
 }
 
@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(256) k_jpeg_rows(const uint32_t* __restrict__ 
             const uint32_t m = meta[base + i];
             const int dc = (int)(int16_t)(m & 0xffffu), prev = i >= C ? (int)(int16_t)(meta[base + i - C] & 0xffffu) : 0;
             const int s = wassjpeg::bit_size(dc - prev);
-            len = (int)(m >> 16) + hf->len[(i % C) == 0 ? 0 : 1][s] + s;
+            len = (int)(m >> 16) + (int)(hf->cl[(i % C) == 0 ? 0 : 1][s] >> 16) + s;
         }
         int tot;
         const int ex = block_excl_scan(len, &tot, lds);
@@ -289,21 +289,20 @@ __global__ void __launch_bounds__(64) k_jpeg_emit(const int16_t* __restrict__ co
     const int16_t* z = coef + ((size_t)(id >> 6) << 12) + (id & 63);
     const int dc = z[0], prev = i >= C ? (int)(int16_t)(meta[id - C] & 0xffffu) : 0, diff = dc - prev;
     int s = wassjpeg::bit_size(diff);
-    bs.put(hf->code[t][s], hf->len[t][s]);
+    { const uint32_t e = hf->cl[t][s]; bs.put(e & 0xffffu, (int)(e >> 16)); }
     if (s) bs.put((uint32_t)(diff < 0 ? diff - 1 : diff), s);
-    const uint16_t* code = hf->code[2 + t];
-    const uint8_t* len = hf->len[2 + t];
+    const uint32_t* cl = hf->cl[2 + t];
     int run = 0;
     for (int k = 1; k < 64; ++k) {
         const int v = z[k * 64];
         if (v == 0) { ++run; continue; }
-        while (run > 15) { bs.put(code[0xF0], len[0xF0]); run -= 16; }
+        while (run > 15) { const uint32_t e = cl[0xF0]; bs.put(e & 0xffffu, (int)(e >> 16)); run -= 16; }
         s = wassjpeg::bit_size(v);
-        bs.put(code[(run << 4) | s], len[(run << 4) | s]);
+        { const uint32_t e = cl[(run << 4) | s]; bs.put(e & 0xffffu, (int)(e >> 16)); }
         bs.put((uint32_t)(v < 0 ? v - 1 : v), s);
         run = 0;
     }
-    if (run) bs.put(code[0x00], len[0x00]);
+    if (run) { const uint32_t e = cl[0x00]; bs.put(e & 0xffffu, (int)(e >> 16)); }
     if (i == n_row - 1) { const int pad = (int)((8u - (ibits[row] & 7u)) & 7u); if (pad) bs.put((1u << pad) - 1u, pad); }    // the interval ends on a byte: ones
     bs.flush();
 }
@@ -400,7 +399,7 @@ int jpeg_tables(wass_ctx* c, hipStream_t st)
     if ((rc = ensure(c, c->jpeg_huff, sizeof(JHuffDev)))) return rc;
     static JHuffDev host;                                                   // (static: the copy below is asynchronous)
     const wassjpeg::HuffSet hs = wassjpeg::make_huff_set();
-    for (int t = 0; t < 4; ++t) for (int i = 0; i < 256; ++i) { host.code[t][i] = hs.t[t].code[i]; host.len[t][i] = hs.t[t].len[i]; }
+    for (int t = 0; t < 4; ++t) for (int i = 0; i < 256; ++i) host.cl[t][i] = (uint32_t)hs.t[t].code[i] | ((uint32_t)hs.t[t].len[i] << 16);
     WASS_HIP(c, hipMemcpyAsync(c->jpeg_huff.p, &host, sizeof host, hipMemcpyHostToDevice, st));
     c->jpeg_tables_ready = true;
     return WASS_OK;

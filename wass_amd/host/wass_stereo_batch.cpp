@@ -18,8 +18,9 @@
 // previews, the rectification's decisions) -> one submitting thread (uploads one frame ahead, every GPU stage enqueued without
 // a host synchronisation, one result record per frame read one frame late) -> writer threads (the log lines that carry
 // numbers, plane.txt, plane_refinement_inliers.xyz, mesh_cam.xyzC).  Configurations that need an intermediate map or mesh on
-// the host (pipeline_eligible), --debug-images, --threads-per-proc > 1 and --stage-by-stage use the synchronous
-// stage-by-stage calls of wass_run_frame instead; the files are the same either way.
+// the host (pipeline_eligible), --threads-per-proc > 1 and --stage-by-stage use the synchronous stage-by-stage calls of
+// wass_run_frame instead; the files are the same either way.  --debug-images (the reference's eight pictures per frame) stays
+// in the pipelined chain: they are rendered and JPEG-coded on the device behind the frame's tail (csrc/jpeg.hip).
 // --skip-existing: the workdir is the checkpoint: a frame whose plane.txt and mesh_cam.xyzC /
 // mesh_cam.xyzbin exist is not recomputed, its plane is read back from plane.txt.
 #include <dirent.h>
