@@ -23,6 +23,8 @@ Prints ONE JSON line (rank 0) with BASELINE.json's metric plus
   wasscli_unchanged     -- 4 concurrent `wass_stereo <config> <workdir>` processes (what wasscli starts, unedited) over a config-B
                            sequence, served by the per-GPU resident worker the first of them starts; `parallel_8`: the same with eight
                            (wasscli's menu setting); `server_ms_per_call`: where a call's time went inside the server
+                           `with_debug_pictures`: the same with the reference's eight debug pictures per frame (its default), rendered and
+                           JPEG-coded on the device
   mode_5path            -- config B in the mode the reference runs (MODE_SGBM, wass_stereo.cpp:775-777): pairs/s of the whole
                            chain, aggregation ms against its own (2*5+4) B/cell roofline
 """

@@ -82,3 +82,108 @@ def test_bad_arguments_are_errors(gpu_ctx):
         gpu_ctx.jpeg_encode(torch.zeros(4, 4, dtype=torch.float32, device="cuda"))
     with pytest.raises(wass_amd.WassError):
         gpu_ctx.jpeg_encode(torch.zeros(4, 4, 2, dtype=torch.uint8, device="cuda"))
+
+
+def _frame_on_device(ctx, w, h, D, frame_idx, roi_l, roi_r, W0, H0):
+    """one small frame through the device chain (SGM on ROI-sized crops ... frame tail with the component mask); what the pictures are drawn from"""
+    import torch
+    import wass_amd
+    from wass_amd import _lib, default_sgm_params, synth
+    dev = torch.device("cuda", 0)
+    p = default_sgm_params(D, ndirs=5)
+    geom = wass_amd.make_geom(synth.rig_geometry(w, h))
+    dr, dl = (torch.from_numpy(a).to(dev) for a in synth.make_pair(w, h, D, frame_idx=frame_idx))
+    d16 = torch.empty((h, w), dtype=torch.int16, device=dev)
+    dispf = torch.empty((h, w), dtype=torch.float32, device=dev)
+    ctx.sgm_disparity_dev(dr, dl, p, d16)
+    ctx.disparity_postprocess_dev(d16, p, 1, 2, 0, dispf)
+    mesh, _ = ctx.triangulate_dev(dispf, W0, H0, roi_l, roi_r, geom, dr, None, None, 20.0, None, 1.0, count=False)
+    desc = _lib.DebugDesc()
+    desc.W0, desc.H0 = W0, H0
+    desc.roi_l[:] = roi_l
+    desc.roi_r[:] = roi_r
+    desc.d_left_crop, desc.d_right_crop, desc.d_disp16, desc.d_dispf = dl.data_ptr(), dr.data_ptr(), d16.data_ptr(), dispf.data_ptr()
+    desc.num_disp, desc.min_disp, desc.disp_offset, desc.disparity_compensation, desc.quality = p.num_disp, p.min_disp, p.disp_offset, 0.0, 95
+    return dict(p=p, dr=dr, dl=dl, d16=d16, dispf=dispf, mesh=mesh, desc=desc)
+
+
+def test_the_eight_pictures_through_the_c_abi(gpu_ctx):
+    """wass_debug_pictures_async on a small frame whose ROIs sit inside a larger picture: sizes and decodability of all eight, three of
+    them against an independent numpy rendering (stereo_input: the padded inputs; disparity_final_scaled: render_disparity_float;
+    stereo: pasted crops, red rectangles, a red line every 20 rows), a slot that is too small, a destination that is not pinned, tickets."""
+    import torch
+    import wass_amd
+    from PIL import Image
+    w, h, D = 320, 240, 64
+    W0, H0 = 400, 300
+    roi_l, roi_r = (40, 30, w, h), (52, 30, w, h)
+    uv = wass_amd.ransac_sample(w, h, 300, 7)
+    gpu_ctx.set_tail_overlap(True)
+    try:
+        f = _frame_on_device(gpu_ctx, w, h, D, 11, roi_l, roi_r, W0, H0)
+        pin = torch.zeros(148 + 6 * w * h, dtype=torch.uint8).pin_memory()
+        cc = torch.zeros(w * h, dtype=torch.uint8).pin_memory()
+        sizes = [(2 * W0, H0, 3), (w + D, 2 * h, 1), (w, h, 1), (w, h, 1), ((W0 + 1) // 2, (H0 + 1) // 2, 3), (W0, H0, 3), (W0, H0, 3), ((w + 1) // 2, (h + 1) // 2, 3)]
+        from wass_amd import _lib
+        import ctypes as C
+        for k, want in enumerate(sizes):
+            a, b, c = C.c_int(), C.c_int(), C.c_int()
+            assert _lib.load().wass_debug_picture_size(C.byref(f["desc"]), k, C.byref(a), C.byref(b), C.byref(c)) == 0 and (a.value, b.value, c.value) == want
+        caps = [((ww * hh * (3 if c == 3 else 2) // 2 + 65536 + 63) // 64) * 64 for ww, hh, c in sizes]
+        caps[5] = 1024                                                # R0 cannot fit: reported, not written, the others unharmed
+        dst = torch.zeros(sum(caps), dtype=torch.uint8).pin_memory()
+        f["mesh"].finish_frame_async(uv, pin.data_ptr(), pin.numel(), component_mask_ptr=cc.data_ptr())
+        with pytest.raises(wass_amd.WassError):
+            f["mesh"].debug_pictures_async(f["desc"], torch.zeros(sum(caps), dtype=torch.uint8).data_ptr(), caps)      # pageable memory
+        t1 = f["mesh"].debug_pictures_async(f["desc"], dst.data_ptr(), caps)
+        f["mesh"].close()
+        fr = gpu_ctx.frame_result()
+        assert fr.found
+        n = gpu_ctx.debug_pictures_result(t1)
+        assert n[5] == 0 and all(v > 600 for i, v in enumerate(n) if i != 5)
+        pics, off = [], 0
+        for k, (ww, hh, c) in enumerate(sizes):
+            if n[k]:
+                blob = dst[off:off + n[k]].numpy().tobytes()
+                assert blob[:2] == b"\xff\xd8" and blob[-2:] == b"\xff\xd9"
+                im = np.asarray(Image.open(io.BytesIO(blob)))
+                assert im.shape == ((hh, ww) if c == 1 else (hh, ww, 3)), k
+                pics.append(im.astype(int))
+            else:
+                pics.append(None)
+            off += caps[k]
+        dr, dl, dispf = f["dr"].cpu().numpy(), f["dl"].cpu().numpy(), f["dispf"].cpu().numpy()
+        # stereo_input.jpg: left above right, zero-padded to w + D (offset 0)
+        want = np.zeros((2 * h, w + D), int)
+        want[:h, D:D + w] = dl
+        want[h:, D:D + w] = dr
+        assert np.abs(pics[1] - want).mean() < 2.5
+        # disparity_final_scaled.jpg
+        mn, mx = min(np.float32(w + 1), dispf.min()), max(np.float32(0), dispf.max())
+        want = ((dispf - mn) / (mx - mn) * np.float32(255.0)).astype(np.uint8).astype(int)
+        assert np.abs(pics[3] - want).mean() < 2.5
+        # stereo.jpg: red lines, red rectangles, the crops pasted at their ROIs, black elsewhere
+        st = pics[0]
+        assert (st[::20, :, 0] > 200).all() and (st[::20, :, 1] < 70).all()
+        body = np.ones((H0, 2 * W0), bool)
+        body[::20] = False
+        left = np.zeros((H0, W0), int); left[roi_l[1]:roi_l[1] + h, roi_l[0]:roi_l[0] + w] = dl[:H0 - roi_l[1], :W0 - roi_l[0]]
+        right = np.zeros((H0, W0), int); right[roi_r[1]:roi_r[1] + h, roi_r[0]:roi_r[0] + w] = dr[:H0 - roi_r[1], :W0 - roi_r[0]]
+        grey = np.concatenate([left, right], 1)
+        inner = np.zeros_like(body)
+        for x0, roi in ((0, roi_l), (W0, roi_r)):
+            inner[roi[1] + 3:roi[1] + min(h, H0 - roi[1]) - 3, x0 + roi[0] + 3:x0 + roi[0] + min(w, W0 - roi[0]) - 3] = True
+        sel = body & inner
+        assert np.abs(st[..., 1][sel] - grey[sel]).mean() < 3.0
+        assert (st[roi_l[1], roi_l[0] + 5:roi_l[0] + 50, 0] > 200).all() and (st[roi_l[1], roi_l[0] + 5:roi_l[0] + 50, 2] < 80).all()     # the rectangle's top edge
+        assert st[5, 5].max() < 12                                                                                                   # outside the ROI: black
+        # graph_components.jpg: green where the component mask kept a point
+        gc = pics[7]
+        keep = cc.numpy().reshape(h, w)[::2, ::2][:gc.shape[0], :gc.shape[1]] > 0
+        assert keep.mean() > 0.2 and (gc[..., 1][keep] > 128).mean() > 0.9
+        # tickets: four are kept
+        with pytest.raises(wass_amd.WassError):
+            gpu_ctx.debug_pictures_result(t1 + 1)
+        assert gpu_ctx.debug_pictures_result(t1) == n
+    finally:
+        gpu_ctx.set_tail_overlap(False)

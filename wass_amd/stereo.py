@@ -212,6 +212,12 @@ class Context:
         self._check(self._lib.wass_ctx_frame_result(self._h, C.byref(res)))
         return res
 
+    def debug_pictures_result(self, ticket: int):
+        """Waits for the pictures of that ticket; the eight file sizes (0: did not fit into its slot, not written)."""
+        n = (C.c_size_t * 8)()
+        self._check(self._lib.wass_debug_pictures_result(self._h, int(ticket), C.byref(n)))
+        return [int(v) for v in n]
+
     def jpeg_encode(self, d_img, quality: int = 95) -> bytes:
         """A picture resident in HBM (torch uint8 CUDA tensor, H x W grey or H x W x 3 r,g,b) as a complete baseline JPEG file
         (wass_jpeg_encode_dev: the encoder of the device-side debug pictures, csrc/jpeg.hip)."""
@@ -478,20 +484,32 @@ class Mesh:
     def finish_frame_async(self, uv, dst_ptr: int, capacity: int, percentile=99.0, ransac_thr=1.0, max_distance=1.5,
                            xmin=-9999., xmax=9999., ymin=-9999., ymax=9999., refine_max_distance=70.0, weight_by_distance=True,
                            central_third_only=False, inliers_ptr: int = 0, inliers_capacity: int = 0, inliers_every: int = 10,
-                           inliers_text_ptr: int = 0, inliers_text_capacity: int = 0) -> None:
+                           inliers_text_ptr: int = 0, inliers_text_capacity: int = 0, component_mask_ptr: int = 0) -> None:
         """remove_outliers -> fit_plane -> xyzC encode + download, enqueued without a host synchronisation
         (wass_stereo.cpp:2046-2123); Context.frame_result() waits and reports.  inliers_ptr (pinned, capacity in points of 3 doubles):
         also every inliers_every-th refinement inlier; inliers_text_ptr (pinned, 40 bytes per point): also the TEXT of
         plane_refinement_inliers.xyz, formatted on the device (wass_mesh_finish_frame_async_ex2)."""
         uv = np.ascontiguousarray(uv, np.int32)
         rp = RefineParams(xmin, xmax, ymin, ymax, refine_max_distance, int(weight_by_distance), int(central_third_only))
-        if inliers_ptr or inliers_text_ptr:
+        if inliers_ptr or inliers_text_ptr or component_mask_ptr:
+            # component_mask_ptr (pinned, one byte per grid point): what the outlier removal left valid -- also kept on the device for
+            # the debug pictures (debug_pictures_async)
             self.ctx._check(self.ctx._lib.wass_mesh_finish_frame_async_ex2(self.ctx._h, self._h, percentile, uv.ctypes.data, len(uv), ransac_thr, C.byref(rp),
-                                                                           max_distance, dst_ptr, capacity, inliers_ptr or None, inliers_capacity, inliers_every, None,
+                                                                           max_distance, dst_ptr, capacity, inliers_ptr or None, inliers_capacity, inliers_every,
+                                                                           component_mask_ptr or None,
                                                                            inliers_text_ptr or None, inliers_text_capacity))
             return
         self.ctx._check(self.ctx._lib.wass_mesh_finish_frame_async(self.ctx._h, self._h, percentile, uv.ctypes.data, len(uv),
                                                                    ransac_thr, C.byref(rp), max_distance, dst_ptr, capacity))
+
+    def debug_pictures_async(self, desc: "_lib.DebugDesc", dst_ptr: int, capacities) -> int:
+        """The reference's eight debug pictures of this frame, rendered and JPEG-coded on the device behind the frame's tail
+        (wass_debug_pictures_async; call after finish_frame_async(..., component_mask_ptr=...), before close()).  Returns the ticket
+        for Context.debug_pictures_result."""
+        caps = (C.c_size_t * 8)(*[int(c) for c in capacities])
+        ticket = C.c_uint64()
+        self.ctx._check(self.ctx._lib.wass_debug_pictures_async(self.ctx._h, self._h, C.byref(desc), dst_ptr, C.byref(caps), C.byref(ticket)))
+        return int(ticket.value)
 
     def ransac_plane(self, uv, thr: float):
         uv = np.ascontiguousarray(uv, np.int32)
