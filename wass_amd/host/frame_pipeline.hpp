@@ -78,8 +78,9 @@ public:
         bool live = false;           // single-frame executable: echo log and progress markers to stdout as the phases end
         bool echo = true;            // live && !echo: the markers are recorded in the frame's log but nothing is printed here (the resident
                                      // worker relays the log to the wass_stereo process that sent the frame, stereo_server.hpp)
-        bool debug_pictures = false; // the reference's debug pictures (stereo.jpg ... graph_components.jpg): every frame's intermediate
-                                     // maps come back to the host once it is complete, which takes the pipeline down to one frame
+        bool debug_pictures = false; // the reference's debug pictures (stereo.jpg ... graph_components.jpg): rendered and JPEG-coded on the device
+                                     // behind the frame's tail (dbg_dev_); in the host form (dbg_host_: PNG format, component-option masks) every
+                                     // frame's intermediate maps come back once it is complete, which takes the pipeline down to one frame
         int max_pending = 2;         // frames whose record has not been read when the next tail is enqueued: 2 keeps a sequence driver two frames
                                      // ahead of the GPU (throughput); 1 hands a frame out one submission earlier (latency: the resident worker,
                                      // whose callers each wait for ONE frame)

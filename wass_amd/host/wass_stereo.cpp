@@ -39,7 +39,7 @@ int main(int argc, char* argv[])
     wass_ctx* ctx = nullptr;
     // A whole frame goes through the device-resident chain the sequence driver uses (frame_pipeline.hpp), one frame deep: nothing
     // comes back to the host between the stages; the debug pictures (on by default, like the reference: WASS_DEBUG_IMAGES=0
-    // switches them off) are drawn from maps fetched after the frame is complete.  The synchronous stage-by-stage calls of
+    // switches them off) are rendered and JPEG-coded on the device behind the frame's tail (csrc/jpeg.hip).  The synchronous stage-by-stage calls of
     // wass_frame.hpp remain for --rectify-only, for the options that need an intermediate mesh on the host
     // (pipeline_eligible) and on request (WASS_STAGE_BY_STAGE=1); the files both ways are the same (tests/test_cli.py).
     bool debug_images = true, stage_by_stage = false;
