@@ -311,8 +311,10 @@ def make_sequence(tmp: str, frames: int, replicate: int, ndirs: int):
     seq = os.path.join(tmp, "output")
     rig = synth.rig_geometry(w, h)
     cfg = os.path.join(tmp, "stereo_config.txt")
-    open(cfg, "w").write(f"MAX_DISPARITY={D}\nRANDOM_SEED=12345\nUSE_CUSTOM_STEREORECTIFY=true\nRECTIFY_ANGLE=1e-6\nDISABLE_RECTIFY_ROI=true\n"
-                         f"DENSE_PATHS={ndirs}\n")
+    # WASS_BENCH_RECTIFY=opencv: the reference's DEFAULT rectification (cv::stereoRectify + remap, USE_CUSTOM_STEREORECTIFY=false) instead
+    # of the built-in one with its ROI switched off -- for scripts/cli_unchanged.py; the bench line itself keeps the configuration below
+    rect = "" if os.environ.get("WASS_BENCH_RECTIFY") == "opencv" else "USE_CUSTOM_STEREORECTIFY=true\nRECTIFY_ANGLE=1e-6\nDISABLE_RECTIFY_ROI=true\n"
+    open(cfg, "w").write(f"MAX_DISPARITY={D}\nRANDOM_SEED=12345\n{rect}DENSE_PATHS={ndirs}\n")
     inputs = ("undistorted/00000000.png", "undistorted/00000001.png", "intrinsics_00000000.xml", "intrinsics_00000001.xml", "ext_R.xml", "ext_T.xml")
     for i in range(frames):
         wd = os.path.join(seq, "%06d_wd" % i)
