@@ -148,6 +148,11 @@ def test_prepare_without_gpu_is_a_loud_failure(prepare, tmp_path):
     r = run(prepare, "--workdir", str(wd), "--calibdir", str(calib), "--c0", str(tmp_path / "cam0.png"), "--c1", str(tmp_path / "cam1.png"))
     assert r.returncode == 255 and "unable to open the GPU" in r.stdout
     assert not os.path.exists(wd / "undistorted" / "00000000.png")
+    # the argv wasscli really sends (wasscli.py:226-227): an EMPTY argument where --demosaic would be, then --continue-if-existing --
+    # boost::program_options ignores positional tokens the program does not declare, so the reference never sees it
+    r = run(prepare, "--workdir", str(wd), "--calibdir", str(calib), "--c0", str(tmp_path / "cam0.png"), "--c1", str(tmp_path / "cam1.png"), "", "--continue-if-existing")
+    assert r.returncode == 255 and "unable to open the GPU" in r.stdout and "unrecognised option" not in r.stdout
+    assert r.stdout.isascii()                                         # (wasscli decodes the output as ASCII)
 
 
 # ------------------------------------------------------------------ GPU: HIP CLAHE vs the oracle, bit-exact
@@ -178,7 +183,8 @@ def test_prepare_writes_the_workdir_wass_stereo_reads(prepare, tmp_path, oracle,
     calib, K0, K1, d0, d1, R, T = _calibdir(tmp_path, w, h, clahe_cfg)
     img0, img1 = _images(tmp_path, w, h)
     wd = tmp_path / "out" / "000000_wd"
-    r = run(prepare, "--workdir", str(wd), "--calibdir", str(calib), "--c0", str(tmp_path / "cam0.png"), "--c1=" + str(tmp_path / "cam1.png"))
+    r = run(prepare, "--workdir", str(wd), "--calibdir", str(calib), "--c0", str(tmp_path / "cam0.png"), "--c1=" + str(tmp_path / "cam1.png"), "",
+            "--continue-if-existing")                                 # (with wasscli's empty argument in --demosaic's place, wasscli.py:226-227)
     assert r.returncode == 0, r.stdout + r.stderr
     marks = [l for l in r.stdout.splitlines() if l.startswith("[P|")]
     assert marks == ["[P|10|100]", "[P|20|100]", "[P|50|100]", "[P|70|100]", "[P|100|100]"]
@@ -321,3 +327,67 @@ def test_raw_sequence_equals_prepare_then_stereo(prepare, tmp_path, save_undisto
         npts = int.from_bytes((wb / "mesh_cam.xyzC").read_bytes()[:4], "little")
         assert npts > 0.5 * w * h                                     # the distortion is mild: the surface is still recovered
     assert (seq_a / "planes.txt").read_text() == (seq_b / "planes.txt").read_text()
+
+
+@pytest.mark.gpu
+def test_the_call_sequence_of_wasscli_prepare_and_stereo(prepare, tmp_path):
+    """What cli/wasscli/wasscli.py does, call for call, from its working directory with RELATIVE paths: find_wass_pipeline (:54-76: every
+    program run without arguments must exit 0), do_prepare (:224-234: one wass_prepare per frame with an EMPTY argument where --demosaic
+    would be, the output decoded as ASCII), do_stereo (:326-346: `wass_stereo config/stereo_config.txt output/%06d_wd`, four at a time,
+    capture_output, plane.txt appended to planes.txt) -- with the per-frame wass_stereo going through the resident worker, debug
+    pictures on as the reference has them."""
+    import shutil
+    from concurrent.futures import ThreadPoolExecutor
+    from wass_amd import build, synth
+    from test_cli import make_workdir
+    w, h, D, N = 160, 120, 16, 6
+    root = tmp_path / "work"
+    for d in ("config", "input/cam0", "input/cam1", "output"):
+        (root / d).mkdir(parents=True)
+    sock = tmp_path / "sock"
+    sock.mkdir()
+    env = dict(os.environ, WASS_SERVER_DIR=str(sock), WASS_SERVER_IDLE="3", PATH=os.path.dirname(build.CLI) + os.pathsep + os.environ.get("PATH", ""))
+    env.pop("WASS_NO_SERVER", None)
+    env.pop("WASS_DEBUG_IMAGES", None)
+    for name in ("wass_prepare", "wass_stereo"):                                   # find_wass_pipeline
+        exe = shutil.which(name, path=env["PATH"])
+        assert exe and os.path.dirname(exe) == os.path.dirname(build.CLI)
+        assert subprocess.run(exe, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env).returncode == 0
+    rig = None
+    for t in range(N):
+        mk = tmp_path / f"mk{t}"
+        mk.mkdir()
+        wd0, cfg, right, left, rig = make_workdir(str(mk), w, h, D, frame=t)
+        _write_png(root / "input" / "cam0" / ("%06d_cam0.png" % t), left)
+        _write_png(root / "input" / "cam1" / ("%06d_cam1.png" % t), right)
+    shutil.copy(cfg, root / "config" / "stereo_config.txt")
+    _write_xml(root / "config" / "intrinsics_00.xml", "intr", rig["K_left"])
+    _write_xml(root / "config" / "intrinsics_01.xml", "intr", rig["K_right"])
+    _write_xml(root / "config" / "ext_R.xml", "R", rig["R"])                       # (what wass_autocalibrate leaves in config/)
+    _write_xml(root / "config" / "ext_T.xml", "T", np.array(rig["T"]).reshape(3, 1) * 2.5)
+    for t in range(N):                                                             # do_prepare
+        ret = subprocess.run(["wass_prepare", "--workdir", "output/%06d_wd" % t, "--calibdir", "config/", "--c0", "input/cam0/%06d_cam0.png" % t,
+                              "--c1", "input/cam1/%06d_cam1.png" % t, "%s" % "", "--continue-if-existing"], capture_output=True, cwd=root, env=env)
+        assert ret.returncode == 0, ret.stdout.decode("ascii")
+        ret.stdout.decode("ascii")
+
+    planes = []
+
+    def stereo_task(t):                                                            # do_stereo's _stereo_task
+        wdirname = "output/%06d_wd" % t
+        ret = subprocess.run(["wass_stereo", "config/stereo_config.txt", wdirname], capture_output=True, cwd=root, env=env)
+        assert ret.returncode == 0, ret.stdout.decode("ascii")
+        text = ret.stdout.decode("ascii")
+        assert "[P|100|100]" in text and wdirname in text
+        with open(root / wdirname / "plane.txt") as f:
+            planes.append((t, (" ".join(f.readlines()).replace("\n", "")) + "\n"))
+        return True
+    with ThreadPoolExecutor(4) as ex:
+        assert all(ex.map(stereo_task, range(N)))
+    assert len(planes) == N and all(len(p.split()) == 4 for _, p in planes)
+    for t in range(N):
+        for f in ("mesh_cam.xyzC", "plane_refinement_inliers.xyz", "stereo.jpg", "undistorted/R0.jpg", "graph_components.jpg", "00000000_s.png", "wass_stereo_log.txt"):
+            assert os.path.getsize(root / "output" / ("%06d_wd" % t) / f) > 100, (t, f)
+    assert not (root / "stereo_config.txt").exists() and not (root / "wass_stereo_log.txt").exists()     # nothing lands in the caller's directory
+    out = subprocess.run(["ps", "-ww", "-eo", "pid,args"], capture_output=True, text=True).stdout
+    assert sum(1 for l in out.splitlines() if "--server" in l and str(sock) in l) == 1                      # one worker served all of it

@@ -104,6 +104,9 @@ int main(int argc, char* argv[])
     bool genconfig = false, cont = false, polarimetric = false;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i], val;
+        // boost::program_options stores no positional token when the program declares none (the reference, :303-346): wasscli relies on it --
+        // it passes "%s" % ("--demosaic" if ... else ""), i.e. an EMPTY argument, for every ordinary camera (wasscli.py:226-227)
+        if (a.empty() || a[0] != '-') continue;
         bool has_val = false;
         const size_t eq = a.find('=');
         if (a.rfind("--", 0) == 0 && eq != std::string::npos) { val = a.substr(eq + 1); a = a.substr(0, eq); has_val = true; }
