@@ -9,4 +9,6 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import bench
 
 debug = os.environ.get("CLI_DEBUG_IMAGES", "0") != "0"          # the reference's eight debug pictures per frame (its default)
-print(json.dumps(bench.wasscli_unchanged_record(int(sys.argv[1]) if len(sys.argv) > 1 else 8, replicate=3 if debug else 12, debug_images=debug)))
+par = int(os.environ.get("CLI_PARALLEL", "4"))                    # 1: one call after the other, what matlab/run_wass.m:242-246 does
+print(json.dumps(bench.wasscli_unchanged_record(int(sys.argv[1]) if len(sys.argv) > 1 else 8, replicate=3 if debug else (4 if par == 1 else 12), parallel=par,
+                                                debug_images=debug)))

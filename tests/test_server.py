@@ -236,11 +236,12 @@ def test_read_ahead_decodes_the_next_workdirs_and_never_serves_a_changed_file(cl
     big = np.zeros((150, 200), np.uint8)
     for k in (0, 1):
         _write_png(str(seq / "000002_wd" / "undistorted" / ("0000000%d.png" % k)), big)      # replaced after it was read
-    r2, r3 = call(2), call(3)
+    r2 = call(2)
+    r3 = subprocess.run([cli, cfg, str(seq / "000003_wd") + "/"], capture_output=True, text=True, env=env)     # (matlab/run_wass.m spells it with a slash)
     assert "image 0 loaded, Size: 200x150" in r2.stdout and "image 1 loaded, Size: 200x150" in r2.stdout
     assert "image 0 loaded, Size: 160x120" in r3.stdout and "%06d_wd" % 3 in r3.stdout
     _wait_gone(sock)
-    rows = {l.split()[0].rsplit("/", 1)[1]: l.split()[1] for l in tlog.read_text().splitlines() if " total " in l}
+    rows = {l.split()[0].rstrip("/").rsplit("/", 1)[1]: l.split()[1] for l in tlog.read_text().splitlines() if " total " in l}
     assert rows["000000_wd"] == rows["000001_wd"] == "demand"          # nothing is decoded before a sequence shows
     assert rows["000002_wd"] == "demand" and rows["000003_wd"] == "ahead"
     assert "1 decoded early and changed since" in tlog.read_text()

@@ -126,8 +126,11 @@ struct ReadAhead {
     }
     // A request for `wd` has arrived.  Returns its decoded pictures if they are here and still those of the files (the entry leaves the
     // cache either way), and queues the workdirs that follow it: every stride-th (a node's callers pick GPU = frame number mod GPUs).
-    std::shared_ptr<Entry> request(const std::string& wd, int stride)
+    std::shared_ptr<Entry> request(const std::string& asked, int stride)
     {
+        // (entries are kept under the name without trailing slashes: matlab/run_wass.m:103 calls with "<dir>/000012_wd/", wasscli without)
+        std::string wd = asked;
+        while (wd.size() > 1 && wd.back() == '/') wd.pop_back();
         std::shared_ptr<Entry> mine;
         {
             std::unique_lock<std::mutex> lk(mu);
@@ -166,6 +169,7 @@ struct ReadAhead {
         const bool fresh = mine->valid && mine->sig[0] == FileSig::of(pic(wd, 0)) && mine->sig[1] == FileSig::of(pic(wd, 1));
         if (!fresh) { ++stale; return nullptr; }
         ++hits;
+        mine->pre.workdir = asked;                                   // load_data takes the pair only for the workdir it is loading, as that is spelt
         return mine;
     }
     void worker()
