@@ -40,6 +40,8 @@ struct FrameJob {
     // wass_prepare would have turned into <workdir>/undistorted/*.png first
     bool raw = false;
     std::string c0, c1;
+    DeferredFiles deferred;          // the files prepare() would have written, when it ran under a DeferredFilesScope (a frame computed before it was
+                                     // asked for: stereo_server.hpp); finish() writes them first
     Preload* pre = nullptr;          // the workdir's two pictures, decoded ahead of the request (the resident worker's read-ahead); used and emptied by prepare
     int prev_w = 0, prev_h = 0;      // size of the scaled previews, written once the undistorted pictures are back (0: none)
     int img_w = 0, img_h = 0;        // size of the cameras' pictures (the driver drops the decoded pictures once they are staged)
@@ -469,12 +471,21 @@ public:
     }
 
     // ---- phase 3 (any thread): everything that is written from the result record (:1374, 1993, 2046-2139)
+    // A frame that was enqueued and will never be finished (computed ahead of a request that did not come, or whose inputs changed):
+    // gives its output set back.  Only for frames that have been collected.
+    void abandon(FrameJob& job)
+    {
+        if (job.out_slot >= 0) { release_out(job.out_slot); job.out_slot = -1; }
+        if (job.mesh) { wass_mesh_destroy(job.mesh); job.mesh = nullptr; }
+    }
+
     void finish(FrameJob& job)
     {
         LogSinkScope sink(&job.log);
         WLOG_SCOPE("wass_stereo");
         Env& env = job.env;
         const double t0 = Timer::now();
+        if (!job.deferred.files.empty()) { if (!job.deferred.write_all()) WLOGE << "Unable to write the files of the frame's preparation"; job.deferred.files.clear(); }
         if (job.rc == 0 && !job.skipped) {
             try {
                 const wass_frame_result& r = job.res;

@@ -140,17 +140,43 @@ inline bool save_matrix_xml(const std::string& filename, const std::string& node
     ofs << "</data></" << node << ">\n</opencv_storage>\n";
     return true;
 }
+// The small text files a frame's PREPARATION leaves in its workdir (stereo_config.txt, P0cam.txt ... scale.txt, H0_rect.txt) go through
+// commit_text_file: written at once -- or, while a DeferredFiles sink is installed for the thread, kept in memory until the caller writes
+// them (the resident worker prepares and computes a frame BEFORE anybody asked for it and must not touch its workdir until then:
+// stereo_server.hpp, "speculation").
+struct DeferredFiles {
+    std::vector<std::pair<std::string, std::string>> files;
+    bool write_all() const
+    {
+        bool ok = true;
+        for (const auto& f : files) { std::ofstream ofs(f.first.c_str(), std::ios::binary); ofs.write(f.second.data(), (std::streamsize)f.second.size()); ok = ok && !ofs.fail(); }
+        return ok;
+    }
+};
+inline DeferredFiles*& deferred_files_sink() { static thread_local DeferredFiles* sink = nullptr; return sink; }
+struct DeferredFilesScope {
+    DeferredFiles* prev;
+    explicit DeferredFilesScope(DeferredFiles* s) : prev(deferred_files_sink()) { deferred_files_sink() = s; }
+    ~DeferredFilesScope() { deferred_files_sink() = prev; }
+};
+inline bool commit_text_file(const std::string& filename, const std::string& content)
+{
+    if (DeferredFiles* s = deferred_files_sink()) { s->files.emplace_back(filename, content); return true; }
+    std::ofstream ofs(filename.c_str(), std::ios::binary);
+    if (ofs.fail()) return false;
+    ofs.write(content.data(), (std::streamsize)content.size());
+    return !ofs.fail();
+}
 inline bool save_matrix_txt(const std::string& filename, const Mat& m)
 {
-    std::ofstream ofs(filename.c_str());
-    if (ofs.fail()) return false;
+    std::ostringstream ofs;
     ofs.precision(16);
     ofs << std::scientific;
     for (int i = 0; i < m.rows; ++i) {
         for (int j = 0; j < m.cols; ++j) { ofs << m(i, j); if (j != m.cols - 1) ofs << " "; }
         if (i != m.rows - 1) ofs << std::endl;
     }
-    return true;
+    return commit_text_file(filename, ofs.str());
 }
 
 // ------------------------------------------------------------------ zlib streams, fast

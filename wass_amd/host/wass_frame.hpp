@@ -181,8 +181,9 @@ void input_scale_outputs(Env& env, const Config& cfg, bool previews, BgTask* bg,
         k0(2, 2) = 1; k1(2, 2) = 1;
         save_matrix_txt(path_join(env.workdir, "K0_small.txt"), k0);
         save_matrix_txt(path_join(env.workdir, "K1_small.txt"), k1);
-        std::ofstream ofs(path_join(env.workdir, "scale.txt").c_str());
+        std::ostringstream ofs;
         ofs.precision(16); ofs << std::scientific << scale;
+        commit_text_file(path_join(env.workdir, "scale.txt"), ofs.str());
     }
 }
 
@@ -314,10 +315,7 @@ int save_configuration(const Config& cfg, const std::string& filename)          
 {
     WLOG_SCOPE("wass_stereo");
     WLOGI << "Writing " << filename;
-    std::ofstream ofs(filename);
-    if (!ofs.is_open()) { WLOGE << "Unable to open " << filename << " for write"; return -1; }
-    ofs << cfg.to_config_string();
-    ofs.close();
+    if (!commit_text_file(filename, cfg.to_config_string())) { WLOGE << "Unable to open " << filename << " for write"; return -1; }
     WLOGI << "Done!";
     return 0;
 }
