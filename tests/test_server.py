@@ -228,7 +228,7 @@ def test_read_ahead_decodes_the_next_workdirs_and_never_serves_a_changed_file(cl
     sock = tmp_path / "sock"
     sock.mkdir()
     tlog = tmp_path / "timing.log"
-    env = _env(sock, WASS_DEBUG_IMAGES="0", WASS_SERVER_TIMING=str(tlog))
+    env = _env(sock, WASS_DEBUG_IMAGES="0", WASS_SERVER_TIMING=str(tlog), WASS_SERVER_SPECULATE="0")     # (decode only; speculation has its own test)
     call = lambda i: subprocess.run([cli, cfg, str(seq / ("%06d_wd" % i))], capture_output=True, text=True, env=env)
     for i in (0, 1):
         assert "image 0 loaded, Size: 160x120" in call(i).stdout
@@ -270,7 +270,7 @@ def test_on_a_multi_gpu_node_frame_i_goes_to_gpu_i_mod_g_and_each_server_reads_i
     sock = tmp_path / "sock"
     sock.mkdir()
     tlog = tmp_path / "timing.log"
-    env = _env(sock, WASS_DEBUG_IMAGES="0", WASS_SERVER_TIMING=str(tlog), WASS_NUM_GPUS="2")
+    env = _env(sock, WASS_DEBUG_IMAGES="0", WASS_SERVER_TIMING=str(tlog), WASS_NUM_GPUS="2", WASS_SERVER_SPECULATE="0")
     env.pop("WASS_GPU_DEVICE", None)
     for i in range(8):
         r = subprocess.run([cli, cfg, str(seq / ("%06d_wd" % i))], capture_output=True, text=True, env=env)
@@ -338,3 +338,98 @@ def test_the_server_survives_garbage_on_its_socket(cli, tmp_path):
         c.close()
     assert [l.split()[0] for l in _servers(sock)] == [srv[0].split()[0]]      # the SAME server, still alive
     _wait_gone(sock)
+
+
+def _seq(tmp_path, n, w=160, h=120, D=32):
+    mk = tmp_path / "mk"
+    mk.mkdir()
+    wd, cfg, *_ = make_workdir(str(mk), w, h, D)
+    seq = tmp_path / "seq"
+    seq.mkdir()
+    for i in range(n):
+        shutil.copytree(wd, seq / ("%06d_wd" % i))
+    return seq, cfg
+
+
+def test_speculation_prepares_ahead_without_touching_the_workdir(cli, tmp_path):
+    """After two requests from a sequence the worker builds (and, with a GPU, computes) the next workdirs' frames before anybody asks:
+    until the caller comes NOTHING is written into such a workdir; then it holds what an ordinary call leaves.  A frame whose input
+    changed in between is recomputed, one whose caller never comes is dropped."""
+    import numpy as np
+    import torch
+    from test_cli import _write_png
+    if torch.cuda.is_available():
+        pytest.skip("the no-GPU behaviour is tested on the build container")
+    seq, cfg = _seq(tmp_path, 7)
+    sock = tmp_path / "sock"
+    sock.mkdir()
+    tlog = tmp_path / "timing.log"
+    env = _env(sock, WASS_DEBUG_IMAGES="0", WASS_SERVER_TIMING=str(tlog))
+    call = lambda i: subprocess.run([cli, cfg, str(seq / ("%06d_wd" % i))], capture_output=True, text=True, env=env)
+    before = {i: sorted(os.listdir(seq / ("%06d_wd" % i))) for i in range(7)}
+    a0, a1 = call(0), call(1)
+    time.sleep(0.6)                                                   # 2, 3, 4 are prepared (and have failed on the missing GPU) by now
+    for i in (2, 3, 4, 5):
+        assert sorted(os.listdir(seq / ("%06d_wd" % i))) == before[i], i            # untouched
+    _write_png(str(seq / "000003_wd" / "undistorted" / "00000000.png"), np.zeros((150, 200), np.uint8))
+    _write_png(str(seq / "000003_wd" / "undistorted" / "00000001.png"), np.zeros((150, 200), np.uint8))
+    r2, r3 = call(2), call(3)
+    for r in (a0, a1, r2):
+        assert r.returncode == 255 and "no usable MI355X GPU" in r.stdout and "image 0 loaded, Size: 160x120" in r.stdout
+    assert "image 0 loaded, Size: 200x150" in r3.stdout               # the frame computed ahead was for other pictures: done again
+    for i in (0, 2):
+        left = sorted(os.listdir(seq / ("%06d_wd" % i)))
+        assert "stereo_config.txt" in left and "P0cam.txt" in left and "wass_stereo_log.txt" in left and "scale.txt" in left
+    assert sorted(os.listdir(seq / "000000_wd")) == sorted(os.listdir(seq / "000002_wd"))      # ahead or on demand: the same files
+    for name in ("stereo_config.txt", "P0cam.txt", "Cam1_poseT.txt", "K0_small.txt", "scale.txt", "H0_rect.txt"):
+        assert (seq / "000000_wd" / name).read_bytes() == (seq / "000002_wd" / name).read_bytes(), name
+    assert sorted(os.listdir(seq / "000006_wd")) == before[6]         # never asked for: never touched
+    _wait_gone(sock)
+    rows = {l.split()[0].rstrip("/").rsplit("/", 1)[1]: l.split()[1] for l in tlog.read_text().splitlines() if " total " in l}
+    assert rows["000000_wd"] == rows["000001_wd"] == "demand" and rows["000002_wd"] == "computed" and rows["000003_wd"] == "demand"
+    assert sorted(os.listdir(seq / "000006_wd")) == before[6] and sorted(os.listdir(seq / "000005_wd")) == before[5]
+    text = tlog.read_text()
+    assert "speculation: 1 frames computed before they were asked for" in text and "dropped unclaimed" in text
+
+
+@pytest.mark.gpu
+def test_frames_computed_ahead_of_their_callers_are_the_frames_of_in_process_runs(cli, tmp_path):
+    """Speculation with a GPU: a slow caller finds most of its frames computed before it asks; what it gets is byte for byte what a process
+    of its own writes -- also for a workdir whose pictures were replaced after the worker had computed the old ones."""
+    import numpy as np
+    from test_cli import _write_png
+    w, h, D = 320, 240, 64
+    nd, nrep = 4, 5
+    seq_a, seq_b = tmp_path / "a", tmp_path / "b"
+    cfg = None
+    for i in range(nd):
+        t = tmp_path / f"mk{i}"
+        t.mkdir()
+        wd, cfg, *_ = make_workdir(str(t), w, h, D, frame=i)
+        shutil.copytree(wd, seq_a / ("%06d_wd" % i))
+        for rep in range(nrep):
+            shutil.copytree(wd, seq_b / ("%06d_wd" % (rep * nd + i)))
+    n = nd * nrep
+    for i in range(nd):
+        r = subprocess.run([cli, cfg, str(seq_a / ("%06d_wd" % i))], capture_output=True, text=True, env=dict(os.environ, WASS_NO_SERVER="1", WASS_DEBUG_IMAGES="0"))
+        assert r.returncode == 0, r.stdout[-1500:]
+    sock = tmp_path / "sock"
+    sock.mkdir()
+    tlog = tmp_path / "timing.log"
+    env = _env(sock, WASS_DEBUG_IMAGES="0", WASS_SERVER_TIMING=str(tlog))
+    swapped = 9                                                          # gets frame 2's pictures while the worker holds a result for frame 1's
+    for i in range(n):
+        if i == 6:
+            time.sleep(0.5)                                              # 7, 8, 9 are computed by now
+            for k in (0, 1):
+                shutil.copy(seq_a / "000002_wd" / "undistorted" / ("0000000%d.png" % k), seq_b / ("%06d_wd" % swapped) / "undistorted" / ("0000000%d.png" % k))
+        r = subprocess.run([cli, cfg, str(seq_b / ("%06d_wd" % i))], capture_output=True, text=True, env=env)
+        assert r.returncode == 0 and "All done." in r.stdout and r.stdout.isascii(), r.stdout[-1500:]
+        time.sleep(0.05)                                                 # a slow caller: the worker gets ahead of it
+        src = 2 if i == swapped else i % nd
+        for name in NAMES + ("H0_rect.txt", "H1_rect.txt"):
+            assert (seq_a / ("%06d_wd" % src) / name).read_bytes() == (seq_b / ("%06d_wd" % i) / name).read_bytes(), f"frame {i}: {name} differs"
+    assert _wait_gone(sock)
+    rows = {l.split()[0].rstrip("/").rsplit("/", 1)[1]: l.split()[1] for l in tlog.read_text().splitlines() if " total " in l}
+    assert rows["%06d_wd" % swapped] == "demand"
+    assert sum(1 for v in rows.values() if v == "computed") >= n // 2, rows

@@ -654,6 +654,7 @@ public:
     // how many frames may be pending when the next tail is enqueued (Options::max_pending), changed between submissions: the resident
     // worker goes two deep only while callers queue up behind the GPU
     void set_max_pending(int n) { max_pending_ = n; }
+    bool host_debug_pictures() const { return dbg_host_; }          // the host renderers are in use: every frame is collected with its maps
     bool pending() const { return !pend_.empty() || !early_.empty(); }   // a submitted frame has not been handed out yet (flush() returns it)
 
 private:

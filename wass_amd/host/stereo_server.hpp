@@ -35,6 +35,8 @@
 
 #include <dirent.h>
 
+#include <algorithm>
+#include <functional>
 #include <map>
 #include <thread>
 
@@ -53,10 +55,14 @@ struct PipeEntry {
     bool bad = false;                  // the configuration text does not parse or is not eligible: the client computes such frames itself
     bool debug = false;                // the reference's debug pictures are drawn (they want the decoded pictures in finish())
 };
+struct RaEntry;
 struct ServerJob : FrameJob {
     int fd = -1;
     PipeEntry* entry = nullptr;
     bool read_ahead = false;           // its pictures were decoded before it asked
+    bool computed_ahead = false;       // ... and the whole frame was computed before it asked (speculation)
+    bool counted = false;              // ... and counts among the frames computed ahead that hold an output set
+    std::shared_ptr<RaEntry> spec;     // set while the frame is nobody's yet: computed ahead, waiting for its caller
     double t_accept = 0, t_decoded = 0, t_submit = 0, t_collected = 0, t_written = 0;     // WASS_SERVER_TIMING
 };
 
@@ -65,6 +71,15 @@ struct ServerJob : FrameJob {
 // been asked for, the pictures of the next few workdirs of that directory are decoded before their callers exist.  A decoded pair is
 // used only if both files still have the inode, size and modification time they had before AND after they were read; anything else
 // (and any workdir nobody predicted) is decoded on demand, as before.  WASS_SERVER_READAHEAD=<n> workdirs (default 6, 0 = off).
+//
+// ---- speculation (WASS_SERVER_SPECULATE=<n>, default 3, 0 = off).  Those workdirs are not only decoded: a frame job is PREPARED for each
+// (calibration, rectification's decisions; the small files prepare() writes are kept in memory, FrameJob::deferred) and, whenever no
+// caller's frame is waiting, sent through the GPU chain -- up to n frames may be complete and waiting for their callers.  Nothing touches the workdir until its caller arrives; then the
+// inputs are checked (both pictures and the four calibration files: inode, size, mtime as before AND after they were read; same
+// configuration text, same configuration path) and the frame's files are written -- the caller waits for its 41 MB, not for its frame.
+// A frame whose caller never comes is dropped when it falls out of the cache or the server goes.  With N callers that each spend most
+// of a call waiting for files, the GPU would otherwise idle between their requests; this way the unchanged command line runs at
+// the sequence driver's rate.
 struct FileSig {
     bool ok = false;
     ino_t ino = 0; off_t size = 0; timespec mtime = { 0, 0 };
@@ -77,15 +92,22 @@ struct FileSig {
     }
     bool operator==(const FileSig& o) const { return ok && o.ok && ino == o.ino && size == o.size && mtime.tv_sec == o.mtime.tv_sec && mtime.tv_nsec == o.mtime.tv_nsec; }
 };
+enum RaState { RA_QUEUED, RA_RUNNING, RA_DONE, RA_PREPARED, RA_ONGPU, RA_COMPUTED, RA_TAKEN };
+struct RaEntry {
+    std::string workdir;
+    RaState state = RA_QUEUED;
+    Preload pre;
+    FileSig sig[2];
+    bool valid = false;                  // the files did not change while they were read
+    // speculation: the frame job built (and possibly computed) for this workdir, owned by the entry until a caller claims it
+    PipeEntry* pe = nullptr;
+    std::string cfgpath;
+    ServerJob* job = nullptr;
+    FileSig calib[4];
+};
 struct ReadAhead {
-    enum State { QUEUED, RUNNING, DONE, TAKEN };
-    struct Entry {
-        std::string workdir;
-        State state = QUEUED;
-        Preload pre;
-        FileSig sig[2];
-        bool valid = false;                  // the files did not change while they were read
-    };
+    typedef RaEntry Entry;
+    static constexpr RaState QUEUED = RA_QUEUED, RUNNING = RA_RUNNING, DONE = RA_DONE, PREPARED = RA_PREPARED, ONGPU = RA_ONGPU, COMPUTED = RA_COMPUTED, TAKEN = RA_TAKEN;
     std::mutex mu;
     std::condition_variable cv;
     std::map<std::string, std::shared_ptr<Entry>> by_dir;
@@ -93,9 +115,18 @@ struct ReadAhead {
     std::deque<std::shared_ptr<Entry>> todo;
     std::map<std::string, int> seen;                   // requests per sequence directory
     int depth = 6;
+    int spec_depth = 3;                                // > 0: they are also prepared as frame jobs, and this many may be computed and waiting for their callers
     size_t cap = 16;
     bool closed = false;
-    std::atomic<uint64_t> hits{ 0 }, misses{ 0 }, stale{ 0 };
+    std::atomic<uint64_t> hits{ 0 }, misses{ 0 }, stale{ 0 }, computed{ 0 }, prepared{ 0 }, dropped{ 0 };
+    std::deque<std::pair<std::string, double>> recent; // the requests of the last seconds: not predicted again (concurrent callers arrive out of order)
+    std::function<void(const std::shared_ptr<Entry>&)> on_prepared;      // a frame job is ready for the GPU thread
+    std::function<void(ServerJob*)> drop_job;                            // give back what a dropped job holds (output set), delete it
+    static std::string calib_file(const std::string& wd, int k)
+    {
+        static const char* const n[4] = { "intrinsics_00000000.xml", "intrinsics_00000001.xml", "ext_R.xml", "ext_T.xml" };
+        return path_join(wd, n[k]);
+    }
 
     static std::string pic(const std::string& wd, int k) { return path_join(wd, k == 0 ? "undistorted/00000000.png" : "undistorted/00000001.png"); }
     // "<parent>/<prefix><digits><suffix>" -> the same name with the number raised by k (same width); empty when the name holds no number
@@ -124,53 +155,96 @@ struct ReadAhead {
         preload_images(e.workdir, e.pre);
         e.valid = e.pre.error.empty() && e.sig[0] == FileSig::of(pic(e.workdir, 0)) && e.sig[1] == FileSig::of(pic(e.workdir, 1));
     }
-    // A request for `wd` has arrived.  Returns its decoded pictures if they are here and still those of the files (the entry leaves the
-    // cache either way), and queues the workdirs that follow it: every stride-th (a node's callers pick GPU = frame number mod GPUs).
-    std::shared_ptr<Entry> request(const std::string& asked, int stride)
+    struct Claim {
+        std::shared_ptr<Entry> pictures;     // decoded ahead: the caller's prepare() takes them
+        ServerJob* job = nullptr;            // prepared ahead (computed = false: goes to the GPU queue) or computed ahead (goes to the writers)
+        bool computed = false;
+    };
+    bool inputs_unchanged(const Entry& e, const std::string& wd) const
+    {
+        if (!e.valid) return false;
+        for (int k = 0; k < 2; ++k) if (!(e.sig[k] == FileSig::of(pic(wd, k)))) return false;
+        if (e.job) for (int k = 0; k < 4; ++k) if (!(e.calib[k] == FileSig::of(calib_file(wd, k)))) return false;
+        return true;
+    }
+    // (mu held) an entry leaves the cache for good: what it owns goes back
+    void discard(const std::shared_ptr<Entry>& e)
+    {
+        if (e->state == QUEUED) e->state = TAKEN;
+        if ((e->state == PREPARED || e->state == COMPUTED || e->state == DONE) && e->job) { ServerJob* j = e->job; e->job = nullptr; e->state = TAKEN; ++dropped; if (drop_job) drop_job(j); }
+    }
+    // A request for `wd` has arrived (configuration `pe`, named `cfgpath` by the caller).  Returns what was done for it ahead of time if that
+    // is still good for the files as they are now (the entry leaves the cache either way), and queues the workdirs that follow it: every
+    // stride-th (a node's callers pick GPU = frame number mod GPUs); the nearest `spec_depth` of them with a frame job (speculate).
+    Claim request(const std::string& asked, int stride, PipeEntry* pe, const std::string& cfgpath, bool speculate)
     {
         // (entries are kept under the name without trailing slashes: matlab/run_wass.m:103 calls with "<dir>/000012_wd/", wasscli without)
         std::string wd = asked;
         while (wd.size() > 1 && wd.back() == '/') wd.pop_back();
         std::shared_ptr<Entry> mine;
+        Claim c;
         {
             std::unique_lock<std::mutex> lk(mu);
-            if (depth <= 0) return nullptr;
+            if (depth <= 0) return c;
             auto it = by_dir.find(wd);
             if (it != by_dir.end()) {
                 mine = it->second;
                 if (mine->state == QUEUED) { mine->state = TAKEN; mine = nullptr; }          // not started: this thread decodes it itself, now
-                else { cv.wait(lk, [&]() { return mine->state == DONE || closed; }); }
+                else cv.wait(lk, [&]() { return (mine->state != RUNNING && mine->state != ONGPU) || closed; });   // (a frame on the GPU: a few ms)
                 by_dir.erase(wd);
                 for (auto o = order.begin(); o != order.end(); ++o) if ((*o)->workdir == wd) { order.erase(o); break; }
             }
+            const double now = Timer::now();
+            recent.emplace_back(wd, now);
+            while (recent.size() > 64 || (!recent.empty() && now - recent.front().second > 0.5)) recent.pop_front();
+            auto asked_lately = [&](const std::string& d) { for (const auto& r : recent) if (r.first == d) return true; return false; };
             const int n = ++seen[parent(wd)];
             if (seen.size() > 64) { seen.clear(); }
             if (n >= 2 && !closed)
                 for (int k = 1; k <= depth; ++k) {
                     const std::string nx = sibling(wd, (unsigned long long)k * (unsigned long long)std::max(1, stride));
-                    if (nx.empty() || by_dir.count(nx)) continue;
+                    if (nx.empty() || by_dir.count(nx) || asked_lately(nx)) continue;
                     if (!FileSig::of(pic(nx, 0)).ok) break;                                // the sequence ends here (or is not one)
                     auto e = std::make_shared<Entry>();
                     e->workdir = nx;
+                    if (speculate) { e->pe = pe; e->cfgpath = cfgpath; }      // (every predicted workdir gets its frame job; how many are COMPUTED ahead is the GPU thread's business)
                     by_dir[nx] = e;
                     order.push_back(e);
                     todo.push_back(e);
-                    while (order.size() > cap) {                                            // predicted and never asked for: oldest out
-                        auto old = order.front();
-                        order.pop_front();
-                        if (old->state == QUEUED) old->state = TAKEN;
+                    for (size_t scan = 0; order.size() > cap && scan < order.size();) {     // predicted and never asked for: oldest out
+                        auto old = order[scan];
+                        if (old->state == RUNNING || old->state == ONGPU) { ++scan; continue; }     // (busy: it goes the next time)
+                        order.erase(order.begin() + (long)scan);
                         by_dir.erase(old->workdir);
+                        discard(old);
                     }
                 }
             cv.notify_all();
-            if (mine && mine->state != DONE) mine = nullptr;
+            if (mine && mine->state != DONE && mine->state != PREPARED && mine->state != COMPUTED) mine = nullptr;
+            if (mine) {
+                // it is this caller's from here on: the GPU thread must not pick a PREPARED job up while the files are being looked at (the
+                // entry is still in its queue; taken twice, the frame went to two writers)
+                const RaState was = mine->state;
+                mine->state = TAKEN;
+                ServerJob* job = mine->job;
+                mine->job = nullptr;
+                const bool same = !job || (mine->pe == pe && mine->cfgpath == cfgpath);
+                lk.unlock();
+                mine->job = job;                                    // (inputs_unchanged looks at the calibration files only for entries with a frame job)
+                const bool fresh = same && inputs_unchanged(*mine, wd);
+                mine->job = nullptr;
+                lk.lock();
+                if (!fresh) { ++stale; if (job) { ++dropped; if (drop_job) drop_job(job); } mine = nullptr; }
+                else if (job) { c.job = job; c.computed = was == COMPUTED; }
+                else if (was == DONE) c.pictures = mine;
+                else mine = nullptr;
+            }
         }
-        if (!mine) { ++misses; return nullptr; }
-        const bool fresh = mine->valid && mine->sig[0] == FileSig::of(pic(wd, 0)) && mine->sig[1] == FileSig::of(pic(wd, 1));
-        if (!fresh) { ++stale; return nullptr; }
+        if (c.job) { if (c.computed) ++computed; else ++prepared; c.job->workdir = asked; c.job->env.workdir = asked; return c; }
+        if (!c.pictures) { ++misses; return c; }
         ++hits;
-        mine->pre.workdir = asked;                                   // load_data takes the pair only for the workdir it is loading, as that is spelt
-        return mine;
+        c.pictures->pre.workdir = asked;                             // load_data takes the pair only for the workdir it is loading, as that is spelt
+        return c;
     }
     void worker()
     {
@@ -186,11 +260,56 @@ struct ReadAhead {
                 e->state = RUNNING;
             }
             decode(*e);
-            { std::lock_guard<std::mutex> lk(mu); e->state = DONE; }
+            ServerJob* job = nullptr;
+            if (e->valid && e->pe) {
+                // the frame job, as a decode thread would build it for a caller -- except that nothing is written (DeferredFilesScope)
+                for (int k = 0; k < 4; ++k) e->calib[k] = FileSig::of(calib_file(e->workdir, k));
+                job = new ServerJob();
+                job->entry = e->pe;
+                job->workdir = e->workdir;
+                job->config_path = e->cfgpath;
+                job->read_ahead = job->computed_ahead = true;
+                job->pre = &e->pre;
+                { DeferredFilesScope quiet(&job->deferred); e->pe->pl->prepare(*job); }
+                job->pre = nullptr;
+                bool same = job->rc == 0;
+                for (int k = 0; k < 4 && same; ++k) same = e->calib[k] == FileSig::of(calib_file(e->workdir, k));
+                if (!same) { delete job; job = nullptr; e->valid = false; }                 // (its caller prepares the frame itself and gets the real message)
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                e->job = job;
+                e->state = job ? PREPARED : DONE;
+                if (job) job->spec = e;
+            }
             cv.notify_all();
+            if (job && on_prepared) on_prepared(e);
         }
     }
-    void close() { { std::lock_guard<std::mutex> lk(mu); closed = true; } cv.notify_all(); }
+    // the GPU thread: this prepared frame goes to the GPU now (false: its caller has come meanwhile, or it was dropped)
+    ServerJob* to_gpu(const std::shared_ptr<Entry>& e)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (e->state != PREPARED || !e->job) return nullptr;
+        e->state = ONGPU;
+        return e->job;
+    }
+    // ... and has come back complete
+    void computed_now(const std::shared_ptr<Entry>& e)
+    {
+        { std::lock_guard<std::mutex> lk(mu); if (e->state == ONGPU) e->state = COMPUTED; }
+        cv.notify_all();
+    }
+    void close()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            closed = true;
+            for (auto& e : order) discard(e);
+            order.clear(); by_dir.clear(); todo.clear();
+        }
+        cv.notify_all();
+    }
 };
 
 template <typename T> class Queue {
@@ -200,22 +319,25 @@ public:
     bool pop(T& out, int timeout_ms = -1)
     {
         std::unique_lock<std::mutex> lk(mu_);
-        auto ready = [&]() { return !q_.empty() || closed_; };
+        auto ready = [&]() { return !q_.empty() || closed_ || kicked_; };
         if (timeout_ms < 0) cv_.wait(lk, ready);
         else if (!cv_.wait_for(lk, std::chrono::milliseconds(timeout_ms), ready)) return false;
+        kicked_ = false;
         if (q_.empty()) return false;
         out = std::move(q_.front());
         q_.pop_front();
         return true;
     }
     void close() { { std::lock_guard<std::mutex> lk(mu_); closed_ = true; } cv_.notify_all(); }
+    // wakes a pop() that is waiting: it returns false as if its time were up (there is other work for the waiting thread)
+    void kick() { { std::lock_guard<std::mutex> lk(mu_); kicked_ = true; } cv_.notify_all(); }
     bool closed() { std::lock_guard<std::mutex> lk(mu_); return closed_; }
     size_t size() { std::lock_guard<std::mutex> lk(mu_); return q_.size(); }
 private:
     std::mutex mu_;
     std::condition_variable cv_;
     std::deque<T> q_;
-    bool closed_ = false;
+    bool closed_ = false, kicked_ = false;
 };
 
 inline int server_main(const std::string& sock, int device)
@@ -228,6 +350,8 @@ inline int server_main(const std::string& sock, int device)
     int nra = 2;                                                   // read-ahead threads (each decodes the two pictures of a workdir side by side)
     ReadAhead readahead;
     if (const char* e = getenv("WASS_SERVER_READAHEAD")) readahead.depth = std::max(0, atoi(e));
+    if (const char* e = getenv("WASS_SERVER_SPECULATE")) readahead.spec_depth = std::max(0, atoi(e));
+    const int spec_max = std::max(1, std::min(8, readahead.spec_depth));   // frames computed ahead and not yet claimed (each holds an output set)
     int deep_at = 2;                                               // callers waiting behind the GPU from which the chain runs two frames deep
     if (const char* e = getenv("WASS_SERVER_DEEP_AT")) deep_at = std::max(0, atoi(e));
     // WASS_SERVER_TIMING=<file>: one line per frame -- where a caller's waiting time went (decode, queue, GPU, files)
@@ -249,7 +373,15 @@ inline int server_main(const std::string& sock, int device)
     std::mutex pipes_mu;
     std::map<std::string, std::unique_ptr<PipeEntry>> pipes;
     Queue<ServerJob*> incoming, ready, towrite;
-    std::atomic<int> in_flight{ 0 };
+    Queue<std::shared_ptr<RaEntry>> spec_q;                        // frame jobs prepared ahead of their callers, for the GPU thread's spare time
+    std::atomic<int> in_flight{ 0 }, spec_live{ 0 };
+    readahead.on_prepared = [&](const std::shared_ptr<RaEntry>& e) { spec_q.push(e); ready.kick(); };
+    readahead.drop_job = [&](ServerJob* j) {
+        if (j->counted) --spec_live;                               // (it had been through the GPU)
+        j->entry->pl->abandon(*j);
+        j->spec.reset();
+        delete j;
+    };
     std::atomic<bool> stopping{ false };
 
     auto reply = [](ServerJob* j) {
@@ -290,7 +422,7 @@ inline int server_main(const std::string& sock, int device)
                     } catch (const std::runtime_error&) { slot->bad = true; }
                     if (!slot->bad) {
                         FramePipeline::Options fo;
-                        fo.out_slots = nwr + 2;
+                        fo.out_slots = nwr + 2 + spec_max;
                         fo.live = true;                          // the progress markers go into the frame's log ...
                         fo.echo = false;                         // ... which is relayed to the client, not printed here
                         fo.max_pending = 1;                      // every caller waits for ONE frame: hand it out as early as possible
@@ -310,9 +442,23 @@ inline int server_main(const std::string& sock, int device)
                 LogSinkScope sink(&j->log);
                 j->rc = -1;
             } else {
-                std::shared_ptr<ReadAhead::Entry> ahead_of_time = readahead.request(wd, stride);      // the pictures may be here already
-                j->pre = ahead_of_time ? &ahead_of_time->pre : nullptr;
-                j->read_ahead = ahead_of_time != nullptr;
+                const bool speculate = readahead.spec_depth > 0 && !pe->pl->host_debug_pictures() && pe->cfg.get_string("LEFT_MASK_IMAGE") == "none" &&
+                                       pe->cfg.get_string("RIGHT_MASK_IMAGE") == "none";
+                ReadAhead::Claim c = readahead.request(wd, stride, pe, cfgpath, speculate);     // something may have been done for this workdir already
+                if (c.job) {
+                    // its frame job exists: prepared (it joins the GPU queue as this caller's) or already computed (straight to the writers)
+                    ServerJob* s = c.job;
+                    s->spec.reset();
+                    s->fd = j->fd; s->t_accept = j->t_accept;
+                    delete j;
+                    s->t_decoded = Timer::now();
+                    if (s->counted) { --spec_live; s->counted = false; ready.kick(); }      // (room for another frame ahead)
+                    if (c.computed) { s->t_submit = s->t_decoded; towrite.push(s); }
+                    else { s->computed_ahead = false; ready.push(s); }
+                    continue;
+                }
+                j->pre = c.pictures ? &c.pictures->pre : nullptr;
+                j->read_ahead = c.pictures != nullptr;
                 pe->pl->prepare(*j);
                 j->pre = nullptr;
             }
@@ -330,7 +476,7 @@ inline int server_main(const std::string& sock, int device)
             reply(j);
             if (tlog) {
                 std::lock_guard<std::mutex> lk(tlog_mu);
-                fprintf(tlog, "%s %s decode %.1f queue %.1f gpu %.1f files %.1f reply %.1f total %.1f ms\n", j->workdir.c_str(), j->read_ahead ? "ahead" : "demand", (j->t_decoded - j->t_accept) * 1e3,
+                fprintf(tlog, "%s %s decode %.1f queue %.1f gpu %.1f files %.1f reply %.1f total %.1f ms\n", j->workdir.c_str(), j->computed_ahead ? "computed" : j->read_ahead ? "ahead" : "demand", (j->t_decoded - j->t_accept) * 1e3,
                         (j->t_submit - j->t_decoded) * 1e3, (j->t_collected - j->t_submit) * 1e3, (j->t_written - j->t_collected) * 1e3,
                         (Timer::now() - j->t_written) * 1e3, (Timer::now() - j->t_accept) * 1e3);
                 fflush(tlog);
@@ -371,7 +517,11 @@ inline int server_main(const std::string& sock, int device)
     std::vector<FrameJob*> done;
     std::deque<ServerJob*> ahead;                                  // staged (pictures on their way to the GPU), not yet submitted; all of `cur`
     auto hand_over = [&]() {
-        for (FrameJob* f : done) towrite.push(static_cast<ServerJob*>(f));
+        for (FrameJob* f : done) {
+            ServerJob* sj = static_cast<ServerJob*>(f);
+            if (std::shared_ptr<RaEntry> e = sj->spec) readahead.computed_now(e);      // nobody's yet: it waits, complete, for its caller (ReadAhead owns it)
+            else towrite.push(sj);
+        }
         done.clear();
     };
     auto submit_oldest = [&]() {
@@ -379,7 +529,8 @@ inline int server_main(const std::string& sock, int device)
         ahead.pop_front();
         // few callers (wasscli's four): each frame is handed out as early as possible; callers queueing up behind the GPU (the menu's
         // "number of parallel workers" raised): two frames deep, the GPU never waits for this thread
-        cur->pl->set_max_pending(deep_at > 0 && (int)(ahead.size() + ready.size()) + 1 >= deep_at ? 2 : 1);
+        // -- and with frames being computed ahead of their callers (speculation) nobody waits for a frame's GPU time at all: two deep, always
+        cur->pl->set_max_pending((deep_at > 0 && (int)(ahead.size() + ready.size()) + 1 >= deep_at) || j->computed_ahead || spec_q.size() > 0 ? 2 : 1);
         cur->pl->submit(*j, done);
         if (!cur->debug) { j->env.left = Image(); j->env.right = Image(); }   // the pictures are in the pinned ring now
         hand_over();
@@ -406,6 +557,10 @@ inline int server_main(const std::string& sock, int device)
         if (ready.pop(j, !ahead.empty() ? 0 : pending ? 2 : 250)) {
             take(j);
             if (ahead.size() < 3 && ready.size() > 0) continue;       // more callers waiting: their pictures first
+        } else if (ahead.empty() && spec_live.load() < spec_max) {
+            // no caller's frame is waiting: one that was prepared ahead of its caller (speculation)
+            std::shared_ptr<RaEntry> e;
+            while (spec_q.pop(e, 0)) if (ServerJob* sj = readahead.to_gpu(e)) { ++spec_live; sj->counted = true; take(sj); break; }
         }
         if (!ahead.empty()) { submit_oldest(); continue; }
         if (pending) { cur->pl->flush(done); hand_over(); }
@@ -423,14 +578,18 @@ inline int server_main(const std::string& sock, int device)
         if (ready.pop(j, 50)) { take(j); submit_oldest(); }
         else drain();
     }
+    drain();
+    readahead.close();                                             // (frames computed ahead and never asked for give their output sets back)
     ready.close();
     towrite.close();
-    readahead.close();
+    spec_q.close();
     for (auto& t : pool) t.join();
     pipes.clear();
     if (tlog) {
         fprintf(tlog, "read-ahead: %llu frames decoded before they were asked for, %llu on demand, %llu decoded early and changed since\n",
                 (unsigned long long)readahead.hits.load(), (unsigned long long)readahead.misses.load(), (unsigned long long)readahead.stale.load());
+        fprintf(tlog, "speculation: %llu frames computed before they were asked for, %llu prepared, %llu dropped unclaimed\n",
+                (unsigned long long)readahead.computed.load(), (unsigned long long)readahead.prepared.load(), (unsigned long long)readahead.dropped.load());
         fclose(tlog);
     }
     return 0;
