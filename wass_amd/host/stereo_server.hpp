@@ -348,6 +348,7 @@ inline int server_main(const std::string& sock, int device)
     if (const char* e = getenv("WASS_SERVER_DECODE")) ndec = std::max(1, atoi(e));
     if (const char* e = getenv("WASS_SERVER_WRITERS")) nwr = std::max(1, atoi(e));
     int nra = 2;                                                   // read-ahead threads (each decodes the two pictures of a workdir side by side)
+    if (const char* e = getenv("WASS_SERVER_RA_THREADS")) nra = std::max(1, std::min(16, atoi(e)));
     ReadAhead readahead;
     if (const char* e = getenv("WASS_SERVER_READAHEAD")) readahead.depth = std::max(0, atoi(e));
     if (const char* e = getenv("WASS_SERVER_SPECULATE")) readahead.spec_depth = std::max(0, atoi(e));
