@@ -23,6 +23,7 @@ Prints ONE JSON line (rank 0) with BASELINE.json's metric plus
   wasscli_unchanged     -- 4 concurrent `wass_stereo <config> <workdir>` processes (what wasscli starts, unedited) over a config-B
                            sequence, served by the per-GPU resident worker the first of them starts; `parallel_8`: the same with eight
                            (wasscli's menu setting); `server_ms_per_call`: where a call's time went inside the server
+                           `one_caller_at_a_time`: a plain loop of calls (matlab/run_wass.m);
                            `with_debug_pictures`: the same with the reference's eight debug pictures per frame (its default), rendered and
                            JPEG-coded on the device
   mode_5path            -- config B in the mode the reference runs (MODE_SGBM, wass_stereo.cpp:775-777): pairs/s of the whole
@@ -463,6 +464,15 @@ def wasscli_unchanged_record(ndirs: int, frames: int = 8, replicate: int = 12, p
             rec["parallel_%d" % (2 * parallel)]["server_ms_per_call"] = {k: med(k) for k in ("decode", "queue", "gpu", "files", "total")}
         except Exception:
             pass
+        # one call after the other, what matlab/run_wass.m:242-246 and test/test_pipeline.m:141-143 do: the worker computes the next frames
+        # while the caller is between two calls
+        if parallel > 1:
+            ns = min(n - 1, 40)
+            t1 = time.perf_counter()
+            res1 = [one(i, env) for i in range(1, ns + 1)]
+            t2 = time.perf_counter()
+            rec["one_caller_at_a_time"] = {"pairs_per_sec": round(ns / (t2 - t1), 2), "calls": ns, "failed_calls": len([1 for rc, _, _ in res1 if rc != 0]),
+                                           "median_call_s": round(sorted(s for _, s, _ in res1)[ns // 2], 4)}
         # the reference's own default: its eight debug pictures per frame (cv::imwrite, unconditional) -- here rendered and JPEG-coded on the
         # device (csrc/jpeg.hip); the numbers above are with WASS_DEBUG_IMAGES=0
         if not debug_images:

@@ -72,7 +72,7 @@ struct ServerJob : FrameJob {
 // used only if both files still have the inode, size and modification time they had before AND after they were read; anything else
 // (and any workdir nobody predicted) is decoded on demand, as before.  WASS_SERVER_READAHEAD=<n> workdirs (default 6, 0 = off).
 //
-// ---- speculation (WASS_SERVER_SPECULATE=<n>, default 3, 0 = off).  Those workdirs are not only decoded: a frame job is PREPARED for each
+// ---- speculation (WASS_SERVER_SPECULATE=<n>, default 5, 0 = off).  Those workdirs are not only decoded: a frame job is PREPARED for each
 // (calibration, rectification's decisions; the small files prepare() writes are kept in memory, FrameJob::deferred) and, whenever no
 // caller's frame is waiting, sent through the GPU chain -- up to n frames may be complete and waiting for their callers.  Nothing touches the workdir until its caller arrives; then the
 // inputs are checked (both pictures and the four calibration files: inode, size, mtime as before AND after they were read; same
@@ -115,7 +115,7 @@ struct ReadAhead {
     std::deque<std::shared_ptr<Entry>> todo;
     std::map<std::string, int> seen;                   // requests per sequence directory
     int depth = 6;
-    int spec_depth = 3;                                // > 0: they are also prepared as frame jobs, and this many may be computed and waiting for their callers
+    int spec_depth = 5;                                // > 0: they are also prepared as frame jobs, and this many may be computed and waiting for their callers
     size_t cap = 16;
     bool closed = false;
     std::atomic<uint64_t> hits{ 0 }, misses{ 0 }, stale{ 0 }, computed{ 0 }, prepared{ 0 }, dropped{ 0 };
@@ -352,7 +352,9 @@ inline int server_main(const std::string& sock, int device)
     ReadAhead readahead;
     if (const char* e = getenv("WASS_SERVER_READAHEAD")) readahead.depth = std::max(0, atoi(e));
     if (const char* e = getenv("WASS_SERVER_SPECULATE")) readahead.spec_depth = std::max(0, atoi(e));
-    const int spec_max = std::max(1, std::min(8, readahead.spec_depth));   // frames computed ahead and not yet claimed (each holds an output set)
+    const int spec_max = std::max(1, std::min(8, readahead.spec_depth));   // frames staged, on the GPU or computed ahead and not yet claimed (the last two kinds hold an output set)
+    int spec_stage = 3;                                            // of which so many may be staged (pictures uploaded) in front of the GPU
+    if (const char* e = getenv("WASS_SERVER_SPEC_STAGE")) spec_stage = std::max(1, std::min(3, atoi(e)));
     int deep_at = 2;                                               // callers waiting behind the GPU from which the chain runs two frames deep
     if (const char* e = getenv("WASS_SERVER_DEEP_AT")) deep_at = std::max(0, atoi(e));
     // WASS_SERVER_TIMING=<file>: one line per frame -- where a caller's waiting time went (decode, queue, GPU, files)
@@ -558,10 +560,13 @@ inline int server_main(const std::string& sock, int device)
         if (ready.pop(j, !ahead.empty() ? 0 : pending ? 2 : 250)) {
             take(j);
             if (ahead.size() < 3 && ready.size() > 0) continue;       // more callers waiting: their pictures first
-        } else if (ahead.empty() && spec_live.load() < spec_max) {
-            // no caller's frame is waiting: one that was prepared ahead of its caller (speculation)
+        } else if ((int)ahead.size() < spec_stage && spec_live.load() < spec_max) {
+            // no caller's frame is waiting: frames that were prepared ahead of their callers (speculation) -- staged like callers' frames,
+            // up to two ahead of the one being submitted (an upload enqueued behind the previous frame's downloads waits for that frame's
+            // tail: staged one at a time the speculative chain ran at 96 frames/s where callers' frames run at 114)
             std::shared_ptr<RaEntry> e;
-            while (spec_q.pop(e, 0)) if (ServerJob* sj = readahead.to_gpu(e)) { ++spec_live; sj->counted = true; take(sj); break; }
+            while ((int)ahead.size() < spec_stage && spec_live.load() < spec_max && spec_q.pop(e, 0))
+                if (ServerJob* sj = readahead.to_gpu(e)) { ++spec_live; sj->counted = true; take(sj); }
         }
         if (!ahead.empty()) { submit_oldest(); continue; }
         if (pending) { cur->pl->flush(done); hand_over(); }
