@@ -433,3 +433,32 @@ def test_frames_computed_ahead_of_their_callers_are_the_frames_of_in_process_run
     rows = {l.split()[0].rstrip("/").rsplit("/", 1)[1]: l.split()[1] for l in tlog.read_text().splitlines() if " total " in l}
     assert rows["%06d_wd" % swapped] == "demand"
     assert sum(1 for v in rows.values() if v == "computed") >= n // 2, rows
+
+
+def test_speculation_on_a_multi_gpu_node_follows_each_servers_stride(cli, tmp_path):
+    """Two pretended GPUs, speculation on: the server of GPU g prepares g + 2, g + 4, ... ahead (never its neighbour's frames), hands
+    them to their callers and leaves the workdirs nobody asked for untouched."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the no-GPU behaviour is tested on the build container")
+    seq, cfg = _seq(tmp_path, 12)
+    sock = tmp_path / "sock"
+    sock.mkdir()
+    tlog = tmp_path / "timing.log"
+    env = _env(sock, WASS_DEBUG_IMAGES="0", WASS_SERVER_TIMING=str(tlog), WASS_NUM_GPUS="2")
+    env.pop("WASS_GPU_DEVICE", None)
+    before = sorted(os.listdir(seq / "000011_wd"))
+    for i in range(8):
+        r = subprocess.run([cli, cfg, str(seq / ("%06d_wd" % i))], capture_output=True, text=True, env=env)
+        assert r.returncode == 255 and "no usable MI355X GPU" in r.stdout and ("%06d_wd" % i) in r.stdout
+        time.sleep(0.15)
+    for i in (8, 9, 10, 11):
+        assert sorted(os.listdir(seq / ("%06d_wd" % i))) == before, i      # prepared (and failed on the missing GPU) in memory only
+    assert len(_servers(sock)) == 2
+    _wait_gone(sock)
+    text = tlog.read_text()
+    rows = {l.split()[0].rsplit("/", 1)[1]: l.split()[1] for l in text.splitlines() if " total " in l}
+    assert [rows["%06d_wd" % i] for i in range(8)] == ["demand"] * 4 + ["computed"] * 4
+    assert text.count("speculation: 2 frames computed before they were asked for") == 2 and text.count("dropped unclaimed") == 2
+    for i in (0, 4):                                                    # on demand or ahead: the same files
+        assert sorted(os.listdir(seq / ("%06d_wd" % i))) == sorted(os.listdir(seq / "000001_wd"))
