@@ -320,7 +320,14 @@ def make_sequence(tmp: str, frames: int, replicate: int, ndirs: int):
     for i in range(frames):
         wd = os.path.join(seq, "%06d_wd" % i)
         os.makedirs(os.path.join(wd, "undistorted"))
-        right, left = [t.cpu().numpy() for t in synth.make_pair_torch(w, h, D, frame_idx=700000 + i)]
+        # (on the GPU when there is one: float64 sines over 5 megapixels take seconds on the host's cores, and torch starts a thread per
+        # hardware thread it sees -- 256 on the pool's boxes, whose cgroup grants 16)
+        try:
+            import torch
+            dev = "cuda" if torch.cuda.is_available() else "cpu"
+            right, left = [t.cpu().numpy() for t in synth.make_pair_torch(w, h, D, frame_idx=700000 + i, device=dev)]
+        except RuntimeError:
+            right, left = [t.cpu().numpy() for t in synth.make_pair_torch(w, h, D, frame_idx=700000 + i)]
         write_png(os.path.join(wd, "undistorted", "00000000.png"), left)
         write_png(os.path.join(wd, "undistorted", "00000001.png"), right)
         write_xml(os.path.join(wd, "intrinsics_00000000.xml"), "intr", rig["K_left"])
