@@ -160,11 +160,12 @@ struct ReadAhead {
         ServerJob* job = nullptr;            // prepared ahead (computed = false: goes to the GPU queue) or computed ahead (goes to the writers)
         bool computed = false;
     };
-    bool inputs_unchanged(const Entry& e, const std::string& wd) const
+    // the files an entry was made from are still those files (with_calib: a frame job also depends on the four calibration files)
+    bool inputs_unchanged(const Entry& e, const std::string& wd, bool with_calib) const
     {
         if (!e.valid) return false;
         for (int k = 0; k < 2; ++k) if (!(e.sig[k] == FileSig::of(pic(wd, k)))) return false;
-        if (e.job) for (int k = 0; k < 4; ++k) if (!(e.calib[k] == FileSig::of(calib_file(wd, k)))) return false;
+        if (with_calib) for (int k = 0; k < 4; ++k) if (!(e.calib[k] == FileSig::of(calib_file(wd, k)))) return false;
         return true;
     }
     // (mu held) an entry leaves the cache for good: what it owns goes back
@@ -189,10 +190,13 @@ struct ReadAhead {
             auto it = by_dir.find(wd);
             if (it != by_dir.end()) {
                 mine = it->second;
+                const std::shared_ptr<Entry> mine0 = mine;
                 if (mine->state == QUEUED) { mine->state = TAKEN; mine = nullptr; }          // not started: this thread decodes it itself, now
                 else cv.wait(lk, [&]() { return (mine->state != RUNNING && mine->state != ONGPU) || closed; });   // (a frame on the GPU: a few ms)
-                by_dir.erase(wd);
-                for (auto o = order.begin(); o != order.end(); ++o) if ((*o)->workdir == wd) { order.erase(o); break; }
+                // (by identity: while this thread waited, the entry may have been evicted and the workdir predicted afresh)
+                auto again = by_dir.find(wd);
+                if (again != by_dir.end() && again->second == mine0) by_dir.erase(again);
+                for (auto o = order.begin(); o != order.end(); ++o) if (*o == mine0) { order.erase(o); break; }
             }
             const double now = Timer::now();
             recent.emplace_back(wd, now);
@@ -230,9 +234,7 @@ struct ReadAhead {
                 mine->job = nullptr;
                 const bool same = !job || (mine->pe == pe && mine->cfgpath == cfgpath);
                 lk.unlock();
-                mine->job = job;                                    // (inputs_unchanged looks at the calibration files only for entries with a frame job)
-                const bool fresh = same && inputs_unchanged(*mine, wd);
-                mine->job = nullptr;
+                const bool fresh = same && inputs_unchanged(*mine, wd, job != nullptr);
                 lk.lock();
                 if (!fresh) { ++stale; if (job) { ++dropped; if (drop_job) drop_job(job); } mine = nullptr; }
                 else if (job) { c.job = job; c.computed = was == COMPUTED; }
@@ -278,6 +280,7 @@ struct ReadAhead {
             }
             {
                 std::lock_guard<std::mutex> lk(mu);
+                if (closed && job) { delete job; job = nullptr; }                           // (the server is going: nobody will claim or drop it)
                 e->job = job;
                 e->state = job ? PREPARED : DONE;
                 if (job) job->spec = e;
