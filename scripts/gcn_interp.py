@@ -1,0 +1,626 @@
+#!/usr/bin/env python3
+"""scripts/gcn_interp.py -- a small in-order interpreter for the gfx9-family ISA subset the chain kernels compile to (one wave,
+64 lanes, numpy), written to look at the round-3 miscompile of k_pair<2, 8, 1> WITHOUT a GPU (NOTES/traps.md): two builds of one
+kernel are run on the same random inputs and their outputs compared.  Everything executes in program order and completes at once
+(`s_waitcnt`, `s_nop` are no-ops): what it can show is a LOGICAL difference between two listings -- not a missing wait or a
+hardware hazard.  It knows only the ~80 opcodes those kernels use and raises on anything else.
+
+    hipcc --offload-arch=gfx950 -O3 ... --cuda-device-only -S sgm_aggregate.hip -o a.s
+    python scripts/gcn_interp.py pair a.s b.s            # k_pair<2, 8, 1>: both listings, chains of 1 .. 4 segments, compare S
+"""
+from __future__ import annotations
+
+import re
+import sys
+
+import numpy as np
+
+M32 = 0xFFFFFFFF
+LANES = np.arange(64)
+
+
+class Unknown(Exception):
+    pass
+
+
+def parse_kernel(path, prefix):
+    s = open(path).read().split("\n")
+    start = [i for i, l in enumerate(s) if l.startswith(prefix) and ":" in l][0]
+    end = [i for i in range(start, len(s)) if s[i].startswith(".Lfunc_end")][0]
+    prog, labels = [], {}
+    for l in s[start + 1:end]:
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if m:
+            labels[m.group(1)] = len(prog)
+            continue
+        t = l.split(";")[0].strip()
+        if not l.startswith("\t") or not t or t.startswith("."):
+            continue
+        op, _, rest = t.partition(" ")
+        rest = rest.strip()
+        # split operands at top-level commas (not inside [...])
+        args, depth, cur = [], 0, ""
+        for ch in rest:
+            if ch == "[":
+                depth += 1
+            if ch == "]":
+                depth -= 1
+            if ch == "," and depth == 0:
+                args.append(cur.strip())
+                cur = ""
+            else:
+                cur += ch
+        if cur.strip():
+            args.append(cur.strip())
+        # the last operand may carry modifiers separated by spaces
+        mods = {}
+        if args:
+            toks = re.findall(r"[^\s\[]+(?:\[[^\]]*\])?", args[-1])
+            args[-1] = toks[0]
+            for tk in toks[1:]:
+                if ":" in tk:
+                    k, v = tk.split(":", 1)
+                    mods[k] = v
+                else:
+                    mods[tk] = True
+        prog.append((op, args, mods, t))
+    return prog, labels
+
+
+class Wave:
+    def __init__(self, mem: np.ndarray, lds_bytes=65536):
+        self.s = np.zeros(128, np.uint64)           # 32-bit values kept in 64-bit slots
+        self.v = np.zeros((256, 64), np.uint64)
+        self.vcc = 0
+        self.exec = (1 << 64) - 1
+        self.scc = 0
+        self.mem = mem                              # flat byte array = the device's address space (addresses are offsets)
+        self.lds = np.zeros(lds_bytes, np.uint8)
+        self.trace = None
+
+    # ---- scalar operands
+    def rs(self, a):
+        if a == "vcc":
+            return self.vcc
+        if a == "exec":
+            return self.exec
+        if a == "scc":
+            return self.scc
+        m = re.match(r"^s(\d+)$", a)
+        if m:
+            return int(self.s[int(m.group(1))])
+        m = re.match(r"^s\[(\d+):(\d+)\]$", a)
+        if m:
+            lo, hi = int(m.group(1)), int(m.group(2))
+            val = 0
+            for k in range(hi, lo - 1, -1):
+                val = (val << 32) | int(self.s[k])
+            return val
+        return self.lit(a)
+
+    @staticmethod
+    def lit(a):
+        try:
+            return int(a, 0)
+        except ValueError:
+            raise Unknown("operand " + a)
+
+    def ws(self, a, val):
+        if a == "vcc":
+            self.vcc = val & ((1 << 64) - 1)
+            return
+        if a == "exec":
+            self.exec = val & ((1 << 64) - 1)
+            return
+        m = re.match(r"^s(\d+)$", a)
+        if m:
+            self.s[int(m.group(1))] = val & M32
+            return
+        m = re.match(r"^s\[(\d+):(\d+)\]$", a)
+        if m:
+            lo, hi = int(m.group(1)), int(m.group(2))
+            for k in range(lo, hi + 1):
+                self.s[k] = val & M32
+                val >>= 32
+            return
+        raise Unknown("scalar destination " + a)
+
+    # ---- vector operands (a lane vector of uint64 holding 32-bit values; 64-bit forms return a Python-int-safe uint64 vector)
+    def rv(self, a):
+        m = re.match(r"^v(\d+)$", a)
+        if m:
+            return self.v[int(m.group(1))].copy()
+        if re.match(r"^(s\d+|vcc|exec|s\[)", a):
+            return np.full(64, self.rs(a) & M32, np.uint64)
+        return np.full(64, self.lit(a) & M32, np.uint64)
+
+    def rv64(self, a):
+        m = re.match(r"^v\[(\d+):(\d+)\]$", a)
+        if m:
+            lo = int(m.group(1))
+            return self.v[lo] | (self.v[lo + 1] << np.uint64(32))
+        m = re.match(r"^s\[(\d+):(\d+)\]$", a)
+        if m:
+            return np.full(64, self.rs(a), np.uint64)
+        return np.full(64, self.lit(a) & ((1 << 64) - 1), np.uint64)
+
+    def mask(self):
+        return ((self.exec >> LANES.astype(object)) & 1).astype(bool) if False else np.array([(self.exec >> i) & 1 for i in range(64)], bool)
+
+    def wv(self, a, val, mask=None):
+        if mask is None:
+            mask = self.mask()
+        m = re.match(r"^v(\d+)$", a)
+        if m:
+            r = int(m.group(1))
+            self.v[r][mask] = (val & np.uint64(M32))[mask]
+            return
+        m = re.match(r"^v\[(\d+):(\d+)\]$", a)
+        if m:
+            lo, hi = int(m.group(1)), int(m.group(2))
+            if isinstance(val, list):
+                for k, part in enumerate(val):
+                    self.v[lo + k][mask] = (part & np.uint64(M32))[mask]
+            else:
+                for k in range(hi - lo + 1):
+                    self.v[lo + k][mask] = ((val >> np.uint64(32 * k)) & np.uint64(M32))[mask]
+            return
+        raise Unknown("vector destination " + a)
+
+    # ---- memory
+    def ld(self, addr, nbytes):
+        return int.from_bytes(self.mem[addr:addr + nbytes].tobytes(), "little") if addr + nbytes <= len(self.mem) else 0
+
+    def ld32v(self, addrs, ndw, mask):
+        out = [np.zeros(64, np.uint64) for _ in range(ndw)]
+        for l in range(64):
+            if mask[l]:
+                a = int(addrs[l])
+                if a < 0 or a + 4 * ndw > len(self.mem):
+                    raise Unknown("load outside the simulated memory: 0x%x" % a)
+                w = np.frombuffer(self.mem[a:a + 4 * ndw].tobytes(), np.uint32)
+                for k in range(ndw):
+                    out[k][l] = w[k]
+        return out
+
+    def st32v(self, addrs, vals, mask):
+        for l in range(64):
+            if mask[l]:
+                a = int(addrs[l])
+                if a < 0 or a + 4 * len(vals) > len(self.mem):
+                    raise Unknown("store outside the simulated memory: 0x%x" % a)
+                for k, part in enumerate(vals):
+                    self.mem[a + 4 * k:a + 4 * k + 4] = np.frombuffer(np.uint32(int(part[l]) & M32).tobytes(), np.uint8)
+
+
+def pk(fn, a, b):
+    lo = fn(a & np.uint64(0xFFFF), b & np.uint64(0xFFFF)) & np.uint64(0xFFFF)
+    hi = fn((a >> np.uint64(16)) & np.uint64(0xFFFF), (b >> np.uint64(16)) & np.uint64(0xFFFF)) & np.uint64(0xFFFF)
+    return lo | (hi << np.uint64(16))
+
+
+def opsel(w: Wave, args, mods):
+    """src0, src1 of a packed op with op_sel_hi applied (default [1,1]: the high half comes from the high half)."""
+    a, b = w.rv(args[1]), w.rv(args[2])
+    hi = mods.get("op_sel_hi", "[1,1]").strip("[]").split(",")
+    if "op_sel" in mods:
+        raise Unknown("op_sel")
+    if hi[0] == "0":
+        a = (a & np.uint64(0xFFFF)) | ((a & np.uint64(0xFFFF)) << np.uint64(16))
+    if hi[1] == "0":
+        b = (b & np.uint64(0xFFFF)) | ((b & np.uint64(0xFFFF)) << np.uint64(16))
+    return a, b
+
+
+def dpp_src(w: Wave, src, mods):
+    """(value per lane, valid per lane) of a DPP source"""
+    val = np.zeros(64, np.uint64)
+    ok = np.ones(64, bool)
+    if "quad_perm" in mods:
+        p = [int(x) for x in mods["quad_perm"].strip("[]").split(",")]
+        idx = (LANES & ~3) + np.array([p[i & 3] for i in range(64)])
+    elif "row_mirror" in mods:
+        idx = (LANES & ~15) + (15 - (LANES & 15))
+    elif "row_half_mirror" in mods:
+        idx = (LANES & ~7) + (7 - (LANES & 7))
+    elif "row_bcast" in mods:
+        n = int(mods["row_bcast"])
+        if n == 15:
+            idx = (LANES & ~15) - 1
+            ok = LANES >= 16
+        else:
+            idx = (LANES & ~31) - 1
+            ok = LANES >= 32
+        idx = np.where(ok, idx, 0)
+    elif "wave_shr" in mods:
+        idx = LANES - 1
+        ok = LANES >= 1
+        idx = np.where(ok, idx, 0)
+    elif "wave_shl" in mods:
+        idx = LANES + 1
+        ok = LANES <= 62
+        idx = np.where(ok, idx, 0)
+    elif "row_shr" in mods:
+        n = int(mods["row_shr"])
+        ok = (LANES & 15) >= n
+        idx = np.where(ok, LANES - n, 0)
+    elif "row_shl" in mods:
+        n = int(mods["row_shl"])
+        ok = (LANES & 15) + n <= 15
+        idx = np.where(ok, LANES + n, 0)
+    else:
+        raise Unknown("dpp control " + str(mods))
+    val = src[idx]
+    # a source lane that is disabled in EXEC counts as invalid too
+    em = w.mask()
+    ok = ok & em[idx]
+    rm, bm = int(mods.get("row_mask", "0xf"), 0), int(mods.get("bank_mask", "0xf"), 0)
+    en = np.array([((rm >> (l >> 4)) & 1) and ((bm >> ((l >> 2) & 3)) & 1) for l in range(64)], bool)
+    if mods.get("bound_ctrl") in ("0", "1", True):
+        val = np.where(ok, val, 0).astype(np.uint64)
+        ok = np.ones(64, bool)
+    return val, ok & en
+
+
+def sat_add16(a, b):
+    return np.minimum(a + b, np.uint64(0xFFFF))
+
+
+def run(prog, labels, w: Wave, max_steps=60_000):
+    pc, steps = 0, 0
+    U64 = np.uint64
+    while True:
+        steps += 1
+        if steps > max_steps:
+            raise Unknown("step limit")
+        op, a, mods, text = prog[pc]
+        pc += 1
+        if w.trace is not None:
+            w.trace(pc - 1, text)
+        # ------------------------------------------------ no-ops / control
+        if op in ("s_nop", "s_waitcnt", "s_barrier", "s_setprio", "s_sleep"):
+            continue
+        if op == "s_endpgm":
+            return steps
+        if op == "s_branch":
+            pc = labels[a[0]]
+            continue
+        if op.startswith("s_cbranch_"):
+            c = op[len("s_cbranch_"):]
+            take = {"scc0": w.scc == 0, "scc1": w.scc == 1, "vccz": w.vcc == 0, "vccnz": w.vcc != 0, "execz": w.exec == 0, "execnz": w.exec != 0}[c]
+            if take:
+                pc = labels[a[0]]
+            continue
+        # ------------------------------------------------ scalar memory
+        if op.startswith("s_load_dword"):
+            n = {"s_load_dword": 1, "s_load_dwordx2": 2, "s_load_dwordx4": 4, "s_load_dwordx8": 8, "s_load_dwordx16": 16}[op]
+            base = w.rs(a[1]) + w.rs(a[2]) + int(mods.get("offset", "0"), 0)
+            lo = int(re.match(r"^s\[?(\d+)", a[0]).group(1))
+            for k in range(n):
+                w.s[lo + k] = w.ld(base + 4 * k, 4)
+            continue
+        # ------------------------------------------------ scalar ALU
+        if op.startswith("s_"):
+            sfx = op[2:]
+            if sfx in ("mov_b32", "mov_b64"):
+                w.ws(a[0], w.rs(a[1]))
+            elif sfx == "movk_i32":
+                k16 = w.lit(a[1]) & 0xFFFF
+                w.ws(a[0], (k16 - 0x10000 if k16 & 0x8000 else k16) & M32)
+            elif sfx in ("add_i32", "add_u32", "sub_i32", "sub_u32", "addc_u32", "subb_u32", "addk_i32"):
+                x, y = (w.rs(a[0]), w.lit(a[1])) if sfx == "addk_i32" else (w.rs(a[1]), w.rs(a[2]))
+                x &= M32
+                y &= M32
+                if sfx in ("add_u32", "addc_u32"):
+                    r = x + y + (w.scc if sfx == "addc_u32" else 0)
+                    w.scc = int(r > M32)
+                elif sfx in ("sub_u32", "subb_u32"):
+                    r = x - y - (w.scc if sfx == "subb_u32" else 0)
+                    w.scc = int(r < 0)
+                else:
+                    sx, sy = x - (1 << 32) * (x >> 31), y - (1 << 32) * (y >> 31)
+                    r = sx + sy if sfx != "sub_i32" else sx - sy
+                    w.scc = int(r > 0x7FFFFFFF or r < -0x80000000)
+                w.ws(a[0], r & M32)
+            elif sfx in ("mul_i32",):
+                w.ws(a[0], (w.rs(a[1]) * w.rs(a[2])) & M32)
+            elif sfx == "mul_hi_u32":
+                w.ws(a[0], ((w.rs(a[1]) & M32) * (w.rs(a[2]) & M32)) >> 32)
+            elif sfx == "mul_hi_i32":
+                x, y = w.rs(a[1]) & M32, w.rs(a[2]) & M32
+                x -= (1 << 32) * (x >> 31)
+                y -= (1 << 32) * (y >> 31)
+                w.ws(a[0], ((x * y) >> 32) & M32)
+            elif sfx in ("lshl_b32", "lshr_b32", "ashr_i32", "lshl_b64", "lshr_b64"):
+                x, sh = w.rs(a[1]), w.rs(a[2])
+                if sfx == "lshl_b32":
+                    r = (x << (sh & 31)) & M32
+                elif sfx == "lshr_b32":
+                    r = (x & M32) >> (sh & 31)
+                elif sfx == "ashr_i32":
+                    x &= M32
+                    x -= (1 << 32) * (x >> 31)
+                    r = (x >> (sh & 31)) & M32
+                elif sfx == "lshl_b64":
+                    r = (x << (sh & 63)) & ((1 << 64) - 1)
+                else:
+                    r = (x & ((1 << 64) - 1)) >> (sh & 63)
+                w.ws(a[0], r)
+                w.scc = int(r != 0)
+            elif sfx in ("and_b32", "or_b32", "xor_b32", "and_b64", "or_b64", "xor_b64", "andn2_b64", "orn2_b64", "andn2_b32"):
+                x, y = w.rs(a[1]), w.rs(a[2])
+                full = M32 if sfx.endswith("b32") else (1 << 64) - 1
+                x &= full
+                y &= full
+                r = {"and": x & y, "or": x | y, "xor": x ^ y, "andn2": x & ~y, "orn2": x | (~y & full)}[sfx.split("_")[0]] & full
+                w.ws(a[0], r)
+                w.scc = int(r != 0)
+            elif sfx in ("cselect_b32", "cselect_b64"):
+                w.ws(a[0], w.rs(a[1]) if w.scc else w.rs(a[2]))
+            elif sfx.startswith("cmp_"):
+                _, cond, ty = sfx.split("_")
+                x, y = w.rs(a[0]), w.rs(a[1])
+                bits = 64 if ty == "u64" else 32
+                full = (1 << bits) - 1
+                x &= full
+                y &= full
+                if ty[0] == "i":
+                    x -= (1 << bits) * (x >> (bits - 1))
+                    y -= (1 << bits) * (y >> (bits - 1))
+                w.scc = int({"eq": x == y, "lg": x != y, "gt": x > y, "ge": x >= y, "lt": x < y, "le": x <= y}[cond])
+            elif sfx in ("max_i32", "min_i32", "max_u32", "min_u32"):
+                x, y = w.rs(a[1]) & M32, w.rs(a[2]) & M32
+                if sfx.endswith("i32"):
+                    sx, sy = x - (1 << 32) * (x >> 31), y - (1 << 32) * (y >> 31)
+                else:
+                    sx, sy = x, y
+                first = sx >= sy if sfx.startswith("max") else sx <= sy
+                w.ws(a[0], x if first else y)
+                w.scc = int(first)
+            elif sfx == "pack_ll_b32_b16":
+                w.ws(a[0], (w.rs(a[1]) & 0xFFFF) | ((w.rs(a[2]) & 0xFFFF) << 16))
+            elif sfx == "bitcmp0_b32":
+                w.scc = int(((w.rs(a[0]) >> (w.rs(a[1]) & 31)) & 1) == 0)
+            elif sfx == "bitcmp1_b32":
+                w.scc = int(((w.rs(a[0]) >> (w.rs(a[1]) & 31)) & 1) == 1)
+            elif sfx == "and_saveexec_b64":
+                old = w.exec
+                w.exec = w.rs(a[1]) & old
+                w.ws(a[0], old)
+                w.scc = int(w.exec != 0)
+            elif sfx == "not_b64":
+                r = ~w.rs(a[1]) & ((1 << 64) - 1)
+                w.ws(a[0], r)
+                w.scc = int(r != 0)
+            else:
+                raise Unknown(text)
+            continue
+        # ------------------------------------------------ vector ALU
+        em = w.mask()
+        if op in ("v_mov_b32_e32", "v_mov_b32_e64"):
+            w.wv(a[0], w.rv(a[1]))
+        elif op == "v_mov_b64_e32":
+            w.wv(a[0], w.rv64(a[1]))
+        elif op == "v_mov_b32_dpp":
+            val, ok = dpp_src(w, w.rv(a[1]), mods)
+            w.wv(a[0], val, em & ok)
+        elif op == "v_min_u32_dpp":
+            val, ok = dpp_src(w, w.rv(a[1]), mods)
+            w.wv(a[0], np.minimum(val, w.rv(a[2])), em & ok)
+        elif op in ("v_min_u32_e32", "v_min_u32_e64"):
+            w.wv(a[0], np.minimum(w.rv(a[1]), w.rv(a[2])))
+        elif op in ("v_pk_min_u16", "v_pk_max_u16", "v_pk_add_u16", "v_pk_sub_i16", "v_pk_sub_u16", "v_pk_add_i16"):
+            x, y = opsel(w, a, mods)
+            if op == "v_pk_min_u16":
+                r = pk(np.minimum, x, y)
+            elif op == "v_pk_max_u16":
+                r = pk(np.maximum, x, y)
+            elif op == "v_pk_add_u16":
+                r = pk(sat_add16 if "clamp" in mods else (lambda p, q: p + q), x, y)
+            elif op == "v_pk_sub_u16":
+                r = pk((lambda p, q: np.where(p >= q, p - q, 0).astype(np.uint64)) if "clamp" in mods else (lambda p, q: (p + np.uint64(0x10000) - q)), x, y)
+            elif op == "v_pk_sub_i16":
+                if "clamp" in mods:
+                    raise Unknown(text)
+                r = pk(lambda p, q: (p + np.uint64(0x10000) - q), x, y)
+            else:
+                if "clamp" in mods:
+                    raise Unknown(text)
+                r = pk(lambda p, q: p + q, x, y)
+            w.wv(a[0], r)
+        elif op == "v_alignbit_b32":
+            sh = w.rv(a[3]) & U64(31)
+            w.wv(a[0], (((w.rv(a[1]) << U64(32)) | w.rv(a[2])) >> sh) & U64(M32))
+        elif op == "v_min_u16_sdwa":
+            def sel(x, how):
+                return {"DWORD": x & U64(0xFFFF), "WORD_0": x & U64(0xFFFF), "WORD_1": (x >> U64(16)) & U64(0xFFFF)}[how]
+            if mods.get("dst_sel") != "DWORD" or mods.get("dst_unused") != "UNUSED_PAD":
+                raise Unknown(text)
+            w.wv(a[0], np.minimum(sel(w.rv(a[1]), mods["src0_sel"]), sel(w.rv(a[2]), mods["src1_sel"])))
+        elif op == "v_readlane_b32":
+            w.ws(a[0], int(w.rv(a[1])[w.rs(a[2]) & 63]))
+        elif op == "v_readfirstlane_b32":
+            first = next((l for l in range(64) if em[l]), 0)
+            w.ws(a[0], int(w.rv(a[1])[first]))
+        elif op in ("v_add_u32_e32", "v_add_u32_e64"):
+            w.wv(a[0], (w.rv(a[1]) + w.rv(a[2])) & U64(M32))
+        elif op in ("v_sub_u32_e32", "v_sub_u32_e64"):
+            w.wv(a[0], (w.rv(a[1]) + U64(1 << 32) - w.rv(a[2])) & U64(M32))
+        elif op in ("v_lshlrev_b32_e32", "v_lshlrev_b32_e64"):
+            w.wv(a[0], (w.rv(a[2]) << (w.rv(a[1]) & U64(31))) & U64(M32))
+        elif op in ("v_lshrrev_b32_e32", "v_lshrrev_b32_e64"):
+            w.wv(a[0], (w.rv(a[2]) >> (w.rv(a[1]) & U64(31))) & U64(M32))
+        elif op in ("v_and_b32_e32", "v_and_b32_e64"):
+            w.wv(a[0], w.rv(a[1]) & w.rv(a[2]))
+        elif op in ("v_or_b32_e32", "v_or_b32_e64"):
+            w.wv(a[0], w.rv(a[1]) | w.rv(a[2]))
+        elif op == "v_lshl_or_b32":
+            w.wv(a[0], ((w.rv(a[1]) << (w.rv(a[2]) & U64(31))) | w.rv(a[3])) & U64(M32))
+        elif op == "v_lshl_add_u32":
+            w.wv(a[0], ((w.rv(a[1]) << (w.rv(a[2]) & U64(31))) + w.rv(a[3])) & U64(M32))
+        elif op == "v_lshl_add_u64":
+            w.wv(a[0], (w.rv64(a[1]) << (w.rv(a[2]) & U64(63))) + w.rv64(a[3]))
+        elif op == "v_min_i32_e32" or op == "v_min_i32_e64" or op == "v_max_i32_e32" or op == "v_max_i32_e64":
+            x, y = w.rv(a[1]).astype(np.int64), w.rv(a[2]).astype(np.int64)
+            x = np.where(x >> 31, x - (1 << 32), x)
+            y = np.where(y >> 31, y - (1 << 32), y)
+            r = np.minimum(x, y) if "min" in op else np.maximum(x, y)
+            w.wv(a[0], (r & M32).astype(np.uint64))
+        elif op in ("v_cmp_ne_u32_e64", "v_cmp_eq_u32_e64", "v_cmp_lt_i64_e64", "v_cmp_eq_u32_e32", "v_cmp_ne_u32_e32", "v_cmp_gt_u32_e64", "v_cmp_lt_u32_e64",
+                    "v_cmp_gt_u32_e32", "v_cmp_lt_u32_e32"):
+            e32 = op.endswith("_e32")
+            srcs = a if e32 else a[1:]
+            if "i64" in op:
+                x, y = w.rv64(srcs[0]).astype(np.int64), w.rv64(srcs[1]).astype(np.int64)
+            else:
+                x, y = w.rv(srcs[0]), w.rv(srcs[1])
+            cond = op.split("_")[2]
+            r = {"ne": x != y, "eq": x == y, "lt": x < y, "gt": x > y}[cond]
+            bits = 0
+            for l in range(64):
+                if em[l] and r[l]:
+                    bits |= 1 << l
+            w.ws("vcc" if e32 else a[0], bits)
+        elif op == "v_cndmask_b32_e64":
+            sel = w.rs(a[3])
+            pick = np.array([(sel >> l) & 1 for l in range(64)], bool)
+            w.wv(a[0], np.where(pick, w.rv(a[2]), w.rv(a[1])))
+        elif op == "v_cndmask_b32_e32":
+            pick = np.array([(w.vcc >> l) & 1 for l in range(64)], bool)
+            w.wv(a[0], np.where(pick, w.rv(a[2]), w.rv(a[1])))
+        # ------------------------------------------------ LDS
+        elif op in ("ds_write2st64_b64", "ds_read2st64_b64", "ds_read_b64", "ds_write_b64", "ds_read_b128", "ds_write_b128", "ds_read2_b64", "ds_write2_b64"):
+            base = w.rv(a[0] if op.startswith("ds_write") else a[1])
+            def lds_rw(off, regs, write, ndw):
+                for l in range(64):
+                    if not em[l]:
+                        continue
+                    ad = int(base[l]) + off
+                    for k in range(ndw):
+                        if write:
+                            w.lds[ad + 4 * k:ad + 4 * k + 4] = np.frombuffer(np.uint32(int(w.v[regs + k][l])).tobytes(), np.uint8)
+                        else:
+                            w.v[regs + k][l] = int(np.frombuffer(w.lds[ad + 4 * k:ad + 4 * k + 4].tobytes(), np.uint32)[0])
+            def lo_of(x):
+                return int(re.match(r"^v\[?(\d+)", x).group(1))
+            if op in ("ds_write2st64_b64", "ds_write2_b64"):
+                unit = 512 if "st64" in op else 8
+                lds_rw(int(mods.get("offset0", "0")) * unit, lo_of(a[1]), True, 2)
+                lds_rw(int(mods.get("offset1", "0")) * unit, lo_of(a[2]), True, 2)
+            elif op in ("ds_read2st64_b64", "ds_read2_b64"):
+                unit = 512 if "st64" in op else 8
+                lds_rw(int(mods.get("offset0", "0")) * unit, lo_of(a[0]), False, 2)
+                lds_rw(int(mods.get("offset1", "0")) * unit, lo_of(a[0]) + 2, False, 2)
+            elif op == "ds_read_b64":
+                lds_rw(int(mods.get("offset", "0")), lo_of(a[0]), False, 2)
+            elif op == "ds_write_b64":
+                lds_rw(int(mods.get("offset", "0")), lo_of(a[1]), True, 2)
+            elif op == "ds_read_b128":
+                lds_rw(int(mods.get("offset", "0")), lo_of(a[0]), False, 4)
+            else:
+                lds_rw(int(mods.get("offset", "0")), lo_of(a[1]), True, 4)
+        # ------------------------------------------------ buffer / global
+        elif op.startswith(("buffer_load_dword", "buffer_store_dword")):
+            ndw = {"dword": 1, "dwordx2": 2, "dwordx3": 3, "dwordx4": 4}[op.split("_")[2]]
+            rs = re.match(r"^s\[(\d+):(\d+)\]$", a[2])
+            lo = int(rs.group(1))
+            base = int(w.s[lo]) | ((int(w.s[lo + 1]) & 0xFFFF) << 32)
+            nrec = int(w.s[lo + 2])
+            if (int(w.s[lo + 1]) >> 16) & 0x3FFF:
+                raise Unknown("strided buffer")
+            off = (w.rv(a[1]) if "offen" in mods else np.zeros(64, np.uint64)) + U64(int(mods.get("offset", "0"), 0))
+            soff = w.rs(a[3]) & M32
+            inb = (off + U64(4 * ndw)) <= U64(nrec)          # raw buffer: range check on the offset without soffset
+            addrs = (U64(base) + off + U64(soff))
+            lo_v = int(re.match(r"^v\[?(\d+)", a[0]).group(1))
+            if op.startswith("buffer_load"):
+                vals = w.ld32v(addrs, ndw, em & inb)
+                for k in range(ndw):
+                    w.v[lo_v + k][em & inb] = vals[k][em & inb]
+                    w.v[lo_v + k][em & ~inb] = 0
+            else:
+                w.st32v(addrs, [w.v[lo_v + k] for k in range(ndw)], em & inb)
+        elif op.startswith(("global_load_dword", "global_store_dword")):
+            ndw = {"dword": 1, "dwordx2": 2, "dwordx3": 3, "dwordx4": 4}[op.split("_")[2]]
+            load = op.startswith("global_load")
+            vaddr, saddr = (a[1], a[2]) if load else (a[0], a[2])
+            data = a[0] if load else a[1]
+            if saddr == "off":
+                addrs = w.rv64(vaddr)
+            else:
+                addrs = U64(w.rs(saddr)) + w.rv(vaddr)
+            addrs = addrs + U64(int(mods.get("offset", "0"), 0) & ((1 << 64) - 1))
+            lo_v = int(re.match(r"^v\[?(\d+)", data).group(1))
+            if load:
+                vals = w.ld32v(addrs, ndw, em)
+                for k in range(ndw):
+                    w.v[lo_v + k][em] = vals[k][em]
+            else:
+                w.st32v(addrs, [w.v[lo_v + k] for k in range(ndw)], em)
+        else:
+            raise Unknown(text)
+
+
+# ------------------------------------------------------------------------------------------------------------ the k_pair experiment
+def pair_case(listing, prefix, width1, h, dx, dy, chain, seed, smode_has_S=True, with_endstate=False, NP=2, K=8):
+    """one wave of k_pair<NP, K, 1> on random inputs; returns the S volume afterwards (uint32 view)"""
+    prog, labels = parse_kernel(listing, prefix)
+    rng = np.random.default_rng(seed)
+    VB = 256 * NP
+    npx = width1 * h
+    maxseg = (max(width1, h) + K - 1) // K + 1
+    nchains = 4 * (width1 + h)
+    sizes = {"args": 4096, "C": npx * VB, "S": npx * VB, "ckpt": nchains * maxseg * VB, "mins": nchains * maxseg * K * 2, "sel16": npx * 2, "selkey": npx * 4,
+             "end": nchains * VB}
+    offs, total = {}, 1 << 16
+    for k, n in sizes.items():
+        offs[k] = total
+        total += (n + 4095) & ~4095
+    mem = np.zeros(total + 4096, np.uint8)
+    # costs small enough that nothing saturates differently; any values serve for a comparison of two listings
+    mem[offs["C"]:offs["C"] + sizes["C"]] = np.frombuffer(rng.integers(0, 2000, sizes["C"] // 2, dtype=np.uint16).tobytes(), np.uint8)
+    mem[offs["S"]:offs["S"] + sizes["S"]] = np.frombuffer(rng.integers(0, 3000, sizes["S"] // 2, dtype=np.uint16).tobytes(), np.uint8)
+    mem[offs["ckpt"]:offs["ckpt"] + sizes["ckpt"]] = np.frombuffer(rng.integers(0, 1500, sizes["ckpt"] // 2, dtype=np.uint16).tobytes(), np.uint8)
+    mem[offs["mins"]:offs["mins"] + sizes["mins"]] = np.frombuffer(rng.integers(0, 1500, sizes["mins"] // 2, dtype=np.uint16).tobytes(), np.uint8)
+    mem[offs["end"]:offs["end"] + sizes["end"]] = np.frombuffer(rng.integers(0, 1500, sizes["end"] // 2, dtype=np.uint16).tobytes(), np.uint8)
+    P1, P2 = 7, 150
+    args = np.zeros(0x68, np.uint8)
+    def put(o, val, n):
+        args[o:o + n] = np.frombuffer(int(val).to_bytes(n, "little"), np.uint8)
+    put(0x00, offs["C"], 8); put(0x08, offs["S"], 8); put(0x10, offs["ckpt"], 8); put(0x18, offs["mins"], 8)
+    for i, val in enumerate((width1, h, dx & M32, dy & M32, P1, P2, nchains, maxseg, 256, 0, 10, 1)):
+        put(0x20 + 4 * i, val, 4)
+    put(0x50, offs["sel16"], 8); put(0x58, offs["selkey"], 8); put(0x60, offs["end"] if with_endstate else 0, 8)
+    mem[offs["args"]:offs["args"] + len(args)] = args
+    w = Wave(mem)
+    w.s[0], w.s[1] = offs["args"] & M32, offs["args"] >> 32
+    w.s[2] = chain // 4                         # workgroup id
+    w.v[0] = (chain % 4) * 64 + LANES           # thread id in the workgroup of 256
+    steps = run(prog, labels, w)
+    return np.frombuffer(mem[offs["S"]:offs["S"] + sizes["S"]].tobytes(), np.uint32).copy(), steps
+
+
+def main():
+    if len(sys.argv) < 4 or sys.argv[1] != "pair":
+        sys.exit(__doc__)
+    a, b = sys.argv[2], sys.argv[3]
+    prefix = sys.argv[4] if len(sys.argv) > 4 else "_ZN4wass6k_pairILi2ELi8ELi1EEE"
+    bad = 0
+    for (w1, h, dx, dy) in ((40, 36, 1, 1), (40, 36, -1, 1), (24, 30, 0, 1)):
+        for chain in range(0, 4 * (w1 + h), 5):
+            for end in (False, True):
+                try:
+                    sa, na = pair_case(a, prefix, w1, h, dx, dy, chain, 1234 + chain, with_endstate=end)
+                    sb, nb = pair_case(b, prefix, w1, h, dx, dy, chain, 1234 + chain, with_endstate=end)
+                except Unknown as e:
+                    print("geometry", (w1, h, dx, dy), "chain", chain, "endstate", end, "->", e)
+                    return 2
+                diff = int((sa != sb).sum())
+                bad += diff > 0
+                print("geometry", (w1, h, dx, dy), "chain", chain, "endstate", end, "instructions", na, nb, "S dwords that differ:", diff, flush=True)
+    print("listings disagree on", bad, "cases")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,82 @@
+"""A net under the chain kernels that needs no GPU: the ISA hipcc emits for k_pair is EXECUTED by a small in-order interpreter
+(scripts/gcn_interp.py: one wave, the ~80 opcodes those kernels use) on random inputs, for two differently optimised builds of the
+same source -- the shipped flags, and the same with the machine-sinking pass off.  Two correct builds compute the same S whatever
+the inputs are; the round-3 miscompile of k_pair<2, 8, 1> (NOTES/traps.md: hand-over vectors prefetched into registers that the
+loop body then uses as temporaries) shows up in this comparison on every chain of two or more full segments, while the build with
+the sinking pass off agrees with the fenced build -- the second test rebuilds that source from the history and checks exactly that."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+
+def _listing(src, out, extra=()):
+    from wass_amd import build
+    flags = [f for f in build.FLAGS if f not in ("-fPIC", "-Wall")]
+    cmd = [build.HIPCC, *flags, *extra, "--cuda-device-only", "-S", src, "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return out
+
+
+def _compare(a, b, prefix, cases):
+    import gcn_interp as g
+    out = []
+    for (geom, chain, end) in cases:
+        sa, _ = g.pair_case(a, prefix, *geom, chain, 4242 + chain, with_endstate=end)
+        sb, _ = g.pair_case(b, prefix, *geom, chain, 4242 + chain, with_endstate=end)
+        out.append(int((sa != sb).sum()))
+    return out
+
+
+# (width1, h, dx, dy), chain, split family: chains of four and of two full segments (+ tails)
+CASES = [((40, 36, 1, 1), 2, False), ((40, 36, 1, 1), 23, True)]
+
+
+def test_two_builds_of_the_shipped_pair_kernels_compute_the_same_S(tmp_path):
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "wass_amd", "csrc", "sgm_aggregate.hip")
+    with ThreadPoolExecutor(2) as ex:
+        fa = ex.submit(_listing, src, str(tmp_path / "shipped.s"))
+        fb = ex.submit(_listing, src, str(tmp_path / "nosink.s"), ("-mllvm", "-disable-machine-sink"))
+        a, b = fa.result(), fb.result()
+    for smode in (0, 1):
+        diffs = _compare(a, b, "_ZN4wass6k_pairILi2ELi8ELi%dEEE" % smode, CASES)
+        assert diffs == [0] * len(CASES), (smode, diffs)
+
+
+def test_the_comparison_sees_the_round_3_miscompile(tmp_path):
+    """The round-3 source (4985bc4) without the compiler fence in Rec::load against the same with the sinking pass off."""
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    csrc = tmp_path / "a" / "b" / "csrc"
+    csrc.mkdir(parents=True)
+    (tmp_path / "a" / "include").mkdir()
+    def show(path):
+        r = subprocess.run(["git", "-C", ROOT, "show", "4985bc4:" + path], capture_output=True)
+        if r.returncode != 0:
+            pytest.skip("no history here")
+        return r.stdout
+    for f in ("sgm_aggregate.hip", "sgm_step.h", "common.h"):
+        (csrc / f).write_bytes(show("wass_amd/csrc/" + f))
+    (tmp_path / "a" / "include" / "wass_gpu.h").write_bytes(show("include/wass_gpu.h"))
+    text = (csrc / "sgm_aggregate.hip").read_text()
+    assert 'asm volatile("" ::: "memory");' in text
+    (csrc / "nofence.hip").write_text(text.replace('asm volatile("" ::: "memory");', "/* no fence */", 1))
+    with ThreadPoolExecutor(3) as ex:
+        f0 = ex.submit(_listing, str(csrc / "sgm_aggregate.hip"), str(tmp_path / "fence.s"))
+        f1 = ex.submit(_listing, str(csrc / "nofence.hip"), str(tmp_path / "nofence.s"))
+        f2 = ex.submit(_listing, str(csrc / "nofence.hip"), str(tmp_path / "nofence_nosink.s"), ("-mllvm", "-disable-machine-sink"))
+        fence, nofence, nosink = f0.result(), f1.result(), f2.result()
+    P = "_ZN4wass6k_pairILi2ELi8ELi1EEE"
+    cases = [((40, 36, 1, 1), 20, False), ((40, 36, 1, 1), 26, False)]      # two full segments; one full segment
+    assert _compare(fence, nosink, P, cases) == [0, 0]
+    bad = _compare(fence, nofence, P, cases)
+    assert bad[0] > 0 and bad[1] == 0, bad
