@@ -324,6 +324,9 @@ def run(prog, labels, w: Wave, max_steps=60_000):
                 w.ws(a[0], r & M32)
             elif sfx in ("mul_i32",):
                 w.ws(a[0], (w.rs(a[1]) * w.rs(a[2])) & M32)
+            elif sfx == "mulk_i32":
+                k16 = w.lit(a[1]) & 0xFFFF
+                w.ws(a[0], (w.rs(a[0]) * (k16 - 0x10000 if k16 & 0x8000 else k16)) & M32)
             elif sfx == "mul_hi_u32":
                 w.ws(a[0], ((w.rs(a[1]) & M32) * (w.rs(a[2]) & M32)) >> 32)
             elif sfx == "mul_hi_i32":
@@ -458,6 +461,8 @@ def run(prog, labels, w: Wave, max_steps=60_000):
             w.wv(a[0], ((w.rv(a[1]) << (w.rv(a[2]) & U64(31))) | w.rv(a[3])) & U64(M32))
         elif op == "v_lshl_add_u32":
             w.wv(a[0], ((w.rv(a[1]) << (w.rv(a[2]) & U64(31))) + w.rv(a[3])) & U64(M32))
+        elif op == "v_mad_u64_u32":                 # v[d:d+1], carry-out pair, a, b, c64
+            w.wv(a[0], ((w.rv(a[2]) * w.rv(a[3])) + w.rv64(a[4])))
         elif op == "v_lshl_add_u64":
             w.wv(a[0], (w.rv64(a[1]) << (w.rv(a[2]) & U64(63))) + w.rv64(a[3]))
         elif op == "v_min_i32_e32" or op == "v_min_i32_e64" or op == "v_max_i32_e32" or op == "v_max_i32_e64":
@@ -561,8 +566,61 @@ def run(prog, labels, w: Wave, max_steps=60_000):
             raise Unknown(text)
 
 
+# ------------------------------------------------------------------------------------------------------------ harnesses
+def kernel_case(listing, prefix, buffers, args, chain, seed, outputs):
+    """One wave (wave `chain % 4` of workgroup `chain // 4`) of a chain kernel.  buffers: name -> (bytes, upper bound of the random u16
+    fill or None for zeros); args: list of ("ptr", name | None) / ("i32", value); outputs: buffer names returned (concatenated, as uint32)."""
+    prog, labels = parse_kernel(listing, prefix)
+    rng = np.random.default_rng(seed)
+    offs, total = {"args": 1 << 16}, (1 << 16) + 4096
+    for k, (n, _) in buffers.items():
+        offs[k] = total
+        total += (n + 4095) & ~4095
+    mem = np.zeros(total + 4096, np.uint8)
+    for k, (n, hi) in buffers.items():
+        if hi:
+            mem[offs[k]:offs[k] + n] = np.frombuffer(rng.integers(0, hi, n // 2, dtype=np.uint16).tobytes(), np.uint8)
+    at = 0
+    for kind, val in args:
+        size = 8 if kind == "ptr" else 4
+        at = (at + size - 1) & ~(size - 1)
+        v = (offs[val] if val is not None else 0) if kind == "ptr" else (val & M32)
+        mem[offs["args"] + at:offs["args"] + at + size] = np.frombuffer(int(v).to_bytes(size, "little"), np.uint8)
+        at += size
+    w = Wave(mem)
+    w.s[0], w.s[1] = offs["args"] & M32, offs["args"] >> 32
+    w.s[2] = chain // 4
+    w.v[0] = (chain % 4) * 64 + LANES
+    steps = run(prog, labels, w)
+    return np.concatenate([np.frombuffer(mem[offs[k]:offs[k] + buffers[k][0]].tobytes(), np.uint32) for k in outputs]), steps
+
+
+def _sizes(width1, h, NP, K):
+    VB = 256 * NP
+    npx = width1 * h
+    maxseg = (max(width1, h) + K - 1) // K + 1
+    nchains = 4 * (width1 + h)
+    return VB, npx, maxseg, nchains
+
+
+def ckpt_case(listing, prefix, width1, h, dx, dy, chain, seed, with_endstate=False, NP=2, K=8):
+    """k_ckpt<NP, K>: the forward sweep of a family -- checkpoints, minima, end states"""
+    VB, npx, maxseg, nchains = _sizes(width1, h, NP, K)
+    buffers = {"C": (npx * VB, 2000), "ckpt": (nchains * maxseg * VB, None), "mins": (nchains * maxseg * K * 2, None), "end": (nchains * VB, None)}
+    args = [("ptr", "C"), ("ptr", "ckpt"), ("ptr", "mins")] + [("i32", v) for v in (width1, h, dx, dy, 7, 150, nchains, maxseg)] + [("ptr", "end" if with_endstate else None)]
+    return kernel_case(listing, prefix, buffers, args, chain, seed, ("ckpt", "mins", "end"))
+
+
+def sweep_case(listing, prefix, width1, h, dx, dy, chain, seed, NP=2, K=8):
+    """k_sweep<NP, SMODE, U>, SMODE 0 / 1: one unpaired path of the 5-path mode"""
+    VB, npx, maxseg, nchains = _sizes(width1, h, NP, K)
+    buffers = {"C": (npx * VB, 2000), "S": (npx * VB, 3000), "sel16": (npx * 2, None), "selkey": (npx * 4, None)}
+    args = [("ptr", "C"), ("ptr", "S")] + [("i32", v) for v in (width1, h, dx, dy, 7, 150, nchains, 256, 0, 10, 1)] + [("ptr", "sel16"), ("ptr", "selkey")]
+    return kernel_case(listing, prefix, buffers, args, chain, seed, ("S",))
+
+
 # ------------------------------------------------------------------------------------------------------------ the k_pair experiment
-def pair_case(listing, prefix, width1, h, dx, dy, chain, seed, smode_has_S=True, with_endstate=False, NP=2, K=8):
+def pair_case(listing, prefix, width1, h, dx, dy, chain, seed, smode_has_S=True, with_endstate=False, NP=2, K=8, whole=False):
     """one wave of k_pair<NP, K, 1> on random inputs; returns the S volume afterwards (uint32 view)"""
     prog, labels = parse_kernel(listing, prefix)
     rng = np.random.default_rng(seed)
@@ -597,6 +655,8 @@ def pair_case(listing, prefix, width1, h, dx, dy, chain, seed, smode_has_S=True,
     w.s[2] = chain // 4                         # workgroup id
     w.v[0] = (chain % 4) * 64 + LANES           # thread id in the workgroup of 256
     steps = run(prog, labels, w)
+    if whole:                                   # everything the kernel may write: S, the selection records
+        return np.frombuffer(mem[offs["S"]:total].tobytes(), np.uint32).copy(), steps
     return np.frombuffer(mem[offs["S"]:offs["S"] + sizes["S"]].tobytes(), np.uint32).copy(), steps
 
 

@@ -39,7 +39,7 @@ def _compare(a, b, prefix, cases):
 CASES = [((40, 36, 1, 1), 2, False), ((40, 36, 1, 1), 23, True)]
 
 
-def test_two_builds_of_the_shipped_pair_kernels_compute_the_same_S(tmp_path):
+def test_two_builds_of_the_shipped_chain_kernels_compute_the_same(tmp_path):
     if not os.path.exists("/opt/rocm/bin/hipcc"):
         pytest.skip("no hipcc")
     src = os.path.join(ROOT, "wass_amd", "csrc", "sgm_aggregate.hip")
@@ -50,6 +50,13 @@ def test_two_builds_of_the_shipped_pair_kernels_compute_the_same_S(tmp_path):
     for smode in (0, 1):
         diffs = _compare(a, b, "_ZN4wass6k_pairILi2ELi8ELi%dEEE" % smode, CASES)
         assert diffs == [0] * len(CASES), (smode, diffs)
+    # the forward sweep of a family (checkpoints, minima, end states) and the unpaired paths of the 5-path mode
+    import gcn_interp as g
+    for fn, prefix, kw in ((g.ckpt_case, "_ZN4wass6k_ckptILi2ELi8EEE", {}), (g.ckpt_case, "_ZN4wass6k_ckptILi2ELi8EEE", {"with_endstate": True}),
+                           (g.sweep_case, "_ZN4wass7k_sweepILi2ELi0ELi8EEE", {}), (g.sweep_case, "_ZN4wass7k_sweepILi2ELi1ELi8EEE", {})):
+        ra, _ = fn(a, prefix, 40, 36, -1, 1, 7, 99, **kw)
+        rb, _ = fn(b, prefix, 40, 36, -1, 1, 7, 99, **kw)
+        assert ra.any() and int((ra != rb).sum()) == 0, (prefix, kw)
 
 
 def test_the_comparison_sees_the_round_3_miscompile(tmp_path):
