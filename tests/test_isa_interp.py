@@ -54,8 +54,8 @@ def test_two_builds_of_the_shipped_chain_kernels_compute_the_same(tmp_path):
     import gcn_interp as g
     for fn, prefix, kw in ((g.ckpt_case, "_ZN4wass6k_ckptILi2ELi8EEE", {}), (g.ckpt_case, "_ZN4wass6k_ckptILi2ELi8EEE", {"with_endstate": True}),
                            (g.sweep_case, "_ZN4wass7k_sweepILi2ELi0ELi8EEE", {}), (g.sweep_case, "_ZN4wass7k_sweepILi2ELi1ELi8EEE", {})):
-        ra, _ = fn(a, prefix, 40, 36, -1, 1, 7, 99, **kw)
-        rb, _ = fn(b, prefix, 40, 36, -1, 1, 7, 99, **kw)
+        ra, _ = fn(a, prefix, 40, 36, 1, 1, 2, 99, **kw)
+        rb, _ = fn(b, prefix, 40, 36, 1, 1, 2, 99, **kw)
         assert ra.any() and int((ra != rb).sum()) == 0, (prefix, kw)
 
 
