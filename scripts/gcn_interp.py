@@ -360,6 +360,13 @@ def run(prog, labels, w: Wave, max_steps=60_000):
                 w.scc = int(r != 0)
             elif sfx in ("cselect_b32", "cselect_b64"):
                 w.ws(a[0], w.rs(a[1]) if w.scc else w.rs(a[2]))
+            elif sfx.startswith("cmpk_"):
+                _, cond, ty = sfx.split("_")
+                x, k16 = w.rs(a[0]) & M32, w.lit(a[1]) & 0xFFFF
+                if ty == "i32":
+                    x -= (1 << 32) * (x >> 31)
+                    k16 = k16 - 0x10000 if k16 & 0x8000 else k16
+                w.scc = int({"eq": x == k16, "lg": x != k16, "gt": x > k16, "ge": x >= k16, "lt": x < k16, "le": x <= k16}[cond])
             elif sfx.startswith("cmp_"):
                 _, cond, ty = sfx.split("_")
                 x, y = w.rs(a[0]), w.rs(a[1])
@@ -391,6 +398,10 @@ def run(prog, labels, w: Wave, max_steps=60_000):
                 w.exec = w.rs(a[1]) & old
                 w.ws(a[0], old)
                 w.scc = int(w.exec != 0)
+            elif sfx == "not_b32":
+                r = ~w.rs(a[1]) & M32
+                w.ws(a[0], r)
+                w.scc = int(r != 0)
             elif sfx == "not_b64":
                 r = ~w.rs(a[1]) & ((1 << 64) - 1)
                 w.ws(a[0], r)
@@ -447,6 +458,12 @@ def run(prog, labels, w: Wave, max_steps=60_000):
             w.ws(a[0], int(w.rv(a[1])[first]))
         elif op in ("v_add_u32_e32", "v_add_u32_e64"):
             w.wv(a[0], (w.rv(a[1]) + w.rv(a[2])) & U64(M32))
+        elif op in ("v_subrev_u32_e32", "v_subrev_u32_e64"):
+            w.wv(a[0], (w.rv(a[2]) + U64(1 << 32) - w.rv(a[1])) & U64(M32))
+        elif op in ("v_ashrrev_i32_e32", "v_ashrrev_i32_e64"):
+            x = w.rv(a[2]).astype(np.int64)
+            x = np.where(x >> 31, x - (1 << 32), x)
+            w.wv(a[0], ((x >> (w.rv(a[1]) & U64(31)).astype(np.int64)) & M32).astype(np.uint64))
         elif op in ("v_sub_u32_e32", "v_sub_u32_e64"):
             w.wv(a[0], (w.rv(a[1]) + U64(1 << 32) - w.rv(a[2])) & U64(M32))
         elif op in ("v_lshlrev_b32_e32", "v_lshlrev_b32_e64"):
@@ -471,21 +488,25 @@ def run(prog, labels, w: Wave, max_steps=60_000):
             y = np.where(y >> 31, y - (1 << 32), y)
             r = np.minimum(x, y) if "min" in op else np.maximum(x, y)
             w.wv(a[0], (r & M32).astype(np.uint64))
-        elif op in ("v_cmp_ne_u32_e64", "v_cmp_eq_u32_e64", "v_cmp_lt_i64_e64", "v_cmp_eq_u32_e32", "v_cmp_ne_u32_e32", "v_cmp_gt_u32_e64", "v_cmp_lt_u32_e64",
-                    "v_cmp_gt_u32_e32", "v_cmp_lt_u32_e32"):
-            e32 = op.endswith("_e32")
-            srcs = a if e32 else a[1:]
-            if "i64" in op:
-                x, y = w.rv64(srcs[0]).astype(np.int64), w.rv64(srcs[1]).astype(np.int64)
+        elif re.match(r"^v_cmp_(ne|eq|lt|gt|le|ge)_(u32|i32|i64|u64)_e(32|64)$", op):
+            srcs = a[1:]                              # (the e32 form spells its destination too: "v_cmp_gt_u32_e32 vcc, 5, v50")
+            ty = op.split("_")[3]
+            if ty in ("i64", "u64"):
+                x, y = w.rv64(srcs[0]), w.rv64(srcs[1])
+                if ty == "i64":
+                    x, y = x.astype(np.int64), y.astype(np.int64)
             else:
-                x, y = w.rv(srcs[0]), w.rv(srcs[1])
+                x, y = w.rv(srcs[0]).astype(np.int64), w.rv(srcs[1]).astype(np.int64)
+                if ty == "i32":
+                    x = np.where(x >> 31, x - (1 << 32), x)
+                    y = np.where(y >> 31, y - (1 << 32), y)
             cond = op.split("_")[2]
-            r = {"ne": x != y, "eq": x == y, "lt": x < y, "gt": x > y}[cond]
+            r = {"ne": x != y, "eq": x == y, "lt": x < y, "gt": x > y, "le": x <= y, "ge": x >= y}[cond]
             bits = 0
             for l in range(64):
                 if em[l] and r[l]:
                     bits |= 1 << l
-            w.ws("vcc" if e32 else a[0], bits)
+            w.ws(a[0], bits)
         elif op == "v_cndmask_b32_e64":
             sel = w.rs(a[3])
             pick = np.array([(sel >> l) & 1 for l in range(64)], bool)
@@ -545,6 +566,16 @@ def run(prog, labels, w: Wave, max_steps=60_000):
                     w.v[lo_v + k][em & ~inb] = 0
             else:
                 w.st32v(addrs, [w.v[lo_v + k] for k in range(ndw)], em & inb)
+        elif op == "global_store_short":
+            addrs = w.rv64(a[0]) if a[2] == "off" else U64(w.rs(a[2])) + w.rv(a[0])
+            addrs = addrs + U64(int(mods.get("offset", "0"), 0) & ((1 << 64) - 1))
+            data = w.rv(a[1])
+            for l in range(64):
+                if em[l]:
+                    ad = int(addrs[l])
+                    if ad < 0 or ad + 2 > len(w.mem):
+                        raise Unknown("store outside the simulated memory: 0x%x" % ad)
+                    w.mem[ad:ad + 2] = np.frombuffer(np.uint16(int(data[l]) & 0xFFFF).tobytes(), np.uint8)
         elif op.startswith(("global_load_dword", "global_store_dword")):
             ndw = {"dword": 1, "dwordx2": 2, "dwordx3": 3, "dwordx4": 4}[op.split("_")[2]]
             load = op.startswith("global_load")
@@ -617,6 +648,15 @@ def sweep_case(listing, prefix, width1, h, dx, dy, chain, seed, NP=2, K=8):
     buffers = {"C": (npx * VB, 2000), "S": (npx * VB, 3000), "sel16": (npx * 2, None), "selkey": (npx * 4, None)}
     args = [("ptr", "C"), ("ptr", "S")] + [("i32", v) for v in (width1, h, dx, dy, 7, 150, nchains, 256, 0, 10, 1)] + [("ptr", "sel16"), ("ptr", "selkey")]
     return kernel_case(listing, prefix, buffers, args, chain, seed, ("S",))
+
+
+def rowsweep_case(listing, prefix, width1, h, row, seed, NP=2, XB=10):
+    """k_rowsweep<NP>: paths 0 and 4 over one row -- entry states per block of XB columns, minima after every step"""
+    VB = 256 * NP
+    nbx = (width1 + XB - 1) // XB
+    buffers = {"C": (width1 * h * VB, 2000), "entF": (h * nbx * VB, None), "entB": (h * nbx * VB, None), "MF": (h * width1 * 2 + 64, None), "MB": (h * width1 * 2 + 64, None)}
+    args = [("ptr", k) for k in ("C", "entF", "entB", "MF", "MB")] + [("i32", v) for v in (width1, h, 7, 150, nbx)]
+    return kernel_case(listing, prefix, buffers, args, row, seed, ("entF", "entB", "MF", "MB"))
 
 
 # ------------------------------------------------------------------------------------------------------------ the k_pair experiment

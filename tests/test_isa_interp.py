@@ -29,8 +29,9 @@ def _compare(a, b, prefix, cases):
     import gcn_interp as g
     out = []
     for (geom, chain, end) in cases:
-        sa, _ = g.pair_case(a, prefix, *geom, chain, 4242 + chain, with_endstate=end)
-        sb, _ = g.pair_case(b, prefix, *geom, chain, 4242 + chain, with_endstate=end)
+        np_ = int(prefix.split("k_pairILi")[1][0])
+        sa, _ = g.pair_case(a, prefix, *geom, chain, 4242 + chain, with_endstate=end, NP=np_)
+        sb, _ = g.pair_case(b, prefix, *geom, chain, 4242 + chain, with_endstate=end, NP=np_)
         out.append(int((sa != sb).sum()))
     return out
 
@@ -57,6 +58,12 @@ def test_two_builds_of_the_shipped_chain_kernels_compute_the_same(tmp_path):
         ra, _ = fn(a, prefix, 40, 36, 1, 1, 2, 99, **kw)
         rb, _ = fn(b, prefix, 40, 36, 1, 1, 2, 99, **kw)
         assert ra.any() and int((ra != rb).sum()) == 0, (prefix, kw)
+    # D = 512 (config E): four packed pairs per lane
+    assert _compare(a, b, "_ZN4wass6k_pairILi4ELi8ELi1EEE", CASES[:1]) == [0]
+    # paths 0 and 4 over one row (entry states per block of columns, minima); a width that leaves a partial block
+    ra, _ = g.rowsweep_case(a, "_ZN4wass10k_rowsweepILi2EEE", 43, 8, 5, 3)
+    rb, _ = g.rowsweep_case(b, "_ZN4wass10k_rowsweepILi2EEE", 43, 8, 5, 3)
+    assert ra.any() and int((ra != rb).sum()) == 0
 
 
 def test_the_comparison_sees_the_round_3_miscompile(tmp_path):
