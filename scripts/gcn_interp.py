@@ -267,6 +267,30 @@ def sat_add16(a, b):
 
 
 def run(prog, labels, w: Wave, max_steps=60_000):
+    """one wave to the end (a barrier is a no-op for a wave alone); returns the number of instructions executed"""
+    gen = run_gen(prog, labels, w, max_steps)
+    while True:
+        try:
+            next(gen)
+        except StopIteration as e:
+            return e.value
+
+
+def run_group(prog, labels, waves, max_steps=200_000):
+    """the waves of one workgroup (they share `lds`), switched at every s_barrier; returns the instructions executed per wave"""
+    gens = [run_gen(prog, labels, w, max_steps) for w in waves]
+    done = [None] * len(waves)
+    while any(d is None for d in done):
+        for i, gen in enumerate(gens):
+            if done[i] is None:
+                try:
+                    next(gen)                       # runs to its next barrier
+                except StopIteration as e:
+                    done[i] = e.value
+    return done
+
+
+def run_gen(prog, labels, w: Wave, max_steps=60_000):
     pc, steps = 0, 0
     U64 = np.uint64
     while True:
@@ -278,7 +302,10 @@ def run(prog, labels, w: Wave, max_steps=60_000):
         if w.trace is not None:
             w.trace(pc - 1, text)
         # ------------------------------------------------ no-ops / control
-        if op in ("s_nop", "s_waitcnt", "s_barrier", "s_setprio", "s_sleep"):
+        if op == "s_barrier":
+            yield "barrier"
+            continue
+        if op in ("s_nop", "s_waitcnt", "s_setprio", "s_sleep"):
             continue
         if op == "s_endpgm":
             return steps
@@ -522,6 +549,11 @@ def run(prog, labels, w: Wave, max_steps=60_000):
                     if not em[l]:
                         continue
                     ad = int(base[l]) + off
+                    if ad + 4 * ndw > len(w.lds):   # beyond the allocation: the hardware drops the write and returns zeros
+                        if not write:
+                            for k in range(ndw):
+                                w.v[regs + k][l] = 0
+                        continue
                     for k in range(ndw):
                         if write:
                             w.lds[ad + 4 * k:ad + 4 * k + 4] = np.frombuffer(np.uint32(int(w.v[regs + k][l])).tobytes(), np.uint8)
@@ -566,6 +598,22 @@ def run(prog, labels, w: Wave, max_steps=60_000):
                     w.v[lo_v + k][em & ~inb] = 0
             else:
                 w.st32v(addrs, [w.v[lo_v + k] for k in range(ndw)], em & inb)
+        elif op.startswith(("scratch_load_dword", "scratch_store_dword")):
+            ndw = {"dword": 1, "dwordx2": 2, "dwordx3": 3, "dwordx4": 4}[op.split("_")[2]]
+            load = op.startswith("scratch_load")
+            vaddr, saddr = (a[1], a[2]) if load else (a[0], a[2])
+            data = a[0] if load else a[1]
+            off = int(mods.get("offset", "0"), 0) + (0 if saddr == "off" else w.rs(saddr))
+            if vaddr != "off":
+                raise Unknown("scratch with a vector address: " + text)
+            lo_v = int(re.match(r"^v\[?(\d+)", data).group(1))
+            if not hasattr(w, "scratch"):
+                w.scratch = np.zeros((64, 4096), np.uint32)
+            for k in range(ndw):
+                if load:
+                    w.v[lo_v + k][em] = w.scratch[:, off // 4 + k][em]
+                else:
+                    w.scratch[:, off // 4 + k][em] = w.v[lo_v + k][em].astype(np.uint32)
         elif op == "global_store_short":
             addrs = w.rv64(a[0]) if a[2] == "off" else U64(w.rs(a[2])) + w.rv(a[0])
             addrs = addrs + U64(int(mods.get("offset", "0"), 0) & ((1 << 64) - 1))
@@ -657,6 +705,46 @@ def rowsweep_case(listing, prefix, width1, h, row, seed, NP=2, XB=10):
     buffers = {"C": (width1 * h * VB, 2000), "entF": (h * nbx * VB, None), "entB": (h * nbx * VB, None), "MF": (h * width1 * 2 + 64, None), "MB": (h * width1 * 2 + 64, None)}
     args = [("ptr", k) for k in ("C", "entF", "entB", "MF", "MB")] + [("i32", v) for v in (width1, h, 7, 150, nbx)]
     return kernel_case(listing, prefix, buffers, args, row, seed, ("entF", "entB", "MF", "MB"))
+
+
+def pairx_case(listing, prefix, width1, h, block, seed, NP=2, K=8, XB=10):
+    """k_pairx<NP, K, ACC = true, DG = false>: the column family with the rows riding along -- one workgroup of XB waves (a block of XB
+    columns, upper or lower half of the image), barriers included.  Random inputs: states, minima and S are whatever they are."""
+    prog, labels = parse_kernel(listing, prefix)
+    rng = np.random.default_rng(seed)
+    VB = 256 * NP
+    npx = width1 * h
+    nbx = (width1 + XB - 1) // XB
+    maxseg = (h + K - 1) // K + 2
+    ncol = 2 * width1 + 16
+    buffers = {"C": (npx * VB, 2000), "S": (npx * VB, 3000), "ckpt": (ncol * maxseg * VB, 1500), "mins": (ncol * maxseg * K * 2, 1500),
+               "entF": (h * nbx * VB, 1500), "entB": (h * nbx * VB, 1500), "MF": (npx * 2 + 64, 1500), "MB": (npx * 2 + 64, 1500), "end": (ncol * VB, 1500)}
+    offs, total = {"args": 1 << 16}, (1 << 16) + 4096
+    for k, (n, _) in buffers.items():
+        offs[k] = total
+        total += (n + 4095) & ~4095
+    mem = np.zeros(total + 4096, np.uint8)
+    for k, (n, hi) in buffers.items():
+        mem[offs[k]:offs[k] + n] = np.frombuffer(rng.integers(0, hi, n // 2, dtype=np.uint16).tobytes(), np.uint8)
+    def put(o, val, n):
+        mem[offs["args"] + o:offs["args"] + o + n] = np.frombuffer(int(val & ((1 << (8 * n)) - 1)).to_bytes(n, "little"), np.uint8)
+    for i, k in enumerate(("C", "S", "ckpt", "mins", "entF", "entB", "MF", "MB")):
+        put(8 * i, offs[k], 8)
+    put(64, nbx, 4)                             # RowSide.nbx; DiagSide (72 .. 127) stays zero: DG = false never reads it
+    for i, v in enumerate((width1, h, 7, 150, maxseg)):
+        put(128 + 4 * i, v, 4)
+    put(152, offs["end"], 8)
+    lds = np.zeros(160 * 1024, np.uint8)
+    waves = []
+    for wv in range(XB):
+        w = Wave(mem)
+        w.lds = lds
+        w.s[0], w.s[1] = offs["args"] & M32, offs["args"] >> 32
+        w.s[2] = block
+        w.v[0] = wv * 64 + LANES
+        waves.append(w)
+    steps = run_group(prog, labels, waves)
+    return np.frombuffer(mem[offs["S"]:offs["S"] + buffers["S"][0]].tobytes(), np.uint32).copy(), steps
 
 
 # ------------------------------------------------------------------------------------------------------------ the k_pair experiment

@@ -1,5 +1,5 @@
 """A net under the chain kernels that needs no GPU: the ISA hipcc emits for k_pair is EXECUTED by a small in-order interpreter
-(scripts/gcn_interp.py: one wave, the ~80 opcodes those kernels use) on random inputs, for two differently optimised builds of the
+(scripts/gcn_interp.py: 64-lane waves, a workgroup's waves switched at barriers, the ~90 opcodes those kernels use) on random inputs, for two differently optimised builds of the
 same source -- the shipped flags, and the same with the machine-sinking pass off.  Two correct builds compute the same S whatever
 the inputs are; the round-3 miscompile of k_pair<2, 8, 1> (NOTES/traps.md: hand-over vectors prefetched into registers that the
 loop body then uses as temporaries) shows up in this comparison on every chain of two or more full segments, while the build with
@@ -64,6 +64,14 @@ def test_two_builds_of_the_shipped_chain_kernels_compute_the_same(tmp_path):
     ra, _ = g.rowsweep_case(a, "_ZN4wass10k_rowsweepILi2EEE", 43, 8, 5, 3)
     rb, _ = g.rowsweep_case(b, "_ZN4wass10k_rowsweepILi2EEE", 43, 8, 5, 3)
     assert ra.any() and int((ra != rb).sum()) == 0
+    # columns + rows in one kernel: a workgroup of ten waves with its barriers (a full block of the upper half, the partial block of the lower)
+    base = None
+    for block in (0, 5):
+        ra, _ = g.pairx_case(a, "_ZN4wass7k_pairxILi2ELi8ELb1ELb0EEE", 23, 44, block, 5)
+        rb, _ = g.pairx_case(b, "_ZN4wass7k_pairxILi2ELi8ELb1ELb0EEE", 23, 44, block, 5)
+        assert int((ra != rb).sum()) == 0, block
+        assert base is None or (ra != base).any()           # (the two workgroups wrote different pixels: the kernel did run)
+        base = ra
 
 
 def test_the_comparison_sees_the_round_3_miscompile(tmp_path):
