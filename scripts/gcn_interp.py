@@ -335,7 +335,11 @@ def run_gen(prog, labels, w: Wave, max_steps=60_000):
                 k16 = w.lit(a[1]) & 0xFFFF
                 w.ws(a[0], (k16 - 0x10000 if k16 & 0x8000 else k16) & M32)
             elif sfx in ("add_i32", "add_u32", "sub_i32", "sub_u32", "addc_u32", "subb_u32", "addk_i32"):
-                x, y = (w.rs(a[0]), w.lit(a[1])) if sfx == "addk_i32" else (w.rs(a[1]), w.rs(a[2]))
+                if sfx == "addk_i32":                # the 16-bit immediate is signed, however it is spelt
+                    k16 = w.lit(a[1]) & 0xFFFF
+                    x, y = w.rs(a[0]), (k16 - 0x10000 if k16 & 0x8000 else k16)
+                else:
+                    x, y = w.rs(a[1]), w.rs(a[2])
                 x &= M32
                 y &= M32
                 if sfx in ("add_u32", "addc_u32"):
@@ -745,6 +749,46 @@ def pairx_case(listing, prefix, width1, h, block, seed, NP=2, K=8, XB=10):
         waves.append(w)
     steps = run_group(prog, labels, waves)
     return np.frombuffer(mem[offs["S"]:offs["S"] + buffers["S"][0]].tobytes(), np.uint32).copy(), steps
+
+
+def family_case(listing, width1, h, dx, dy, seed, NP=2, K=8, P1=7, P2=150, cmax=2000):
+    """A whole diagonal family of a small image through the two kernels that compute it -- k_ckpt<NP, K> (forward sweep: checkpoints,
+    minima) and then k_pair<NP, K, 0> (S = L_forward + L_backward) -- every chain, one wave at a time, on one memory image.
+    Returns (C as u16 [h][width1][128 * NP], S likewise)."""
+    ck = parse_kernel(listing, "_ZN4wass6k_ckptILi%dELi%dEEE" % (NP, K))
+    pr = parse_kernel(listing, "_ZN4wass6k_pairILi%dELi%dELi0EEE" % (NP, K))
+    rng = np.random.default_rng(seed)
+    VB, npx, maxseg, _ = _sizes(width1, h, NP, K)
+    nchains = width1 + h - 1
+    buffers = {"C": npx * VB, "S": npx * VB, "ckpt": (nchains + 4) * maxseg * VB, "mins": (nchains + 4) * maxseg * K * 2 + 64, "sel16": npx * 2, "selkey": npx * 4}
+    offs, total = {"args": 1 << 16}, (1 << 16) + 4096
+    for k, n in buffers.items():
+        offs[k] = total
+        total += (n + 4095) & ~4095
+    mem = np.zeros(total + (1 << 20), np.uint8)    # (the pair kernel re-reads up to K vectors past a chain's end: harmless, but it must be memory)
+    mem[offs["C"]:offs["C"] + buffers["C"]] = np.frombuffer(rng.integers(0, cmax, buffers["C"] // 2, dtype=np.uint16).tobytes(), np.uint8)
+    mem[offs["S"]:offs["S"] + buffers["S"]] = 0xEE                     # SMODE 0 writes S, it does not read it
+    def launch(kernel, args):
+        at = 0
+        for kind, val in args:
+            size = 8 if kind == "ptr" else 4
+            at = (at + size - 1) & ~(size - 1)
+            v = (offs[val] if val is not None else 0) if kind == "ptr" else (val & M32)
+            mem[offs["args"] + at:offs["args"] + at + size] = np.frombuffer(int(v).to_bytes(size, "little"), np.uint8)
+            at += size
+        for c in range(nchains):
+            w = Wave(mem)
+            w.s[0], w.s[1] = offs["args"] & M32, offs["args"] >> 32
+            w.s[2] = c // 4
+            w.v[0] = (c % 4) * 64 + LANES
+            run(kernel[0], kernel[1], w)
+    ints = [("i32", v) for v in (width1, h, dx, dy, P1, P2, nchains, maxseg)]
+    launch(ck, [("ptr", "C"), ("ptr", "ckpt"), ("ptr", "mins")] + ints + [("ptr", None)])
+    launch(pr, [("ptr", "C"), ("ptr", "S"), ("ptr", "ckpt"), ("ptr", "mins")] + ints + [("i32", v) for v in (128 * NP, 0, 10, 1)] +
+           [("ptr", "sel16"), ("ptr", "selkey"), ("ptr", None)])
+    shape = (h, width1, 128 * NP)
+    return (np.frombuffer(mem[offs["C"]:offs["C"] + buffers["C"]].tobytes(), np.uint16).reshape(shape).copy(),
+            np.frombuffer(mem[offs["S"]:offs["S"] + buffers["S"]].tobytes(), np.uint16).reshape(shape).copy())
 
 
 # ------------------------------------------------------------------------------------------------------------ the k_pair experiment

@@ -40,14 +40,21 @@ def _compare(a, b, prefix, cases):
 CASES = [((40, 36, 1, 1), 2, False), ((40, 36, 1, 1), 23, True)]
 
 
-def test_two_builds_of_the_shipped_chain_kernels_compute_the_same(tmp_path):
+@pytest.fixture(scope="module")
+def listings(tmp_path_factory):
+    """sgm_aggregate.hip compiled to ISA text twice: the shipped flags, and the same with the machine-sinking pass off"""
     if not os.path.exists("/opt/rocm/bin/hipcc"):
         pytest.skip("no hipcc")
+    d = tmp_path_factory.mktemp("isa")
     src = os.path.join(ROOT, "wass_amd", "csrc", "sgm_aggregate.hip")
     with ThreadPoolExecutor(2) as ex:
-        fa = ex.submit(_listing, src, str(tmp_path / "shipped.s"))
-        fb = ex.submit(_listing, src, str(tmp_path / "nosink.s"), ("-mllvm", "-disable-machine-sink"))
-        a, b = fa.result(), fb.result()
+        fa = ex.submit(_listing, src, str(d / "shipped.s"))
+        fb = ex.submit(_listing, src, str(d / "nosink.s"), ("-mllvm", "-disable-machine-sink"))
+        return fa.result(), fb.result()
+
+
+def test_two_builds_of_the_shipped_chain_kernels_compute_the_same(listings):
+    a, b = listings
     for smode in (0, 1):
         diffs = _compare(a, b, "_ZN4wass6k_pairILi2ELi8ELi%dEEE" % smode, CASES)
         assert diffs == [0] * len(CASES), (smode, diffs)
@@ -102,3 +109,35 @@ def test_the_comparison_sees_the_round_3_miscompile(tmp_path):
     assert _compare(fence, nosink, P, cases) == [0, 0]
     bad = _compare(fence, nofence, P, cases)
     assert bad[0] > 0 and bad[1] == 0, bad
+
+
+def _sgm_family_model(C, dx, dy, P1, P2):
+    """L_r(p, d) = C(p, d) + min(L_r(p - r, d), L_r(p - r, d +- 1) + P1, min_k L_r(p - r, k) + P2) - min_k L_r(p - r, k), zero state outside the
+    image, for r = (dx, dy) and its opposite; returns their sum"""
+    h, w, D = C.shape
+    S = np.zeros(C.shape, np.int64)
+    big = 1 << 20
+    for sx, sy in ((dx, dy), (-dx, -dy)):
+        L = np.zeros(C.shape, np.int64)
+        for y in (range(h) if sy > 0 else range(h - 1, -1, -1)):
+            for x in range(w):
+                px, py = x - sx, y - sy
+                prev = L[py, px] if 0 <= px < w and 0 <= py < h else np.zeros(D, np.int64)
+                m = prev.min()
+                lo = np.concatenate(([big], prev[:-1])) + P1
+                hi = np.concatenate((prev[1:], [big])) + P1
+                L[y, x] = C[y, x] + np.minimum(np.minimum(prev, lo), np.minimum(hi, m + P2)) - m
+        S += L
+    return S
+
+
+def test_the_shipped_isa_computes_a_diagonal_family_like_the_recurrence(listings):
+    """Not a comparison of two builds but of the ISA with the algorithm: k_ckpt<2, 8> and k_pair<2, 8, 0> as hipcc emits them, run by the
+    interpreter over every chain of a small image, against the path recurrence written out in numpy -- every cell of S."""
+    import gcn_interp as g
+    a = listings[0]
+    for (w1, h, dx, dy) in ((26, 30, 1, 1), (21, 12, -1, 1)):           # chains of up to three full segments + tail; the anti-diagonals
+        C, S = g.family_case(a, w1, h, dx, dy, 11)
+        M = _sgm_family_model(C.astype(np.int64), dx, dy, 7, 150)
+        assert M.max() < 32767
+        assert np.array_equal(S.astype(np.int64), M), (w1, h, dx, dy, int((S.astype(np.int64) != M).sum()))
