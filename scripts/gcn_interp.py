@@ -791,6 +791,83 @@ def family_case(listing, width1, h, dx, dy, seed, NP=2, K=8, P1=7, P2=150, cmax=
             np.frombuffer(mem[offs["S"]:offs["S"] + buffers["S"]].tobytes(), np.uint16).reshape(shape).copy())
 
 
+class Device:
+    """a memory image with named buffers and kernel launches on it (one wave per 64 threads; the waves of a workgroup share LDS)"""
+    def __init__(self, buffers, pad=1 << 20):
+        self.offs, total = {"args": 1 << 16}, (1 << 16) + 4096
+        self.size = dict(buffers)
+        for k, n in buffers.items():
+            self.offs[k] = total
+            total += (n + 4095) & ~4095
+        self.mem = np.zeros(total + pad, np.uint8)
+
+    def fill_u16(self, name, rng, hi):
+        n = self.size[name]
+        self.mem[self.offs[name]:self.offs[name] + n] = np.frombuffer(rng.integers(0, hi, n // 2, dtype=np.uint16).tobytes(), np.uint8)
+
+    def u16(self, name):
+        return np.frombuffer(self.mem[self.offs[name]:self.offs[name] + self.size[name]].tobytes(), np.uint16).copy()
+
+    def launch(self, kernel, grid, waves_per_group, args, lds_bytes=65536):
+        """args: ("ptr", buffer name | None | (name, byte offset)) / ("i32", value) / ("pad", bytes), laid out with natural alignment"""
+        at = 0
+        a0 = self.offs["args"]
+        self.mem[a0:a0 + 4096] = 0
+        for kind, val in args:
+            if kind == "pad":
+                at += val
+                continue
+            size = 8 if kind == "ptr" else 4
+            at = (at + size - 1) & ~(size - 1)
+            if kind == "ptr":
+                v = 0 if val is None else (self.offs[val[0]] + val[1] if isinstance(val, tuple) else self.offs[val])
+            else:
+                v = val & M32
+            self.mem[a0 + at:a0 + at + size] = np.frombuffer(int(v).to_bytes(size, "little"), np.uint8)
+            at += size
+        for g_ in range(grid):
+            lds = np.zeros(lds_bytes, np.uint8)
+            waves = []
+            for wv in range(waves_per_group):
+                w = Wave(self.mem)
+                w.lds = lds
+                w.s[0], w.s[1] = a0 & M32, a0 >> 32
+                w.s[2] = g_
+                w.v[0] = wv * 64 + LANES
+                waves.append(w)
+            if waves_per_group == 1 or not any(p[0] == "s_barrier" for p in kernel[0]):
+                for w in waves:
+                    run(kernel[0], kernel[1], w)
+            else:
+                run_group(kernel[0], kernel[1], waves)
+
+
+def columns_rows_case(listing, width1, h, seed, NP=2, K=8, XB=10, P1=7, P2=150, cmax=2000, smax=3000):
+    """The fused half of the 8-path schedule on a small image, as the host launches it: k_rowsweep<NP> (paths 0 and 4: entry states, minima),
+    k_ckpt<NP, K> over the split column family, k_pairx<NP, K, ACC = true, DG = false> (S += L_2 + L_6 + L_0 + L_4), every workgroup.
+    Returns (C, S before, S after) as u16 [h][width1][128 * NP]."""
+    rs_k = parse_kernel(listing, "_ZN4wass10k_rowsweepILi%dEEE" % NP)
+    ck_k = parse_kernel(listing, "_ZN4wass6k_ckptILi%dELi%dEEE" % (NP, K))
+    px_k = parse_kernel(listing, "_ZN4wass7k_pairxILi%dELi%dELb1ELb0EEE" % (NP, K))
+    rng = np.random.default_rng(seed)
+    VB, vec = 256 * NP, 64 * NP
+    npx, nbx = width1 * h, (width1 + XB - 1) // XB
+    nch = 2 * width1
+    mseg = ((h - h // 2) + K - 1) // K
+    dev = Device({"C": npx * VB, "S": npx * VB, "ckpt": nch * (mseg + 1) * VB, "mins": nch * mseg * K * 2 + 256, "entF": h * nbx * VB, "entB": h * nbx * VB,
+                  "MF": h * nbx * XB * 2 + 256, "MB": h * nbx * XB * 2 + 256})
+    dev.fill_u16("C", rng, cmax)
+    dev.fill_u16("S", rng, smax)
+    s_before = dev.u16("S")
+    dev.launch(rs_k, (h + 3) // 4, 4, [("ptr", k) for k in ("C", "entF", "entB", "MF", "MB")] + [("i32", v) for v in (width1, h, P1, P2, nbx)])
+    end = ("ckpt", nch * mseg * vec * 4)
+    dev.launch(ck_k, (nch + 3) // 4, 4, [("ptr", "C"), ("ptr", "ckpt"), ("ptr", "mins")] + [("i32", v) for v in (width1, h, 0, 1, P1, P2, nch, mseg)] + [("ptr", end)])
+    dev.launch(px_k, 2 * nbx, XB, [("ptr", k) for k in ("C", "S", "ckpt", "mins", "entF", "entB", "MF", "MB")] + [("i32", nbx), ("pad", 4), ("pad", 56)] +
+               [("i32", v) for v in (width1, h, P1, P2, mseg)] + [("ptr", end)], lds_bytes=XB * 2 * K * vec * 4)
+    shape = (h, width1, 128 * NP)
+    return dev.u16("C").reshape(shape), s_before.reshape(shape), dev.u16("S").reshape(shape)
+
+
 # ------------------------------------------------------------------------------------------------------------ the k_pair experiment
 def pair_case(listing, prefix, width1, h, dx, dy, chain, seed, smode_has_S=True, with_endstate=False, NP=2, K=8, whole=False):
     """one wave of k_pair<NP, K, 1> on random inputs; returns the S volume afterwards (uint32 view)"""

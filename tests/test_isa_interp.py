@@ -120,7 +120,7 @@ def _sgm_family_model(C, dx, dy, P1, P2):
     for sx, sy in ((dx, dy), (-dx, -dy)):
         L = np.zeros(C.shape, np.int64)
         for y in (range(h) if sy > 0 else range(h - 1, -1, -1)):
-            for x in range(w):
+            for x in (range(w) if sx >= 0 else range(w - 1, -1, -1)):
                 px, py = x - sx, y - sy
                 prev = L[py, px] if 0 <= px < w and 0 <= py < h else np.zeros(D, np.int64)
                 m = prev.min()
@@ -141,3 +141,15 @@ def test_the_shipped_isa_computes_a_diagonal_family_like_the_recurrence(listings
         M = _sgm_family_model(C.astype(np.int64), dx, dy, 7, 150)
         assert M.max() < 32767
         assert np.array_equal(S.astype(np.int64), M), (w1, h, dx, dy, int((S.astype(np.int64) != M).sum()))
+
+
+def test_the_shipped_isa_computes_columns_and_rows_like_the_recurrence(listings):
+    """The fused half of the 8-path schedule as the host launches it -- k_rowsweep<2> (entry states, minima), k_ckpt<2, 8> over the split
+    column family, k_pairx<2, 8, true, false> in workgroups of ten waves with their barriers -- on a small image with a partial block
+    of columns and tail segments in both halves: S grows by exactly L_0 + L_4 + L_2 + L_6 of the recurrence, every cell."""
+    import gcn_interp as g
+    C, S0, S1 = g.columns_rows_case(listings[0], 23, 44, 3)
+    Ci = C.astype(np.int64)
+    M = S0.astype(np.int64) + _sgm_family_model(Ci, 0, 1, 7, 150) + _sgm_family_model(Ci, 1, 0, 7, 150)
+    assert M.max() < 32767
+    assert np.array_equal(S1.astype(np.int64), M), int((S1.astype(np.int64) != M).sum())
