@@ -424,6 +424,20 @@ def run_gen(prog, labels, w: Wave, max_steps=60_000):
                 w.scc = int(((w.rs(a[0]) >> (w.rs(a[1]) & 31)) & 1) == 0)
             elif sfx == "bitcmp1_b32":
                 w.scc = int(((w.rs(a[0]) >> (w.rs(a[1]) & 31)) & 1) == 1)
+            elif sfx == "andn2_saveexec_b64":
+                old = w.exec
+                w.exec = w.rs(a[1]) & ~old & ((1 << 64) - 1)
+                w.ws(a[0], old)
+                w.scc = int(w.exec != 0)
+            elif sfx == "or_saveexec_b64":
+                old = w.exec
+                w.exec = (w.rs(a[1]) | old) & ((1 << 64) - 1)
+                w.ws(a[0], old)
+                w.scc = int(w.exec != 0)
+            elif sfx == "bcnt1_i32_b64":
+                r = bin(w.rs(a[1]) & ((1 << 64) - 1)).count("1")
+                w.ws(a[0], r)
+                w.scc = int(r != 0)
             elif sfx == "and_saveexec_b64":
                 old = w.exec
                 w.exec = w.rs(a[1]) & old
@@ -509,6 +523,80 @@ def run_gen(prog, labels, w: Wave, max_steps=60_000):
             w.wv(a[0], ((w.rv(a[1]) << (w.rv(a[2]) & U64(31))) | w.rv(a[3])) & U64(M32))
         elif op == "v_lshl_add_u32":
             w.wv(a[0], ((w.rv(a[1]) << (w.rv(a[2]) & U64(31))) + w.rv(a[3])) & U64(M32))
+        elif op == "v_add3_u32":
+            w.wv(a[0], (w.rv(a[1]) + w.rv(a[2]) + w.rv(a[3])) & U64(M32))
+        elif op in ("v_min3_u32",):
+            w.wv(a[0], np.minimum(np.minimum(w.rv(a[1]), w.rv(a[2])), w.rv(a[3])))
+        elif op == "v_or3_b32":
+            w.wv(a[0], w.rv(a[1]) | w.rv(a[2]) | w.rv(a[3]))
+        elif op == "v_and_or_b32":
+            w.wv(a[0], (w.rv(a[1]) & w.rv(a[2])) | w.rv(a[3]))
+        elif op == "v_bfi_b32":
+            m_ = w.rv(a[1])
+            w.wv(a[0], (m_ & w.rv(a[2])) | (~m_ & U64(M32) & w.rv(a[3])))
+        elif op in ("v_xor_b32_e32", "v_xor_b32_e64"):
+            w.wv(a[0], w.rv(a[1]) ^ w.rv(a[2]))
+        elif op in ("v_mul_lo_u32",):
+            w.wv(a[0], (w.rv(a[1]) * w.rv(a[2])) & U64(M32))
+        elif op == "v_mul_hi_u32":
+            w.wv(a[0], np.array([(int(x) * int(y)) >> 32 for x, y in zip(w.rv(a[1]), w.rv(a[2]))], np.uint64))
+        elif op in ("v_mul_u32_u24_e32", "v_mul_u32_u24_e64", "v_mul_u32_u24_sdwa"):
+            x, y = w.rv(a[1]), w.rv(a[2])
+            if op.endswith("sdwa"):
+                if mods.get("dst_sel") != "DWORD" or mods.get("dst_unused") != "UNUSED_PAD":
+                    raise Unknown(text)
+                pick = {"DWORD": lambda q: q, "WORD_0": lambda q: q & U64(0xFFFF), "WORD_1": lambda q: (q >> U64(16)) & U64(0xFFFF),
+                        "BYTE_0": lambda q: q & U64(0xFF), "BYTE_1": lambda q: (q >> U64(8)) & U64(0xFF), "BYTE_2": lambda q: (q >> U64(16)) & U64(0xFF),
+                        "BYTE_3": lambda q: (q >> U64(24)) & U64(0xFF)}
+                x, y = pick[mods["src0_sel"]](x), pick[mods["src1_sel"]](y)
+            w.wv(a[0], ((x & U64(0xFFFFFF)) * (y & U64(0xFFFFFF))) & U64(M32))
+        elif op in ("v_addc_co_u32_e32", "v_addc_co_u32_e64", "v_add_co_u32_e32", "v_add_co_u32_e64", "v_sub_co_u32_e32", "v_sub_co_u32_e64",
+                    "v_subb_co_u32_e32", "v_subb_co_u32_e64"):
+            x, y = w.rv(a[2]).astype(object), w.rv(a[3]).astype(object)
+            cin = np.zeros(64, object)
+            if "addc" in op or "subb" in op:
+                cm = w.rs(a[4])
+                cin = np.array([(cm >> l) & 1 for l in range(64)], object)
+            r = x - y - cin if "sub" in op else x + y + cin
+            carry = 0
+            for l in range(64):
+                if em[l] and (r[l] < 0 or r[l] > M32):
+                    carry |= 1 << l
+            w.wv(a[0], np.array([int(q) & M32 for q in r], np.uint64))
+            w.ws(a[1], carry)
+        elif op in ("v_cvt_f32_u32_e32", "v_cvt_f32_u32_e64"):
+            w.wv(a[0], w.rv(a[1]).astype(np.float32).view(np.uint32).astype(np.uint64))
+        elif op in ("v_cvt_i32_f32_e32", "v_cvt_u32_f32_e32"):
+            f = w.rv(a[1]).astype(np.uint32).view(np.float32).astype(np.float64)
+            lo_, hi_ = (-2147483648.0, 2147483647.0) if "i32" in op else (0.0, 4294967295.0)
+            t_ = np.clip(np.trunc(np.nan_to_num(f)), lo_, hi_).astype(np.int64)
+            w.wv(a[0], (t_ & M32).astype(np.uint64))
+        elif op in ("v_mul_f32_e32", "v_mul_f32_e64"):
+            f1 = w.rv(a[1]).astype(np.uint32).view(np.float32)
+            f2 = w.rv(a[2]).astype(np.uint32).view(np.float32)
+            w.wv(a[0], (f1 * f2).astype(np.float32).view(np.uint32).astype(np.uint64))
+        elif op in ("v_rcp_iflag_f32_e32", "v_rcp_f32_e32"):
+            f1 = w.rv(a[1]).astype(np.uint32).view(np.float32)
+            with np.errstate(divide="ignore", over="ignore"):
+                w.wv(a[0], (np.float32(1.0) / f1).astype(np.float32).view(np.uint32).astype(np.uint64))
+        elif op == "v_perm_b32":
+            s0, s1, sel = w.rv(a[1]), w.rv(a[2]), w.rv(a[3])
+            both = s1 | (s0 << U64(32))
+            out = np.zeros(64, np.uint64)
+            for k in range(4):
+                sb = (sel >> U64(8 * k)) & U64(0xFF)
+                if ((sb >= 8) & (sb < 12)).any():
+                    raise Unknown("v_perm_b32 sign selectors")
+                byte = np.where(sb < 8, (both >> (np.minimum(sb, 7) * U64(8))) & U64(0xFF), np.where(sb == 12, 0, 0xFF)).astype(np.uint64)
+                out |= byte << U64(8 * k)
+            w.wv(a[0], out)
+        elif op == "v_writelane_b32":
+            w.v[int(a[0][1:])][w.rs(a[2]) & 63] = w.rs(a[1]) & M32
+        elif op == "v_bfe_u32":
+            off_, wid = w.rv(a[2]) & U64(31), w.rv(a[3]) & U64(31)
+            w.wv(a[0], (w.rv(a[1]) >> off_) & ((U64(1) << wid) - U64(1)))
+        elif op in ("v_max_u32_e32", "v_max_u32_e64"):
+            w.wv(a[0], np.maximum(w.rv(a[1]), w.rv(a[2])))
         elif op == "v_mad_u64_u32":                 # v[d:d+1], carry-out pair, a, b, c64
             w.wv(a[0], ((w.rv(a[2]) * w.rv(a[3])) + w.rv64(a[4])))
         elif op == "v_lshl_add_u64":
@@ -751,12 +839,12 @@ def pairx_case(listing, prefix, width1, h, block, seed, NP=2, K=8, XB=10):
     return np.frombuffer(mem[offs["S"]:offs["S"] + buffers["S"][0]].tobytes(), np.uint32).copy(), steps
 
 
-def family_case(listing, width1, h, dx, dy, seed, NP=2, K=8, P1=7, P2=150, cmax=2000):
+def family_case(listing, width1, h, dx, dy, seed, NP=2, K=8, P1=7, P2=150, cmax=2000, smode=0, smax=3000):
     """A whole diagonal family of a small image through the two kernels that compute it -- k_ckpt<NP, K> (forward sweep: checkpoints,
     minima) and then k_pair<NP, K, 0> (S = L_forward + L_backward) -- every chain, one wave at a time, on one memory image.
     Returns (C as u16 [h][width1][128 * NP], S likewise)."""
     ck = parse_kernel(listing, "_ZN4wass6k_ckptILi%dELi%dEEE" % (NP, K))
-    pr = parse_kernel(listing, "_ZN4wass6k_pairILi%dELi%dELi0EEE" % (NP, K))
+    pr = parse_kernel(listing, "_ZN4wass6k_pairILi%dELi%dELi%dEEE" % (NP, K, smode))   # 1: S += ...; 2: the last family (S finished, selection; keepS stores it)
     rng = np.random.default_rng(seed)
     VB, npx, maxseg, _ = _sizes(width1, h, NP, K)
     nchains = width1 + h - 1
@@ -768,6 +856,9 @@ def family_case(listing, width1, h, dx, dy, seed, NP=2, K=8, P1=7, P2=150, cmax=
     mem = np.zeros(total + (1 << 20), np.uint8)    # (the pair kernel re-reads up to K vectors past a chain's end: harmless, but it must be memory)
     mem[offs["C"]:offs["C"] + buffers["C"]] = np.frombuffer(rng.integers(0, cmax, buffers["C"] // 2, dtype=np.uint16).tobytes(), np.uint8)
     mem[offs["S"]:offs["S"] + buffers["S"]] = 0xEE                     # SMODE 0 writes S, it does not read it
+    if smode != 0:
+        mem[offs["S"]:offs["S"] + buffers["S"]] = np.frombuffer(rng.integers(0, smax, buffers["S"] // 2, dtype=np.uint16).tobytes(), np.uint8)
+    s_before = np.frombuffer(mem[offs["S"]:offs["S"] + buffers["S"]].tobytes(), np.uint16).copy()
     def launch(kernel, args):
         at = 0
         for kind, val in args:
@@ -787,8 +878,9 @@ def family_case(listing, width1, h, dx, dy, seed, NP=2, K=8, P1=7, P2=150, cmax=
     launch(pr, [("ptr", "C"), ("ptr", "S"), ("ptr", "ckpt"), ("ptr", "mins")] + ints + [("i32", v) for v in (128 * NP, 0, 10, 1)] +
            [("ptr", "sel16"), ("ptr", "selkey"), ("ptr", None)])
     shape = (h, width1, 128 * NP)
-    return (np.frombuffer(mem[offs["C"]:offs["C"] + buffers["C"]].tobytes(), np.uint16).reshape(shape).copy(),
-            np.frombuffer(mem[offs["S"]:offs["S"] + buffers["S"]].tobytes(), np.uint16).reshape(shape).copy())
+    out = (np.frombuffer(mem[offs["C"]:offs["C"] + buffers["C"]].tobytes(), np.uint16).reshape(shape).copy(),
+           np.frombuffer(mem[offs["S"]:offs["S"] + buffers["S"]].tobytes(), np.uint16).reshape(shape).copy())
+    return out if smode == 0 else out + (s_before.reshape(shape),)
 
 
 class Device:

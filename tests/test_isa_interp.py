@@ -141,6 +141,15 @@ def test_the_shipped_isa_computes_a_diagonal_family_like_the_recurrence(listings
         M = _sgm_family_model(C.astype(np.int64), dx, dy, 7, 150)
         assert M.max() < 32767
         assert np.array_equal(S.astype(np.int64), M), (w1, h, dx, dy, int((S.astype(np.int64) != M).sum()))
+    # the accumulating form, and the LAST family's: S is read, finished with one saturation at 0x7FFF and (debug fetch) stored again --
+    # the selection code runs behind it
+    for smode, smax in ((1, 3000), (2, 31000)):
+        C, S, S0 = g.family_case(a, 21, 27, -1, 1, 5, smode=smode, smax=smax)
+        M = S0.astype(np.int64) + _sgm_family_model(C.astype(np.int64), -1, 1, 7, 150)
+        if smode == 2:
+            assert (M > 0x7FFF).any()
+            M = np.minimum(M, 0x7FFF)
+        assert np.array_equal(S.astype(np.int64), M), (smode, int((S.astype(np.int64) != M).sum()))
 
 
 def test_the_shipped_isa_computes_columns_and_rows_like_the_recurrence(listings):
