@@ -144,8 +144,14 @@ class Wave:
             return np.full(64, self.rs(a), np.uint64)
         return np.full(64, self.lit(a) & ((1 << 64) - 1), np.uint64)
 
+    _masks = {}
+
     def mask(self):
-        return ((self.exec >> LANES.astype(object)) & 1).astype(bool) if False else np.array([(self.exec >> i) & 1 for i in range(64)], bool)
+        m = Wave._masks.get(self.exec)
+        if m is None:
+            m = Wave._masks[self.exec] = np.array([(self.exec >> i) & 1 for i in range(64)], bool)
+            m.setflags(write=False)
+        return m
 
     def wv(self, a, val, mask=None):
         if mask is None:
@@ -173,24 +179,25 @@ class Wave:
 
     def ld32v(self, addrs, ndw, mask):
         out = [np.zeros(64, np.uint64) for _ in range(ndw)]
-        for l in range(64):
-            if mask[l]:
-                a = int(addrs[l])
-                if a < 0 or a + 4 * ndw > len(self.mem):
-                    raise Unknown("load outside the simulated memory: 0x%x" % a)
-                w = np.frombuffer(self.mem[a:a + 4 * ndw].tobytes(), np.uint32)
-                for k in range(ndw):
-                    out[k][l] = w[k]
+        if not mask.any():
+            return out
+        a = addrs[mask].astype(np.int64)
+        if a.min() < 0 or a.max() + 4 * ndw > len(self.mem) or (a & 3).any():
+            raise Unknown("load outside the simulated memory (or not dword-aligned): 0x%x" % int(a.max()))
+        m32 = self.mem.view(np.uint32)
+        for k in range(ndw):
+            out[k][mask] = m32[(a >> 2) + k]
         return out
 
     def st32v(self, addrs, vals, mask):
-        for l in range(64):
-            if mask[l]:
-                a = int(addrs[l])
-                if a < 0 or a + 4 * len(vals) > len(self.mem):
-                    raise Unknown("store outside the simulated memory: 0x%x" % a)
-                for k, part in enumerate(vals):
-                    self.mem[a + 4 * k:a + 4 * k + 4] = np.frombuffer(np.uint32(int(part[l]) & M32).tobytes(), np.uint8)
+        if not mask.any():
+            return
+        a = addrs[mask].astype(np.int64)
+        if a.min() < 0 or a.max() + 4 * len(vals) > len(self.mem) or (a & 3).any():
+            raise Unknown("store outside the simulated memory (or not dword-aligned): 0x%x" % int(a.max()))
+        m32 = self.mem.view(np.uint32)
+        for k, part in enumerate(vals):
+            m32[(a >> 2) + k] = (part[mask] & np.uint64(M32)).astype(np.uint32)
 
 
 def pk(fn, a, b):
@@ -637,20 +644,17 @@ def run_gen(prog, labels, w: Wave, max_steps=60_000):
         elif op in ("ds_write2st64_b64", "ds_read2st64_b64", "ds_read_b64", "ds_write_b64", "ds_read_b128", "ds_write_b128", "ds_read2_b64", "ds_write2_b64"):
             base = w.rv(a[0] if op.startswith("ds_write") else a[1])
             def lds_rw(off, regs, write, ndw):
-                for l in range(64):
-                    if not em[l]:
-                        continue
-                    ad = int(base[l]) + off
-                    if ad + 4 * ndw > len(w.lds):   # beyond the allocation: the hardware drops the write and returns zeros
-                        if not write:
-                            for k in range(ndw):
-                                w.v[regs + k][l] = 0
-                        continue
-                    for k in range(ndw):
-                        if write:
-                            w.lds[ad + 4 * k:ad + 4 * k + 4] = np.frombuffer(np.uint32(int(w.v[regs + k][l])).tobytes(), np.uint8)
-                        else:
-                            w.v[regs + k][l] = int(np.frombuffer(w.lds[ad + 4 * k:ad + 4 * k + 4].tobytes(), np.uint32)[0])
+                ad = base.astype(np.int64) + off
+                ok = em & (ad + 4 * ndw <= len(w.lds))          # beyond the allocation: the hardware drops the write and returns zeros
+                if (ad[ok] & 3).any():
+                    raise Unknown("LDS access not dword-aligned")
+                l32 = w.lds.view(np.uint32)
+                for k in range(ndw):
+                    if write:
+                        l32[(ad[ok] >> 2) + k] = w.v[regs + k][ok].astype(np.uint32)
+                    else:
+                        w.v[regs + k][ok] = l32[(ad[ok] >> 2) + k]
+                        w.v[regs + k][em & ~ok] = 0
             def lo_of(x):
                 return int(re.match(r"^v\[?(\d+)", x).group(1))
             if op in ("ds_write2st64_b64", "ds_write2_b64"):
