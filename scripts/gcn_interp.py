@@ -82,6 +82,9 @@ class Wave:
     def rs(self, a):
         if a == "vcc":
             return self.vcc
+        if a in ("vcc_lo", "vcc_hi", "exec_lo", "exec_hi"):
+            whole = self.vcc if a.startswith("vcc") else self.exec
+            return (whole >> (32 if a.endswith("hi") else 0)) & M32
         if a == "exec":
             return self.exec
         if a == "scc":
@@ -109,6 +112,15 @@ class Wave:
         if a == "vcc":
             self.vcc = val & ((1 << 64) - 1)
             return
+        if a in ("vcc_lo", "vcc_hi", "exec_lo", "exec_hi"):
+            sh = 32 if a.endswith("hi") else 0
+            whole = self.vcc if a.startswith("vcc") else self.exec
+            whole = (whole & ~(M32 << sh)) | ((val & M32) << sh)
+            if a.startswith("vcc"):
+                self.vcc = whole
+            else:
+                self.exec = whole
+            return
         if a == "exec":
             self.exec = val & ((1 << 64) - 1)
             return
@@ -130,7 +142,7 @@ class Wave:
         m = re.match(r"^v(\d+)$", a)
         if m:
             return self.v[int(m.group(1))].copy()
-        if re.match(r"^(s\d+|vcc|exec|s\[)", a):
+        if re.match(r"^(s\d+|vcc|exec|s\[)", a):   # (vcc_lo / exec_hi too)
             return np.full(64, self.rs(a) & M32, np.uint64)
         return np.full(64, self.lit(a) & M32, np.uint64)
 
@@ -936,6 +948,23 @@ class Device:
                     run(kernel[0], kernel[1], w)
             else:
                 run_group(kernel[0], kernel[1], waves)
+
+
+def single_path_case(listing, width1, h, dx, dy, seed, smode=1, NP=2, U=8, P1=7, P2=150, cmax=2000, smax=3000):
+    """k_sweep<NP, SMODE, U> over every chain of a small image: one unpaired path of the 5-path mode (S = / += L_r; 2: the last one, finished and
+    stored for the debug fetch).  Returns (C, S before, S after) as u16 [h][width1][128 * NP]."""
+    k = parse_kernel(listing, "_ZN4wass7k_sweepILi%dELi%dELi%dEEE" % (NP, smode, U))
+    rng = np.random.default_rng(seed)
+    VB, npx = 256 * NP, width1 * h
+    nch = h if dy == 0 else (width1 if dx == 0 else width1 + h - 1)
+    dev = Device({"C": npx * VB, "S": npx * VB, "sel16": npx * 2 + 256, "selkey": npx * 4 + 256})
+    dev.fill_u16("C", rng, cmax)
+    dev.fill_u16("S", rng, smax)
+    s_before = dev.u16("S")
+    dev.launch(k, (nch + 3) // 4, 4, [("ptr", "C"), ("ptr", "S")] + [("i32", v) for v in (width1, h, dx, dy, P1, P2, nch, 128 * NP, 0, 10, 1)] +
+               [("ptr", "sel16"), ("ptr", "selkey")])
+    shape = (h, width1, 128 * NP)
+    return dev.u16("C").reshape(shape), s_before.reshape(shape), dev.u16("S").reshape(shape)
 
 
 def columns_rows_case(listing, width1, h, seed, NP=2, K=8, XB=10, P1=7, P2=150, cmax=2000, smax=3000):

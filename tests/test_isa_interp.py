@@ -111,13 +111,13 @@ def test_the_comparison_sees_the_round_3_miscompile(tmp_path):
     assert bad[0] > 0 and bad[1] == 0, bad
 
 
-def _sgm_family_model(C, dx, dy, P1, P2):
+def _sgm_family_model(C, dx, dy, P1, P2, both=True):
     """L_r(p, d) = C(p, d) + min(L_r(p - r, d), L_r(p - r, d +- 1) + P1, min_k L_r(p - r, k) + P2) - min_k L_r(p - r, k), zero state outside the
     image, for r = (dx, dy) and its opposite; returns their sum"""
     h, w, D = C.shape
     S = np.zeros(C.shape, np.int64)
     big = 1 << 20
-    for sx, sy in ((dx, dy), (-dx, -dy)):
+    for sx, sy in (((dx, dy), (-dx, -dy)) if both else ((dx, dy),)):
         L = np.zeros(C.shape, np.int64)
         for y in (range(h) if sy > 0 else range(h - 1, -1, -1)):
             for x in (range(w) if sx >= 0 else range(w - 1, -1, -1)):
@@ -162,3 +162,16 @@ def test_the_shipped_isa_computes_columns_and_rows_like_the_recurrence(listings)
     M = S0.astype(np.int64) + _sgm_family_model(Ci, 0, 1, 7, 150) + _sgm_family_model(Ci, 1, 0, 7, 150)
     assert M.max() < 32767
     assert np.array_equal(S1.astype(np.int64), M), int((S1.astype(np.int64) != M).sum())
+
+
+def test_the_shipped_isa_computes_an_unpaired_path_like_the_recurrence(listings):
+    """5-path mode (what the reference runs): paths 1 and 3 have no partner and go through k_sweep -- the accumulating form on a diagonal, the
+    last form (saturation, stored for the debug fetch, selection behind it) on the other."""
+    import gcn_interp as g
+    for dx, dy, smode, smax in ((1, 1, 1, 3000), (-1, 1, 2, 31500)):
+        C, S0, S1 = g.single_path_case(listings[0], 22, 19, dx, dy, 9, smode=smode, smax=smax)
+        M = S0.astype(np.int64) + _sgm_family_model(C.astype(np.int64), dx, dy, 7, 150, both=False)
+        if smode == 2:
+            assert (M > 0x7FFF).any()
+            M = np.minimum(M, 0x7FFF)
+        assert np.array_equal(S1.astype(np.int64), M), (dx, dy, smode, int((S1.astype(np.int64) != M).sum()))
