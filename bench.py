@@ -635,9 +635,13 @@ def main():
     pipe = FramePipeline(ctx, w, h, params, geom, tail_overlap=tail_overlap, inliers_text=args.inlier_text) if args.stage == "full" else None
     sgm_out = torch.empty((h, w), dtype=torch.int16, device=dev)
 
-    def run_pass(resident: bool, steps: int, warmup: int, pipe=pipe, params=params):
-        """W untimed steps, then exactly `steps` timed ones between two barriers; returns what the JSON line needs."""
+    def run_pass(resident: bool, steps: int, warmup: int, pipe=pipe, params=params, kernel_events: bool = False):
+        """W untimed steps, then exactly `steps` timed ones between two barriers; returns what the JSON line needs.
+        kernel_events (never in a pass whose rate is reported): every launch of the cost stage and of the aggregation family bracketed by
+        hipEvents on its own stream, read after every step -- the SGM streams are waited for, the frame's tail still runs underneath the
+        next frame's kernels."""
         planes, npts_hist, nbytes_hist, overflows = [], [], [], []
+        kms = {}
 
         def keep(o):
             if o is not None:
@@ -685,16 +689,26 @@ def main():
 
         # Stage timings come from hipEvents recorded on the context's own stream; call n's are read after call n+2 has been
         # enqueued (the library keeps four sets), so the reader never waits for a frame that is still running
+        if kernel_events:
+            ctx.set_kernel_events(True)
         t0 = time.perf_counter()
         c0 = ctx.sgm_call_count()
-        for i in range(steps):
-            step(warmup + i)
-            if i > 1:
-                take(ctx.sgm_call_timings(c0 + i - 1))
-        barrier()
+        try:
+            for i in range(steps):
+                step(warmup + i)
+                if kernel_events:
+                    for name, ms in ctx.sgm_kernel_times():
+                        kms.setdefault(name, []).append(ms)
+                if i > 1:
+                    take(ctx.sgm_call_timings(c0 + i - 1))
+            barrier()
+        finally:
+            if kernel_events:
+                ctx.set_kernel_events(False)
         for k in range(max(steps - 2, 0), steps):
             take(ctx.sgm_call_timings(c0 + k + 1))
-        return {"elapsed": time.perf_counter() - t0, "planes": planes, "npts": npts_hist, "nbytes": nbytes_hist, "overflows": overflows, "tm": tm}
+        return {"elapsed": time.perf_counter() - t0, "planes": planes, "npts": npts_hist, "nbytes": nbytes_hist, "overflows": overflows, "tm": tm,
+                "kernel_ms": {k: round(float(np.mean(v)), 3) for k, v in kms.items()}}
 
     # the metric's pass includes the H2D of both pictures.  (Round 4 had the resident pass as `value`; the two
     # differ by a fraction of a percent -- the 10 MB upload hides under the previous frame -- and both are always reported.)
@@ -708,14 +722,23 @@ def main():
         other_pass = run_pass(not resident_main, args.steps, min(args.warmup, 5))
     # The mode the reference actually runs: StereoSGBM::create leaves MODE_SGBM, five paths (wass_stereo.cpp:775-777).  Same
     # frames, same chain, same brackets, inputs uploaded inside the step like the headline pass.
-    pass5 = None
+    # what the column paths add to the cost stage's vertical sum, measured on the last frame's horizontal sums (plain sum vs
+    # the production kernel, best of three each, outside the timed region).  The probe re-launches the LAST call's form of the kernel,
+    # so it comes right behind the pass it belongs to (round 5 probed after the 5-path pass and charged the 8-path record with the
+    # 5-path kernel).
+    vsum_probe = ctx.sgm_probe_vsum()
+    # per-kernel times of the family (hipEvents around every launch, a few pipelined frames outside the timed passes): the record
+    # can be re-derived from the line alone
+    kernel_ms = None
+    if world == 1 and args.stage == "full":
+        kernel_ms = run_pass(resident_main, 6, 2, kernel_events=True)["kernel_ms"]
+    pass5 = vsum_probe5 = kernel_ms5 = None
     if world == 1 and args.config == "B" and args.stage == "full" and args.ndirs == 8 and not args.no_5path:
         params5 = wass_amd.default_sgm_params(D, ndirs=5)
         pipe5 = FramePipeline(ctx, w, h, params5, geom, tail_overlap=tail_overlap)
         pass5 = run_pass(False, min(args.steps, 64), min(args.warmup, 5), pipe=pipe5, params=params5)
-    # what the column paths add to the cost stage's vertical sum, measured on the last frame's horizontal sums (plain sum vs
-    # the production kernel, best of three each, outside the timed region)
-    vsum_probe = ctx.sgm_probe_vsum()
+        vsum_probe5 = ctx.sgm_probe_vsum()
+        kernel_ms5 = run_pass(False, 6, 2, pipe=pipe5, params=params5, kernel_events=True)["kernel_ms"]
     # Coll-1: sequence mean plane = NaN-aware mean over every rank's frames (5 doubles all-reduced over RCCL)
     acc = wass_amd.planes_mean_accumulate(np.array(planes).reshape(-1, 4)) if planes else np.zeros(5)
     rank_rates = [args.steps / elapsed]
@@ -815,6 +838,10 @@ def main():
             "value_is": "resident_inputs" if resident_main else "pcie_inclusive",
             "roofline": {"bound": "hbm", "kernel": "path aggregation family (k_rowsweep + k_ckpt + k_pairx + k_pair [+ k_sweep]), all launches "
                                                    "of one frame, side stream included",
+                         # launch durations inside pipelined frames (hipEvents around every launch, 6 frames outside the timed passes);
+                         # k_rowsweep and the second k_ckpt run on the side stream beside the main stream's kernels, so the sum
+                         # exceeds `ms`: the bracket is main-stream time
+                         "kernel_ms": kernel_ms,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": int(traffic[0]) if traffic else None,
@@ -862,6 +889,7 @@ def main():
             alg5 = cells * (2 * 5 + 4)
             t5 = float(np.mean(pass5["tm"]["agg"])) * 1e-3
             tr5 = measured_traffic(args.config, 5)
+            p2m5 = max(0.0, vsum_probe5[1] - vsum_probe5[0]) * 1e-3
             line["mode_5path"] = {
                 "workload": f"config {args.config}: {w}x{h}, D={D}, 5-path MODE_SGBM (what wass_stereo.cpp:775-777 runs), whole chain a1-a20, "
                             f"pictures uploaded inside the step, {s5} frames",
@@ -869,10 +897,18 @@ def main():
                 "aggregate_ms": round(t5 * 1e3, 3),
                 "stage_ms": {"cost_volume": round(float(np.mean(pass5["tm"]["cost"])), 3), "aggregate": round(t5 * 1e3, 3),
                              "sgm_total": round(float(np.mean(pass5["tm"]["sgm"])), 3)},
-                "roofline": {"bound": "hbm", "kernel": "k_sweep (paths 1, 3) + k_ckpt + k_pair (rows); path 2 rides in k_vsum_col",
+                "roofline": {"bound": "hbm", "kernel": "k_sweep (path 1, writes S) + k_rowsweep + k_pairx<ONE> (path 2 + rows 0/4, S +=) + k_sweep (path 3, "
+                                                       "selection); path 2's forward sweep rides in k_vsum_col (checkpoints only)",
                              "achieved": round(alg5 / t5 / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(alg5 / t5 / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": alg5,
-                             "traffic": int(tr5[0]) if tr5 else None, "traffic_source": tr5[1] if tr5 else None},
+                             "frac": round(alg5 / t5 / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": alg5, "ms": round(t5 * 1e3, 3),
+                             "traffic": int(tr5[0]) if tr5 else None, "traffic_source": tr5[1] if tr5 else None,
+                             "effective_tbps": round(tr5[0] / t5 / 1e12, 3) if tr5 else None,
+                             "kernel_ms": kernel_ms5,
+                             "strict": {"achieved": round(alg5 / (t5 + p2m5) / 1e9, 1), "frac": round(alg5 / (t5 + p2m5) / 1e9 / HBM_PEAK_GBS, 4),
+                                        "ms": round((t5 + p2m5) * 1e3, 3),
+                                        "vertical_sum_ms": {"plain": round(vsum_probe5[0], 3), "with_column_paths": round(vsum_probe5[1], 3)},
+                                        "note": "same bytes; time = aggregation launches + what the column path adds to the cost stage's vertical "
+                                                "sum (production kernel minus plain sum on the same data, probed right behind this pass)"}},
                 "repeat_check": repeat_check(pass5["planes"], pass5["npts"], min(args.warmup, 5), nf),
                 "cost_overflow": int(max(pass5["overflows"])) if pass5["overflows"] else 0}
         if world == 1 and args.config == "B" and args.stage == "full" and not args.no_config_e:

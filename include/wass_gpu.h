@@ -168,6 +168,13 @@ int wass_sgm_selftest(wass_ctx* ctx, int w, int h, int num_disp, int ndirs, uint
  * context's stream.  production_ms - plain_ms is what the column paths add to the cost stage.  Synchronises. */
 int wass_sgm_probe_vsum(wass_ctx* ctx, float* plain_ms, float* production_ms);
 
+/* Measurement hook (bench.py, "kernel_ms"): with on != 0 every kernel launch of the cost stage and of the aggregation family is
+ * bracketed by two hipEvents on the stream it is launched on (main or side).  wass_sgm_kernel_times then returns the LAST SGM call's
+ * launches in launch order: their names, '\n'-separated, into names[names_cap], and their durations into ms[max_kernels]; *n_kernels
+ * = how many.  Off by default (an event between two kernels is a marker packet on the queue); synchronises. */
+int wass_ctx_set_kernel_events(wass_ctx* ctx, int on);
+int wass_sgm_kernel_times(wass_ctx* ctx, char* names, size_t names_cap, float* ms, int max_kernels, int* n_kernels);
+
 /* Test hooks: copy intermediates of the last wass_sgm_disparity call to host.
  * C/S are [h][width1][num_disp] int16 with width1 = w + max(disp_offset,0) -
  * min_disp (C without the +P2 bias); raw is the padded-width disparity before

@@ -816,7 +816,7 @@ def rowsweep_case(listing, prefix, width1, h, row, seed, NP=2, XB=10):
 
 
 def pairx_case(listing, prefix, width1, h, block, seed, NP=2, K=8, XB=10):
-    """k_pairx<NP, K, ACC = true, DG = false>: the column family with the rows riding along -- one workgroup of XB waves (a block of XB
+    """k_pairx<NP, K, ACC = true, ONE = false>: the column family with the rows riding along -- one workgroup of XB waves (a block of XB
     columns, upper or lower half of the image), barriers included.  Random inputs: states, minima and S are whatever they are."""
     prog, labels = parse_kernel(listing, prefix)
     rng = np.random.default_rng(seed)
@@ -838,10 +838,10 @@ def pairx_case(listing, prefix, width1, h, block, seed, NP=2, K=8, XB=10):
         mem[offs["args"] + o:offs["args"] + o + n] = np.frombuffer(int(val & ((1 << (8 * n)) - 1)).to_bytes(n, "little"), np.uint8)
     for i, k in enumerate(("C", "S", "ckpt", "mins", "entF", "entB", "MF", "MB")):
         put(8 * i, offs[k], 8)
-    put(64, nbx, 4)                             # RowSide.nbx; DiagSide (72 .. 127) stays zero: DG = false never reads it
+    put(64, nbx, 4)                             # RowSide.nbx (+ 4 bytes of padding)
     for i, v in enumerate((width1, h, 7, 150, maxseg)):
-        put(128 + 4 * i, v, 4)
-    put(152, offs["end"], 8)
+        put(72 + 4 * i, v, 4)
+    put(96, offs["end"], 8)
     lds = np.zeros(160 * 1024, np.uint8)
     waves = []
     for wv in range(XB):
@@ -967,13 +967,14 @@ def single_path_case(listing, width1, h, dx, dy, seed, smode=1, NP=2, U=8, P1=7,
     return dev.u16("C").reshape(shape), s_before.reshape(shape), dev.u16("S").reshape(shape)
 
 
-def columns_rows_case(listing, width1, h, seed, NP=2, K=8, XB=10, P1=7, P2=150, cmax=2000, smax=3000):
+def columns_rows_case(listing, width1, h, seed, NP=2, K=8, XB=10, P1=7, P2=150, cmax=2000, smax=3000, one=False):
     """The fused half of the 8-path schedule on a small image, as the host launches it: k_rowsweep<NP> (paths 0 and 4: entry states, minima),
-    k_ckpt<NP, K> over the split column family, k_pairx<NP, K, ACC = true, DG = false> (S += L_2 + L_6 + L_0 + L_4), every workgroup.
+    k_ckpt<NP, K> over the split column family, k_pairx<NP, K, ACC = true, ONE = false> (S += L_2 + L_6 + L_0 + L_4), every workgroup.
+    one: the 5-path form k_pairx<NP, K, true, ONE = true> (S += L_2 + L_0 + L_4: the upward column path is computed and left out).
     Returns (C, S before, S after) as u16 [h][width1][128 * NP]."""
     rs_k = parse_kernel(listing, "_ZN4wass10k_rowsweepILi%dEEE" % NP)
     ck_k = parse_kernel(listing, "_ZN4wass6k_ckptILi%dELi%dEEE" % (NP, K))
-    px_k = parse_kernel(listing, "_ZN4wass7k_pairxILi%dELi%dELb1ELb0EEE" % (NP, K))
+    px_k = parse_kernel(listing, "_ZN4wass7k_pairxILi%dELi%dELb1ELb%dEEE" % (NP, K, 1 if one else 0))
     rng = np.random.default_rng(seed)
     VB, vec = 256 * NP, 64 * NP
     npx, nbx = width1 * h, (width1 + XB - 1) // XB
@@ -987,7 +988,7 @@ def columns_rows_case(listing, width1, h, seed, NP=2, K=8, XB=10, P1=7, P2=150, 
     dev.launch(rs_k, (h + 3) // 4, 4, [("ptr", k) for k in ("C", "entF", "entB", "MF", "MB")] + [("i32", v) for v in (width1, h, P1, P2, nbx)])
     end = ("ckpt", nch * mseg * vec * 4)
     dev.launch(ck_k, (nch + 3) // 4, 4, [("ptr", "C"), ("ptr", "ckpt"), ("ptr", "mins")] + [("i32", v) for v in (width1, h, 0, 1, P1, P2, nch, mseg)] + [("ptr", end)])
-    dev.launch(px_k, 2 * nbx, XB, [("ptr", k) for k in ("C", "S", "ckpt", "mins", "entF", "entB", "MF", "MB")] + [("i32", nbx), ("pad", 4), ("pad", 56)] +
+    dev.launch(px_k, 2 * nbx, XB, [("ptr", k) for k in ("C", "S", "ckpt", "mins", "entF", "entB", "MF", "MB")] + [("i32", nbx), ("pad", 4)] +
                [("i32", v) for v in (width1, h, P1, P2, mseg)] + [("ptr", end)], lds_bytes=XB * 2 * K * vec * 4)
     shape = (h, width1, 128 * NP)
     return dev.u16("C").reshape(shape), s_before.reshape(shape), dev.u16("S").reshape(shape)

@@ -15,7 +15,7 @@ import sys
 from collections import defaultdict
 
 out, config, ndirs = sys.argv[1], sys.argv[2], int(sys.argv[3])
-AGG = ("k_ckpt", "k_pair", "k_sweep", "k_rowsweep", "k_diagsweep")          # k_pair also matches k_pairx
+AGG = ("k_ckpt", "k_pair", "k_sweep", "k_rowsweep")          # k_pair also matches k_pairx
 
 
 def per_kernel(sub, ctr):

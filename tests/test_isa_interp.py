@@ -164,6 +164,18 @@ def test_the_shipped_isa_computes_columns_and_rows_like_the_recurrence(listings)
     assert np.array_equal(S1.astype(np.int64), M), int((S1.astype(np.int64) != M).sum())
 
 
+def test_the_shipped_isa_computes_path_2_and_the_rows_of_the_5_path_mode_like_the_recurrence(listings):
+    """Round 6, 5-path mode (MODE_SGBM, what the reference runs): the same walk with k_pairx<2, 8, true, ONE = true> -- of the column family only
+    the downward path counts (forward recomputation in the upper half of the image, backward path in the lower half, which starts from the
+    upper half's end state); S grows by exactly L_2 + L_0 + L_4."""
+    import gcn_interp as g
+    C, S0, S1 = g.columns_rows_case(listings[0], 23, 44, 4, one=True)
+    Ci = C.astype(np.int64)
+    M = S0.astype(np.int64) + _sgm_family_model(Ci, 0, 1, 7, 150, both=False) + _sgm_family_model(Ci, 1, 0, 7, 150)
+    assert M.max() < 32767
+    assert np.array_equal(S1.astype(np.int64), M), int((S1.astype(np.int64) != M).sum())
+
+
 def test_the_shipped_isa_computes_an_unpaired_path_like_the_recurrence(listings):
     """5-path mode (what the reference runs): paths 1 and 3 have no partner and go through k_sweep -- the accumulating form on a diagonal, the
     last form (saturation, stored for the debug fetch, selection behind it) on the other."""

@@ -290,65 +290,45 @@ def test_random_parameter_sets_match_the_oracle(gpu_ctx, oracle):
     assert done >= 25
 
 
-# ---- round 5: the three-guest schedule (columns + rows + DIAGONALS in k_pairx, S written once; WASS_DIAG_FUSE=1).  Off by default
-# because it measured slower (NOTES/aggregation.md), but built, selectable and held to the same bar: S bit-exact against the oracle
-# for every NP it is built for, for heights that put every combination of full segments / tail segments / the two halves' block
-# boundaries through k_diagsweep's edge schedule and the partial-block form of the phase, and on the device self-test.
-@pytest.fixture(scope="module")
-def diagfuse_ctx():
-    import wass_amd
-    old = os.environ.get("WASS_DIAG_FUSE")
-    os.environ["WASS_DIAG_FUSE"] = "1"                     # read when the context is created
-    try:
-        ctx = wass_amd.Context(0)
-    finally:
-        if old is None:
-            os.environ.pop("WASS_DIAG_FUSE", None)
-        else:
-            os.environ["WASS_DIAG_FUSE"] = old
-    yield ctx
-    ctx.close()
+# ---- round 6: the 5-path mode (MODE_SGBM, what the reference runs) on the fused kernel of the 8-path schedule: path 1's sweep writes S,
+# k_pairx<.., ONE> adds path 2 and both row paths in one pass, path 3's sweep reads S and selects (S written twice instead of three
+# times).  S bit-exact against the oracle for every NP the fused kernel is built for, for heights that put every combination of full
+# segments / tail segments of the split column family through it, and widths with a partial block of columns.
+_FUSED5_CASES = [(64, 48, 16), (160, 120, 32), (200, 90, 64), (150, 70, 128), (131, 77, 48), (320, 64, 256), (340, 32, 272), (560, 24, 512),
+                 (600, 64, 512), (460, 48, 384), (40, 300, 16), (33, 29, 16), (257, 33, 96), (300, 37, 256), (290, 131, 192)]
 
 
-_DIAG_CASES = [(64, 48, 16), (160, 120, 32), (200, 90, 64), (150, 70, 128), (131, 77, 48), (320, 64, 256), (340, 32, 272), (560, 24, 512),
-               (600, 64, 512), (460, 48, 384), (40, 300, 16), (33, 29, 16), (257, 33, 96), (300, 37, 256), (290, 131, 192)]
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("w,h,D", _DIAG_CASES)
-def test_diagonal_fusion_is_bit_exact(diagfuse_ctx, oracle, w, h, D):
+@pytest.mark.parametrize("w,h,D", _FUSED5_CASES)
+def test_fused_5path_schedule_is_bit_exact(gpu_ctx, oracle, w, h, D):
     right, left = synth.make_pair(w, h, D, frame_idx=w + h + D)
-    p = default_sgm_params(D, ndirs=8)
-    ctx = diagfuse_ctx
-    ctx.set_debug(True)
+    p = default_sgm_params(D, ndirs=5)
+    gpu_ctx.set_debug(True)
     try:
-        got = ctx.sgm_disparity(right, left, p)
-        Cg, Sg, rawg = ctx.sgm_debug_fetch(w, h, p)
+        got = gpu_ctx.sgm_disparity(right, left, p)
+        Cg, Sg, rawg = gpu_ctx.sgm_debug_fetch(w, h, p)
     finally:
-        ctx.set_debug(False)
-    np.testing.assert_array_equal(ctx.sgm_disparity(right, left, p), got)          # production mode (S not kept)
+        gpu_ctx.set_debug(False)
+    np.testing.assert_array_equal(gpu_ctx.sgm_disparity(right, left, p), got)          # production mode (S not kept)
     R, L = _pad(right, left, D, 0)
     disp, st, Co, So, rawo = oracle.sgbm_compute(R, L, _oracle_params(oracle, p), dump=True)
     assert not st.overflow
-    np.testing.assert_array_equal(Sg, So, err_msg="aggregated volume S (diagonal family folded into k_pairx)")
+    np.testing.assert_array_equal(Sg, So, err_msg="aggregated volume S (path 2 + rows in k_pairx<.., ONE>)")
     np.testing.assert_array_equal(got, disp[:, D:D + w])
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("h", [1, 2, 3, 5, 8, 9, 15, 16, 17, 18, 23, 31, 33, 34, 47])
-def test_diagonal_fusion_short_chains(diagfuse_ctx, oracle, h):
-    for D in (64, 256, 384, 512):
-        w = D + 70
-        right, left = synth.make_pair(w, h, D, frame_idx=h * 7 + D)
-        p = default_sgm_params(D, ndirs=8)
-        got = diagfuse_ctx.sgm_disparity(right, left, p)
-        ref, st = oracle.dense_disparity16(right, left, _oracle_params(oracle, p), 0)
-        if not st.overflow:
-            np.testing.assert_array_equal(got, ref, err_msg=f"h={h} D={D}")
-
-
-@pytest.mark.gpu
-def test_diagonal_fusion_device_selftest(diagfuse_ctx):
-    for D in (128, 256, 384, 512):
-        for (w, h) in ((D + 64, 64), (D + 150, 41)):
-            assert diagfuse_ctx.sgm_selftest(w, h, D, 8) == 0
+def test_kernel_events_report_the_schedule(gpu_ctx):
+    """wass_ctx_set_kernel_events / wass_sgm_kernel_times (bench.py's kernel_ms): the launches of one SGM call by name, in launch order."""
+    w, h, D = 320, 64, 256
+    right, left = synth.make_pair(w, h, D, frame_idx=5)
+    gpu_ctx.set_kernel_events(True)
+    try:
+        for ndirs, want in ((8, ["k_prefilter", "k_hsum_q", "k_vsum_col", "k_rowsweep", "k_ckpt(family 1)", "k_ckpt(family 2)", "k_pair(family 1)",
+                                 "k_pairx", "k_pair(family 2)"]),
+                            (5, ["k_prefilter", "k_hsum_q", "k_vsum_col", "k_rowsweep", "k_sweep(path 1)", "k_pairx", "k_sweep(path 3 + selection)"])):
+            a = gpu_ctx.sgm_disparity(right, left, default_sgm_params(D, ndirs=ndirs))
+            times = gpu_ctx.sgm_kernel_times()
+            assert [n for n, _ in times] == want
+            assert all(ms > 0 for _, ms in times)
+    finally:
+        gpu_ctx.set_kernel_events(False)
+    np.testing.assert_array_equal(gpu_ctx.sgm_disparity(right, left, default_sgm_params(D, ndirs=5)), a)

@@ -73,7 +73,6 @@ static int make_dims(wass_ctx* c, int w, int h, const wass_sgm_params* p, SgmDim
     d.ftzero = (p->prefilter_cap > 15 ? p->prefilter_cap : 15) | 1;
     if (d.ftzero > 127) return set_err(c, WASS_ERR_UNSUPPORTED, "DENSE_PREFILTER_CAP %d > 126", p->prefilter_cap);
     d.ndirs = p->ndirs;
-    d.diag_fuse = c->diag_fuse ? 1 : 0;
     if (d.width1 <= d.SW2) return set_err(c, WASS_ERR_INVALID_ARG, "image too narrow for the matching window");
     return WASS_OK;
 }
@@ -114,7 +113,6 @@ int wass_ctx_create(int device_id, wass_ctx** out)
     if (ensure(c, c->flags, 64) != WASS_OK) { wass_ctx_destroy(c); return WASS_ERR_NO_MEMORY; }
     if (hipHostMalloc((void**)&c->h_flags, 64, hipHostMallocDefault) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_NO_MEMORY; }
     for (int k = 0; k < 16; ++k) c->h_flags[k] = 0;       // one status word per timing set, 16 bytes apart
-    if (const char* e = getenv("WASS_DIAG_FUSE")) c->diag_fuse = atoi(e) != 0;   // 1: the three-guest schedule of round 5 (A/B runs on one box)
     mesh_pool_ctx_alive(c, true);
     *out = c;
     return WASS_OK;
@@ -134,6 +132,7 @@ void wass_ctx_destroy(wass_ctx* c)
                     &c->jpeg_out, &c->jpeg_info, &c->jpeg_part })
         release(*b);
     for (auto& e : c->ev_dbg) if (e) (void)hipEventDestroy(e);
+    for (auto& k : c->kev) { if (k.a) (void)hipEventDestroy(k.a); if (k.b) (void)hipEventDestroy(k.b); }
     if (c->h_dbg_info) (void)hipHostFree(c->h_dbg_info);
     for (auto& set : c->evs) for (auto& e : set) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_ckpt) if (e) (void)hipEventDestroy(e);
@@ -299,6 +298,7 @@ int wass_sgm_disparity_dev(wass_ctx* c, const uint8_t* d_right, const uint8_t* d
 
     hipStream_t s = c->stream;
     c->timings_valid = false;
+    c->kev_n = 0;
     const int set = (int)(c->nsgm % wass_ctx::NSGM_SETS);
     c->ev = c->evs[set];
     WASS_HIP(c, hipEventRecord(c->ev[0], s));
@@ -387,6 +387,35 @@ int wass_sgm_prev_timings(wass_ctx* c, wass_sgm_timings* out)
     if (!c || !out) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
     if (c->nsgm < 2) return set_err(c, WASS_ERR_INVALID_ARG, "fewer than two wass_sgm_disparity calls so far");
     return read_timings(c, c->nsgm - 2, out);
+}
+
+int wass_ctx_set_kernel_events(wass_ctx* c, int on)
+{
+    if (!c) return WASS_ERR_INVALID_ARG;
+    c->kernel_events = on != 0;
+    return WASS_OK;
+}
+
+int wass_sgm_kernel_times(wass_ctx* c, char* names, size_t names_cap, float* ms, int max_kernels, int* n_kernels)
+{
+    if (!c || !names || !ms || !n_kernels || names_cap == 0) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
+    if (!c->kernel_events || c->nsgm == 0) return set_err(c, WASS_ERR_INVALID_ARG, "no SGM call with wass_ctx_set_kernel_events(ctx, 1) so far");
+    WASS_HIP(c, hipSetDevice(c->device));
+    WASS_HIP(c, hipStreamSynchronize(c->stream));
+    WASS_HIP(c, hipStreamSynchronize(c->side));
+    std::string all;
+    int n = 0;
+    for (int i = 0; i < c->kev_n && n < max_kernels; ++i) {
+        float t = 0;
+        WASS_HIP(c, hipEventElapsedTime(&t, c->kev[i].a, c->kev[i].b));
+        ms[n++] = t;
+        all += c->kev[i].name;
+        all += '\n';
+    }
+    if (all.size() + 1 > names_cap) return set_err(c, WASS_ERR_INVALID_ARG, "names buffer too small (%zu bytes needed)", all.size() + 1);
+    memcpy(names, all.c_str(), all.size() + 1);
+    *n_kernels = n;
+    return WASS_OK;
 }
 
 int wass_sgm_selftest(wass_ctx* c, int w, int h, int num_disp, int ndirs, uint64_t* mismatches)

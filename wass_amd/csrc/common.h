@@ -90,7 +90,6 @@ struct SgmDims {
     int ndirs;
     int off_pos, comp;   // max(off,0), max(-off,0)
     int speckle_win = 0, speckle_range = 0;   // cv::filterSpeckles inside compute() when speckle_win > 0
-    int diag_fuse = 0;   // 8 paths, D <= 512: the diagonal family rides on k_pairx too (round 5; wass_ctx::diag_fuse)
     size_t cells() const { return (size_t)h * width1 * Dp; }
 };
 
@@ -209,9 +208,13 @@ struct wass_ctx {
     wass::SgmDims last = {};
     bool have_last = false;
     bool debug = false;            // keep the finished S volume for wass_sgm_debug_fetch
-    // 8 paths, D <= 512: fold the diagonal family into k_pairx as well (round 5; WASS_DIAG_FUSE=1 in the environment when the context is
-    // created).  Bit-exact, 28.1 instead of 31.6 GB per config-B frame -- and slower (7.25 against 6.36 ms, NOTES/aggregation.md): OFF.
-    bool diag_fuse = false;
+    // wass_ctx_set_kernel_events: every launch of the cost stage and of the aggregation family bracketed by two hipEvents on its own
+    // stream (one set, re-recorded by every SGM call; read with wass_sgm_kernel_times after a synchronisation).  Off by default: an
+    // event between two kernels is a marker packet on the queue.
+    bool kernel_events = false;
+    struct KernelEv { const char* name = nullptr; hipEvent_t a = nullptr, b = nullptr; };
+    KernelEv kev[24];
+    int kev_n = 0;
     wass_sgm_timings timings = {};
     bool timings_valid = false;
 };
@@ -274,15 +277,32 @@ struct CkptLayout {
     size_t moff[4] = {};             // byte offsets of the per-step minima records (K u16 per segment) into c->ckpt
     size_t total = 0;                // bytes of c->ckpt
     bool cols_from_cost = false;     // family 0 is the column family and its checkpoints come from k_vsum_col
-    bool rows_fused = false;         // 8 paths: the row family is folded into the column family's pair kernel (k_pairx)
+    bool rows_fused = false;         // D <= 512: the row family is folded into the column family's pair kernel (k_pairx); 5 paths: path 2 + rows
     int nbx = 0;                     // ... blocks of 8 columns per row
     size_t roff[4] = {};             // ... byte offsets into c->ckpt: entry states of paths 0 / 4, minima of paths 0 / 4
     bool path2_from_cost = false;    // 5-path mode: k_vsum_col has already written S = L_2 (path 2 has no partner)
-    bool diag_fused = false;         // round 5: the diagonal family is folded into k_pairx as well (k_diagsweep); families: columns, anti-diagonals
-    int nyb = 0, pm = 0;             // ... blocks of K rows in image order; u16 per chain in the minima records
-    size_t doff[6] = {};             // ... byte offsets into c->ckpt: ET1, EL1, EB7, ER7 (entry states), M1, M7 (minima)
 };
 CkptLayout ckpt_layout(const SgmDims& d);
+
+// brackets a launch with two events when the context asks for per-kernel times (wass_ctx_set_kernel_events); nothing otherwise
+struct KernelClock {
+    wass_ctx* c;
+    explicit KernelClock(wass_ctx* ctx) : c(ctx) {}
+    void begin(const char* name, hipStream_t s)
+    {
+        if (!c->kernel_events || c->kev_n >= (int)(sizeof c->kev / sizeof c->kev[0])) return;
+        wass_ctx::KernelEv& e = c->kev[c->kev_n];
+        if (!e.a && (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess)) return;
+        e.name = name;
+        (void)hipEventRecord(e.a, s);
+    }
+    void end(hipStream_t s)
+    {
+        if (!c->kernel_events || c->kev_n >= (int)(sizeof c->kev / sizeof c->kev[0]) || !c->kev[c->kev_n].b) return;
+        (void)hipEventRecord(c->kev[c->kev_n].b, s);
+        ++c->kev_n;
+    }
+};
 
 void coll_release(wass_ctx* c);               // coll.hip
 // post_opt.hip: optional parts of sgbm_dense_stereo (row a9)

@@ -674,184 +674,6 @@ k_rowsweep(const uint32_t* __restrict__ C, uint32_t* __restrict__ entF, uint32_t
     }
 }
 
-// ---------------------------------------------------------------------------
-// Round 5: the DIAGONAL family (paths 1 and 7) rides on the column family's kernel as well, so that S is written ONCE (by
-// k_pairx) and read once (by the anti-diagonal kernel): the S pass of k_pair<.., 0> on the diagonals and the S read of
-// k_pairx are gone (-2.6 GB written, -2.6 GB read per config-B frame) for the states with which the two paths enter every
-// block (+0.43 volumes).
-//   k_diagsweep (pure read stream, both paths in one wave like k_rowsweep): paths 1 and 7 over every diagonal, keeping the
-//     normalised state with which a path enters a block of k_pairx -- through its top / bottom edge (every row that starts /
-//     ends a K-row segment of the split column family, every x) or through its left / right edge (every XB-th column, every
-//     y) -- and min_d L after every step (chain-major u16 records).
-//   k_pairx<.., DG = true>: a third phase between the row phase and the backward column pass.  The K x XB block has
-//     K + XB - 1 diagonals of 1 .. K pixels; wrapped around the block's width they are XB chains of exactly K pixels: wave w
-//     is at column (w + i) mod XB in image row i.  It walks path 1 down and path 7 up that wrapped diagonal at once (no
-//     reductions: the minima are recorded), switching to the left / right edge's entry state where it wraps, and adds
-//     L_1 / L_7 into the forward costs waiting in LDS.  Within a row every wave is at a different column, whatever step it
-//     is at: the phase needs no synchronisation inside, one barrier towards the row phase in front of it.
-// ---------------------------------------------------------------------------
-// The blocks of k_pairx in y are the K-row segments of the split column family (half_chain_geometry): the top half counts
-// them from row 0 downwards, the bottom half from row h-1 upwards, each with its short tail segment at the middle.  yb is
-// the block's index in image order; top / bot: y is the first / last image row of its block.
-__host__ __device__ __forceinline__ void yblock(int y, int h, int K, int& yb, bool& top, bool& bot)
-{
-    const int mid = h / 2;
-    const int nb0 = (mid + K - 1) / K, nb1 = (h - mid + K - 1) / K;
-    if (y < mid) { yb = y / K; top = (y % K) == 0; bot = (y % K) == K - 1 || y == mid - 1; }
-    else { const int z = h - 1 - y; yb = nb0 + nb1 - 1 - z / K; bot = (z % K) == 0; top = (z % K) == K - 1 || y == mid; }
-}
-__host__ __device__ inline int yblock_count(int h, int K) { const int mid = h / 2; return (mid + K - 1) / K + (h - mid + K - 1) / K; }
-
-template <int NP>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4)))
-k_diagsweep(const uint32_t* __restrict__ C, uint32_t* __restrict__ ET1, uint32_t* __restrict__ EL1, uint32_t* __restrict__ EB7,
-            uint32_t* __restrict__ ER7, uint16_t* __restrict__ M1, uint16_t* __restrict__ M7, int width1, int h, int P1, int P2, int nbx, int pm)
-{
-    constexpr int XB = Fuse<NP>::XB, K = ckpt_k(NP), U = 8;
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
-    if (c >= width1 + h - 1) return;
-    int x0, y0, n;
-    chain_geometry(c, 1, 1, width1, h, x0, y0, n);
-    constexpr int VB = 256 * NP;
-    const long long vec = 64 * NP;
-    ChainAddr af, ab;                                       // step t: path 1 is at (x0 + t, y0 + t), path 7 at (x0 + n-1-t, y0 + n-1-t)
-    af.pixstep = (long long)width1 + 1;    af.pix0 = (long long)y0 * width1 + x0;                          af.sstep = (int)af.pixstep * VB;
-    ab.pixstep = -((long long)width1 + 1); ab.pix0 = (long long)(y0 + n - 1) * width1 + (x0 + n - 1);      ab.sstep = (int)ab.pixstep * VB;
-    const uint32_t voff = lane * NP * 4;
-    const us2 P1v = pk_splat(P1);
-    uint32_t* m1row = (uint32_t*)(M1 + (size_t)c * pm);     // pm is even: dword aligned
-    uint16_t* m7row = M7 + (size_t)c * pm;
-    // x mod XB / x div XB of both paths, advanced step by step
-    int cx1 = x0 % XB, bx1 = x0 / XB, cx7 = (x0 + n - 1) % XB, bx7 = (x0 + n - 1) / XB;
-
-    PathState<NP> sf, sb;
-    sf.reset();
-    sb.reset();
-    // The state with which a path ENTERS the pixel it is about to step on is kept where that pixel lies on a block edge.  Which of
-    // the U = K steps of a group those are is worked out once per group as bit masks (wave-uniform scalar arithmetic; a first form
-    // that decided per step cost 170 scalar instructions per step, and one with bool& outputs went through scratch memory):
-    //   block-top rows (path 1):    y = 0 mod K below the middle row, the middle row itself, y = h mod K above it
-    //   block-bottom rows (path 7): y = K-1 mod K below the middle row, the row above the middle, y = h-1 mod K from the middle on
-    //   block-left / -right columns: x = 0 / XB-1 mod XB -- at most one per group (U <= XB)
-    // The chain's own first pixels (t = 0) get their all-zero entry state stored like any other; nobody reads it.
-    static_assert(K == U && U <= XB, "one block-top row of each kind and one block-left column per group of U steps");
-    const int mid = h / 2, nyb = yblock_count(h, K);
-    auto st_entry = [&](uint32_t* base, uint32_t off, const PathState<NP>& st) {
-        const us2 mv = pk_splat(st.m);
-        us2 nrm[NP];
-#pragma unroll
-        for (int j = 0; j < NP; ++j) nrm[j] = st.L[j] - mv;
-        buf_st<NP>(mk_rsrc(base), voff, off, nrm);
-    };
-    auto yb_of = [&](int y) { return y < mid ? y / K : nyb - 1 - (h - 1 - y) / K; };
-#define WASS_DIAG_MASKS(t0_)                                                                                                         \
-        const int y1a = y0 + (t0_), y7a = y0 + n - 1 - (t0_);   /* rows of the group: path 1 y1a .. y1a+U-1, path 7 y7a .. y7a-(U-1) */ \
-        uint32_t mt, mb;                                                                                                             \
-        {                                                                                                                            \
-            const int ua = (-y1a) & (K - 1), um = mid - y1a, uc = (h - y1a) & (K - 1);                                               \
-            mt = (y1a + ua < mid ? 1u << ua : 0u) | ((unsigned)um < (unsigned)U ? 1u << um : 0u) | (y1a + uc > mid ? 1u << uc : 0u);  \
-            const int va = (y7a + 1) & (K - 1), vm = y7a - (mid - 1), vc = (y7a + 1 - h) & (K - 1);                                  \
-            mb = (y7a - va < mid ? 1u << va : 0u) | ((unsigned)vm < (unsigned)U ? 1u << vm : 0u) | (y7a - vc >= mid ? 1u << vc : 0u); \
-        }                                                                                                                            \
-        const int ul = cx1 == 0 ? 0 : XB - cx1, ur = cx7 == XB - 1 ? 0 : cx7 + 1;                                                    \
-        const uint32_t o_l = ((uint32_t)(y1a + ul) * (uint32_t)nbx + (uint32_t)(bx1 + (cx1 == 0 ? 0 : 1))) * VB;                     \
-        const uint32_t o_r = ((uint32_t)(y7a - ur) * (uint32_t)nbx + (uint32_t)(bx7 - (cx7 == XB - 1 ? 0 : 1))) * VB;
-#define WASS_DIAG_ENTRIES(t0_, u_)                                                                                                   \
-            if (mt & (1u << (u_))) st_entry(ET1, ((uint32_t)yb_of(y1a + (u_)) * (uint32_t)width1 + (uint32_t)(x0 + (t0_) + (u_))) * VB, sf);         \
-            else if ((u_) == ul) st_entry(EL1, o_l, sf);                                                                             \
-            if (mb & (1u << (u_))) st_entry(EB7, ((uint32_t)yb_of(y7a - (u_)) * (uint32_t)width1 + (uint32_t)(x0 + n - 1 - (t0_) - (u_))) * VB, sb); \
-            else if ((u_) == ur) st_entry(ER7, o_r, sb);
-    us2 rf[U][NP], rb[U][NP];
-    const int G = n / U, rem = n - G * U;                   // G groups of U steps, then rem steps
-    if (G > 0) {
-        const rsrc_t r0 = af.run<NP>(C, 0, U), r1 = ab.run<NP>(C, 0, U);
-        const uint32_t b1 = ab.bias(U);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            buf_ld<NP>(r0, voff, u * af.sstep, rf[u]);
-            buf_ld<NP>(r1, voff, b1 + u * ab.sstep, rb[u]);
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): nothing in flight when the loop is entered
-    }
-    for (int g = 0; g < G; ++g) {
-        const int t0 = g * U;
-        // refill from the next group; steps past the end of the chain re-read its last pixel and are never consumed
-        const int nxt = min(t0 + U, n - 1), cnn = min(U, n - nxt);
-        const rsrc_t rnf = af.run<NP>(C, nxt, cnn), rnb = ab.run<NP>(C, nxt, cnn);
-        const uint32_t bnb = ab.bias(cnn);
-        uint32_t msf[U], msb[U];
-        WASS_DIAG_MASKS(t0)
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            WASS_DIAG_ENTRIES(t0, u)
-            us2 Lf[NP], Lb[NP];
-            sgm_step_pair<NP>(sf, rf[u], Lf, sb, rb[u], Lb, P1v, P2);
-            msf[u] = sf.m;
-            msb[U - 1 - u] = sb.m;                          // in position order: position n-1-t0-u
-            const int uc = min(u, cnn - 1);
-            buf_ld<NP>(rnf, voff, uc * af.sstep, rf[u]);
-            buf_ld<NP>(rnb, voff, bnb + uc * ab.sstep, rb[u]);
-        }
-        cx1 += U; if (cx1 >= XB) { cx1 -= XB; ++bx1; }
-        cx7 -= U; if (cx7 < 0) { cx7 += XB; --bx7; }
-        store_minima<U>(m1row + (size_t)g * (U / 2), msf, lane);
-        {                                                   // path 7's minima cover positions n-t0-U .. n-1-t0: not aligned
-            uint32_t v = msb[0];
-#pragma unroll
-            for (int i = 1; i < U; ++i) v = lane == i ? msb[i] : v;
-            if (lane < U) m7row[n - t0 - U + lane] = (uint16_t)v;
-        }
-    }
-    if (rem > 0) {                                          // the last rem steps, guarded
-        const int t0 = G * U;
-        if (G == 0) {
-            const rsrc_t r0 = af.run<NP>(C, 0, rem), r1 = ab.run<NP>(C, 0, rem);
-            const uint32_t b1 = ab.bias(rem);
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (u < rem) {
-                    buf_ld<NP>(r0, voff, u * af.sstep, rf[u]);
-                    buf_ld<NP>(r1, voff, b1 + u * ab.sstep, rb[u]);
-                }
-        }
-        uint32_t msf[U], msb[U];
-#pragma unroll
-        for (int i = 0; i < U; ++i) msf[i] = msb[i] = 0;
-        WASS_DIAG_MASKS(t0)
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (u < rem) {
-                WASS_DIAG_ENTRIES(t0, u)
-                us2 Lf[NP], Lb[NP];
-                sgm_step_pair<NP>(sf, rf[u], Lf, sb, rb[u], Lb, P1v, P2);
-                msf[u] = sf.m;
-#pragma unroll
-                for (int i = 0; i < U; ++i) msb[i] = i == rem - 1 - u ? sb.m : msb[i];     // position rem-1-u
-            }
-        {                                                   // positions t0 .. t0+rem-1 (t0 is even: whole dwords, the pad is never read)
-            uint32_t v = msf[0] | (msf[1] << 16);
-#pragma unroll
-            for (int i = 1; i < U / 2; ++i) v = lane == i ? (msf[2 * i] | (msf[2 * i + 1] << 16)) : v;
-            if (lane < (rem + 1) / 2) m1row[(size_t)G * (U / 2) + lane] = v;
-        }
-        {
-            uint32_t v = msb[0];
-#pragma unroll
-            for (int i = 1; i < U; ++i) v = lane == i ? msb[i] : v;
-            if (lane < rem) m7row[lane] = (uint16_t)v;
-        }
-    }
-}
-#undef WASS_DIAG_MASKS
-#undef WASS_DIAG_ENTRIES
-
-struct DiagSide {                    // what k_diagsweep left behind
-    const uint32_t* ET1; const uint32_t* EL1; const uint32_t* EB7; const uint32_t* ER7;
-    const uint16_t* M1; const uint16_t* M7;
-    int pm;                          // u16 per chain in M1 / M7
-};
-
 struct RowSide {                     // what k_rowsweep left behind
     const uint32_t* entF; const uint32_t* entB;
     const uint16_t* MF; const uint16_t* MB;
@@ -859,13 +681,16 @@ struct RowSide {                     // what k_rowsweep left behind
 };
 
 // ACC: S already holds another family's sum (S += ...); otherwise this kernel writes S first.
-// DG: the diagonal family rides along too (paths 1 and 7 from the entry states of k_diagsweep); S = L_2 + L_6 + L_0 + L_4 + L_1 + L_7.
-template <int NP, int K, bool ACC, bool DG>
+// ONE (5-path mode, MODE_SGBM): of the column family only the DOWNWARD path (path 2) exists.  The walk is the same -- the hand-over
+// block is what the row phase works on, and S has to be touched anyway -- but the upward path's costs are left out of the sum:
+// in the upper half of the image (walked downwards) path 2 is the forward recomputation and the backward path is dropped, in the
+// lower half (walked upwards) path 2 is the backward path, arriving with the upper half's end state, and the forward
+// recomputation's costs are dropped.  S += L_2 + L_0 + L_4.
+template <int NP, int K, bool ACC, bool ONE>
 __global__ void __launch_bounds__(64 * Fuse<NP>::XB) __attribute__((amdgpu_waves_per_eu(Fuse<NP>::MINW, Fuse<NP>::MAXW)))
 k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t* __restrict__ ckpt, const uint16_t* __restrict__ mins,
-        const RowSide rs, const DiagSide dg, int width1, int h, int P1, int P2, int maxseg, const uint32_t* __restrict__ endstate)
+        const RowSide rs, int width1, int h, int P1, int P2, int maxseg, const uint32_t* __restrict__ endstate)
 {
-    static_assert(!(ACC && DG), "with the diagonals folded in this kernel is the first writer of S");
     constexpr int XB = Fuse<NP>::XB;
     static_assert(K % 2 == 0 && K <= XB && XB % 2 == 0, "one wave per row of a K-row segment; minima records are read as dwords");
     static_assert((size_t)XB * 2 * K * 256 * NP <= 160 * 1024, "the hand-over block must fit a CU's LDS");
@@ -880,6 +705,14 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bx = blockIdx.x >> 1, half = blockIdx.x & 1;
+    // ONE: which of the two column paths of this half counts (wave-uniform masks; all ones otherwise)
+    const uint32_t keepF = (!ONE || half == 0) ? 0xFFFFFFFFu : 0u, keepB = (!ONE || half == 1) ? 0xFFFFFFFFu : 0u;
+    auto drop = [](us2 (&v)[NP], uint32_t keep) {
+        if constexpr (ONE) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) v[j] = as_us2(as_u32(v[j]) & keep);
+        }
+    };
     const int X0 = bx * XB, ncol = min(XB, width1 - X0);
     const bool colact = wv < ncol;                         // this wave owns a column (the last block of a row may be short)
     const int x = colact ? X0 + wv : X0;
@@ -983,134 +816,6 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
         __syncthreads();
     };
 
-    // ---- the diagonal phase (DG): wave w walks the wrapped diagonal w of the block -- column (w + i) mod ncol in image row i --
-    // with path 1 downwards and path 7 upwards at once.  Image row i of a cnt-row segment is element e = i (top half, walked
-    // downwards) or cnt-1-i (bottom half, walked upwards), which lies in slot (rev ? K-1-e : e).
-    us2 dT[NP], dL[NP], dB[NP], dR[NP];                    // entry states: path 1 through the top / left edge, path 7 through the bottom / right edge
-    uint32_t r1v = 0, r7v = 0;                             // minima records: lane i holds min_d L_1 / L_7 at this wave's pixel of image row i
-    auto seg_top = [&](int seg, int cnt) { return dy > 0 ? y0 + seg * K : y0 - seg * K - (cnt - 1); };
-    auto ld_state = [&](const uint32_t* base, size_t idx, us2 (&dst)[NP]) { buf_ld<NP>(mk_rsrc(base + idx * vec), voff, 0, dst); };
-    auto zero_state = [&](us2 (&dst)[NP]) {
-#pragma unroll
-        for (int j = 0; j < NP; ++j) dst[j] = pk_splat(0);
-    };
-    // index of pixel (px, py) in the chain-major minima records of the (1,1) family (chain_geometry)
-    auto mrec_index = [&](int px, int py) { return px >= py ? (size_t)(px - py) * dg.pm + py : (size_t)(width1 - 1 + py - px) * dg.pm + px; };
-    // complete blocks (XB columns, K rows): everything the phase needs from HBM is requested before the column phase that precedes it
-    auto diag_fetch = [&](int seg, int cnt) {
-        if constexpr (DG) {
-            if (ncol == XB && cnt == K) {
-                const int ytop = seg_top(seg, K), ybot = ytop + K - 1, iw = XB - wv;      // the wave wraps to column 0 in image row iw
-                int yb;
-                bool tp, bt;
-                yblock(ytop, h, K, yb, tp, bt);
-                if (ytop > 0 && X0 + wv > 0) ld_state(dg.ET1, (size_t)yb * width1 + (X0 + wv), dT); else zero_state(dT);   // (the image border: all-zero, never stored)
-                int cbot = wv + K - 1; cbot -= cbot >= XB ? XB : 0;
-                if (ybot < h - 1 && X0 + cbot < width1 - 1) ld_state(dg.EB7, (size_t)yb * width1 + (X0 + cbot), dB); else zero_state(dB);
-                if (iw < K && bx >= 1) ld_state(dg.EL1, (size_t)(ytop + iw) * rs.nbx + bx, dL); else zero_state(dL);
-                if (iw < K && X0 + XB < width1) ld_state(dg.ER7, (size_t)(ytop + iw - 1) * rs.nbx + bx, dR); else zero_state(dR);
-                const int li = min(lane, K - 1);            // lanes K.. repeat the last row's address (never read)
-                int cl = wv + li; cl -= cl >= XB ? XB : 0;
-                const size_t mi = mrec_index(X0 + cl, ytop + li);
-                r1v = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(mk_rsrc(dg.M1), (uint32_t)(mi * 2), 0, 0);
-                r7v = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(mk_rsrc(dg.M7), (uint32_t)(mi * 2), 0, 0);
-                asm volatile("" : "+v"(r1v), "+v"(r7v) :: "memory");   // the loads stay here (see Rec::load)
-            }
-        }
-    };
-    auto diag_phase = [&](int seg, int cnt, bool rev) {    // entered right behind the row phase's closing barrier
-        if constexpr (DG) {
-            uint32_t* const lb = hand_raw + lane * NP;
-            auto add_into = [&](uint32_t* lp, const us2 (&x)[NP]) {
-                us2 t[NP];
-                lds_ld<NP>(lp, t);
-#pragma unroll
-                for (int q = 0; q < NP; ++q) t[q] = pk_adds(t[q], x[q]);
-                lds_st<NP>(lp, t);
-            };
-            if (ncol == XB && cnt == K) {
-                const bool flip = rev != (dy < 0);          // image row i lies in slot (flip ? K-1-i : i)
-                const int iw = XB - wv;
-                PathState<NP> fa, fb;
-                fa.load_normalised(dT);
-                fb.load_normalised(dB);
-                auto slot_of = [&](int i, int col) { return lb + (flip ? K - 1 - i : i) * SS + col * VW; };
-                int c1 = wv, c7 = wv + K - 1;
-                c7 -= c7 >= XB ? XB : 0;
-                us2 can[NP], cbn[NP];
-                lds_ld<NP>(slot_of(0, c1), can);
-                lds_ld<NP>(slot_of(K - 1, c7), cbn);
-#pragma unroll
-                for (int t = 0; t < K; ++t) {
-                    const int i1 = t, i7 = K - 1 - t;
-                    uint32_t* const p1 = slot_of(i1, c1);
-                    uint32_t* const p7 = slot_of(i7, c7);
-                    us2 ca[NP], cb[NP], La[NP], Lb[NP];
-#pragma unroll
-                    for (int j = 0; j < NP; ++j) { ca[j] = can[j]; cb[j] = cbn[j]; }
-                    const bool w1 = t > 0 && i1 == iw, w7 = t > 0 && i7 == iw - 1;      // the path comes in through the side edge here
-                    if (w1) fa.load_normalised(dL);
-                    if (w7) fb.load_normalised(dR);
-                    const uint32_t ma = (t == 0 || w1) ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)r1v, i1 - 1);
-                    const uint32_t mb = (t == 0 || w7) ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)r7v, t == 0 ? 0 : i7 + 1);
-                    int n1 = c1 + 1; n1 -= n1 >= XB ? XB : 0;
-                    int n7 = c7 - 1; n7 += n7 < 0 ? XB : 0;
-                    if (t + 1 < K) {
-                        lds_ld<NP>(slot_of(i1 + 1, n1), can);
-                        lds_ld<NP>(slot_of(i7 - 1, n7), cbn);
-                    }
-                    sgm_step_ff<NP>(fa, ma, ca, La, fb, mb, cb, Lb, P1v, P2);
-                    add_into(p1 + KS, La);
-                    add_into(p7 + KS, Lb);
-                    c1 = n1; c7 = n7;
-                }
-            } else if (wv < ncol) {
-                // partial blocks (the short tail segment at the middle of the image, the short block at the right border): one path
-                // after the other, states and minima fetched when they are needed
-                const int ytop = seg_top(seg, cnt);
-                auto slot_of = [&](int i, int col) {
-                    const int e = dy > 0 ? i : cnt - 1 - i;
-                    return lb + (rev ? K - 1 - e : e) * SS + col * VW;
-                };
-                auto min_at = [&](const uint16_t* M, int px, int py) {
-                    const uint32_t v = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(mk_rsrc(M), (uint32_t)(mrec_index(px, py) * 2), 0, 0);
-                    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-                };
-                int yb;
-                bool tp, bt;
-                yblock(ytop, h, K, yb, tp, bt);
-                PathState<NP> st;
-                for (int i = 0; i < cnt; ++i) {             // path 1, downwards
-                    const int col = (wv + i) % ncol, px = X0 + col, py = ytop + i;
-                    uint32_t m = 0;
-                    us2 e[NP];
-                    if (i == 0) { if (py > 0 && px > 0) ld_state(dg.ET1, (size_t)yb * width1 + px, e); else zero_state(e); st.load_normalised(e); }
-                    else if (col == 0) { if (bx >= 1) ld_state(dg.EL1, (size_t)py * rs.nbx + bx, e); else zero_state(e); st.load_normalised(e); }
-                    else m = min_at(dg.M1, px - 1, py - 1);
-                    us2 cv[NP], L[NP];
-                    uint32_t* const sp = slot_of(i, col);
-                    lds_ld<NP>(sp, cv);
-                    sgm_step_f<NP>(st, m, cv, L, P1v, P2);
-                    add_into(sp + KS, L);
-                }
-                for (int i = cnt - 1; i >= 0; --i) {        // path 7, upwards
-                    const int col = (wv + i) % ncol, px = X0 + col, py = ytop + i;
-                    uint32_t m = 0;
-                    us2 e[NP];
-                    if (i == cnt - 1) { if (py < h - 1 && px < width1 - 1) ld_state(dg.EB7, (size_t)yb * width1 + px, e); else zero_state(e); st.load_normalised(e); }
-                    else if (col == ncol - 1) { if (px < width1 - 1) ld_state(dg.ER7, (size_t)py * rs.nbx + bx, e); else zero_state(e); st.load_normalised(e); }
-                    else m = min_at(dg.M7, px + 1, py + 1);
-                    us2 cv[NP], L[NP];
-                    uint32_t* const sp = slot_of(i, col);
-                    lds_ld<NP>(sp, cv);
-                    sgm_step_f<NP>(st, m, cv, L, P1v, P2);
-                    add_into(sp + KS, L);
-                }
-            }
-            __syncthreads();
-        }
-    };
-
     PathState<NP> bw, fw;
     us2 cf[K][NP];                                         // ring: cost vectors of the segment the forward recomputation covers next
     us2 sr[ACC ? K : 1][NP];                               // ring (ACC): S of the segment the backward path covers next
@@ -1129,7 +834,6 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
             if (top >= 1) mB.load(mrow + (size_t)(top - 1) * (K / 2), lane);
         }
         row_fetch(top, cn);
-        diag_fetch(top, cn);
         if (colact) {
             bw.reset();
             {                                              // the backward path arrives from the other half of the chain
@@ -1163,6 +867,7 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
                 if (u < cn) {
                     us2 L[NP];
                     sgm_step<NP>(fw, c0[u], L, P1v, P2);
+                    drop(L, keepF);
                     lds_st<NP>(hc + u * SS, c0[u]);
                     lds_st<NP>(hc + KS + u * SS, L);
                 }
@@ -1205,6 +910,8 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
                 lds_ld<NP>(pn + KS, lfn);                                                                               \
             }                                                                                                           \
             sgm_step_fb<NP>(fw, mB.before(u), cf[u], Lf, bw, cb, Lb, P1v, P2);                                   \
+            drop(Lf, keepF);                                                                                            \
+            drop(Lb, keepB);                                                                                            \
             _Pragma("unroll") for (int j = 0; j < NP; ++j) sv[j] = pk_adds(lfv[j], Lb[j]);                               \
             if constexpr (ACC) { _Pragma("unroll") for (int j = 0; j < NP; ++j) sv[j] = pk_adds(sv[j], sr[v][j]); }     \
             buf_st<NP>(rsO, voff, bK + v * a.sstep, sv);                                                                \
@@ -1241,6 +948,7 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
                 lds_ld<NP>(hc + slot * SS, cb);                                                                         \
                 lds_ld<NP>(hc + KS + slot * SS, lfv);                                                                   \
                 sgm_step<NP>(bw, cb, Lb, P1v, P2);                                                                      \
+                drop(Lb, keepB);                                                                                        \
                 _Pragma("unroll") for (int j = 0; j < NP; ++j) sv[j] = pk_adds(lfv[j], Lb[j]);                           \
                 if constexpr (ACC) { _Pragma("unroll") for (int j = 0; j < NP; ++j) sv[j] = pk_adds(sv[j], sr[v][j]); } \
                 buf_st<NP>(rsO, voff, bO + v * a.sstep, sv);                                                            \
@@ -1248,6 +956,7 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
             if (hasfw_) {                                                                                               \
                 if constexpr (ACC) buf_ld<NP>(rsN, voff, bK + v * a.sstep, sr[v]);   /* segment s-1 is complete */       \
                 sgm_step_f<NP>(fw, mB.before(u), cf[u], Lf, P1v, P2);                                            \
+                drop(Lf, keepF);                                                                                        \
                 lds_st<NP>(hc + slot * SS, cf[u]);                                                                      \
                 lds_st<NP>(hc + KS + slot * SS, Lf);                                                                    \
                 buf_ld<NP>(rcN, voff, bK + u * a.sstep, cf[u]);                                                          \
@@ -1264,9 +973,8 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
     bool nat = true;                                       // iteration 0 filled the slots in natural order
     if (top == F) {                                        // r > 0: the backward path starts on the short tail segment
         row_phase(s, r, !nat);
-        diag_phase(s, r, !nat);
         const bool hasfw = s >= 1;
-        if (hasfw) { row_fetch(s - 1, K); diag_fetch(s - 1, K); }
+        if (hasfw) row_fetch(s - 1, K);
         WASS_PX_SLOW(nat, s, r, hasfw)
         if (!hasfw) return;
         nat = !nat;                                        // the forward results went into the slots as they were drained
@@ -1278,15 +986,12 @@ k_pairx(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, const uint32_t
     }
     while (s >= 1) {
         row_phase(s, K, !nat);
-        diag_phase(s, K, !nat);
         row_fetch(s - 1, K);
-        diag_fetch(s - 1, K);
         WASS_PX_FAST(s)
         nat = !nat;
         --s;
     }
     row_phase(0, K, !nat);
-    diag_phase(0, K, !nat);
     WASS_PX_SLOW(nat, 0, K, false)
 #undef WASS_PX_FAST
 #undef WASS_PX_SLOW
@@ -1296,6 +1001,10 @@ CkptLayout ckpt_layout(const SgmDims& d)
 {
     CkptLayout L;
     L.K = ckpt_k(d.NP);
+    // the column family's forward sweeps ride on the cost stage (k_vsum_col) whenever a pair kernel of that family follows: always
+    // with 8 paths, and with 5 paths where the fused kernel is built (the column walk then carries path 2 and both row paths)
+    const bool fused = d.NP <= WASS_FUSE_NP;
+    L.cols_from_cost = d.ndirs == 8 || fused;
     auto add = [&](int dx, int dy, int smode) {
         const int f = L.nfam++;
         L.dx[f] = dx; L.dy[f] = dy; L.smode[f] = smode;
@@ -1304,8 +1013,8 @@ CkptLayout ckpt_layout(const SgmDims& d)
         // Every family is split in the middle (half_chain_geometry) for twice the waves: 2 058 rows / 2 456 columns are
         // two waves per SIMD, and the longest chain of a diagonal family halves.  Measured at config B, same box, three
         // runs each: columns split 1.40 -> 1.11 ms (k_vsum_col), diagonals split 7.90 -> 7.60 ms (aggregation).
-        // The column family is only split when the cost stage produces it (8 paths).
-        L.split[f] = dx != 0 || d.ndirs == 8;
+        // The column family is only split when the cost stage produces it.
+        L.split[f] = dx != 0 || L.cols_from_cost;
         if (L.split[f]) { L.nch[f] *= 2; maxlen = maxlen - maxlen / 2; }
         L.mseg[f] = (maxlen + L.K - 1) / L.K;
         const size_t b = (size_t)L.nch[f] * (L.mseg[f] + (L.split[f] ? 1 : 0)) * (64 * d.NP) * sizeof(uint32_t);   // + the end states
@@ -1313,16 +1022,7 @@ CkptLayout ckpt_layout(const SgmDims& d)
     };
     // The kernel that carries the winner-take-all goes last and should have the most chains (the WTA adds ~50
     // instructions per pixel): the anti-diagonals (width1 + h - 1 chains).
-    if (d.ndirs == 8 && d.NP <= WASS_FUSE_NP && d.diag_fuse) {
-        // Round 5: columns + rows + diagonals in ONE kernel (k_pairx<.., DG>), which writes S; the anti-diagonal kernel reads it and
-        // selects.  Pure read sweeps in front: k_rowsweep, k_diagsweep (entry states of the folded paths), k_ckpt (anti-diagonals).
-        L.cols_from_cost = true;
-        L.rows_fused = true;
-        L.diag_fused = true;
-        add(0, 1, 0);                // columns + rows + diagonals: paths 2 + 6, 0 + 4, 1 + 7 (k_pairx, S written)
-        add(-1, 1, 2);               // anti-diagonals: paths 3 + 5, winner-take-all fused, last
-    } else if (d.ndirs == 8 && d.NP <= WASS_FUSE_NP) {
-        L.cols_from_cost = true;
+    if (d.ndirs == 8 && fused) {
         L.rows_fused = true;
         // Order of the pair kernels: diagonals, columns + rows, anti-diagonals.  The fused kernel needs the row sweeps, whose
         // chains are the longest in the image (1.4 ms alone); with the diagonal family first the main stream has 2 ms of
@@ -1332,14 +1032,20 @@ CkptLayout ckpt_layout(const SgmDims& d)
         add(1, 1, 0);                // diagonals:      paths 1 + 7 (S written), first
         add(-1, 1, 2);               // anti-diagonals: paths 3 + 5, winner-take-all fused, last
     } else if (d.ndirs == 8) {
-        // D > 256: a pixel vector is 1 KiB or more; the fused kernel's hand-over block (XB columns x K rows, two kinds) would
-        // be the CU's whole LDS at K = 8, and with K = 4, where it fits, it ran its two barriers every four rows with six of
-        // ten waves idle in the row phase (measured at config E: 28.1 against 23.3 ms).  One pair kernel per family.
-        L.cols_from_cost = true;
+        // D > 512: a pixel vector is 1.25 KiB or more; the fused kernel's hand-over block (XB columns x K rows, two kinds) does not
+        // fit a CU's LDS with K >= 4 and >= 8 columns.  One pair kernel per family.
         add(0, 1, 0);                // columns:        paths 2 + 6   (S written)
         add(1, 0, 1);                // rows:           paths 0 + 4
         add(1, 1, 1);                // diagonals:      paths 1 + 7
         add(-1, 1, 2);               // anti-diagonals: paths 3 + 5, winner-take-all fused
+    } else if (fused) {
+        // 5 paths (MODE_SGBM, what the reference runs), round 6: paths 1, 2 and 3 have no partner, so each used to be a pass of its
+        // own over S (S = L_2 written by the cost stage, += L_1, += L_0 + L_4, + L_3 and selection: S written three times, read three
+        // times).  Now path 1's sweep writes S first (beside the row sweeps on the side stream), the fused kernel of the 8-path
+        // schedule adds path 2 and both row paths in one pass (k_pairx<.., ONE>), path 3's sweep reads S and selects: S written
+        // twice and read twice, and the cost stage carries only the column family's checkpoints.
+        L.rows_fused = true;
+        add(0, 1, 1);                // column walk: path 2 and rows 0 + 4 (k_pairx<.., ONE>, S +=)
     } else {
         L.path2_from_cost = true;
         add(1, 0, 1);                // rows: paths 0 + 4, added to the S = L_2 that the cost stage left behind
@@ -1358,20 +1064,6 @@ CkptLayout ckpt_layout(const SgmDims& d)
         L.roff[1] = o; o += eb;
         L.roff[2] = o; o += mb;
         L.roff[3] = o; o += mb;
-    }
-    if (L.diag_fused) {              // k_diagsweep: entry states through the blocks' top / left / bottom / right edges, minima per chain
-        const size_t vb = (size_t)(64 * d.NP) * sizeof(uint32_t);
-        L.nyb = yblock_count(d.h, L.K);
-        L.pm = (((d.width1 < d.h ? d.width1 : d.h) + 7) & ~7) + 8;
-        const size_t et = ((size_t)L.nyb * d.width1 * vb + 255) & ~(size_t)255;
-        const size_t el = ((size_t)d.h * L.nbx * vb + 255) & ~(size_t)255;
-        const size_t mm = ((size_t)(d.width1 + d.h - 1) * L.pm * sizeof(uint16_t) + 255) & ~(size_t)255;
-        L.doff[0] = o; o += et;      // ET1
-        L.doff[1] = o; o += el;      // EL1
-        L.doff[2] = o; o += et;      // EB7
-        L.doff[3] = o; o += el;      // ER7
-        L.doff[4] = o; o += mm;      // M1
-        L.doff[5] = o; o += mm;      // M7
     }
     L.total = o;
     return L;
@@ -1397,28 +1089,23 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
     const int nf = lay.nfam;
     int rc = ensure(c, c->ckpt, lay.total);
     if (rc) return rc;
+    KernelClock kc(c);                               // per-kernel hipEvents, only when the context asks for them (wass_ctx_set_kernel_events)
 
     WASS_HIP(c, hipEventRecord(c->ev_cost, c->stream));
     WASS_HIP(c, hipStreamWaitEvent(c->side, c->ev_cost, 0));
     char* const ckb = (char*)c->ckpt.p;
     if (lay.rows_fused) {                            // the row sweeps come first: the first kernel on the main stream needs them
         if constexpr (NP <= WASS_FUSE_NP) {
+            kc.begin("k_rowsweep", c->side);
             hipLaunchKernelGGL((k_rowsweep<NP>), dim3((d.h + 3) / 4), dim3(256), 0, c->side, C, (uint32_t*)(ckb + lay.roff[0]),
                                (uint32_t*)(ckb + lay.roff[1]), (uint16_t*)(ckb + lay.roff[2]), (uint16_t*)(ckb + lay.roff[3]), d.width1, d.h,
                                d.P1, d.P2, lay.nbx);
+            kc.end(c->side);
             WASS_HIP(c, hipEventRecord(c->ev_ckpt[3], c->side));
             ++nl;
         }
     }
-    if (lay.diag_fused) {                            // the diagonal sweep on the main stream, beside the row sweeps: the fused kernel needs both
-        if constexpr (NP <= WASS_FUSE_NP) {
-            const int nch = d.width1 + d.h - 1;
-            hipLaunchKernelGGL((k_diagsweep<NP>), dim3((nch + 3) / 4), dim3(256), 0, c->stream, C, (uint32_t*)(ckb + lay.doff[0]),
-                               (uint32_t*)(ckb + lay.doff[1]), (uint32_t*)(ckb + lay.doff[2]), (uint32_t*)(ckb + lay.doff[3]),
-                               (uint16_t*)(ckb + lay.doff[4]), (uint16_t*)(ckb + lay.doff[5]), d.width1, d.h, d.P1, d.P2, lay.nbx, lay.pm);
-            ++nl;
-        }
-    }
+    const bool three = lay.rows_fused && nf == 3;    // the 8-path schedule with the fused kernel in the middle
     for (int f = 0; f < nf; ++f) {
         if (f == 0 && lay.cols_from_cost) {         // written by k_vsum_col on the main stream already
             WASS_HIP(c, hipEventRecord(c->ev_ckpt[f], c->stream));
@@ -1430,23 +1117,33 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
         // That was a loss while the fused kernel, which needs them, came first; it is free now that the diagonal family's
         // sweep and pair kernel, 2 ms of main-stream work, come first.  s_setprio in k_rowsweep changes nothing.)
         // fused schedule: the diagonal sweep goes on the MAIN stream (its pair kernel follows it there), beside the row sweeps
-        hipStream_t ss = (lay.rows_fused && !lay.diag_fused && f == 1) ? c->stream : c->side;
+        hipStream_t ss = (three && f == 1) ? c->stream : c->side;
+        kc.begin(f == 1 ? "k_ckpt(family 1)" : (f == 2 ? "k_ckpt(family 2)" : (f == 3 ? "k_ckpt(family 3)" : "k_ckpt(family 0)")), ss);
         hipLaunchKernelGGL((k_ckpt<NP, K>), dim3((nch + 3) / 4), dim3(256), 0, ss, C, ckf, (uint16_t*)((char*)c->ckpt.p + lay.moff[f]),
                            d.width1, d.h, lay.dx[f], lay.dy[f], d.P1, d.P2, nch, mseg,
                            lay.split[f] ? ckf + (size_t)nch * mseg * (64 * NP) : (uint32_t*)nullptr);
+        kc.end(ss);
         WASS_HIP(c, hipEventRecord(c->ev_ckpt[f], ss));
         ++nl;
     }
 
-    if (lay.path2_from_cost) {       // path 1 needs no checkpoints: it runs while the row checkpoints are produced
+    if (d.ndirs == 5) {
+        // path 1 needs no checkpoints: it runs while the row sweeps / row checkpoints are produced.  Fused schedule: it is the first
+        // writer of S (SMODE 0); otherwise it adds to the S = L_2 of the cost stage.
         const int nch = nchains(1, 1);
-        hipLaunchKernelGGL((k_sweep<NP, 1, U>), dim3((nch + 3) / 4), dim3(256), 0, c->stream, C, S, d.width1, d.h, 1, 1, d.P1, d.P2,
-                           nch, d.D, d.minD, d.uniq, c->debug ? 1 : 0, sd, sk);
+        kc.begin("k_sweep(path 1)", c->stream);
+        if (lay.rows_fused)
+            hipLaunchKernelGGL((k_sweep<NP, 0, U>), dim3((nch + 3) / 4), dim3(256), 0, c->stream, C, S, d.width1, d.h, 1, 1, d.P1, d.P2,
+                               nch, d.D, d.minD, d.uniq, c->debug ? 1 : 0, sd, sk);
+        else
+            hipLaunchKernelGGL((k_sweep<NP, 1, U>), dim3((nch + 3) / 4), dim3(256), 0, c->stream, C, S, d.width1, d.h, 1, 1, d.P1, d.P2,
+                               nch, d.D, d.minD, d.uniq, c->debug ? 1 : 0, sd, sk);
+        kc.end(c->stream);
         ++nl;
     }
     for (int fi = 0; fi < nf; ++fi) {
         const int fused_order[3] = { 1, 0, 2 };
-        const int f = (lay.rows_fused && !lay.diag_fused) ? fused_order[fi] : fi;
+        const int f = three ? fused_order[fi] : fi;
         const int nch = lay.nch[f], mseg = lay.mseg[f];
         const uint32_t* ck = (const uint32_t*)((char*)c->ckpt.p + lay.off[f]);
         const uint16_t* mn = (const uint16_t*)((char*)c->ckpt.p + lay.moff[f]);
@@ -1464,31 +1161,36 @@ static int launch_aggregate_np(wass_ctx* c, const SgmDims& d, int* n_launches)
                                      (const uint16_t*)(ckb + lay.roff[2]), (const uint16_t*)(ckb + lay.roff[3]), lay.nbx };
                 constexpr int XB = Fuse<NP>::XB;
                 const size_t ldsx = (size_t)XB * 2 * K * (64 * NP) * sizeof(uint32_t);
-                if (lay.diag_fused) {
-                    const DiagSide dg = { (const uint32_t*)(ckb + lay.doff[0]), (const uint32_t*)(ckb + lay.doff[1]), (const uint32_t*)(ckb + lay.doff[2]),
-                                          (const uint32_t*)(ckb + lay.doff[3]), (const uint16_t*)(ckb + lay.doff[4]), (const uint16_t*)(ckb + lay.doff[5]), lay.pm };
-                    WASS_HIP(c, hipFuncSetAttribute((const void*)k_pairx<NP, K, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx));
-                    hipLaunchKernelGGL((k_pairx<NP, K, false, true>), dim3(2 * lay.nbx), dim3(64 * XB), ldsx, c->stream, C, S, ck, mn, rs, dg, d.width1, d.h,
+                kc.begin("k_pairx", c->stream);
+                if (d.ndirs == 5) {
+                    WASS_HIP(c, hipFuncSetAttribute((const void*)k_pairx<NP, K, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx));
+                    hipLaunchKernelGGL((k_pairx<NP, K, true, true>), dim3(2 * lay.nbx), dim3(64 * XB), ldsx, c->stream, C, S, ck, mn, rs, d.width1, d.h,
                                        d.P1, d.P2, mseg, (const uint32_t*)(ck + (size_t)nch * mseg * (64 * NP)));
                 } else {
-                    const DiagSide dg = {};
                     WASS_HIP(c, hipFuncSetAttribute((const void*)k_pairx<NP, K, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx));
-                    hipLaunchKernelGGL((k_pairx<NP, K, true, false>), dim3(2 * lay.nbx), dim3(64 * XB), ldsx, c->stream, C, S, ck, mn, rs, dg, d.width1, d.h,
+                    hipLaunchKernelGGL((k_pairx<NP, K, true, false>), dim3(2 * lay.nbx), dim3(64 * XB), ldsx, c->stream, C, S, ck, mn, rs, d.width1, d.h,
                                        d.P1, d.P2, mseg, (const uint32_t*)(ck + (size_t)nch * mseg * (64 * NP)));
                 }
+                kc.end(c->stream);
             } else {
                 return set_err(c, WASS_ERR_UNSUPPORTED, "row fusion is not built for NP = %d", NP);
             }
-        } else if (lay.smode[f] == 0) WASS_PAIR(0);
-        else if (lay.smode[f] == 1) WASS_PAIR(1);
-        else WASS_PAIR(2);
+        } else {
+            kc.begin(f == 1 ? "k_pair(family 1)" : (f == 2 ? "k_pair(family 2)" : (f == 3 ? "k_pair(family 3)" : "k_pair(family 0)")), c->stream);
+            if (lay.smode[f] == 0) WASS_PAIR(0);
+            else if (lay.smode[f] == 1) WASS_PAIR(1);
+            else WASS_PAIR(2);
+            kc.end(c->stream);
+        }
 #undef WASS_PAIR
         ++nl;
     }
     if (d.ndirs == 5) {              // path 3, winner-take-all fused (paths 2, 1, 0 + 4 are in S by now)
         const int nch = nchains(-1, 1);
+        kc.begin("k_sweep(path 3 + selection)", c->stream);
         hipLaunchKernelGGL((k_sweep<NP, 2, U>), dim3((nch + 3) / 4), dim3(256), 0, c->stream, C, S, d.width1, d.h, -1, 1, d.P1, d.P2,
                            nch, d.D, d.minD, d.uniq, c->debug ? 1 : 0, sd, sk);
+        kc.end(c->stream);
         ++nl;
     }
     if (n_launches) *n_launches = nl;

@@ -108,8 +108,11 @@ int launch_prefilter(wass_ctx* c, const SgmDims& d, const uint8_t* d_img1, const
     // the slack columns of bt2 are never written; their content only ever feeds padded disparity slots, which k_vsum
     // overwrites with 0xFFFF.
     const PadImg i1 = { d_img1, pitch, d.w, d.D }, i2 = { d_img2, pitch, d.w, d.D + d.off_pos - d.comp };
+    KernelClock kc(c);
+    kc.begin("k_prefilter", c->stream);
     hipLaunchKernelGGL(k_prefilter, grid, dim3(256), 0, c->stream, i1, i2, d.Wp, d.h, d.ftzero, (uint2*)c->bt1.p,
                        (unsigned short*)c->bt2.p + BT2_FRONT, pitch2, (uint32_t*)c->flags.p);
+    kc.end(c->stream);
     WASS_HIP(c, hipGetLastError());
     return WASS_OK;
 }
@@ -540,9 +543,12 @@ static int launch_cost_np(wass_ctx* c, const SgmDims& d)
         const size_t ldsq = (size_t)4 * WIN * NP * 64 * sizeof(uint32_t);
         if (ldsq > 160 * 1024) return set_err(c, WASS_ERR_UNSUPPORTED, "WINSIZE %d too large for the LDS ring", WIN);
         WASS_HIP(c, hipFuncSetAttribute((const void*)k_hsum_q<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq));
+        KernelClock kc(c);
+        kc.begin("k_hsum_q", c->stream);
         hipLaunchKernelGGL((k_hsum_q<NP>), dim3((nch + 3) / 4, d.h), dim3(256), ldsq, c->stream, (const uint2*)c->bt1.p,
                            (const unsigned short*)c->bt2.p + BT2_FRONT, bt2_pitch(d.Wp), d.Wp, d.width1, d.minX1, d.minD, d.SW2,
                            XQ, off, nch, (uint32_t*)c->hsum.p);
+        kc.end(c->stream);
     }
     WASS_HIP(c, hipEventRecord(c->ev[7], c->stream));                        // start of the vertical sum (wass_sgm_timings.vsum_ms)
     return launch_vsum_np<NP>(c, d, false);
@@ -557,8 +563,10 @@ static int launch_vsum_np(wass_ctx* c, const SgmDims& d, bool plain)
     const size_t lds2 = (size_t)4 * (2 * d.SW2 + 1) * NP * 64 * sizeof(uint32_t);
     if (lds2 > 160 * 1024) return set_err(c, WASS_ERR_UNSUPPORTED, "WINSIZE %d too large for the LDS ring", 2 * d.SW2 + 1);
     const CkptLayout lay = ckpt_layout(d);
+    KernelClock kc(c);
     if (!plain && (lay.cols_from_cost || lay.path2_from_cost)) {
         constexpr int K = ckpt_k(NP);
+        kc.begin(lay.path2_from_cost ? "k_vsum_col(path 2, writes S)" : "k_vsum_col", c->stream);
         int rc = ensure(c, c->ckpt, lay.total);
         if (rc) return rc;
         const dim3 grid((d.width1 + 3) / 4), block(256);
@@ -580,6 +588,7 @@ static int launch_vsum_np(wass_ctx* c, const SgmDims& d, bool plain)
                                d.SW2, d.P1, d.P2, (uint32_t*)c->C.p, (uint32_t*)c->ckpt.p, (uint16_t*)c->ckpt.p, 0, (uint32_t*)c->S.p,
                                (uint32_t*)c->flags.p, (uint32_t*)nullptr);
         }
+        kc.end(c->stream);
         WASS_HIP(c, hipGetLastError());
         return WASS_OK;
     }

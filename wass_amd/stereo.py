@@ -142,6 +142,18 @@ class Context:
         self._check(self._lib.wass_sgm_probe_vsum(self._h, C.byref(a), C.byref(b)))
         return float(a.value), float(b.value)
 
+    def set_kernel_events(self, on: bool) -> None:
+        """Bracket every launch of the cost stage and of the aggregation family with hipEvents (measurement only)."""
+        self._check(self._lib.wass_ctx_set_kernel_events(self._h, 1 if on else 0))
+
+    def sgm_kernel_times(self):
+        """[(kernel name, ms)] of the last SGM call's launches, in launch order (needs set_kernel_events(True) before the call)."""
+        names = C.create_string_buffer(4096)
+        ms = (C.c_float * 32)()
+        n = C.c_int()
+        self._check(self._lib.wass_sgm_kernel_times(self._h, names, 4096, ms, 32, C.byref(n)))
+        return list(zip(names.value.decode().split("\n"), [float(ms[i]) for i in range(n.value)]))
+
     def sgm_timings(self, previous: bool = False) -> SgmTimings:
         """Stage times of the last SGM call (previous=True: of the call before it, which a pipelined driver can
         read without waiting for the frame it has just enqueued)."""
