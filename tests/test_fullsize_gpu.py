@@ -75,6 +75,19 @@ def test_config_e_4k_512_disparities(gpu_ctx):
     assert np.abs(a[m] / 16.0 - gt[m]).mean() < 0.3
 
 
+def test_config_e_8path_bit_exact_vs_oracle(gpu_ctx, oracle):
+    """BASELINE.json configs[4] in the mode the roofline is quoted on: 3840 x 2160, D = 512, 8 paths (MODE_HH), the whole picture --
+    every disparity of the 8.3 M equals the oracle's (about a minute and a half of scalar oracle; round 5 had the band and the flip
+    property only)."""
+    w, h, D = 3840, 2160, 512
+    right, left = synth.make_pair(w, h, D, frame_idx=5)
+    p = default_sgm_params(D, ndirs=8)
+    got = gpu_ctx.sgm_disparity(right, left, p)
+    ref, st = oracle.dense_disparity16(right, left, _oracle_params(oracle, p))
+    assert not st.overflow
+    np.testing.assert_array_equal(got, ref)
+
+
 def test_wass_default_640_disparities_band(gpu_ctx, oracle):
     """MAX_DISPARITY=640 (the WASS default, NP=5) on a band the oracle finishes quickly."""
     w, h, D = 1400, 96, 640

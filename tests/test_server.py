@@ -294,6 +294,136 @@ def test_on_a_multi_gpu_node_frame_i_goes_to_gpu_i_mod_g_and_each_server_reads_i
     _wait_gone(sock)
 
 
+def test_visibility_variables_and_foreign_parts_limit_the_gpus_a_caller_counts(cli, tmp_path):
+    """Round-5 advisor: the GPU count came from the KFD topology alone -- on an 8-GPU node restricted to one device seven of eight callers
+    asked for a GPU their server could not open.  The count is now what a server process of THIS environment could use: gfx950 nodes only
+    (no APU / iGPU / CPU nodes), at most as many as HIP_VISIBLE_DEVICES & co. list."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the no-GPU behaviour is tested on the build container")
+    topo = tmp_path / "nodes"
+    for i, (simd, target) in enumerate([(0, 0)] + [(1024, 90500)] * 4 + [(8, 100306)]):      # a CPU node, four MI355X, an iGPU
+        (topo / str(i)).mkdir(parents=True)
+        (topo / str(i) / "properties").write_text(f"cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\ngfx_target_version {target}\n")
+    mk = tmp_path / "mk"
+    mk.mkdir()
+    wd, cfg, *_ = make_workdir(str(mk), 160, 120, 32)
+    seq = tmp_path / "seq"
+    seq.mkdir()
+    for i in range(6):
+        shutil.copytree(wd, seq / ("%06d_wd" % i))
+
+    def sockets(extra):
+        sock = tmp_path / ("sock%d" % len(os.listdir(tmp_path)))
+        sock.mkdir()
+        env = _env(sock, WASS_DEBUG_IMAGES="0", WASS_KFD_NODES=str(topo), WASS_SERVER_SPECULATE="0", WASS_SERVER_READAHEAD="0", **extra)
+        for v in ("WASS_GPU_DEVICE", "WASS_NUM_GPUS", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL"):
+            if v not in extra:
+                env.pop(v, None)
+        for i in range(6):
+            r = subprocess.run([cli, cfg, str(seq / ("%06d_wd" % i))], capture_output=True, text=True, env=env)
+            assert "%06d_wd" % i in r.stdout
+        names = sorted(f for f in os.listdir(sock) if f.endswith(".sock"))
+        _wait_gone(sock)
+        return [n.split("_gpu")[1][:-5] for n in names]
+    assert sockets({}) == ["0", "1", "2", "3"]                          # the four gfx950 nodes, not six
+    assert sockets({"HIP_VISIBLE_DEVICES": "2"}) == ["0"]               # one visible device: the runtime calls it 0
+    assert sockets({"ROCR_VISIBLE_DEVICES": "0,3"}) == ["0", "1"]
+    assert sockets({"WASS_NUM_GPUS": "3", "HIP_VISIBLE_DEVICES": "0"}) == ["0", "1", "2"]      # the override is an override
+
+
+def test_a_configuration_beyond_the_servers_limit_is_computed_by_its_caller(cli, tmp_path):
+    """Every distinct configuration text is a pipeline with a context and gigabytes of scratch of its own; the server holds at most
+    WASS_SERVER_MAX_CONFIGS (4) of them and REFUSES a further one -- that caller computes its frame in-process -- instead of running
+    the GPU out of memory for everybody (round-5 advisor)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the no-GPU behaviour is tested on the build container")
+    wd, cfg, *_ = make_workdir(str(tmp_path), 160, 120, 32)
+    cfg2 = str(tmp_path / "cfg2.txt")
+    open(cfg2, "w").write(open(cfg).read() + "DENSE_UNIQUENESS_RATIO=5\n")
+    sock = tmp_path / "sock"
+    sock.mkdir()
+    tlog = tmp_path / "timing.log"
+    env = _env(sock, WASS_DEBUG_IMAGES="0", WASS_SERVER_MAX_CONFIGS="1", WASS_SERVER_TIMING=str(tlog))
+    a = subprocess.run([cli, cfg, wd], capture_output=True, text=True, env=env)
+    b = subprocess.run([cli, cfg2, wd], capture_output=True, text=True, env=env)
+    c = subprocess.run([cli, cfg, wd], capture_output=True, text=True, env=env)
+    for r in (a, b, c):
+        assert r.returncode == 255 and "no usable MI355X GPU" in r.stdout and r.stdout.count("wass_stereo  v.") == 1
+    _wait_gone(sock)
+    assert len([l for l in tlog.read_text().splitlines() if " total " in l]) == 2       # a and c went through the server, b did not
+
+
+@pytest.mark.gpu
+def test_two_sequences_of_different_picture_size_share_one_server(cli, tmp_path):
+    """Round-5 advisor (high): the server keeps up to three frames STAGED in front of the GPU; a frame of another picture size used to
+    re-allocate the input buffers underneath them (same configuration text = same pipeline).  Two sequences of different cameras, four
+    callers, interleaved: every file equals the in-process run's."""
+    sizes = ((320, 240), (272, 200))
+    nd = 6
+    seqs = []
+    cfg = None
+    for s, (w, h) in enumerate(sizes):
+        a, b = tmp_path / f"a{s}", tmp_path / f"b{s}"
+        for i in range(nd):
+            t = tmp_path / f"mk{s}_{i}"
+            t.mkdir()
+            wd, c, *_ = make_workdir(str(t), w, h, 64, frame=i)
+            if cfg is None:
+                cfg = c
+            else:
+                assert open(c).read() == open(cfg).read()                 # one configuration text: one pipeline in the server
+            for seq in (a, b):
+                shutil.copytree(wd, seq / ("%06d_wd" % i))
+        seqs.append((a, b))
+    for a, _ in seqs:
+        for i in range(nd):
+            r = subprocess.run([cli, cfg, str(a / ("%06d_wd" % i))], capture_output=True, text=True, env=dict(os.environ, WASS_NO_SERVER="1", WASS_DEBUG_IMAGES="0"))
+            assert r.returncode == 0, r.stdout[-1500:]
+    sock = tmp_path / "sock"
+    sock.mkdir()
+    jobs = [str(seqs[i % 2][1] / ("%06d_wd" % (i // 2))) for i in range(2 * nd)]           # sizes alternate
+    for rnd in range(2):                                                                   # (second round: speculated frames of both sizes in the cache)
+        with ThreadPoolExecutor(4) as ex:
+            res = list(ex.map(lambda wd: subprocess.run([cli, cfg, wd], capture_output=True, text=True, env=_env(sock, WASS_DEBUG_IMAGES="0")), jobs))
+        assert len(_servers(sock)) == 1
+        for wd, r in zip(jobs, res):
+            assert r.returncode == 0, r.stdout[-1500:]
+            ref = wd.replace("/b0/", "/a0/").replace("/b1/", "/a1/")
+            for name in NAMES:
+                assert open(os.path.join(ref, name), "rb").read() == open(os.path.join(wd, name), "rb").read(), (rnd, wd, name)
+    _wait_gone(sock)
+
+
+@pytest.mark.gpu
+def test_the_server_applies_each_callers_options_not_its_own_environment(cli, tmp_path):
+    """Round-5 advisor: WASS_DEBUG_FORMAT / WASS_HOST_INLIER_TEXT were forwarded and keyed but read from the SERVER's environment, i.e.
+    from whichever caller had started it.  A server started without them serves a caller that sets them, and the other way round."""
+    wd, cfg, *_ = make_workdir(str(tmp_path), 320, 240, 64)
+    wds = [str(tmp_path / ("w%d_wd" % k)) for k in range(3)]
+    for d in wds:
+        shutil.copytree(wd, d)
+    sock = tmp_path / "sock"
+    sock.mkdir()
+    plain, png = _env(sock), _env(sock, WASS_DEBUG_FORMAT="png", WASS_HOST_INLIER_TEXT="1")
+    for e in (plain, png):
+        for v in ("WASS_DEBUG_IMAGES",):
+            e.pop(v, None)
+    a = subprocess.run([cli, cfg, wds[0]], capture_output=True, text=True, env=plain)       # starts the server: its environment has neither
+    b = subprocess.run([cli, cfg, wds[1]], capture_output=True, text=True, env=png)
+    c = subprocess.run([cli, cfg, wds[2]], capture_output=True, text=True, env=plain)
+    assert a.returncode == b.returncode == c.returncode == 0, a.stdout[-600:] + b.stdout[-600:]
+    assert len(_servers(sock)) == 1
+    for d, ext, other in ((wds[0], "jpg", "png"), (wds[1], "png", "jpg"), (wds[2], "jpg", "png")):
+        assert os.path.exists(os.path.join(d, "stereo." + ext)) and not os.path.exists(os.path.join(d, "stereo." + other)), (d, ext)
+    ref = subprocess.run([cli, cfg, wd], capture_output=True, text=True, env=dict(os.environ, WASS_NO_SERVER="1", WASS_DEBUG_FORMAT="png", WASS_HOST_INLIER_TEXT="1"))
+    assert ref.returncode == 0
+    for name in ("stereo.png", "disparity_final_scaled.png", "graph_components.png", "plane_refinement_inliers.xyz", "mesh_cam.xyzC"):
+        assert open(os.path.join(wd, name), "rb").read() == open(os.path.join(wds[1], name), "rb").read(), name
+    _wait_gone(sock)
+
+
 def test_the_server_survives_garbage_on_its_socket(cli, tmp_path):
     """Anything may connect to a unix socket in /tmp: a wrong magic, a truncated request, an oversized length or a caller that hangs
     up early costs that connection only -- the next real caller is served by the same server."""

@@ -88,6 +88,9 @@ public:
                                      // whose callers each wait for ONE frame)
         bool device_previews = true; // the scaled previews 0000000X_s.png are resized on the GPU and written by finish() (sequence drivers);
                                      // false: load_data writes them from the decoded pictures before the GPU is needed, like the reference
+        // -1: as this process's environment says (WASS_DEBUG_FORMAT=png, WASS_HOST_INLIER_TEXT, WASS_HOST_DEBUG_PICTURES); 0 / 1: as the
+        // CALLER's environment says -- the resident worker serves callers whose environments differ from the one it was started in
+        int debug_png = -1, host_inlier_text = -1, host_debug_pictures = -1;
         const PrepareSetup* prep = nullptr;   // prepare-less mode: the calibration directory (jobs with raw = true need it)
         bool save_undistorted = false;        // ... and whether undistorted/0000000X.png are written all the same
     };
@@ -97,9 +100,12 @@ public:
     FramePipeline(int device, const Config& cfg, const std::string& config_path, const Options& opt)
         : device_(device), cfg_(cfg), config_path_(config_path), opt_(opt), max_pending_(opt.max_pending)
     {
+        if (opt_.host_inlier_text >= 0) device_text_ = opt_.host_inlier_text == 0;
         if (opt_.debug_pictures) {
             const char* e = getenv("WASS_HOST_DEBUG_PICTURES");
-            dbg_host_ = debug_png() || cfg.get_int("DENSE_DISPARITY_BIGGEST_COMPONENT_THRESHOLD") > 0 || (e && atoi(e) != 0);
+            const bool png = opt_.debug_png >= 0 ? opt_.debug_png != 0 : debug_png();
+            const bool host = opt_.host_debug_pictures >= 0 ? opt_.host_debug_pictures != 0 : (e && atoi(e) != 0);
+            dbg_host_ = png || cfg.get_int("DENSE_DISPARITY_BIGGEST_COMPONENT_THRESHOLD") > 0 || host;
             dbg_dev_ = !dbg_host_;
         }
         sp_.min_disp = cfg.get_int("MIN_DISPARITY");
@@ -228,9 +234,18 @@ public:
     }
     // ---- phase 2 (owner thread): the frame's pictures into the pinned ring and on their way to HBM.  Called for frame n+1
     // right before frame n is submitted (when frame n+1 is ready by then), so that the transfer runs underneath frame n.
-    void stage(FrameJob& job)
+    // A frame whose pictures or ROIs differ in size from the buffers as they are is NOT staged ahead of its turn while frames staged
+    // before it wait for theirs: ensure_buffers would free the very buffers their pictures are in (a server fed by two sequences of
+    // different cameras with one configuration text did exactly that).  Its turn comes in submit() (its_turn), by which time they have
+    // been submitted; a frame staged AFTER it in the meantime goes back to "not staged" and is staged again when it is submitted.
+    void stage(FrameJob& job, bool its_turn = false)
     {
         if (job.staged || job.rc != 0 || job.skipped) return;
+        if (!staged_.empty() && !same_geometry(job)) {
+            if (!its_turn) return;
+            for (FrameJob* s : staged_) { s->staged = false; s->in_slot = -1; }
+            staged_.clear();
+        }
         LogSinkScope sink(&job.log);
         try {
             const Env& env = job.env;
@@ -254,6 +269,7 @@ public:
                 }
             job.in_slot = k;
             job.staged = true;
+            staged_.push_back(&job);
         } catch (const std::exception& e) {
             WLOG_SCOPE("wass_stereo");
             WLOGE << e.what();
@@ -271,7 +287,8 @@ public:
             done.push_back(&job);
             return;
         }
-        stage(job);
+        stage(job, true);
+        for (auto it = staged_.begin(); it != staged_.end(); ++it) if (*it == &job) { staged_.erase(it); break; }
         if (job.rc != 0) { while (FrameJob* p = collect()) done.push_back(p); done.push_back(&job); return; }
         // debug pictures: the previous frame's maps are fetched from buffers this frame is about to overwrite
         if (dbg_host_) while (FrameJob* p = collect()) done.push_back(p);
@@ -473,7 +490,7 @@ public:
     // ---- phase 3 (any thread): everything that is written from the result record (:1374, 1993, 2046-2139)
     // A frame that was enqueued and will never be finished (computed ahead of a request that did not come, or whose inputs changed):
     // gives its output set back.  Only for frames that have been collected.
-    void abandon(FrameJob& job)
+    void abandon(FrameJob& job)                 // (any thread; never a frame that is staged and not yet submitted)
     {
         if (job.out_slot >= 0) { release_out(job.out_slot); job.out_slot = -1; }
         if (job.mesh) { wass_mesh_destroy(job.mesh); job.mesh = nullptr; }
@@ -481,6 +498,7 @@ public:
 
     void finish(FrameJob& job)
     {
+        DebugFormatScope fmt(opt_.debug_png);       // the host renderers' file format: the caller's, not this process's
         LogSinkScope sink(&job.log);
         WLOG_SCOPE("wass_stereo");
         Env& env = job.env;
@@ -890,6 +908,7 @@ private:
     std::condition_variable out_cv_;
     std::deque<FrameJob*> pend_;     // submitted, record not read yet: at most two
     int nsub_ = 0;
+    std::deque<FrameJob*> staged_;   // staged (pictures in the input ring), not yet submitted: oldest first
     std::vector<FrameJob*> early_;   // frames collected before their turn (ensure_buffers); handed out by the next submit / flush
     size_t live_pos_ = 0;
     bool timing_ = getenv("WASS_PIPE_TIMING") && atoi(getenv("WASS_PIPE_TIMING")) != 0;

@@ -59,7 +59,19 @@ inline bool write_png_raw(const std::string& filename, int w, int h, int channel
 inline bool write_png_rgb(const std::string& f, const ImageRGB& im) { return write_png_raw(f, im.w, im.h, 3, im.px.data()); }
 
 // debug pictures: <stem>.jpg like the reference, or <stem>.png with WASS_DEBUG_FORMAT=png
-inline bool debug_png() { const char* e = getenv("WASS_DEBUG_FORMAT"); return e && !strcmp(e, "png"); }
+// (per thread: a writer thread of the resident worker finishes frames of callers whose environments differ -- DebugFormatScope)
+inline int& debug_png_override() { static thread_local int v = -1; return v; }
+inline bool debug_png()
+{
+    if (debug_png_override() >= 0) return debug_png_override() != 0;
+    const char* e = getenv("WASS_DEBUG_FORMAT");
+    return e && !strcmp(e, "png");
+}
+struct DebugFormatScope {
+    int saved;
+    explicit DebugFormatScope(int v) : saved(debug_png_override()) { if (v >= 0) debug_png_override() = v; }
+    ~DebugFormatScope() { debug_png_override() = saved; }
+};
 inline bool write_debug_gray(const std::string& stem, const Image& im)
 {
     return debug_png() ? write_png_gray(stem + ".png", im) : write_jpeg_raw(stem + ".jpg", im.w, im.h, 1, im.px.data());

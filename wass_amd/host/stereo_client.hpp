@@ -73,20 +73,36 @@ inline bool recv_str(int fd, std::string& s, size_t limit = 64u << 20)
     return n == 0 || recv_all(fd, &s[0], n);
 }
 
-// GPUs of this node without touching HIP (a client must stay cheap): KFD topology nodes with SIMDs
+// GPUs of this node that a server process of THIS environment could use, without touching HIP (a client must stay cheap): KFD topology
+// nodes with SIMDs whose target is gfx950 (APUs' and other parts' nodes are not counted), at most as many as the visibility variables
+// of the HIP / ROCr runtimes leave (HIP_VISIBLE_DEVICES, ROCR_VISIBLE_DEVICES, CUDA_VISIBLE_DEVICES, GPU_DEVICE_ORDINAL: a comma-
+// separated list; the runtime numbers what is visible from 0, so only the COUNT matters here).  WASS_NUM_GPUS overrides.
 inline int count_gpus()
 {
     if (const char* e = getenv("WASS_NUM_GPUS")) { const int n = atoi(e); if (n > 0) return n; }
     int n = 0;
-    if (DIR* d = opendir("/sys/class/kfd/kfd/topology/nodes")) {
+    std::string nodes = "/sys/class/kfd/kfd/topology/nodes";
+    if (const char* e = getenv("WASS_KFD_NODES")) nodes = e;            // (tests: a made-up topology)
+    if (DIR* d = opendir(nodes.c_str())) {
         while (dirent* e = readdir(d)) {
             if (e->d_name[0] == '.') continue;
-            std::ifstream f(std::string("/sys/class/kfd/kfd/topology/nodes/") + e->d_name + "/properties");
-            std::string k; long long v;
-            while (f >> k >> v) if (k == "simd_count" && v > 0) { ++n; break; }
+            std::ifstream f(nodes + "/" + e->d_name + "/properties");
+            std::string k; long long v, simd = 0, target = -1;
+            while (f >> k >> v) { if (k == "simd_count") simd = v; else if (k == "gfx_target_version") target = v; }
+            if (simd > 0 && (target < 0 || target == 90500)) ++n;
         }
         closedir(d);
     }
+    for (const char* var : { "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL" })
+        if (const char* e = getenv(var)) {
+            int listed = 0;
+            bool in = false;
+            for (const char* c = e; ; ++c) {
+                if (*c == ',' || *c == '\0') { if (in) ++listed; in = false; if (!*c) break; }
+                else if (*c != ' ') in = true;
+            }
+            if (n == 0 || listed < n) n = listed;          // (an empty list hides every device: one "GPU", whose server fails loudly)
+        }
     return n > 0 ? n : 1;
 }
 // The number in a workdir's name -- "<parent>/<prefix><digits><suffix>", the LAST run of digits of the last component, as in wasscli's
@@ -108,25 +124,42 @@ inline bool workdir_number(const std::string& wd, unsigned long long* value, siz
     if (end) *end = e;
     return true;
 }
+// Where the socket and its lock live: WASS_SERVER_DIR, else $XDG_RUNTIME_DIR (per user, mode 0700 by contract), else a directory of
+// this user's own under /tmp -- created 0700, and used only if it IS a directory (not a link), owned by this user, closed to everybody
+// else: predictable names straight in a world-writable /tmp would let another local user put a socket there first and answer for the
+// server.  Empty: no safe place, the caller computes its frame in-process.
 inline std::string socket_path(int device)
 {
+    std::string base;
     const char* dir = getenv("WASS_SERVER_DIR");
     if (!dir || !*dir) dir = getenv("XDG_RUNTIME_DIR");
-    if (!dir || !*dir || access(dir, W_OK) != 0) dir = "/tmp";
+    if (dir && *dir && access(dir, W_OK) == 0) base = dir;
+    else {
+        char own[64];
+        snprintf(own, sizeof own, "/tmp/wass_stereo_%u", (unsigned)getuid());
+        if (mkdir(own, 0700) != 0 && errno != EEXIST) return std::string();
+        struct stat st;
+        if (lstat(own, &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != getuid() || (st.st_mode & 077) != 0) return std::string();
+        base = own;
+    }
     char b[64];
     snprintf(b, sizeof b, "wass_stereo_%u_gpu%d.sock", (unsigned)getuid(), device);
-    return join_path(dir, b);
+    return join_path(base, b);
 }
 inline int connect_to(const std::string& path)
 {
     sockaddr_un a;
     memset(&a, 0, sizeof a);
     a.sun_family = AF_UNIX;
-    if (path.size() >= sizeof a.sun_path) return -1;
+    if (path.empty() || path.size() >= sizeof a.sun_path) return -1;
     memcpy(a.sun_path, path.c_str(), path.size() + 1);
     const int fd = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
     if (fd < 0) return -1;
     if (connect(fd, (sockaddr*)&a, sizeof a) != 0) { close(fd); return -1; }
+    // whoever listens there must be this user (a server is always started by one of its own callers)
+    struct ucred cr;
+    socklen_t len = sizeof cr;
+    if (getsockopt(fd, SOL_SOCKET, SO_PEERCRED, &cr, &len) != 0 || cr.uid != getuid()) { close(fd); return -1; }
     return fd;
 }
 
@@ -160,11 +193,12 @@ inline int client_run(const char* self_exe, const char* cfg_path, const std::str
         else if (g > 1) device = (int)((unsigned)getpid() % (unsigned)g);
     }
     const std::string sock = socket_path(device);
+    if (sock.empty()) return -2;
     int fd = connect_to(sock);
     if (fd < 0) {
         // nobody there: one of the callers starts the server, the others wait at the lock and then find it
         const std::string lock = sock + ".lock";
-        const int lfd = open(lock.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+        const int lfd = open(lock.c_str(), O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0600);
         if (lfd < 0) return -2;
         if (flock(lfd, LOCK_EX) != 0) { close(lfd); return -2; }
         fd = connect_to(sock);
@@ -197,7 +231,9 @@ inline int client_run(const char* self_exe, const char* cfg_path, const std::str
     std::string wd = workdir;
     if (!wd.empty() && wd[0] != '/' && getcwd(cwd, sizeof cwd)) wd = join_path(cwd, wd);
     std::string opts = std::string("debug=") + (debug_images ? "1" : "0") + ";stride=" + std::to_string(stride);
-    for (const char* v : { "WASS_DEBUG_FORMAT", "WASS_HOST_INLIER_TEXT" })
+    // what of this caller's environment changes the files of its frame: the server applies these per request (FramePipeline::Options),
+    // it does not read its own environment for them
+    for (const char* v : { "WASS_DEBUG_FORMAT", "WASS_HOST_INLIER_TEXT", "WASS_HOST_DEBUG_PICTURES" })
         if (const char* e = getenv(v)) opts += std::string(";") + v + "=" + e;
     const uint32_t n = 4;
     bool ok = send_all(fd, "WSRV1\n", 6) && send_all(fd, &n, 4) && send_str(fd, cfg_path) && send_str(fd, cfg_text) && send_str(fd, wd) && send_str(fd, opts);

@@ -364,6 +364,11 @@ inline int server_main(const std::string& sock, int device)
     FILE* tlog = nullptr;
     std::mutex tlog_mu;
     if (const char* e = getenv("WASS_SERVER_TIMING")) if (*e) tlog = fopen(e, "a");
+    // a device this environment does not have (the count honours the runtimes' visibility variables): no server -- the caller that
+    // started this process sees it go and computes its frame itself
+    if (device < 0 || device >= count_gpus()) return 1;
+    int max_configs = 4;                                           // live pipelines (each owns a context and 5-8 GB of scratch once used)
+    if (const char* e = getenv("WASS_SERVER_MAX_CONFIGS")) max_configs = std::max(1, atoi(e));
     unlink(sock.c_str());
     const int lfd = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
     sockaddr_un a;
@@ -412,10 +417,21 @@ inline int server_main(const std::string& sock, int device)
             const bool debug = opts.find("debug=1") != std::string::npos;
             int stride = 1;
             { const size_t sp = opts.find("stride="); if (sp != std::string::npos) stride = std::max(1, atoi(opts.c_str() + sp + 7)); }
+            // what of the caller's environment changes its frame's files is applied per pipeline (the key holds the options)
+            auto opt_on = [&](const char* name, const char* value) {
+                const std::string k = std::string(name) + "=";
+                const size_t at = opts.find(k);
+                if (at == std::string::npos) return false;
+                const std::string v = opts.substr(at + k.size(), opts.find(';', at) == std::string::npos ? std::string::npos : opts.find(';', at) - at - k.size());
+                return value ? v == value : atoi(v.c_str()) != 0;
+            };
             const std::string key = opts + "\n" + cfgtext;
-            PipeEntry* pe;
+            PipeEntry* pe = nullptr;
             {
                 std::lock_guard<std::mutex> lk(pipes_mu);
+                // a configuration nobody has sent before while the server already holds max_configs pipelines (a parameter sweep): this
+                // caller computes its frame itself, the server's HBM stays bounded
+                if (!pipes.count(key) && (int)pipes.size() >= max_configs) { refuse(j->fd); delete j; --in_flight; continue; }
                 auto& slot = pipes[key];
                 if (!slot) {
                     slot.reset(new PipeEntry());
@@ -433,6 +449,9 @@ inline int server_main(const std::string& sock, int device)
                         fo.echo = false;                         // ... which is relayed to the client, not printed here
                         fo.max_pending = 1;                      // every caller waits for ONE frame: hand it out as early as possible
                         fo.debug_pictures = debug;
+                        fo.debug_png = opt_on("WASS_DEBUG_FORMAT", "png") ? 1 : 0;
+                        fo.host_inlier_text = opt_on("WASS_HOST_INLIER_TEXT", nullptr) ? 1 : 0;
+                        fo.host_debug_pictures = opt_on("WASS_HOST_DEBUG_PICTURES", nullptr) ? 1 : 0;
                         slot->debug = debug;
                         fo.inliers_file = true;
                         slot->pl.reset(new FramePipeline(device, slot->cfg, cfgpath, fo));
@@ -445,7 +464,7 @@ inline int server_main(const std::string& sock, int device)
             j->workdir = wd;
             j->config_path = cfgpath;
             if (!exists(wd)) {
-                LogSinkScope sink(&j->log);
+                j->log = wd + " does not exists, aborting.\n";      // wass_stereo.cpp:1836 (the reference's wording)
                 j->rc = -1;
             } else {
                 const bool speculate = readahead.spec_depth > 0 && !pe->pl->host_debug_pictures() && pe->cfg.get_string("LEFT_MASK_IMAGE") == "none" &&
