@@ -366,10 +366,6 @@ int wass_mesh_refinement_inliers(wass_ctx* ctx, wass_mesh* m, const wass_refine_
  *                               (wass_stereo.cpp:2062-2107); found == 0: nothing cropped, plane = NaN */
 int wass_mesh_remove_outliers(wass_ctx* ctx, wass_mesh* m, double percentile, double* zgap_out, uint64_t* n_gaps,
                               uint64_t* size_out);
-/* Test hook: how the last wass_mesh_remove_outliers call found its order statistic -- 0 no gaps, 1 an end of the sampled bracket (ties),
- * 2 among the keys collected inside the bracket (the common case), 3 the whole-data path (the bracket missed) -- and how many keys the
- * exact pass collected. */
-int wass_mesh_zgap_select_info(wass_ctx* ctx, int* path, uint64_t* collected);
 typedef struct {
     int      found;                 /* RANSAC succeeded (best >= width*height/10)   */
     double   ransac_plane[4];

@@ -211,8 +211,6 @@ struct wass_ctx {
     // wass_ctx_set_kernel_events: every launch of the cost stage and of the aggregation family bracketed by two hipEvents on its own
     // stream (one set, re-recorded by every SGM call; read with wass_sgm_kernel_times after a synchronisation).  Off by default: an
     // event between two kernels is a marker packet on the queue.
-    int last_zgap_path = 0;        // wass_mesh_remove_outliers: how the order statistic was found (wass_mesh_zgap_select_info)
-    unsigned long long last_zgap_collected = 0;
     bool kernel_events = false;
     struct KernelEv { const char* name = nullptr; hipEvent_t a = nullptr, b = nullptr; };
     KernelEv kev[24];

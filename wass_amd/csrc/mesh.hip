@@ -403,260 +403,92 @@ struct DevState {
     unsigned long long ntri;                              // valid points the triangulation produced
     unsigned int ninl_sel, inl_text_bad;                  // refinement inliers seen by the selection for plane_refinement_inliers.xyz;
     unsigned long long inl_text_bytes;                    // ... bytes of that file's text when the device formatted it, numbers it could not format
-    // z-gap order statistic by sampled bracket (round 6): keys of the sample, the bracket [gs_lo, gs_hi] it gave, and what the one exact
-    // pass over all gaps counted: keys below the bracket, equal to its ends, strictly inside it (those are collected), all of them
-    unsigned long long gs_lo, gs_hi, gs_below, gs_total;
-    unsigned int gs_nsample, gs_ncollect, gs_eqlo, gs_eqhi;
-    int gs_path, gs_pad;                                  // how the answer was found: 1 an end of the bracket, 2 inside it, 3 the whole-data path
 };
 
-// ---- the z-gap order statistic (PovMesh.cpp:888-926: zgaps[floor(p/100 * n)] of the sorted list of |z - z(neighbour in the row above)|,
-// three neighbours per point), exact, in ONE pass over the points plus small change.  Rounds 1-5 ran a six-pass radix select over all
-// 14 M gaps of a config-B frame (12 launches, 1.5 ms of tail-stream time underneath the next frame's aggregation kernels: histograms
-// whose LDS atomics all hit the few bins of one exponent).  Now:
-//   k_gap_sample   every stride-th point's gaps -> up to GAP_SAMPLE keys
-//   k_gap_bracket  one workgroup sorts the sample in LDS and takes the sample quantiles at p -/+ 6 sigma as bracket [lo, hi]
-//   k_gap_collect  the one exact pass: counts the keys below lo, equal to lo, equal to hi and all of them, and appends the keys strictly
-//                  inside the bracket (1-2 % of them) to a buffer -- compares and ballots, no histogram
-//   k_gap_final    one workgroup: rank k = floor(p/100 * n) from the exact total; the answer is lo, hi, or the (k - below - eqlo)-th of
-//                  the collected keys (radix select over that small buffer).  If the rank falls outside the bracket or the buffer
-//                  overflowed (never seen; ties at the bracket's ends are counted, not collected) the same workgroup runs the
-//                  six-pass select over ALL gaps itself: slow (one CU), exact, no extra launches in the common case.
-// Keys are the fp64 bit patterns of non-negative numbers: unsigned order = numeric order.
-constexpr int GAP_SAMPLE = 16384;                         // keys the bracket kernel sorts in LDS (128 KiB)
-constexpr int GAP_BITS = 11, GAP_BINS = 1 << GAP_BITS, GAP_PASSES = 6;     // 5 x 11 + 9 bits = 64
-// the (up to) three gaps of point (i, j); returns how many exist
-__device__ __forceinline__ int point_gaps(const uint8_t* __restrict__ valid, const double* __restrict__ Z, int w, int i, int j, unsigned long long (&key)[3], bool (&has)[3])
+// z gaps computed on the fly (no gap array): histogram of one 11-bit digit of the fp64 bit patterns that match the
+// prefix found so far.  Blocks own a 256-column strip and walk rows (no index divisions); their totals go to one of
+// GAP_HIST_COPIES copies of the global histogram (same-address atomics serialise), which k_radix_pick adds up.
+constexpr int GAP_HIST_COPIES = 4;
+// 5 x 11 + 9 bits = 64.  (13-bit digits, five passes: measured SLOWER -- 42 + 23 us per pass against 26 + 11: the 32 KB
+// histogram per workgroup costs occupancy and the pick kernel scans four times the bins.)
+constexpr int GAP_BITS = 11, GAP_BINS = 1 << GAP_BITS, GAP_PASSES = 6;
+__global__ void __launch_bounds__(256) k_gap_hist(const uint8_t* __restrict__ valid, const double* __restrict__ Z, int w, int h,
+                                                  int shift, unsigned int mask, const DevState* __restrict__ ds,
+                                                  unsigned int* __restrict__ hist)
 {
-    // all loads first and unconditionally (rows i-1 and i exist, columns j-1 .. j+1 too): independent requests in flight
-    const size_t c = (size_t)i * w + j, up = c - w;
-    const uint8_t vc = valid[c], v0 = valid[up - 1], v1 = valid[up], v2 = valid[up + 1];
-    const double z = Z[c], z0 = Z[up - 1], z1 = Z[up], z2 = Z[up + 1];
-    const double zn[3] = { z0, z1, z2 };
-    const uint8_t vn[3] = { v0, v1, v2 };
-    int n = 0;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        has[k] = vc && vn[k];
-        key[k] = (unsigned long long)__double_as_longlong(fabs(z - zn[k]));
-        n += has[k] ? 1 : 0;
-    }
-    return n;
-}
-__global__ void __launch_bounds__(256) k_gap_sample(const uint8_t* __restrict__ valid, const double* __restrict__ Z, int w, int h, unsigned int npts,
-                                                    unsigned int stride, DevState* __restrict__ ds, unsigned long long* __restrict__ sample)
-{
-    const unsigned int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= npts) return;
-    const size_t idx = (size_t)s * stride + stride / 2;
-    const int i = (int)(idx / (size_t)w), j = (int)(idx % (size_t)w);
-    if (i < 1 || i >= h || j < 1 || j >= w - 1) return;
-    unsigned long long key[3];
-    bool has[3];
-    if (point_gaps(valid, Z, w, i, j, key, has) == 0) return;
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-        if (has[k]) {
-            const unsigned int at = atomicAdd(&ds->gs_nsample, 1u);
-            if (at < (unsigned)GAP_SAMPLE) sample[at] = key[k];
-        }
-}
-// One workgroup of 1024: the digit of rank k in a 2^nbits-bin histogram in LDS, and the rank inside that bin.  Every thread returns the same.
-__device__ __forceinline__ int wg_pick_digit(const unsigned int* lh, int nbits, unsigned long long& k, unsigned long long* wsum, int* res)
-{
-    const int nb = 1 << nbits, per = (nb + 1023) / 1024;      // bins per thread (2 at 11 bits)
-    const int b0 = threadIdx.x * per;
-    unsigned long long s = 0;
-    for (int b = b0; b < min(nb, b0 + per); ++b) s += lh[b];
-    // exclusive prefix over the 1024 threads: wave scan + the 16 wave totals
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    unsigned long long inc = s;
-    for (int o = 1; o < 64; o <<= 1) { const unsigned long long t = __shfl_up(inc, o); if (lane >= o) inc += t; }
-    if (lane == 63) wsum[wv] = inc;
-    if (threadIdx.x == 0) res[0] = -1;
-    __syncthreads();
-    unsigned long long before = inc - s;
-    for (int q = 0; q < wv; ++q) before += wsum[q];
-    if (k >= before && k < before + s) {                       // exactly one thread, if the rank is inside the histogram at all
-        unsigned long long r = k - before;
-        int b = b0;
-        for (; b < min(nb, b0 + per); ++b) { if (r < lh[b]) break; r -= lh[b]; }
-        res[0] = b;
-        wsum[16] = r;
-    }
-    __syncthreads();
-    const int digit = res[0];
-    if (digit >= 0) k = wsum[16];
-    __syncthreads();
-    return digit;
-}
-// One workgroup of 1024: the key of rank k (0-based) among the keys that `visit` hands to its argument, keys < 2^bits, by an MSD radix
-// select with GAP_BITS-bit digits taken from bit `bits` downwards.  visit(f) calls f(key) for every key THIS thread is responsible for
-// and must do so identically every time it is called.  ok = false: the rank is not among the keys.
-template <typename Visit>
-__device__ __forceinline__ unsigned long long wg_radix_select(Visit visit, int bits, unsigned long long k, unsigned int* lh, unsigned long long* wsum,
-                                                              int* res, bool& ok)
-{
-    unsigned long long prefix = 0;
-    int hi_shift = 64;
-    ok = true;
-    int shift = bits;
-    while (shift > 0) {
-        const int nshift = max(shift - GAP_BITS, 0), nbits = shift - nshift;
-        const unsigned int mask = (1u << nbits) - 1u;
-        for (int i = threadIdx.x; i < GAP_BINS; i += 1024) lh[i] = 0;
-        __syncthreads();
-        visit([&](unsigned long long key) {
-            if (hi_shift < 64 && (key >> hi_shift) != prefix) return;
-            atomicAdd(&lh[(unsigned)(key >> nshift) & mask], 1u);
-        });
-        __syncthreads();
-        const int digit = wg_pick_digit(lh, nbits, k, wsum, res);
-        if (digit < 0) { ok = false; return 0; }
-        prefix = (prefix << nbits) | (unsigned long long)digit;
-        hi_shift = nshift;
-        shift = nshift;
-    }
-    return prefix;
-}
-__global__ void __launch_bounds__(1024) k_gap_bracket(DevState* __restrict__ ds, const unsigned long long* __restrict__ sample, double percentile)
-{
-    extern __shared__ unsigned long long sk[];             // GAP_SAMPLE keys
     __shared__ unsigned int lh[GAP_BINS];
-    __shared__ unsigned long long wsum[17];
-    __shared__ int res[1];
-    const unsigned int ns = min(ds->gs_nsample, (unsigned)GAP_SAMPLE);
-    for (unsigned int i = threadIdx.x; i < ns; i += 1024) sk[i] = sample[i];
+    for (int i = threadIdx.x; i < GAP_BINS; i += 256) lh[i] = 0;
     __syncthreads();
-    unsigned long long lo = 0, hi = ~0ull;
-    if (ns >= 64) {
-        // the sample's keys come three to a point and neighbouring gaps are correlated: sigma as for ns / 3 independent draws
-        const double f = fmin(fmax(percentile / 100.0, 0.0), 1.0);
-        const double d = 6.0 * sqrt(f * (1.0 - f) * 3.0 / (double)ns) + 3.0 / (double)ns;
-        const double rl = floor((f - d) * (double)ns) - 1.0, rh = ceil((f + d) * (double)ns) + 1.0;
-        auto visit = [&](auto f_) { for (unsigned int i = threadIdx.x; i < ns; i += 1024) f_(sk[i]); };
-        bool ok;
-        if (rl >= 0.0) { const unsigned long long v = wg_radix_select(visit, 64, (unsigned long long)rl, lh, wsum, res, ok); if (ok) lo = v; }
-        if (rh < (double)ns) { const unsigned long long v = wg_radix_select(visit, 64, (unsigned long long)rh, lh, wsum, res, ok); if (ok) hi = v; }
-    }
-    if (threadIdx.x == 0) { ds->gs_lo = lo; ds->gs_hi = hi; }
-}
-constexpr int GAP_STAGE = 1024;                           // keys a workgroup of k_gap_collect gathers in LDS before it reserves room for them
-__global__ void __launch_bounds__(256) k_gap_collect(const uint8_t* __restrict__ valid, const double* __restrict__ Z, int w, int h,
-                                                     DevState* __restrict__ ds, unsigned long long* __restrict__ out, unsigned int cap)
-{
-    __shared__ unsigned long long s_tot, s_below, stage[GAP_STAGE];
-    __shared__ unsigned int s_eqlo, s_eqhi, s_n, s_base;
-    if (threadIdx.x == 0) { s_tot = s_below = 0; s_eqlo = s_eqhi = 0; s_n = 0; }
-    __syncthreads();
-    const unsigned long long lo = ds->gs_lo, hi = ds->gs_hi;
+    const int hi_shift = ds->sel_hi_shift;
+    const unsigned long long prefix = ds->sel_prefix;
     const int j = blockIdx.x * 256 + threadIdx.x;
-    const bool act = j >= 1 && j < w - 1;
-    const int lane = threadIdx.x & 63;
-    unsigned int total = 0, below = 0, eqlo = 0, eqhi = 0;
-    for (int i = 1 + blockIdx.y; i < h; i += gridDim.y) {      // (wave-uniform trip count: the ballots below need every lane)
-        unsigned long long key[3] = { 0, 0, 0 };
-        bool has[3] = { false, false, false };
-        if (act) point_gaps(valid, Z, w, i, j, key, has);
+    if (j >= 1 && j < w - 1)
+        for (int i = 1 + blockIdx.y; i < h; i += gridDim.y) {
+            // all loads first and unconditionally (rows i-1 and i exist, columns j-1 .. j+1 too): independent requests in flight
+            const size_t c = (size_t)i * w + j, up = c - w;
+            const uint8_t vc = valid[c], v0 = valid[up - 1], v1 = valid[up], v2 = valid[up + 1];
+            const double z = Z[c], z0 = Z[up - 1], z1 = Z[up], z2 = Z[up + 1];
+            if (!vc) continue;
+            const double zn[3] = { z0, z1, z2 };
+            const uint8_t vn[3] = { v0, v1, v2 };
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const bool g = has[k];
-            total += g ? 1u : 0u;
-            below += (g && key[k] < lo) ? 1u : 0u;
-            eqlo += (g && key[k] == lo) ? 1u : 0u;
-            eqhi += (g && key[k] == hi && hi != lo) ? 1u : 0u;
-            const bool mid = g && key[k] > lo && key[k] < hi;
-            const unsigned long long m = __ballot(mid);
-            if (m) {
-                // keys inside the bracket (1-2 %): one LDS counter update per wave; the workgroup reserves its room in the output ONCE at
-                // the end (a global atomic per wave made the 2 560 workgroups queue at one address: 0.5 ms)
-                const int leader = __ffsll((long long)m) - 1;
-                unsigned int base = 0;
-                if (lane == leader) base = atomicAdd(&s_n, (unsigned)__popcll(m));
-                base = __shfl(base, leader);
-                const unsigned int pos = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-                if (mid) {
-                    if (pos < (unsigned)GAP_STAGE) stage[pos] = key[k];
-                    else { const unsigned int at = atomicAdd(&ds->gs_ncollect, 1u); if (at < cap) out[at] = key[k]; }   // (a workgroup with more than GAP_STAGE)
-                }
+            for (int k = 0; k < 3; ++k) {
+                if (!vn[k]) continue;
+                const unsigned long long key = (unsigned long long)__double_as_longlong(fabs(z - zn[k]));
+                if (hi_shift < 64 && (key >> hi_shift) != prefix) continue;
+                atomicAdd(&lh[(unsigned)(key >> shift) & mask], 1u);
             }
         }
-    }
-    for (int o = 32; o > 0; o >>= 1) { total += __shfl_down(total, o); below += __shfl_down(below, o); eqlo += __shfl_down(eqlo, o); eqhi += __shfl_down(eqhi, o); }
-    if (lane == 0) {
-        if (total) atomicAdd(&s_tot, (unsigned long long)total);
-        if (below) atomicAdd(&s_below, (unsigned long long)below);
-        if (eqlo) atomicAdd(&s_eqlo, eqlo);
-        if (eqhi) atomicAdd(&s_eqhi, eqhi);
-    }
     __syncthreads();
-    const unsigned int ns = min(s_n, (unsigned)GAP_STAGE);
-    if (threadIdx.x == 0) {
-        if (s_tot) atomicAdd(&ds->gs_total, s_tot);
-        if (s_below) atomicAdd(&ds->gs_below, s_below);
-        if (s_eqlo) atomicAdd(&ds->gs_eqlo, s_eqlo);
-        if (s_eqhi) atomicAdd(&ds->gs_eqhi, s_eqhi);
-        s_base = ns ? atomicAdd(&ds->gs_ncollect, ns) : 0u;
-    }
-    __syncthreads();
-    for (unsigned int i = threadIdx.x; i < ns; i += 256)
-        if (s_base + i < cap) out[s_base + i] = stage[i];
+    unsigned int* mine = hist + (size_t)((blockIdx.x + blockIdx.y) % GAP_HIST_COPIES) * GAP_BINS;
+    for (int i = threadIdx.x; i < GAP_BINS; i += 256)
+        if (lh[i]) atomicAdd(&mine[i], lh[i]);
 }
-__global__ void __launch_bounds__(1024) k_gap_final(const uint8_t* __restrict__ valid, const double* __restrict__ Z, int w, int h,
-                                                    DevState* __restrict__ ds, const unsigned long long* __restrict__ mid, unsigned int cap, double percentile)
+// one workgroup: pick the bin that holds rank k, extend the prefix; pass 0 also derives k from the percentile
+__global__ void __launch_bounds__(256) k_radix_pick(unsigned int* __restrict__ hist, int pass, int shift, int nbits,
+                                                    double percentile, DevState* __restrict__ ds)
 {
-    __shared__ unsigned int lh[GAP_BINS];
-    __shared__ unsigned long long wsum[17];
-    __shared__ int res[1];
-    const unsigned long long total = ds->gs_total;
-    if (total == 0) {                                          // no gaps: NaN (compute_zgap_percentile on an empty list)
-        if (threadIdx.x == 0) { ds->sel_total = 0; ds->sel_fail = 1; ds->zgap = __longlong_as_double(0x7FF8000000000000ll); }
-        return;
+    __shared__ unsigned long long tot[256];
+    const int nb = 1 << nbits, per = (nb + 255) / 256;
+    for (int i = threadIdx.x; i < GAP_BINS; i += 256) {                                  // fold the copies into copy 0
+        unsigned int t = hist[i];
+        for (int cpy = 1; cpy < GAP_HIST_COPIES; ++cpy) t += hist[(size_t)cpy * GAP_BINS + i];
+        hist[i] = t;
     }
-    unsigned long long k = (unsigned long long)floor(percentile / 100.0 * (double)total);      // PovMesh.cpp:924
-    if (k >= total) k = total - 1;
-    const unsigned long long lo = ds->gs_lo, hi = ds->gs_hi, below = ds->gs_below, eqlo = ds->gs_eqlo, eqhi = ds->gs_eqhi, ncol = ds->gs_ncollect;
-    int path = 3;
-    unsigned long long answer = 0;
-    bool ok = true;
-    if (ncol <= cap) {
-        if (k >= below && k < below + eqlo) { path = 1; answer = lo; }
-        else if (k >= below + eqlo && k < below + eqlo + ncol) path = 2;
-        else if (k >= below + eqlo + ncol && k < below + eqlo + ncol + eqhi) { path = 1; answer = hi; }
-    }
-    if (path == 2) {
-        // among the collected keys, all strictly inside (lo, hi): select on key - lo, whose significant bits start where hi - lo's do -- the
-        // first digit then spreads over the histogram instead of hitting the two or three bins that the keys' common exponent would
-        const int bits = 64 - __clzll((long long)(hi - lo));
-        auto visit = [&](auto f_) { for (unsigned int i = threadIdx.x; i < (unsigned int)ncol; i += 1024) f_(mid[i] - lo); };
-        answer = lo + wg_radix_select(visit, bits, k - below - eqlo, lh, wsum, res, ok);
-        if (!ok) path = 3;                                     // (cannot happen: the counts said the rank is among them)
-    }
-    if (path == 3) {
-        // the bracket missed (or the buffer overflowed): every gap, computed on the fly, through this one workgroup -- slow, exact, and rare
-        k = (unsigned long long)floor(percentile / 100.0 * (double)total);
-        if (k >= total) k = total - 1;
-        const size_t npx = (size_t)w * h;
-        auto visit = [&](auto f_) {
-            for (size_t c = (size_t)w + threadIdx.x; c < npx; c += 1024) {
-                const int i = (int)(c / (size_t)w), j = (int)(c % (size_t)w);
-                if (j < 1 || j >= w - 1) continue;
-                unsigned long long key[3];
-                bool has[3];
-                point_gaps(valid, Z, w, i, j, key, has);
-#pragma unroll
-                for (int q = 0; q < 3; ++q) if (has[q]) f_(key[q]);
-            }
-        };
-        answer = wg_radix_select(visit, 64, k, lh, wsum, res, ok);
-        if (!ok) { if (threadIdx.x == 0) { ds->sel_total = total; ds->sel_fail = 2; } return; }
-    }
+    __syncthreads();
+    unsigned long long s = 0;
+    for (int b = threadIdx.x * per; b < min(nb, (threadIdx.x + 1) * per); ++b) s += hist[b];
+    tot[threadIdx.x] = s;
+    __syncthreads();
     if (threadIdx.x == 0) {
-        ds->sel_total = total;
-        ds->sel_fail = 0;
-        ds->gs_path = path;
-        ds->zgap = __longlong_as_double((long long)answer);
+        unsigned long long k = ds->sel_k;
+        if (pass == 0) {
+            unsigned long long total = 0;
+            for (int t = 0; t < 256; ++t) total += tot[t];
+            ds->sel_total = total;
+            k = (unsigned long long)floor(percentile / 100.0 * (double)total);      // PovMesh.cpp:924
+            if (total && k >= total) k = total - 1;
+            ds->sel_prefix = 0;
+            ds->sel_fail = total == 0;
+        }
+        if (!ds->sel_fail) {
+            int t = 0;
+            for (; t < 256; ++t) { if (k < tot[t]) break; k -= tot[t]; }
+            int b = t * per;
+            const int be = min(nb, (t + 1) * per);
+            for (; b < be; ++b) { if (k < hist[b]) break; k -= hist[b]; }
+            if (t >= 256 || b >= be) ds->sel_fail = 2;
+            else {
+                ds->sel_k = k;
+                ds->sel_prefix = (ds->sel_prefix << nbits) | (unsigned long long)b;
+                ds->sel_hi_shift = shift;
+                if (shift == 0) ds->zgap = __longlong_as_double((long long)ds->sel_prefix);
+            }
+        }
+        if (ds->sel_fail == 1) ds->zgap = __longlong_as_double(0x7FF8000000000000ll);     // no gaps: NaN
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < GAP_BINS * GAP_HIST_COPIES; i += 256) hist[i] = 0;        // ready for the next pass
 }
 
 // ------------------------------------------------------------------ RANSAC (PovMesh.cpp:665-777)
@@ -1748,7 +1580,8 @@ __global__ void __launch_bounds__(256) k_xyzc_pack_dev(const uint8_t* __restrict
     xyzc_pack_body(valid, X, Y, Z, n, rt, ds->mn[0], ds->mn[1], ds->mn[2], ds->sc[0], ds->sc[1], ds->sc[2], blockoff, out);
 }
 
-constexpr size_t DSTATE_STRIDE = (sizeof(DevState) + 255) & ~(size_t)255;
+constexpr size_t DSTATE_HIST_OFF = (sizeof(DevState) + 255) & ~(size_t)255;
+constexpr size_t DSTATE_STRIDE = (DSTATE_HIST_OFF + (size_t)GAP_HIST_COPIES * GAP_BINS * 4 + 255) & ~(size_t)255;
 // two records (+ histograms), alternated by the frame tail (wass_ctx::ds_slot): frame n's is downloaded while frame n+1's is being built
 static int dstate(wass_ctx* c, DevState** ds)
 {
@@ -1837,29 +1670,18 @@ static int enqueue_remove_outliers(wass_ctx* c, wass_mesh* m, double percentile,
     DevState* ds = nullptr;
     int rc = dstate(c, &ds);
     if (rc) return rc;
+    unsigned int* hist = (unsigned int*)((char*)ds + DSTATE_HIST_OFF);      // 256-byte aligned: one fill kernel, not three
     unsigned char* stage = nullptr;
     if ((rc = host_stage(c, &stage))) return rc;
-    // sample keys | keys collected inside the bracket: in the stage scratch that the connected components re-use right behind (same stream)
-    const size_t n = m->n();
-    const unsigned int cap = (unsigned int)std::min<size_t>((size_t)4 << 20, std::max<size_t>(3 * n, 1));
-    if ((rc = ensure(c, c->scratch, std::max(n * 12, (size_t)GAP_SAMPLE * 8 + (size_t)cap * 8)))) return rc;
-    unsigned long long* sample = (unsigned long long*)c->scratch.p;
-    unsigned long long* mid = sample + GAP_SAMPLE;
     WASS_HIP(c, hipStreamWaitEvent(c->ts(), c->fslot[c->ds_slot & 1].ev_copy, 0));   // the download that read THIS record: two frames ago
     WASS_HIP(c, hipMemcpyAsync(ds, stage, sizeof(DevState), hipMemcpyHostToDevice, c->ts()));
-    {
-        WASS_HIP(c, hipFuncSetAttribute((const void*)k_gap_bracket, hipFuncAttributeMaxDynamicSharedMemorySize, GAP_SAMPLE * 8));
-        const unsigned int want = GAP_SAMPLE / 3;                         // sampled points (up to three keys each)
-        const unsigned int stride = (unsigned int)std::max<size_t>(1, n / want);
-        const unsigned int npts = (unsigned int)std::min<size_t>(want, n / stride);
-        static const bool skip_select = getenv("WASS_X_SKIP_ZGAP") && atoi(getenv("WASS_X_SKIP_ZGAP")) != 0;   // measurement only: zgap stays 0
-        if (skip_select) goto select_done;
-        if (npts > 0)
-            hipLaunchKernelGGL(k_gap_sample, dim3((npts + 255) / 256), dim3(256), 0, c->ts(), m->valid, m->z, m->w, m->h, npts, stride, ds, sample);
-        hipLaunchKernelGGL(k_gap_bracket, dim3(1), dim3(1024), GAP_SAMPLE * 8, c->ts(), ds, (const unsigned long long*)sample, percentile);
-        hipLaunchKernelGGL(k_gap_collect, dim3((m->w + 255) / 256, 256), dim3(256), 0, c->ts(), m->valid, m->z, m->w, m->h, ds, mid, cap);
-        hipLaunchKernelGGL(k_gap_final, dim3(1), dim3(1024), 0, c->ts(), m->valid, m->z, m->w, m->h, ds, (const unsigned long long*)mid, cap, percentile);
-    select_done:;
+    WASS_HIP(c, hipMemsetAsync(hist, 0, (size_t)GAP_HIST_COPIES * GAP_BINS * 4, c->ts()));
+    for (int pass = 0; pass < GAP_PASSES; ++pass) {
+        const int shift = pass < GAP_PASSES - 1 ? 64 - GAP_BITS * (pass + 1) : 0;       // 53, 42, 31, 20, 9, 0 (last digit: 9 bits)
+        const int nbits = pass < GAP_PASSES - 1 ? GAP_BITS : 64 - GAP_BITS * (GAP_PASSES - 1);
+        hipLaunchKernelGGL(k_gap_hist, dim3((m->w + 255) / 256, 256), dim3(256), 0, c->ts(), m->valid, m->z, m->w, m->h, shift, (1u << nbits) - 1u,
+                           (const DevState*)ds, hist);
+        hipLaunchKernelGGL(k_radix_pick, dim3(1), dim3(256), 0, c->ts(), hist, pass, shift, nbits, percentile, ds);
     }
     if (c->ev_tail[2]) (void)hipEventRecord(c->ev_tail[2], c->ts());
     if ((rc = enqueue_ccl(c, m, ds))) return rc;
@@ -1882,16 +1704,6 @@ int wass_mesh_remove_outliers(wass_ctx* c, wass_mesh* m, double percentile, doub
     if (zgap_out) *zgap_out = h.zgap;
     if (n_gaps) *n_gaps = h.sel_total;
     if (size_out) *size_out = h.ccl_best >> 32;
-    c->last_zgap_path = h.gs_path;
-    c->last_zgap_collected = h.gs_ncollect;
-    return WASS_OK;
-}
-
-int wass_mesh_zgap_select_info(wass_ctx* c, int* path, uint64_t* collected)
-{
-    if (!c || !path || !collected) return set_err(c, WASS_ERR_INVALID_ARG, "null argument");
-    *path = c->last_zgap_path;
-    *collected = c->last_zgap_collected;
     return WASS_OK;
 }
 

@@ -483,12 +483,6 @@ class Mesh:
         self.ctx._check(self.ctx._lib.wass_mesh_remove_outliers(self.ctx._h, self._h, pct, C.byref(z), C.byref(n), C.byref(sz)))
         return z.value, int(n.value), int(sz.value)
 
-    def zgap_select_info(self):
-        """(path, keys collected) of the last remove_outliers call: wass_mesh_zgap_select_info."""
-        p = C.c_int(); n = C.c_uint64()
-        self.ctx._check(self.ctx._lib.wass_mesh_zgap_select_info(self.ctx._h, C.byref(p), C.byref(n)))
-        return p.value, int(n.value)
-
     def fit_plane(self, uv, ransac_thr=1.0, max_distance=1.5, xmin=-9999., xmax=9999., ymin=-9999., ymax=9999.,
                   refine_max_distance=70.0, weight_by_distance=True, central_third_only=False) -> PlaneResult:
         """ransac_plane -> crop_plane -> refine_plane -> crop_plane in one call (wass_stereo.cpp:2062-2107)."""
