@@ -284,9 +284,13 @@ def config_e_record(dev_index: int, ndirs: int, steps: int = 5, warmup: int = 2,
             "cost_overflow": int(overflow)}
 
 
-def make_sequence(tmp: str, frames: int, replicate: int, ndirs: int):
+def make_sequence(tmp: str, frames: int, replicate: int, ndirs: int, png_level: int = 1, raw: bool = False):
     """A config-B sequence of workdirs as wass_prepare / wass_autocalibrate leave them (PNG + XML) under tmp/output: `frames` distinct
-    synthetic pairs, each workdir replicated `replicate` times with symlinked inputs.  Returns (sequence dir, config file, workdirs)."""
+    synthetic pairs, each workdir replicated `replicate` times with symlinked inputs.  Returns (sequence dir, config file, workdirs).
+    png_level: 1 = deflated like cv::imwrite's default (the reference's wass_prepare); 0 = stored blocks (this product's wass_prepare).
+    raw: instead of workdirs, what `wass_stereo_batch --raw` starts from -- tmp/calib (intrinsics, distortion, extrinsics) and
+    tmp/input/cam{0,1}/<n>_frame.png, frames * replicate pictures per camera (symlinks to the distinct ones); returns (calib dir, config
+    file, pictures per camera)."""
     import struct
     import zlib
     from wass_amd import synth
@@ -300,7 +304,7 @@ def make_sequence(tmp: str, frames: int, replicate: int, ndirs: int):
             return c + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
         with open(path, "wb") as f:
             f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", img.shape[1], img.shape[0], 8, 0, 0, 0, 0)) +
-                    chunk(b"IDAT", zlib.compress(raw, 1)) + chunk(b"IEND", b""))
+                    chunk(b"IDAT", zlib.compress(raw, png_level)) + chunk(b"IEND", b""))
 
     def write_xml(path, node, m):
         m = np.atleast_2d(np.asarray(m, float))
@@ -317,6 +321,30 @@ def make_sequence(tmp: str, frames: int, replicate: int, ndirs: int):
     rect = "" if os.environ.get("WASS_BENCH_RECTIFY") == "opencv" else "USE_CUSTOM_STEREORECTIFY=true\nRECTIFY_ANGLE=1e-6\nDISABLE_RECTIFY_ROI=true\n"
     open(cfg, "w").write(f"MAX_DISPARITY={D}\nRANDOM_SEED=12345\n{rect}DENSE_PATHS={ndirs}\n")
     inputs = ("undistorted/00000000.png", "undistorted/00000001.png", "intrinsics_00000000.xml", "intrinsics_00000001.xml", "ext_R.xml", "ext_T.xml")
+    if raw:
+        calib = os.path.join(tmp, "calib")
+        cams = [os.path.join(tmp, "input", "cam%d" % k) for k in (0, 1)]
+        for d in [calib] + cams:
+            os.makedirs(d)
+        write_xml(os.path.join(calib, "intrinsics_00.xml"), "intr", rig["K_left"])
+        write_xml(os.path.join(calib, "intrinsics_01.xml"), "intr", rig["K_right"])
+        write_xml(os.path.join(calib, "distortion_00.xml"), "dist", np.array([-0.012, 0.004, 2e-4, -1e-4, 0.0]).reshape(5, 1))
+        write_xml(os.path.join(calib, "distortion_01.xml"), "dist", np.array([0.009, -0.003, -1e-4, 2e-4, 1e-3]).reshape(5, 1))
+        write_xml(os.path.join(calib, "ext_R.xml"), "R", rig["R"])
+        write_xml(os.path.join(calib, "ext_T.xml"), "T", np.array(rig["T"]).reshape(3, 1) * 2.5)
+        import torch
+        dev = "cuda" if torch.cuda.is_available() else "cpu"
+        for i in range(frames):
+            right, left = [x.cpu().numpy() for x in synth.make_pair_torch(w, h, D, frame_idx=700000 + i, device=dev)]
+            write_png(os.path.join(cams[0], "%06d_frame.png" % i), left)
+            write_png(os.path.join(cams[1], "%06d_frame.png" % i), right)
+        n = frames
+        for _ in range(1, replicate):
+            for i in range(frames):
+                for c in cams:
+                    os.symlink(os.path.join(c, "%06d_frame.png" % i), os.path.join(c, "%06d_frame.png" % n))
+                n += 1
+        return calib, cfg, n
     for i in range(frames):
         wd = os.path.join(seq, "%06d_wd" % i)
         os.makedirs(os.path.join(wd, "undistorted"))
@@ -346,7 +374,7 @@ def make_sequence(tmp: str, frames: int, replicate: int, ndirs: int):
 
 
 def cxx_driver_record(ndirs: int, frames: int = 8, replicate: int = 24, decode_threads: int = 8, writer_threads: int = 4,
-                      gpus: int = 1, procs_per_gpu: int = 1):
+                      gpus: int = 1, procs_per_gpu: int = 1, png_level: int = 1, raw: bool = False):
     """What drops into wasscli: the C++ sequence driver (wass_amd/host/wass_stereo_batch.cpp, frame_pipeline.hpp -- decode threads
     -> device-resident frame chain -> writer threads) on a sequence of config-B workdirs as wass_prepare / wass_autocalibrate
     leave them (PNG + XML), one worker process on this GPU, every output a tool reads written (mesh_cam.xyzC, plane.txt, the
@@ -382,9 +410,13 @@ def cxx_driver_record(ndirs: int, frames: int = 8, replicate: int = 24, decode_t
         return {"error": f"no directory with {need / 1e9:.0f} GB free for the sequence (/dev/shm, {tempfile.gettempdir()})"}
     tmp = tempfile.mkdtemp(prefix="wass_bench_seq_", dir=base)
     try:
-        seq, cfg, n = make_sequence(tmp, frames, replicate, ndirs)
+        seq, cfg, n = make_sequence(tmp, frames, replicate, ndirs, png_level=png_level, raw=raw)
+        where = ["--sequence", seq]
+        if raw:                                     # seq is the calibration directory here; the workdirs are created by the driver
+            where = ["--raw", seq, "--cam0", os.path.join(tmp, "input", "cam0"), "--cam1", os.path.join(tmp, "input", "cam1"), "--sequence", os.path.join(tmp, "output")]
+            seq = os.path.join(tmp, "output")
         t0 = time.perf_counter()
-        r = subprocess.run([build.BATCH, cfg, "--sequence", seq, "--gpus", str(max(1, gpus)), "--decode-threads", str(decode_threads),
+        r = subprocess.run([build.BATCH, cfg] + where + ["--gpus", str(max(1, gpus)), "--decode-threads", str(decode_threads),
                             "--writer-threads", str(writer_threads)] + (["--procs-per-gpu", str(procs_per_gpu)] if procs_per_gpu > 1 else []),
                            capture_output=True, text=True)
         wall = time.perf_counter() - t0
@@ -402,6 +434,9 @@ def cxx_driver_record(ndirs: int, frames: int = 8, replicate: int = 24, decode_t
                 "frames": n, "distinct_frames": frames, "workers": nworkers, "gpus": max(1, gpus), "decode_threads": decode_threads,
                 "writer_threads": writer_threads,
                 "ndirs": ndirs, "pipelined": "pipelined" in r.stdout, "host_cpu_ms_per_frame": cpu_ms, "host_cores_busy": cores,
+                "inputs": ("the cameras' raw pictures (PNG, zlib level 1) + calibration directory: wass_stereo_batch --raw, undistortion on the device" if raw else
+                           "workdirs as the reference's wass_prepare leaves them: undistorted/*.png deflated at zlib level 1 (cv::imwrite's default)" if png_level else
+                           "workdirs as THIS product's wass_prepare leaves them: undistorted/*.png as stored blocks (valid PNG, inflate = copy)"),
                 "outputs": "all files wass_stereo writes without its debug pictures, per workdir: mesh_cam.xyzC "
                            f"({sizes[0] / 1e6:.1f} MB), plane.txt, plane_refinement_inliers.xyz ({sizes[1] / 1e6:.1f} MB), camera / pose files, "
                            "scaled previews, stereo_config.txt, wass_stereo_log.txt; planes.txt + planes_mean.txt for the sequence",
@@ -926,8 +961,15 @@ def main():
                 ctx = None
             try:
                 line["cxx_driver"] = cxx_driver_record(args.ndirs)
+                # the same driver on inputs that cost the host less: workdirs written by this product's own wass_prepare (stored PNG
+                # blocks), and no workdirs at all (--raw: undistortion inside the frame chain) -- host_cpu_ms_per_frame is what sets
+                # how many cores a GPU needs
+                keep = ("pairs_per_sec", "frames", "host_cpu_ms_per_frame", "host_cores_busy", "inputs", "error")
+                for name, kw in (("product_prepared_inputs", {"png_level": 0}), ("raw_inputs", {"raw": True})):
+                    sub = cxx_driver_record(args.ndirs, replicate=12, **kw)
+                    line["cxx_driver"][name] = {k: sub[k] for k in keep if k in sub}
             except Exception as e:                          # the headline must not depend on a scratch directory
-                line["cxx_driver"] = {"error": f"{type(e).__name__}: {e}"}
+                line.setdefault("cxx_driver", {})["error"] = f"{type(e).__name__}: {e}"
             try:
                 line["wasscli_unchanged"] = wasscli_unchanged_record(args.ndirs)
             except Exception as e:

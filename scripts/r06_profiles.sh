@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-4 profile set on one box: stats + FETCH/WRITE passes for config B (8- and 5-path) and config E (row-fused now), the
+# Round-6 profile set on one box: stats + FETCH/WRITE passes for config B (8- and 5-path) and config E (row-fused now), the
 # driver-style bench line, the config E / 5-path bench lines.
-#   scripts/r04_profiles.sh <tag>
-TAG=${1:-r04}
+#   scripts/r06_profiles.sh <tag>
+TAG=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$ROOT"
 scripts/profile.sh ${TAG}_B8 > /dev/null 2>&1

@@ -120,6 +120,55 @@ def test_a_five_megapixel_sub_filtered_picture_like_cv_imwrite_writes(dump, tmp_
         np.testing.assert_array_equal(np.frombuffer(r.stdout[8:], np.uint8).reshape(h, w), img[:, :, 0])
 
 
+def _py_decode(path):
+    """an independent PNG decoder (struct + zlib: chunk CRCs and the stream's Adler-32 are checked), filter None only"""
+    blob = open(path, "rb").read()
+    assert blob[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w, h = 8, b"", 0, 0
+    while pos < len(blob):
+        n, t = struct.unpack(">I4s", blob[pos:pos + 8])
+        d = blob[pos + 8:pos + 8 + n]
+        assert zlib.crc32(t + d) & 0xFFFFFFFF == struct.unpack(">I", blob[pos + 8 + n:pos + 12 + n])[0]
+        if t == b"IHDR":
+            w, h, depth, ctype = struct.unpack(">IIBB", d[:10]); assert (depth, ctype) == (8, 0)
+        elif t == b"IDAT":
+            idat += d
+        pos += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, w + 1)
+    assert (raw[:, 0] == 0).all()
+    return raw[:, 1:], idat
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (3, 70000), (37, 53), (300, 437), (2058, 2456)])
+def test_stored_pictures_as_the_products_wass_prepare_writes_them(dump, tmp_path, shape):
+    """Round 6: undistorted/*.png are written as zlib streams of STORED blocks (write_png_gray level 0): valid PNG for every reader, and a
+    frame's two inflates (2 x 17 ms of its 60 ms of host time) become copies.  The writer against an independent decoder; the reader's
+    fast path (file bytes straight into the picture) on its own files, on zlib's level-0 streams cut into IDAT chunks anywhere, and on
+    stored streams whose rows are filtered after all (general path)."""
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    h, w = shape
+    img = rng.integers(0, 256, (h, w, 1), dtype=np.uint8)
+    src = str(tmp_path / "src.png")
+    _write_png(src, img, [1] * h, level=1)
+    out0, out1 = str(tmp_path / "stored.png"), str(tmp_path / "l1.png")
+    for out, level in ((out0, 0), (out1, 1)):
+        assert subprocess.run([dump, "repng", src, out, str(level)]).returncode == 0
+        px, idat = _py_decode(out)
+        np.testing.assert_array_equal(px, img[:, :, 0])
+        np.testing.assert_array_equal(_decode(dump, out), img[:, :, 0])
+    raw_bytes = (w + 1) * h
+    _, idat0 = _py_decode(out0)
+    assert len(idat0) == raw_bytes + 5 * max(1, -(-raw_bytes // 65535)) + 6           # header, 5 bytes per stored block, Adler-32
+    # zlib's own level-0 stream, IDAT cut into seven pieces
+    p = str(tmp_path / "z0.png")
+    _write_png(p, img, [0] * h, level=0, idat_split=7)
+    np.testing.assert_array_equal(_decode(dump, p), img[:, :, 0])
+    # stored blocks, filtered rows: not the fast path's business
+    filt = rng.integers(0, 5, h) if h * w < 200000 else [1] * h
+    _write_png(p, img, filt, level=0, idat_split=2)
+    np.testing.assert_array_equal(_decode(dump, p), img[:, :, 0])
+
+
 def test_broken_files_are_errors_not_crashes(dump, tmp_path):
     img = np.arange(20 * 30, dtype=np.uint8).reshape(20, 30, 1)
     p = str(tmp_path / "ok.png")

@@ -593,8 +593,8 @@ public:
                     Image cam[2] = { Image(job.prev_w, job.prev_h), Image(job.prev_w, job.prev_h) };
                     memcpy(cam[env.left_index].px.data(), o.prev[0], pn);
                     memcpy(cam[env.right_index].px.data(), o.prev[1], pn);
-                    write_png_gray(path_join(env.workdir, "00000000_s.png"), cam[0]);
-                    write_png_gray(path_join(env.workdir, "00000001_s.png"), cam[1]);
+                    write_png_gray(path_join(env.workdir, "00000000_s.png"), cam[0], prepared_png_level());
+                    write_png_gray(path_join(env.workdir, "00000001_s.png"), cam[1], prepared_png_level());
                 }
                 if (job.raw && opt_.save_undistorted) {
                     // wass_prepare's own output, on request: the undistorted pictures came back with the result (und[0] = LEFT, und[1] = right)
@@ -603,8 +603,8 @@ public:
                     Image cam[2] = { Image(job.img_w, job.img_h), Image(job.img_w, job.img_h) };
                     memcpy(cam[env.left_index].px.data(), o.und[0], n);
                     memcpy(cam[env.right_index].px.data(), o.und[1], n);
-                    write_png_gray(path_join(path_join(env.workdir, "undistorted"), "00000000.png"), cam[0]);
-                    write_png_gray(path_join(path_join(env.workdir, "undistorted"), "00000001.png"), cam[1]);
+                    write_png_gray(path_join(path_join(env.workdir, "undistorted"), "00000000.png"), cam[0], prepared_png_level());
+                    write_png_gray(path_join(path_join(env.workdir, "undistorted"), "00000001.png"), cam[1], prepared_png_level());
                 }
                 marker(job, 100);
                 // the time table (render.hpp:175-191) with the reference's rows.  A pipelined frame has no per-stage WALL times (its

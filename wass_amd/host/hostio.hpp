@@ -317,6 +317,30 @@ inline Image read_png_gray(const std::string& filename)
     const int ch = ctype == 0 ? 1 : (ctype == 4 ? 2 : (ctype == 2 ? 3 : 4));
     const size_t stride = (size_t)w * ch;
     const size_t rawn = (stride + 1) * h;
+    // A grey picture whose zlib stream is stored blocks throughout and whose rows carry the filter None -- what this product's own
+    // wass_prepare writes (write_png_gray level 0) -- goes from the file's bytes straight into the picture: no inflate, no second buffer.
+    if (ch == 1 && zlen >= 7 && (f[zpos] & 0x0f) == 8 && (f[zpos + 1] & 0x20) == 0 && (f[zpos + 2] & 6) == 0) {
+        Image img(w, h);
+        const uint8_t* z = f.data() + zpos;
+        size_t at = 2, pos = 0;                                  // offset in the stream / in the unfiltered-row sequence
+        bool good = true, last = false;
+        while (good && !last && at + 5 <= zlen) {
+            last = z[at] & 1;
+            if (z[at] & 6) { good = false; break; }              // a deflated block after all: the general path
+            const size_t len = z[at + 1] | ((size_t)z[at + 2] << 8), nlen = z[at + 3] | ((size_t)z[at + 4] << 8);
+            at += 5;
+            if ((len ^ nlen) != 0xFFFF || at + len > zlen || pos + len > rawn) { good = false; break; }
+            for (size_t done = 0; done < len;) {
+                const size_t row = (pos + done) / (stride + 1), col = (pos + done) % (stride + 1);
+                if (col == 0) { if (z[at + done] != 0) { good = false; break; } ++done; continue; }
+                const size_t n = std::min(len - done, stride + 1 - col);
+                memcpy(&img.px[row * stride + (col - 1)], z + at + done, n);
+                done += n;
+            }
+            at += len; pos += len;
+        }
+        if (good && last && pos == rawn) return img;            // (the Adler-32 is not checked: the chunk's CRC is not either, as in every fast path here)
+    }
     std::unique_ptr<uint8_t[]> rawbuf(new uint8_t[rawn]);      // (not a vector: zero-filling 5 MB that inflate overwrites is a millisecond per picture)
     uint8_t* const raw = rawbuf.get();
     if (!zlib_inflate_exact(f.data() + zpos, zlen, raw, rawn))
@@ -427,13 +451,36 @@ inline Image resize_cubic(const Image& src, int nw, int nh)
     return dst;
 }
 
-inline bool write_png_gray(const std::string& filename, const Image& img)
+// level 1 .. 9: deflated (1 = cv::imwrite's default, Z_BEST_SPEED).  level 0: a zlib stream of STORED blocks -- still a PNG every reader
+// takes (libpng, cv::imread, this file's reader), 0.03 % larger than the pixels, and its "inflate" is a memcpy: what this product's own
+// wass_prepare writes undistorted/*.png with (two 5-megapixel pictures cost a frame 2 x 17 ms of inflate at level 1, a third of its host
+// time; nothing downstream reads the files' bytes, only their pixels).
+inline int prepared_png_level()                 // WASS_PREPARE_PNG_LEVEL=1: deflated like the reference's cv::imwrite; default 0: stored
+{
+    const char* e = getenv("WASS_PREPARE_PNG_LEVEL");
+    return e && *e ? std::max(0, std::min(9, atoi(e))) : 0;
+}
+inline bool write_png_gray(const std::string& filename, const Image& img, int level = 1)
 {
     std::vector<uint8_t> raw((size_t)(img.w + 1) * img.h);
     for (int y = 0; y < img.h; ++y) { raw[(size_t)(img.w + 1) * y] = 0; memcpy(&raw[(size_t)(img.w + 1) * y + 1], &img.px[(size_t)y * img.w], img.w); }
-    // level 1, like cv::imwrite's default (Z_BEST_SPEED): a valid PNG with these pixels is the contract, not its bytes
+    // a valid PNG with these pixels is the contract, not its bytes
     std::vector<uint8_t> comp;
-    if (!zlib_deflate_fast(raw.data(), raw.size(), 1, comp)) return false;
+    if (level <= 0) {
+        const size_t n = raw.size(), nblk = (n + 65534) / 65535;
+        comp.reserve(n + 5 * std::max<size_t>(nblk, 1) + 6);
+        comp.push_back(0x78); comp.push_back(0x01);             // CM = 8, 32 K window, no dictionary, fastest
+        for (size_t at = 0, b = 0; b < std::max<size_t>(nblk, 1); ++b) {
+            const size_t len = std::min<size_t>(65535, n - at);
+            comp.push_back(at + len == n ? 1 : 0);             // BFINAL, BTYPE = 00
+            comp.push_back((uint8_t)len); comp.push_back((uint8_t)(len >> 8));
+            comp.push_back((uint8_t)~len); comp.push_back((uint8_t)(~len >> 8));
+            comp.insert(comp.end(), raw.begin() + (long)at, raw.begin() + (long)(at + len));
+            at += len;
+        }
+        const uLong ad = adler32(adler32(0L, Z_NULL, 0), raw.data(), (uInt)n);
+        for (int s = 24; s >= 0; s -= 8) comp.push_back((uint8_t)(ad >> s));
+    } else if (!zlib_deflate_fast(raw.data(), raw.size(), level, comp)) return false;
     const size_t clen = comp.size();
     std::ofstream ofs(filename.c_str(), std::ios::binary);
     if (ofs.fail()) return false;

@@ -148,8 +148,8 @@ bool images_loaded(Env& env)
 
 inline void write_previews(const std::string& wd, const Image& cam0, const Image& cam1, int nw, int nh)   // :413-418
 {
-    write_png_gray(path_join(wd, "00000000_s.png"), resize_cubic(cam0, nw, nh));
-    write_png_gray(path_join(wd, "00000001_s.png"), resize_cubic(cam1, nw, nh));
+    write_png_gray(path_join(wd, "00000000_s.png"), resize_cubic(cam0, nw, nh), prepared_png_level());
+    write_png_gray(path_join(wd, "00000001_s.png"), resize_cubic(cam1, nw, nh), prepared_png_level());
 }
 
 // :401-434.  previews = false: everything but the two scaled pictures (the caller writes them later: *nw, *nh say at which size)

@@ -84,7 +84,7 @@ bool process_image(Gpu& gpu, const std::string& filename, const Mat& K, const Ma
         WLOGE << "undistort: " << wass_last_error(gpu.ctx);
         return false;
     }
-    if (!write_png_gray(join(outdir, outfile + ".png"), und)) { WLOGE << "Unable to write " << join(outdir, outfile + ".png"); return false; }
+    if (!write_png_gray(join(outdir, outfile + ".png"), und, prepared_png_level())) { WLOGE << "Unable to write " << join(outdir, outfile + ".png"); return false; }
     WLOGI << "Output image size: " << und.w << "x" << und.h;
     return true;
 }
