@@ -95,6 +95,50 @@ def test_failed_frame_is_reported_and_left_out(exes, tmp_path):
     np.testing.assert_allclose([float(x) for x in (out / "planes_mean.txt").read_text().split()], [0.2, 0.2, 0.2, -5.0], rtol=1e-15)
 
 
+def test_without_rccl_the_parent_reduces_the_planes_itself(exes, tmp_path):
+    """--rccl-always on a box where librccl cannot be loaded (WASS_RCCL_LIB points nowhere and the default names are hidden by an empty
+    LD_LIBRARY_PATH on the build container; on a GPU box this test finds RCCL and is skipped): the sequence is not lost -- round 5 printed
+    "planes will be reduced by the parent process" and then gave up."""
+    out = tmp_path / "output"
+    out.mkdir()
+    for i in range(4):
+        _finished_workdir(str(out), i, "0.1 0.2 0.3 %d" % i)
+    cfg = tmp_path / "cfg.txt"
+    cfg.write_text("MAX_DISPARITY=64\n")
+    env = dict(os.environ, WASS_RCCL_LIB=str(tmp_path / "nowhere.so"))
+    r = subprocess.run([exes[1], str(cfg), "--sequence", str(out), "--gpus", "1", "--rccl-always", "--skip-existing"], capture_output=True, text=True, env=env)
+    if "RCCL is not available" not in r.stderr:
+        assert r.returncode == 0 and "(RCCL all-reduce)" in r.stdout      # a box with a loadable librccl: the leg ran with a world of one
+    else:
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "(RCCL all-reduce)" not in r.stdout
+    np.testing.assert_allclose([float(x) for x in (out / "planes_mean.txt").read_text().split()], [0.1, 0.2, 0.3, 1.5], rtol=1e-15)
+
+
+@pytest.mark.gpu
+def test_a_worker_without_pytorch_in_its_process_finds_rccl_and_reduces_with_a_world_of_one(exes, tmp_path):
+    """Row e readiness (no multi-GPU node has ever been available): `bench.py` and the Python tests run RCCL inside a process that has
+    PyTorch's copy loaded.  The shipped workers do not.  --rccl-always makes ONE worker run the leg the N-GPU run depends on -- the
+    parent takes the unique id (librccl by dlopen), forks the worker, the worker builds a communicator of one rank from it on its own
+    context's stream and all-reduces the five doubles -- so the library search, the fork pattern and the call sequence are tested on a
+    1-GPU box."""
+    cli, batch = exes
+    w, h, D = 320, 240, 64
+    seq = tmp_path / "seq"
+    cfg = None
+    for i in range(3):
+        t = tmp_path / f"mk{i}"
+        t.mkdir()
+        wd, cfg, *_ = make_workdir(str(t), w, h, D, frame=i)
+        shutil.copytree(wd, seq / ("%06d_wd" % i))
+    env = {k: v for k, v in os.environ.items() if k != "WASS_RCCL_LIB"}
+    r = subprocess.run([batch, cfg, "--sequence", str(seq), "--gpus", "1", "--rccl-always"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "RCCL is not available" not in r.stderr and "(RCCL all-reduce)" in r.stdout
+    planes = np.array([[float(x) for x in l.split()] for l in (seq / "planes.txt").read_text().strip().split("\n")])
+    np.testing.assert_allclose([float(x) for x in (seq / "planes_mean.txt").read_text().split()], np.nanmean(planes, axis=0), rtol=1e-14)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("layout", [("--procs-per-gpu", "2"), ("--threads-per-proc", "3"), ("--procs-per-gpu", "2", "--threads-per-proc", "2")])
 def test_batch_equals_one_process_per_frame(exes, tmp_path, layout):

@@ -157,7 +157,7 @@ int worker(int rank, int world, int device, bool distinct_gpus, const unsigned c
     if (status) return status;
     Tail t = {};
     t.magic = 0x57415353;
-    if (world > 1 && distinct_gpus) {
+    if (distinct_gpus) {
         // Coll-1 over RCCL: needs a context (a worker with no frames creates one just for the collective)
         if (!ctx && wass_ctx_create(device, &ctx) != WASS_OK) return 3;
         if (wass_coll_init(ctx, rank, world, uid) != WASS_OK || wass_coll_allreduce_sum_f64(ctx, acc, 5) != WASS_OK) {
@@ -332,7 +332,7 @@ int worker_pipelined(int rank, int world, int device, bool distinct_gpus, const 
     Tail t = {};
     t.magic = 0x57415353;
     t.first_done = first_done; t.last_done = last_done; t.computed = computed;
-    if (world > 1 && distinct_gpus) {
+    if (distinct_gpus) {
         // Coll-1 over RCCL: needs a context (a worker without frames to compute creates one just for the collective)
         wass_ctx* ctx = pl.context();
         if (!ctx) return 3;
@@ -357,6 +357,7 @@ int main(int argc, char* argv[])
                      "  --raw <calibdir> --cam0 <dir> --cam1 <dir> --sequence <output_dir> [--frames N] [--save-undistorted]\n"
                      "                      prepare-less mode: wass_prepare's undistortion (and CLAHE) runs on the GPU inside the frame chain, from\n"
                      "                      the cameras' raw pictures; undistorted/*.png are only written with --save-undistorted\n"
+                     "  --rccl-always       the RCCL all-reduce of the mean plane also with one worker (test of the library search on a 1-GPU box)\n"
                      "  --no-inliers-file   do not write plane_refinement_inliers.xyz (14 MB of text per 5-megapixel frame that nothing reads)\n"
                      "  --stage-by-stage    synchronous per-stage calls instead of the pipelined chain (same files)\n"
                      "  --threads-per-proc T  stage-by-stage only: frames in flight per worker process, each on a thread and a context of its own\n"
@@ -367,7 +368,7 @@ int main(int argc, char* argv[])
     std::vector<std::string> wds;
     std::string outdir;
     int gpus = 1, ppg = 1, tpp = 1;
-    bool verbose = false, skip_existing = false, debug_images = false, stage_by_stage = false, in_process = false;
+    bool verbose = false, skip_existing = false, debug_images = false, stage_by_stage = false, in_process = false, rccl_always = false;
     PipeOptions po;
     std::string raw_calibdir, cam0_dir, cam1_dir, raw_out;
     long max_frames = -1;
@@ -384,6 +385,7 @@ int main(int argc, char* argv[])
         else if (a == "--decode-threads" && i + 1 < argc) po.decode_threads = atoi(argv[++i]);
         else if (a == "--writer-threads" && i + 1 < argc) po.writer_threads = atoi(argv[++i]);
         else if (a == "--no-inliers-file") po.inliers_file = false;
+        else if (a == "--rccl-always") rccl_always = true;         // the RCCL leg of the mean plane also with ONE worker (a world of one)
         else if (a == "--in-process") in_process = true;           // one worker, not forked: lets a profiler (rocprofv3) see the GPU work
         else if (a == "--raw" && i + 1 < argc) raw_calibdir = argv[++i];
         else if (a == "--cam0" && i + 1 < argc) cam0_dir = argv[++i];
@@ -452,11 +454,15 @@ int main(int argc, char* argv[])
     if (po.prep && !pipelined) { std::cerr << "--raw needs the pipelined chain (no --stage-by-stage / --threads-per-proc, an eligible configuration)" << std::endl; return -1; }
     if (outdir.empty()) outdir = ".";
     const int world = gpus * ppg;
-    const bool distinct = ppg == 1;
+    // Coll-1 over RCCL: every worker owns a GPU (one worker per GPU) and there is more than one of them -- or --rccl-always, which runs the
+    // same leg with a world of one (how a single-GPU box tests that a worker WITHOUT PyTorch in its process finds librccl, builds a
+    // communicator from the parent's unique id and all-reduces).  If this process cannot load librccl the sequence is not lost: the
+    // parent gathers every frame's plane anyway and reduces them itself.
+    bool distinct = ppg == 1 && (world > 1 || rccl_always);
     unsigned char uid[128] = {};
-    if (world > 1 && distinct && wass_coll_unique_id(uid) != WASS_OK) {
+    if (distinct && wass_coll_unique_id(uid) != WASS_OK) {
         std::cerr << "RCCL is not available (wass_coll_unique_id failed); planes will be reduced by the parent process" << std::endl;
-        return -1;
+        distinct = false;
     }
 
     std::cout << "wass_stereo_batch: " << wds.size() << " frame(s), " << world << " worker process(es) x " << tpp << " thread(s) on " << gpus << " GPU(s)"
@@ -571,7 +577,7 @@ int main(int argc, char* argv[])
     }
     double mean[4]; int nvalid = 0;
     wass_planes_mean_finish(acc, mean, &nvalid);
-    if (world > 1 && distinct && ok) {         // what the workers agreed on over RCCL must be what the parent sees
+    if (distinct && ok) {                      // what the workers agreed on over RCCL must be what the parent sees
         for (int r = 0; r < world; ++r)
             if (!tails[r].used_rccl || tails[r].n_valid != nvalid) { std::cerr << "RCCL mean plane disagrees with the gathered planes" << std::endl; ok = false; }
         for (int k = 0; k < 4 && ok; ++k) mean[k] = tails[0].mean[k];
@@ -583,7 +589,7 @@ int main(int argc, char* argv[])
     }
     const double dt = now() - t0;
     std::cout << "mean plane over " << nvalid << " frame(s): " << std::setprecision(12) << mean[0] << " " << mean[1] << " " << mean[2] << " " << mean[3]
-              << (world > 1 && distinct ? "  (RCCL all-reduce)" : "") << std::endl;
+              << (distinct ? "  (RCCL all-reduce)" : "") << std::endl;
     std::cout << wds.size() - nfail << "/" << wds.size() << " frame(s) ok in " << dt << " s (" << (wds.size() / dt) << " frames/s)" << std::endl;
     {
         double steady = 0;
