@@ -87,9 +87,42 @@ bool read_plane_txt(const std::string& wd, FrameSummary& fs)
     return true;
 }
 
-int worker(int rank, int world, int device, bool distinct_gpus, const unsigned char* uid, const char* cfg,
+// Coll-1's unique id.  It is taken by WORKER 0, not by the parent: ncclGetUniqueId initialises the RCCL / HIP runtimes of the calling
+// process, and a process that has done that must not fork workers which then use the GPU (round 6: the first torch-less worker forked
+// behind the parent's ncclGetUniqueId died with SIGSEGV in its first HIP call -- on a 1-GPU box, with --rccl-always; every N-GPU run
+// would have).  Worker 0 sends [ok, id] up its own pipe right after it starts; the parent relays it down one pipe per other worker;
+// workers read it when they get to the all-reduce.  ok = 0 (no loadable librccl): nobody calls RCCL, the parent reduces the planes.
+struct CollSetup {
+    bool use = false;
+    int up_fd = -1;        // worker 0 -> parent
+    int down_fd = -1;      // parent -> this worker (ranks >= 1)
+    unsigned char uid[128] = {};
+    bool ok = false;
+    void at_start(int rank)
+    {
+        if (!use || rank != 0) return;
+        ok = wass_coll_unique_id(uid) == WASS_OK;
+        unsigned char msg[129];
+        msg[0] = ok ? 1 : 0;
+        memcpy(msg + 1, uid, 128);
+        (void)write_all(up_fd, msg, sizeof msg);
+    }
+    bool before_allreduce(int rank)       // true: go through RCCL
+    {
+        if (!use) return false;
+        if (rank != 0) {
+            unsigned char msg[129] = {};
+            ok = read_all(down_fd, msg, sizeof msg) && msg[0] == 1;
+            memcpy(uid, msg + 1, 128);
+        }
+        return ok;
+    }
+};
+
+int worker(int rank, int world, int device, CollSetup coll, const char* cfg,
            const std::vector<std::string>& wds, bool verbose, bool skip_existing, bool debug_images, int fd, int threads)
 {
+    coll.at_start(rank);
     if (!verbose) {                       // per-frame logs still go to <workdir>/wass_stereo_log.txt
         const int nul = open("/dev/null", O_WRONLY);
         if (nul >= 0) { dup2(nul, 1); close(nul); }
@@ -157,10 +190,10 @@ int worker(int rank, int world, int device, bool distinct_gpus, const unsigned c
     if (status) return status;
     Tail t = {};
     t.magic = 0x57415353;
-    if (distinct_gpus) {
+    if (coll.before_allreduce(rank)) {
         // Coll-1 over RCCL: needs a context (a worker with no frames creates one just for the collective)
         if (!ctx && wass_ctx_create(device, &ctx) != WASS_OK) return 3;
-        if (wass_coll_init(ctx, rank, world, uid) != WASS_OK || wass_coll_allreduce_sum_f64(ctx, acc, 5) != WASS_OK) {
+        if (wass_coll_init(ctx, rank, world, coll.uid) != WASS_OK || wass_coll_allreduce_sum_f64(ctx, acc, 5) != WASS_OK) {
             std::cerr << "worker " << rank << ": RCCL all-reduce failed: " << wass_last_error(ctx) << std::endl;
             return 4;
         }
@@ -194,9 +227,10 @@ struct PipeOptions {
 };
 
 // One worker process, one context, frames rank, rank + world, ... through FramePipeline.
-int worker_pipelined(int rank, int world, int device, bool distinct_gpus, const unsigned char* uid, const char* cfgpath, const Config& cfg,
+int worker_pipelined(int rank, int world, int device, CollSetup coll, const char* cfgpath, const Config& cfg,
                      const std::vector<std::string>& wds, bool verbose, bool skip_existing, int fd, const PipeOptions& po)
 {
+    coll.at_start(rank);
     if (!verbose) {
         const int nul = open("/dev/null", O_WRONLY);
         if (nul >= 0) { dup2(nul, 1); close(nul); }
@@ -332,11 +366,11 @@ int worker_pipelined(int rank, int world, int device, bool distinct_gpus, const 
     Tail t = {};
     t.magic = 0x57415353;
     t.first_done = first_done; t.last_done = last_done; t.computed = computed;
-    if (distinct_gpus) {
+    if (coll.before_allreduce(rank)) {
         // Coll-1 over RCCL: needs a context (a worker without frames to compute creates one just for the collective)
         wass_ctx* ctx = pl.context();
         if (!ctx) return 3;
-        if (wass_coll_init(ctx, rank, world, uid) != WASS_OK || wass_coll_allreduce_sum_f64(ctx, acc, 5) != WASS_OK) {
+        if (wass_coll_init(ctx, rank, world, coll.uid) != WASS_OK || wass_coll_allreduce_sum_f64(ctx, acc, 5) != WASS_OK) {
             std::cerr << "worker " << rank << ": RCCL all-reduce failed: " << wass_last_error(ctx) << std::endl;
             return 4;
         }
@@ -459,11 +493,14 @@ int main(int argc, char* argv[])
     // communicator from the parent's unique id and all-reduces).  If this process cannot load librccl the sequence is not lost: the
     // parent gathers every frame's plane anyway and reduces them itself.
     bool distinct = ppg == 1 && (world > 1 || rccl_always);
-    unsigned char uid[128] = {};
-    if (distinct && wass_coll_unique_id(uid) != WASS_OK) {
-        std::cerr << "RCCL is not available (wass_coll_unique_id failed); planes will be reduced by the parent process" << std::endl;
-        distinct = false;
+    int uid_up[2] = { -1, -1 };
+    std::vector<int> uid_down_r(world, -1), uid_down_w(world, -1);
+    if (distinct) {
+        bool pipes_ok = pipe(uid_up) == 0;
+        for (int r = 1; r < world && pipes_ok; ++r) { int pfd2[2]; pipes_ok = pipe(pfd2) == 0; if (pipes_ok) { uid_down_r[r] = pfd2[0]; uid_down_w[r] = pfd2[1]; } }
+        if (!pipes_ok) { perror("pipe"); return -1; }
     }
+    auto coll_of = [&](int r) { CollSetup c; c.use = distinct; c.up_fd = uid_up[1]; c.down_fd = uid_down_r[r]; return c; };
 
     std::cout << "wass_stereo_batch: " << wds.size() << " frame(s), " << world << " worker process(es) x " << tpp << " thread(s) on " << gpus << " GPU(s)"
               << (pipelined ? ", pipelined (" + std::to_string(po.decode_threads) + " decode / " + std::to_string(po.writer_threads) + " writer threads per worker)" : std::string(", stage by stage")) << std::endl;
@@ -477,7 +514,7 @@ int main(int argc, char* argv[])
         if (in_process && world == 1 && pipelined) {
             // profiling aid: the worker as a thread of this process (records still travel through the pipe; verbose, so that stdout stays ours)
             const int wfd = pfd[1];
-            inproc = std::thread([&, wfd]() { (void)worker_pipelined(0, 1, 0, distinct, uid, cfg, config, wds, true, skip_existing, wfd, po); close(wfd); });
+            inproc = std::thread([&, wfd]() { (void)worker_pipelined(0, 1, 0, coll_of(0), cfg, config, wds, true, skip_existing, wfd, po); close(wfd); });
             pids[r] = -1; fds[r] = pfd[0];
             continue;
         }
@@ -486,11 +523,26 @@ int main(int argc, char* argv[])
         if (pid == 0) {
             close(pfd[0]);
             for (int q = 0; q < r; ++q) close(fds[q]);
-            _exit(pipelined ? worker_pipelined(r, world, r / ppg, distinct, uid, cfg, config, wds, verbose, skip_existing, pfd[1], po)
-                            : worker(r, world, r / ppg, distinct, uid, cfg, wds, verbose, skip_existing, debug_images, pfd[1], tpp));
+            if (uid_up[0] >= 0) close(uid_up[0]);
+            for (int q = 0; q < world; ++q) { if (uid_down_w[q] >= 0) close(uid_down_w[q]); if (q != r && uid_down_r[q] >= 0) close(uid_down_r[q]); }
+            _exit(pipelined ? worker_pipelined(r, world, r / ppg, coll_of(r), cfg, config, wds, verbose, skip_existing, pfd[1], po)
+                            : worker(r, world, r / ppg, coll_of(r), cfg, wds, verbose, skip_existing, debug_images, pfd[1], tpp));
         }
         close(pfd[1]);
         pids[r] = pid; fds[r] = pfd[0];
+    }
+    if (distinct) {
+        // worker 0's [ok, id] -> every other worker (worker 0 sends it before anything else; a worker 0 that died sends nothing: ok = 0)
+        const bool threaded = inproc.joinable();
+        if (!threaded) close(uid_up[1]);
+        unsigned char msg[129] = {};
+        if (!read_all(uid_up[0], msg, sizeof msg)) memset(msg, 0, sizeof msg);
+        for (int r = 1; r < world; ++r) { (void)write_all(uid_down_w[r], msg, sizeof msg); close(uid_down_w[r]); close(uid_down_r[r]); }
+        close(uid_up[0]);
+        if (msg[0] != 1) {
+            std::cerr << "RCCL is not available (wass_coll_unique_id failed in worker 0); planes will be reduced by the parent process" << std::endl;
+            distinct = false;
+        }
     }
     std::vector<Record> recs(wds.size());
     std::vector<char> got(wds.size(), 0);
