@@ -41,6 +41,9 @@ typedef enum {
 typedef struct wass_ctx wass_ctx;
 
 int wass_ctx_create(int device_id, wass_ctx** out);
+/* Devices the HIP runtime of this process shows (0 without a usable GPU or runtime).  Lets a host tell "no GPU at all" (every entry
+ * point fails loudly) from "this device index does not exist here" (another process, or device 0, can take the frame). */
+int wass_device_count(int* n_devices);
 void wass_ctx_destroy(wass_ctx* ctx);
 const char* wass_last_error(const wass_ctx* ctx);
 /* raw hipStream_t of the context (for callers that enqueue their own work) */

@@ -397,6 +397,31 @@ def test_two_sequences_of_different_picture_size_share_one_server(cli, tmp_path)
 
 
 @pytest.mark.gpu
+def test_a_frame_sent_to_a_gpu_that_is_not_there_is_computed_by_its_caller(cli, tmp_path):
+    """Round-5 advisor: a caller picks GPU = frame number mod (GPUs it counts); where the count is too high (WASS_NUM_GPUS, or a topology that
+    shows more than the runtime gives this process) the server of the missing device used to ANSWER "no usable GPU" and the frame was lost.
+    It now refuses, and the caller computes the frame itself: on this one-GPU box with WASS_NUM_GPUS=2 every second frame takes that route."""
+    w, h, D = 320, 240, 64
+    wd, cfg, *_ = make_workdir(str(tmp_path), w, h, D)
+    seq = tmp_path / "seq"
+    for i in range(4):
+        shutil.copytree(wd, seq / ("%06d_wd" % i))
+    ref = subprocess.run([cli, cfg, wd], capture_output=True, text=True, env=dict(os.environ, WASS_NO_SERVER="1", WASS_DEBUG_IMAGES="0"))
+    assert ref.returncode == 0
+    sock = tmp_path / "sock"
+    sock.mkdir()
+    env = _env(sock, WASS_DEBUG_IMAGES="0", WASS_NUM_GPUS="2")
+    env.pop("WASS_GPU_DEVICE", None)
+    for i in range(4):
+        r = subprocess.run([cli, cfg, str(seq / ("%06d_wd" % i))], capture_output=True, text=True, env=env)
+        assert r.returncode == 0 and "All done." in r.stdout and r.stdout.count("wass_stereo  v.") == 1, (i, r.stdout[-800:])
+        for name in NAMES:
+            assert open(os.path.join(wd, name), "rb").read() == (seq / ("%06d_wd" % i) / name).read_bytes(), (i, name)
+    assert sorted(f for f in os.listdir(sock) if f.endswith(".sock")) == ["wass_stereo_%d_gpu0.sock" % os.getuid(), "wass_stereo_%d_gpu1.sock" % os.getuid()]
+    _wait_gone(sock)
+
+
+@pytest.mark.gpu
 def test_the_server_applies_each_callers_options_not_its_own_environment(cli, tmp_path):
     """Round-5 advisor: WASS_DEBUG_FORMAT / WASS_HOST_INLIER_TEXT were forwarded and keyed but read from the SERVER's environment, i.e.
     from whichever caller had started it.  A server started without them serves a caller that sets them, and the other way round."""

@@ -113,6 +113,7 @@ SYMBOLS = {
     "wass_sgm_debug_fetch": (_i, [_vp, _vp, _vp, _vp]),
     "wass_sgm_probe_vsum": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "wass_sgm_selftest": (_i, [_vp, _i, _i, _i, _i, C.POINTER(C.c_uint64)]),
+    "wass_device_count": (_i, [C.POINTER(_i)]),
     "wass_ctx_set_kernel_events": (_i, [_vp, _i]),
     "wass_sgm_kernel_times": (_i, [_vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_float), _i, C.POINTER(_i)]),
     "wass_disparity_postprocess": (_i, [_vp, _vp, _i, _i, C.POINTER(SgmParams), _i, _i, _i, _vp]),

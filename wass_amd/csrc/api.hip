@@ -85,6 +85,15 @@ extern "C" {
 
 const char* wass_version(void) { return "wass_amd 0.1 (gfx950)"; }
 
+int wass_device_count(int* n_devices)
+{
+    if (!n_devices) return WASS_ERR_INVALID_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 0) n = 0;
+    *n_devices = n;
+    return WASS_OK;
+}
+
 int wass_ctx_create(int device_id, wass_ctx** out)
 {
     if (!out) return WASS_ERR_INVALID_ARG;

@@ -564,9 +564,15 @@ inline int server_main(const std::string& sock, int device)
         while (!ahead.empty()) submit_oldest();
         if (cur && cur->pl->pending()) { cur->pl->flush(done); hand_over(); }
     };
+    bool foreign_device = false;                                   // this server's device index does not exist in this process's HIP runtime
     auto take = [&](ServerJob* j) {
         last_activity = (long long)time(nullptr);
         if (j->entry != cur) { drain(); cur = j->entry; }
+        // A GPU that is not there although others are (WASS_NUM_GPUS / the topology said more than the runtime shows): the caller computes
+        // its frame itself, on the device an in-process run picks -- slow, not lost.  (No GPU at all stays what it was: the frame fails
+        // loudly, with its log, whoever computes it.)
+        if (!foreign_device && device > 0 && !cur->pl->context()) { int n = 0; foreign_device = wass_device_count(&n) == WASS_OK && n > 0 && device >= n; }
+        if (foreign_device && j->fd >= 0) { refuse(j->fd); j->fd = -1; cur->pl->abandon(*j); delete j; --in_flight; return; }
         // Staged as soon as it is here, up to two frames ahead of the one being submitted: uploads and downloads share one copy queue,
         // and an upload enqueued behind the previous frame's downloads waits for that frame's TAIL -- the SGM stage behind the upload
         // then starts after the tail instead of beside it (8 callers: 11 ms per frame instead of 8.6).
@@ -582,7 +588,7 @@ inline int server_main(const std::string& sock, int device)
         if (ready.pop(j, !ahead.empty() ? 0 : pending ? 2 : 250)) {
             take(j);
             if (ahead.size() < 3 && ready.size() > 0) continue;       // more callers waiting: their pictures first
-        } else if ((int)ahead.size() < spec_stage && spec_live.load() < spec_max) {
+        } else if (!foreign_device && (int)ahead.size() < spec_stage && spec_live.load() < spec_max) {
             // no caller's frame is waiting: frames that were prepared ahead of their callers (speculation) -- staged like callers' frames,
             // up to two ahead of the one being submitted (an upload enqueued behind the previous frame's downloads waits for that frame's
             // tail: staged one at a time the speculative chain ran at 96 frames/s where callers' frames run at 114)
@@ -603,7 +609,7 @@ inline int server_main(const std::string& sock, int device)
     incoming.close();
     while (in_flight.load() > 0) {                                 // a request that slipped in between the last check and the unlink
         ServerJob* j = nullptr;
-        if (ready.pop(j, 50)) { take(j); submit_oldest(); }
+        if (ready.pop(j, 50)) { take(j); if (!ahead.empty()) submit_oldest(); }
         else drain();
     }
     drain();
