@@ -101,6 +101,15 @@ int wass_ctx_create(int device_id, wass_ctx** out)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return WASS_ERR_DEVICE;
     if (hipSetDevice(device_id) != hipSuccess) return WASS_ERR_DEVICE;
+    // Host threads that wait for the GPU sleep instead of spinning (hipDeviceScheduleAuto spins while there are fewer contexts than cores,
+    // and the hipEventBlockingSync flag of an event alone did not change that): a sequence driver's submitting thread spent 5 ms of CPU per
+    // config-B frame waiting for the frame before last -- 33.5 -> 27.8 ms of host CPU per frame, same frames/s (round 6,
+    // scripts/host_cost.py).  Takes effect when this is the first HIP call of the process on that device (the shipped executables; in a
+    // process whose runtime is already up -- bench.py under PyTorch -- the call is refused and nothing changes).  WASS_BLOCKING_SYNC=0: spin.
+    {
+        const char* e = getenv("WASS_BLOCKING_SYNC");
+        if (!e || atoi(e) != 0) { (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); }
+    }
     wass_ctx* c = new (std::nothrow) wass_ctx();
     if (!c) return WASS_ERR_NO_MEMORY;
     c->device = device_id;

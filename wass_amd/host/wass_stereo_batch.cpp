@@ -28,6 +28,7 @@
 #include <sys/resource.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
+#include <map>
 #include <poll.h>
 #include <signal.h>
 #include <unistd.h>
@@ -263,6 +264,7 @@ int worker_pipelined(int rank, int world, int device, CollSetup coll, const char
         std::mutex out_mu;                                         // the pipe, the plane sum, stdout
 
         auto loader = [&]() {
+            pthread_setname_np(pthread_self(), "wass-decode");
             for (;;) {
                 size_t pos;
                 {
@@ -286,6 +288,7 @@ int worker_pipelined(int rank, int world, int device, CollSetup coll, const char
             }
         };
         auto writer = [&]() {
+            pthread_setname_np(pthread_self(), "wass-write");
             for (;;) {
                 size_t pos;
                 {
@@ -315,6 +318,7 @@ int worker_pipelined(int rank, int world, int device, CollSetup coll, const char
                 jobs[pos].reset();
             }
         };
+        pthread_setname_np(pthread_self(), "wass-hip-rt");       // (threads the HIP / ROCr runtime starts from this one inherit the name ...)
         std::vector<std::thread> loaders, writers;
         for (int t = 0; t < po.decode_threads; ++t) loaders.emplace_back(loader);
         for (int t = 0; t < po.writer_threads; ++t) writers.emplace_back(writer);
@@ -337,6 +341,7 @@ int worker_pipelined(int rank, int world, int device, CollSetup coll, const char
                 if (nxt && pos + 2 < n && ready[pos + 2]) nxt2 = jobs[pos + 2].get();
             }
             pl.stage(*cur);
+            if (pos == 0) pthread_setname_np(pthread_self(), "wass-submit");   // (... this thread takes its own once the runtime is up)
             // uploads run two frames ahead, in order (FramePipeline::NIN): underneath this frame, in front of its downloads in the copy stream
             const bool ahead1 = nxt && nxt->rc == 0 && !nxt->skipped && pl.same_geometry(*nxt);
             if (ahead1) pl.stage(*nxt);
@@ -359,6 +364,28 @@ int worker_pipelined(int rank, int world, int device, CollSetup coll, const char
         }
         cv_write.notify_all();
         cv_window.notify_all();
+        if (getenv("WASS_THREAD_CPU")) {
+            // diagnostic: CPU seconds per thread of this worker, by thread name (the unnamed ones are the HIP / ROCr runtime's)
+            std::map<std::string, std::pair<int, double>> by;
+            if (DIR* d = opendir("/proc/self/task")) {
+                while (dirent* e = readdir(d)) {
+                    if (e->d_name[0] == '.') continue;
+                    std::ifstream f(std::string("/proc/self/task/") + e->d_name + "/stat");
+                    std::string line;
+                    std::getline(f, line);
+                    const size_t a = line.find('('), b = line.rfind(')');
+                    if (a == std::string::npos || b == std::string::npos) continue;
+                    std::istringstream is(line.substr(b + 2));
+                    std::string tok;
+                    unsigned long long ut = 0, st = 0;
+                    for (int k = 3; k <= 15 && (is >> tok); ++k) { if (k == 14) ut = strtoull(tok.c_str(), nullptr, 10); if (k == 15) st = strtoull(tok.c_str(), nullptr, 10); }
+                    auto& s = by[line.substr(a + 1, b - a - 1)];
+                    s.first++; s.second += (double)(ut + st) / (double)sysconf(_SC_CLK_TCK);
+                }
+                closedir(d);
+            }
+            for (const auto& kv : by) fprintf(stderr, "thread CPU: %-16s x%-3d %.3f s\n", kv.first.c_str(), kv.second.first, kv.second.second);
+        }
         for (auto& t : loaders) t.join();
         for (auto& t : writers) t.join();
     }
