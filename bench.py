@@ -31,6 +31,12 @@ Prints ONE JSON line (rank 0) with BASELINE.json's metric plus
 """
 from __future__ import annotations
 
+import os as _os
+# Six hardware queues instead of the runtime's four, set before PyTorch brings the HIP runtime up: every stream of the context (SGM, side,
+# copy, tail) and the process's null stream then have a queue of their own.  With four, two of them share one and the runtime's choice
+# among equally loaded queues differs from run to run -- tail + side on one queue costs the aggregation 0.35 ms, tail + SGM the whole
+# tail (wass_amd/csrc/api.hip default_hw_queues; profiles/r06_x_streams.log).  The shipped executables set the same default themselves.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
 import argparse
 import json
 import os

@@ -85,9 +85,20 @@ extern "C" {
 
 const char* wass_version(void) { return "wass_amd 0.1 (gfx950)"; }
 
+// The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and a hardware queue is in-order.
+// A context has four streams (SGM, side, copy, tail) and the process has its null stream: with four queues two of them share one, and
+// WHICH two is decided by the runtime among equally loaded queues -- it differs from run to run.  When the tail stream lands on the side
+// stream's queue the anti-diagonal checkpoint sweep waits behind the previous frame's tail kernels (aggregation 6.2 instead of 5.85 ms);
+// on the SGM stream's queue the frame period becomes SGM + tail (115 instead of 130 pairs/s); with the null or the copy stream it is
+// harmless.  Round 6 found this as the "slow boxes" of four rounds (profiles/r06_x_streams.log, r06_x_hwqueues.log).  Six queues: every
+// stream of a context has its own (5 and 6 measure the same, 8 is 1.5 % slower).  Only effective before the runtime initialises -- i.e.
+// in the shipped executables, whose first HIP call is made here; bench.py sets the same default before it imports PyTorch.
+static void default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "6", 0); }
+
 int wass_device_count(int* n_devices)
 {
     if (!n_devices) return WASS_ERR_INVALID_ARG;
+    default_hw_queues();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n < 0) n = 0;
     *n_devices = n;
@@ -98,6 +109,7 @@ int wass_ctx_create(int device_id, wass_ctx** out)
 {
     if (!out) return WASS_ERR_INVALID_ARG;
     *out = nullptr;
+    default_hw_queues();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return WASS_ERR_DEVICE;
     if (hipSetDevice(device_id) != hipSuccess) return WASS_ERR_DEVICE;
@@ -113,6 +125,9 @@ int wass_ctx_create(int device_id, wass_ctx** out)
     wass_ctx* c = new (std::nothrow) wass_ctx();
     if (!c) return WASS_ERR_NO_MEMORY;
     c->device = device_id;
+    if (const char* e = getenv("WASS_X_DUMMY_STREAMS")) {      // measurement only (profiles/r06_x_streams.log): shifts which of the context's streams share a hardware queue
+        for (int i = 0; i < atoi(e); ++i) { hipStream_t d; (void)hipStreamCreateWithFlags(&d, hipStreamNonBlocking); }
+    }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
     if (hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
