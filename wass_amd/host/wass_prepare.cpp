@@ -93,6 +93,9 @@ bool process_image(Gpu& gpu, const std::string& filename, const Mat& K, const Ma
 
 int main(int argc, char* argv[])
 {
+    // six hardware queues for the HIP runtime, while this process is still single-threaded (libwassgpu sets the same default before its first
+    // HIP call -- wass_amd/csrc/api.hip default_hw_queues has the story -- but setenv() there would race with the getenv() of other threads)
+    (void)setenv("GPU_MAX_HW_QUEUES", "6", 0);
     std::cout << "wass_prepare  v. " << WASS_AMD_VERSION << std::endl;
     std::cout << "----------------------------------------------" << std::endl;
     std::cout << " [Release] MI355X / gfx950 HIP build, " << wass_version() << std::endl << std::endl;

@@ -12,6 +12,9 @@ using namespace wassframe;
 
 int main(int argc, char* argv[])
 {
+    // six hardware queues for the HIP runtime, while this process is still single-threaded (libwassgpu sets the same default before its first
+    // HIP call -- wass_amd/csrc/api.hip default_hw_queues has the story -- but setenv() there would race with the getenv() of other threads)
+    (void)setenv("GPU_MAX_HW_QUEUES", "6", 0);
     // the resident worker that later wass_stereo processes hand their frames to (stereo_server.hpp); started by the first of them
     if (argc >= 3 && std::string("--server") == argv[1]) return wassserver::server_main(argv[2], argc >= 4 ? atoi(argv[3]) : 0);
 

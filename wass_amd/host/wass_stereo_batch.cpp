@@ -411,6 +411,9 @@ int worker_pipelined(int rank, int world, int device, CollSetup coll, const char
 
 int main(int argc, char* argv[])
 {
+    // six hardware queues for the HIP runtime, while this process is still single-threaded (libwassgpu sets the same default before its first
+    // HIP call -- wass_amd/csrc/api.hip default_hw_queues has the story -- but setenv() there would race with the getenv() of other threads)
+    (void)setenv("GPU_MAX_HW_QUEUES", "6", 0);
     if (argc < 3) {
         std::cout << "Usage:\n  wass_stereo_batch <config_file> <workdir>... [--gpus G] [--procs-per-gpu P] [--out <dir>] [--verbose] [--skip-existing] [--debug-images]\n"
                      "  wass_stereo_batch <config_file> --sequence <output_dir> [--gpus G] ...\n"
