@@ -90,7 +90,8 @@ const char* wass_version(void) { return "wass_amd 0.1 (gfx950)"; }
 // WHICH two is decided by the runtime among equally loaded queues -- it differs from run to run.  When the tail stream lands on the side
 // stream's queue the anti-diagonal checkpoint sweep waits behind the previous frame's tail kernels (aggregation 6.2 instead of 5.85 ms);
 // on the SGM stream's queue the frame period becomes SGM + tail (115 instead of 130 pairs/s); with the null or the copy stream it is
-// harmless.  Round 6 found this as the "slow boxes" of four rounds (profiles/r06_x_streams.log, r06_x_hwqueues.log).  Six queues: every
+// harmless.  Round 6 found this as the "slow boxes" of four rounds (profiles/r06_x_streams.log -- made with a knob, since removed, that
+// created dummy streams in front of the context's to shift the assignment -- and r06_x_hwqueues.log).  Six queues: every
 // stream of a context has its own (5 and 6 measure the same, 8 is 1.5 % slower).  Only effective before the runtime initialises -- i.e.
 // in the shipped executables, whose first HIP call is made here; bench.py sets the same default before it imports PyTorch.
 static void default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "6", 0); }
@@ -125,9 +126,6 @@ int wass_ctx_create(int device_id, wass_ctx** out)
     wass_ctx* c = new (std::nothrow) wass_ctx();
     if (!c) return WASS_ERR_NO_MEMORY;
     c->device = device_id;
-    if (const char* e = getenv("WASS_X_DUMMY_STREAMS")) {      // measurement only (profiles/r06_x_streams.log): shifts which of the context's streams share a hardware queue
-        for (int i = 0; i < atoi(e); ++i) { hipStream_t d; (void)hipStreamCreateWithFlags(&d, hipStreamNonBlocking); }
-    }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
     if (hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) != hipSuccess) { wass_ctx_destroy(c); return WASS_ERR_DEVICE; }
