@@ -657,11 +657,13 @@ def main():
         host.append((r.cpu().pin_memory(), l.cpu().pin_memory()))
     del r, l
     torch.cuda.synchronize()
-    NBUF = 4                                             # a frame's inputs must stay untouched until its record has been read: two frames stay pending
+    NBUF = 6                                             # two frames staged ahead, the one being submitted, two pending, one whose tail may still read its picture (FramePipeline::NIN)
     # resident pass: every distinct frame (both pictures + the burned-area mask of the right one) sits in HBM before the clock
-    # starts.  PCIe pass: a ring of three input sets, frame i+1 uploaded from pinned memory right before frame i is submitted
-    # (what the C++ driver does after decoding) through wass_upload_async -- the context's copy stream + an event the SGM
-    # stream waits for (a separate upload stream of torch's ended up sharing a hardware queue with the context's tail stream).
+    # starts.  PCIe pass: a ring of six input sets, frame i+2 uploaded from pinned memory right before frame i is submitted
+    # (what the C++ driver does after decoding: frame_pipeline.hpp stages two frames ahead) through wass_upload_async -- the context's
+    # copy stream + an event the SGM stream waits for.  Two ahead, not one (round 6): the copy stream carries frame i's downloads, which
+    # wait for its tail, in front of the next upload; one ahead, the SGM stage of frame i+2 had 0.4 ms of slack behind the tail of
+    # frame i (NOTES/measurement.md "Round 6") -- a box whose tail kernels stretch paid that in pairs/s.
     dres = [tuple(torch.empty((h, w), dtype=torch.uint8, device=dev) for _ in range(3)) for _ in range(nf)]
     dring = [tuple(torch.empty((h, w), dtype=torch.uint8, device=dev) for _ in range(3)) for _ in range(NBUF)]
     for k in range(nf):
@@ -697,13 +699,14 @@ def main():
             if resident:
                 dr, dl, dm = dres[i % nf]
             else:
-                # one upload per step, of the NEXT frame: the transfer runs on the copy stream underneath frame i; buffer
-                # (i+1) % 3 was last used by frame i-2
+                # one upload per step, of the frame after next: the transfer runs on the copy stream underneath frame i; buffer
+                # (i+2) % 6 was last used by frame i-4
                 dr, dl, dm = dring[i % NBUF]
                 if i == 0:
                     upload(0)
+                    upload(1)
                 ctx.burned_area_mask_dev(dr, dm)            # DISCARD_BURNED_AREAS mask of the right image (wass_stereo.cpp:1072)
-                upload(i + 1)
+                upload(i + 2)
             if args.stage == "sgm":
                 ctx.sgm_disparity_dev(dr, dl, params, sgm_out)
             else:
